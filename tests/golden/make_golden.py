@@ -1,0 +1,272 @@
+"""
+Generates the golden vectors under tests/golden/ by running the UNMODIFIED reference modules, imported from
+/root/reference, in the build container.  Run from the repository root:
+
+    python tests/golden/make_golden.py
+
+Nothing from the reference is copied: the script imports `empose.*`, feeds it seeded synthetic inputs and stores
+inputs + outputs as .npz.  Third-party modules the image lacks are replaced by the stand-ins in oracle/refstubs
+(see its README): that makes the body-model arithmetic the oracle's own (PARITY UNPINNED at that boundary), while
+the loop, the autograd gradient, the networks, the losses and the virtual-sensor code are the reference's.
+
+The script cannot run on the GPU box (/root/reference does not exist there); only its outputs travel.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+_tmp = tempfile.mkdtemp(prefix='empose_golden_')
+for k in ('EM_DATA_SYNTH', 'EM_EXPERIMENTS', 'SMPL_MODELS', 'EM_DATA_REAL'):
+    os.environ[k] = _tmp
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'refstubs'))
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from em_pose_amd import synthetic  # noqa: E402  (data generation only)
+
+torch.set_num_threads(4)
+
+
+def build_small_model():
+    model = synthetic.make_model(nu=8, nv=20, seed=160, n_shape=16)
+    d = os.path.join(_tmp, 'smplh_amass', 'neutral')
+    os.makedirs(d, exist_ok=True)
+    np.savez(os.path.join(d, 'model.npz'), **model)
+    return model
+
+
+def ref_config(**kw):
+    from empose.helpers.configuration import Configuration
+    argv_backup = sys.argv
+    sys.argv = ['x']
+    cfg = Configuration.parse_cmd()
+    sys.argv = argv_backup
+    for k, v in kw.items():
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, v)
+    return cfg
+
+
+def lgd_flags(n_markers, rnn, N, hidden, rnn_hidden, ws=32):
+    return dict(m_type='ief', m_hidden_size=hidden, m_num_layers=2, m_num_iterations=N, window_size=ws,
+                use_marker_pos=True, use_marker_ori=True, use_real_offsets=True, offset_noise_level=0,
+                m_average_shape=True, m_use_gradient=True, m_reprojection_loss_weight=0.01, eval_window_size=256,
+                m_rnn_init=rnn, m_rnn_hidden_size=rnn_hidden, lr=0.0005 if rnn else 0.001, n_markers=n_markers,
+                m_pose_loss_weight=10.0, m_fk_loss=0.1)
+
+
+def randomize_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def make_net(flags, seed, vertex_ids):
+    from empose.bodymodels.smpl import create_default_smpl_model
+    from empose.nn.models import create_model
+    smpl = create_default_smpl_model(torch.device('cpu'))
+    torch.manual_seed(seed)
+    net = create_model(ref_config(**flags), smpl)
+    with torch.no_grad():
+        randomize_bn(net, seed + 1)
+        # Default init gives tiny updates; scale the output heads so that the N iterations move the estimate visibly.
+        for name, p in net.named_parameters():
+            if 'hidden_to_output' in name or name in ('pose_net_init.weight', 'pose_net_init.bias',
+                                                      'shape_net_init.weight', 'shape_net_init.bias'):
+                p.mul_(3.0)
+    net.eval()
+    net.vertex_ids = list(vertex_ids)  # instance attribute (reference models.py:383); the small mesh has V=160
+    return net, smpl
+
+
+def sensors_from_reference(net, smpl):
+    def fn(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = net.get_estimated_real_markers(torch.from_numpy(poses), torch.from_numpy(betas),
+                                                     torch.from_numpy(o_r), torch.from_numpy(o_t), net.vertex_ids)
+        return p.numpy(), o.numpy()
+    return fn
+
+
+class _SynthBatch(object):
+    """Minimal ABatch-like container with marker_masks=None (the AMASS-batch contract, reference data.py:433-459)."""
+
+    def __init__(self, w, seq_lengths):
+        from empose.data.data import ABatch
+        self.__class__ = type('SynthBatch', (ABatch,), {'get_inputs': _SynthBatch._get_inputs})
+        B, F = w['poses'].shape[:2]
+        ABatch.__init__(self, list(range(B)), seq_lengths, torch.from_numpy(w['poses']),
+                        torch.from_numpy(w['shapes']), torch.zeros(B, F, 3), None)
+        self.w = w
+
+    def _get_inputs(self, sf=None, ef=None, **kwargs):
+        w = self.w
+        return {'marker_pos': torch.from_numpy(w['marker_pos'])[:, sf:ef],
+                'marker_oris': torch.from_numpy(w['marker_oris'])[:, sf:ef],
+                'marker_normals': None, 'joints': None,
+                'offset_t': torch.from_numpy(w['offset_t']), 'offset_r': torch.from_numpy(w['offset_r']),
+                'marker_masks': None}
+
+
+def real_batch(w, seq_lengths, masks=None, sf=None, ef=None):
+    from empose.data.data import RealBatch
+    B, F = w['poses'].shape[:2]
+    sl = slice(sf, ef)
+    masks = np.ones((B, F, 12), dtype=np.float32) if masks is None else masks
+    b = RealBatch(list(range(B)), seq_lengths, torch.from_numpy(w['poses'][:, sl]), torch.from_numpy(w['shapes']),
+                  torch.zeros(B, F, 3)[:, sl], torch.from_numpy(w['marker_pos'][:, sl].copy()),
+                  torch.from_numpy(w['marker_oris'][:, sl].copy()), torch.from_numpy(masks[:, sl].copy()),
+                  torch.from_numpy(w['offset_t']), torch.from_numpy(w['offset_r']))
+    b.joints_hat = torch.zeros(B, b.seq_length, 66)  # set by the SMPLFK transform in the reference's eval flow
+    return b
+
+
+def run_and_record(net, batch, is_new_sequence=True):
+    """Run the reference forward; capture the gradient features fed to pose_net_iter (models.py:578-584)."""
+    feats = []
+    h = net.pose_net_iter.register_forward_pre_hook(lambda m, inp: feats.append(inp[0].detach().clone()))
+    out = net(batch, is_new_sequence=is_new_sequence)
+    h.remove()
+    d_in = net.input_size
+    rec = {'out_' + k: v.detach().numpy() for k, v in out.items()}
+    for name in ('pose', 'shape', 'joints', 'markers', 'markers_ori'):
+        hist = getattr(net, name + '_hat_history')
+        rec['hist_' + name] = np.stack([t.detach().numpy().reshape(batch.batch_size, batch.seq_length, -1)
+                                        for t in hist])
+    rec['g_pose'] = np.stack([f[:, d_in + 76:d_in + 142].numpy() for f in feats])
+    rec['g_shape'] = np.stack([f[:, d_in + 142:].numpy() for f in feats])
+    if net.rnn_init:
+        rec['rnn_h'] = net.rnn.final_state[0].detach().numpy()
+        rec['rnn_c'] = net.rnn.final_state[1].detach().numpy()
+    return rec
+
+
+def save_case(name, net, w, recs, extra=None):
+    data = {}
+    for k, v in net.state_dict().items():
+        if k.startswith('smpl.'):
+            continue  # the body model is stored once in smpl_small.npz
+        data['sd/' + k] = v.numpy()
+    for k, v in w.items():
+        data['in/' + k] = v
+    for tag, rec in recs.items():
+        for k, v in rec.items():
+            data['{}/{}'.format(tag, k)] = v
+    for k, v in (extra or {}).items():
+        data['meta/' + k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **data)
+    print('wrote', path, '%.0f KB' % (os.path.getsize(path) / 1024))
+
+
+def main():
+    model = build_small_model()
+    np.savez_compressed(os.path.join(HERE, 'smpl_small.npz'), **{k: v for k, v in model.items()})
+    vids = synthetic.small_vertex_ids(160)
+    H = 32
+
+    from empose.helpers.configuration import CONSTANTS as C
+    assert torch.device('cpu') == C.DEVICE
+
+    # ---- known answers: parameter counts and model names of the released configurations (README.md:51,228,229)
+    known = {}
+    from empose.nn.models import create_model
+    from empose.bodymodels.smpl import create_default_smpl_model
+    smpl = create_default_smpl_model(torch.device('cpu'))
+    for tag, fl in (('lgd_rnn_6_N2', dict(lgd_flags(6, True, 2, 512, 512))),
+                    ('lgd_rnn_12_N4', dict(lgd_flags(12, True, 4, 512, 512), lr=0.001)),
+                    ('lgd_12_N4', dict(lgd_flags(12, False, 4, 512, 512)))):
+        net = create_model(ref_config(**fl), smpl)
+        n_par = sum(p.numel() for n, p in net.named_parameters() if p.requires_grad and not n.startswith('smpl.'))
+        known[tag] = {'params_without_bodymodel': int(n_par), 'model_name': net.model_name()}
+    with open(os.path.join(HERE, 'known_answers.json'), 'w') as f:
+        json.dump(known, f, indent=2, sort_keys=True)
+    print(known)
+
+    # ---- case A: LGD-12 (no RNN), N=4, B=2, F=32, marker_masks=None
+    net, smpl = make_net(lgd_flags(12, False, 4, H, H), 1614785570, vids)
+    w = synthetic.make_windows(2, 32, 1614785570, sensors_from_reference(net, smpl))
+    rec = run_and_record(net, _SynthBatch(w, torch.tensor([32, 32])))
+    save_case('lgd12_n4', net, w, {'run': rec}, {'n_markers': 12, 'N': 4, 'rnn': 0, 'vertex_ids': vids})
+
+    # ---- case B: LGD-RNN-12, N=4, B=2, two consecutive 32-frame chunks of a 64-frame window with LSTM carry
+    net, smpl = make_net(lgd_flags(12, True, 4, H, H), 1615200973, vids)
+    w = synthetic.make_windows(2, 64, 1615200973, sensors_from_reference(net, smpl))
+    sl = torch.tensor([32, 32])
+    rec0 = run_and_record(net, real_batch(w, sl, sf=0, ef=32), is_new_sequence=True)
+    rec1 = run_and_record(net, real_batch(w, sl, sf=32, ef=64), is_new_sequence=False)
+    save_case('lgdrnn12_n4_carry', net, w, {'chunk0': rec0, 'chunk1': rec1},
+              {'n_markers': 12, 'N': 4, 'rnn': 1, 'vertex_ids': vids})
+
+    # ---- case C: LGD-RNN-6, N=2 (the released 1615631737 configuration), B=2, F=32
+    net, smpl = make_net(lgd_flags(6, True, 2, H, H), 1615631737, vids)
+    w = synthetic.make_windows(2, 32, 1615631737, sensors_from_reference(net, smpl))
+    rec = run_and_record(net, real_batch(w, torch.tensor([32, 32])))
+    save_case('lgdrnn6_n2', net, w, {'run': rec}, {'n_markers': 6, 'N': 2, 'rnn': 1, 'vertex_ids': vids})
+
+    # ---- case D: ragged batch (padded frames) + missing sensors, LGD-RNN-12, N=3, B=3, F=24
+    net, smpl = make_net(lgd_flags(12, True, 3, H, H), 77, vids)
+    w = synthetic.make_windows(3, 24, 77, sensors_from_reference(net, smpl))
+    masks = np.ones((3, 24, 12), dtype=np.float32)
+    masks[0, 3:6, 4] = 0.0
+    masks[1, 0, 0] = 0.0
+    masks[2, 5, [2, 7]] = 0.0
+    lengths = torch.tensor([24, 17, 6])
+    for b, n in enumerate(lengths.tolist()):  # padding as pad_sequence would leave it
+        for k in ('marker_pos', 'marker_oris', 'poses'):
+            w[k][b, n:] = 0.0
+        masks[b, n:] = 0.0
+    rec = run_and_record(net, real_batch(w, lengths, masks=masks))
+    w2 = dict(w)
+    w2['marker_masks'] = masks
+    w2['seq_lengths'] = lengths.numpy()
+    save_case('lgdrnn12_n3_ragged_masked', net, w2, {'run': rec},
+              {'n_markers': 12, 'N': 3, 'rnn': 1, 'vertex_ids': vids})
+
+    # ---- component vectors straight from reference functions
+    from empose.nn.loss import reconstruction_loss
+    from empose.helpers.utils import mask_from_seq_lengths, compute_vertex_and_face_normals
+    from empose.data.virtual_sensors import VirtualMarkerHelper
+    g = torch.Generator().manual_seed(5)
+    gt, hat = torch.randn(3, 7, 12, 3, generator=g), torch.randn(3, 7, 12, 3, generator=g)
+    mm = (torch.rand(3, 7, 12, generator=g) > 0.1).float()
+    sl = torch.tensor([7, 4, 2])
+    comp = {'rl_gt': gt.numpy(), 'rl_hat': hat.numpy(), 'rl_mask': mm.numpy(), 'rl_len': sl.numpy(),
+            'rl_plain': reconstruction_loss(gt, hat).numpy(),
+            'rl_len_only': reconstruction_loss(gt, hat, sl).numpy(),
+            'rl_full': reconstruction_loss(gt, hat, sl, mm).numpy(),
+            'mask_from_len': mask_from_seq_lengths(sl).numpy()}
+    verts = torch.from_numpy(model['v_template'])[None] + 0.01 * torch.randn(2, 160, 3, generator=g)
+    helper = VirtualMarkerHelper(smpl)
+    pos, ori, nor = helper.get_virtual_pos_and_rot(verts, vids)
+    faces, vf = helper.get_sub_faces(tuple(vids))
+    comp.update({'vs_verts': verts.numpy(), 'vs_pos': pos.numpy(), 'vs_ori': ori.numpy(), 'vs_nor': nor.numpy(),
+                 'vs_sub_faces': faces.numpy(), 'vs_sub_vertex_faces': vf.numpy(),
+                 'vs_helpers': np.asarray(helper.get_vertex_helpers(tuple(vids)))})
+    vn, fn = compute_vertex_and_face_normals(verts, smpl.faces, smpl.vertex_faces(160))
+    comp.update({'full_vertex_normals': vn.numpy(), 'full_face_normals': fn.numpy()})
+    # SMPLLayer wrapper semantics on the small model (reference smpl.py:81-122)
+    p = 0.3 * torch.randn(4, 63, generator=g)
+    bt = torch.randn(4, 16, generator=g)
+    rt = 0.3 * torch.randn(4, 3, generator=g)
+    v1, j1 = smpl(poses_body=p, betas=bt, poses_root=rt)
+    v2, j2 = smpl(poses_body=p, betas=bt[0])
+    comp.update({'fk_pose': p.numpy(), 'fk_betas': bt.numpy(), 'fk_root': rt.numpy(), 'fk_v': v1.numpy(),
+                 'fk_j': j1.numpy(), 'fk_v_noroot_bcast': v2.numpy(), 'fk_j_noroot_bcast': j2.numpy()})
+    np.savez_compressed(os.path.join(HERE, 'components.npz'), **comp)
+    print('wrote components.npz')
+
+
+if __name__ == '__main__':
+    main()

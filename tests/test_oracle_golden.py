@@ -1,0 +1,96 @@
+"""
+Pins the oracle (oracle/torch_ref.py) against vectors recorded from the unmodified reference
+(tests/golden/make_golden.py).  CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from tests import helpers as H
+
+TOL = 2e-5  # fp32 restatement vs fp32 reference, different op order
+
+
+def _check(rec, out, hist, tol=TOL):
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        np.testing.assert_allclose(out[k].numpy(), rec['out_' + k], atol=tol, rtol=0)
+    B, F = rec['out_pose_hat'].shape[:2]
+    for name in ('pose', 'shape', 'joints', 'markers', 'markers_ori'):
+        mine = np.stack([t.numpy().reshape(B, F, -1) for t in hist[name]])
+        np.testing.assert_allclose(mine, rec['hist_' + name], atol=tol, rtol=0)
+    # gradient features are O(10): relative tolerance
+    gp = np.stack([t.numpy() for t in hist['g_pose']])
+    gs = np.stack([t.numpy() for t in hist['g_shape']])
+    np.testing.assert_allclose(gp, rec['g_pose'], atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(gs, rec['g_shape'], atol=5e-4, rtol=1e-4)
+
+
+def test_known_answers():
+    with open(os.path.join(H.GOLDEN, 'known_answers.json')) as f:
+        known = json.load(f)
+    # reference README.md:228: 5 721 419 trainable parameters = 5 721 250 network + 169 BodyModel parameters
+    assert known['lgd_rnn_6_N2']['params_without_bodymodel'] + 169 == 5721419
+    assert known['lgd_rnn_6_N2']['model_name'] == 'IEF-2x512-N2-RNN-2x512-r0.01-ws32-lr0.0005-grad-n6'
+    assert known['lgd_12_N4']['model_name'] == 'IEF-2x512-N4-r0.01-ws32-lr0.001-grad-n12'
+
+
+def test_lgd12_no_rnn():
+    case = H.load_case('lgd12_n4')
+    out, hist = H.run_oracle(case, 'run', H.oracle_inputs(case['in']))
+    _check(case['run'], out, hist)
+
+
+def test_lgdrnn12_carry():
+    case = H.load_case('lgdrnn12_n4_carry')
+    out0, hist0 = H.run_oracle(case, 'chunk0', H.oracle_inputs(case['in'], sf=0, ef=32))
+    _check(case['chunk0'], out0, hist0)
+    np.testing.assert_allclose(hist0['rnn_state'][0].numpy(), case['chunk0']['rnn_h'], atol=TOL)
+    np.testing.assert_allclose(hist0['rnn_state'][1].numpy(), case['chunk0']['rnn_c'], atol=TOL)
+    out1, hist1 = H.run_oracle(case, 'chunk1', H.oracle_inputs(case['in'], sf=32, ef=64), state=hist0['rnn_state'])
+    _check(case['chunk1'], out1, hist1)
+
+
+def test_lgdrnn6():
+    case = H.load_case('lgdrnn6_n2')
+    out, hist = H.run_oracle(case, 'run', H.oracle_inputs(case['in']))
+    _check(case['run'], out, hist)
+
+
+def test_ragged_masked():
+    case = H.load_case('lgdrnn12_n3_ragged_masked')
+    out, hist = H.run_oracle(case, 'run', H.oracle_inputs(case['in'], sl=case['in']['seq_lengths']))
+    _check(case['run'], out, hist)
+    np.testing.assert_allclose(hist['rnn_state'][0].numpy(), case['run']['rnn_h'], atol=TOL)
+
+
+def test_components():
+    z = np.load(os.path.join(H.GOLDEN, 'components.npz'))
+    gt, hat = torch.from_numpy(z['rl_gt']), torch.from_numpy(z['rl_hat'])
+    sl, mm = torch.from_numpy(z['rl_len']), torch.from_numpy(z['rl_mask'])
+    np.testing.assert_allclose(R.reconstruction_loss(gt, hat).numpy(), z['rl_plain'], rtol=1e-6)
+    np.testing.assert_allclose(R.reconstruction_loss(gt, hat, sl).numpy(), z['rl_len_only'], rtol=1e-6)
+    np.testing.assert_allclose(R.reconstruction_loss(gt, hat, sl, mm).numpy(), z['rl_full'], rtol=1e-6)
+    assert (R.mask_from_seq_lengths(sl).numpy() == z['mask_from_len']).all()
+
+    model = H.small_model()
+    vids = [int(v) for v in H.load_case('lgd12_n4')['meta']['vertex_ids']]
+    tables = R.sensor_tables(model['f'], vids)
+    assert (tables[0] == z['vs_sub_faces']).all()
+    assert (tables[1] == z['vs_sub_vertex_faces']).all()
+    assert (tables[2] == z['vs_helpers']).all()
+    pos, ori, nor = R.virtual_pos_and_rot(torch.from_numpy(z['vs_verts']), vids, tables)
+    np.testing.assert_allclose(pos.numpy(), z['vs_pos'], atol=1e-7)
+    np.testing.assert_allclose(ori.numpy(), z['vs_ori'], atol=2e-6)
+    np.testing.assert_allclose(nor.numpy(), z['vs_nor'], atol=1e-8)
+
+    bm = R.BodyModelTensors(model)
+    v, j = R.smpl_fk(bm, torch.from_numpy(z['fk_pose']), torch.from_numpy(z['fk_betas']),
+                     torch.from_numpy(z['fk_root']))
+    np.testing.assert_allclose(v.numpy(), z['fk_v'], atol=1e-6)
+    np.testing.assert_allclose(j.numpy(), z['fk_j'], atol=1e-6)
+    v, j = R.smpl_fk(bm, torch.from_numpy(z['fk_pose']), torch.from_numpy(z['fk_betas'][0]))
+    np.testing.assert_allclose(v.numpy(), z['fk_v_noroot_bcast'], atol=1e-6)
