@@ -1,0 +1,152 @@
+"""
+ctypes binding of the C ABI declared in include/empose_hip.h (libempose_hip.so, built in-tree by em_pose_amd/build.py).
+
+There is no fallback: if the shared library is missing the import of any compute entry point raises, and every
+compute call insists on CUDA(ROCm)-resident tensors.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libempose_hip.so')
+
+MAX_DENSE = 8
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+
+class SmplDesc(C.Structure):
+    _fields_ = [('n_sensors', C.c_int), ('nv', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
+                ('max_deg', C.c_int),
+                ('wc', c_float_p), ('wct', c_float_p), ('parents', c_int_p),
+                ('skin_idx', c_int_p), ('skin_w', c_float_p),
+                ('bone_ptr', c_int_p), ('bone_vert', c_int_p), ('bone_w', c_float_p),
+                ('s_center', c_int_p), ('s_helper', c_int_p), ('s_deg', c_int_p), ('s_faces', c_int_p),
+                ('path_ptr', c_int_p), ('path', c_int_p), ('sub_ptr', c_int_p), ('sub', c_int_p)]
+
+
+class DenseDesc(C.Structure):
+    _fields_ = [('in_dim', C.c_int), ('out_dim', C.c_int), ('weight', c_float_p), ('bias', c_float_p),
+                ('bn_weight', c_float_p), ('bn_bias', c_float_p), ('bn_mean', c_float_p), ('bn_var', c_float_p),
+                ('bn_eps', C.c_float), ('has_prelu', C.c_int), ('prelu', C.c_float)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [('n_layers', C.c_int), ('skip', C.c_int), ('layers', DenseDesc * MAX_DENSE)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [('num_layers', C.c_int), ('input_size', C.c_int), ('hidden_size', C.c_int),
+                ('w_ih', c_float_p * 4), ('w_hh', c_float_p * 4), ('b_ih', c_float_p * 4), ('b_hh', c_float_p * 4)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [('smpl', SmplDesc), ('n_markers', C.c_int), ('marker_idx', C.c_int * 12),
+                ('n_iterations', C.c_int), ('step_size', C.c_float), ('shape_avg', C.c_int),
+                ('use_gradient', C.c_int), ('rnn_init', C.c_int),
+                ('rnn', LstmDesc), ('pose_head', DenseDesc), ('shape_head', DenseDesc),
+                ('pose_init', MlpDesc), ('shape_init', MlpDesc), ('pose_iter', MlpDesc), ('shape_iter', MlpDesc)]
+
+
+class LgdIO(C.Structure):
+    _fields_ = [('B', C.c_int), ('F', C.c_int),
+                ('marker_pos', C.c_void_p), ('marker_oris', C.c_void_p), ('offset_t', C.c_void_p),
+                ('offset_r', C.c_void_p), ('marker_masks', C.c_void_p), ('seq_lengths', C.c_void_p),
+                ('h0', C.c_void_p), ('c0', C.c_void_p), ('h_n', C.c_void_p), ('c_n', C.c_void_p),
+                ('pose_hat', C.c_void_p), ('shape_hat', C.c_void_p), ('joints_hat', C.c_void_p),
+                ('hist_pose', C.c_void_p), ('hist_shape', C.c_void_p), ('hist_joints', C.c_void_p),
+                ('hist_markers', C.c_void_p), ('hist_markers_ori', C.c_void_p),
+                ('trace_g_pose', C.c_void_p), ('trace_g_shape', C.c_void_p)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [('n_vertices', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
+                ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p)]
+
+
+# symbol -> (restype, argtypes); this table is also what tests check against the header.
+SIGNATURES = {
+    'empose_last_error': (C.c_char_p, []),
+    'empose_version': (C.c_int, []),
+    'empose_arch': (C.c_char_p, []),
+    'empose_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
+    'empose_model_destroy': (None, [C.c_void_p]),
+    'empose_lgd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'empose_lgd_forward': (C.c_int, [C.c_void_p, C.POINTER(LgdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_smpl_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_smpl_sensors_fwd_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_update_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_update_nets_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_lstm_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'empose_lstm_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    'empose_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    'empose_mesh_create': (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
+    'empose_mesh_destroy': (None, [C.c_void_p]),
+    'empose_mesh_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_mesh_vertices_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+
+
+class EmposeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EmposeError('HIP extension not built: {} is missing. Run `python em_pose_amd/build.py` '
+                              '(or __graft_entry__.build()). There is no CPU fallback.'.format(LIB_PATH))
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EmposeError('libempose_hip: error {}: {}'.format(rc, lib().empose_last_error().decode()))
+
+
+def fptr(arr):
+    """Host pointer of a C-contiguous float32 numpy array (kept alive by the caller)."""
+    assert arr.dtype == np.float32 and arr.flags['C_CONTIGUOUS']
+    return arr.ctypes.data_as(c_float_p)
+
+
+def iptr(arr):
+    assert arr.dtype == np.int32 and arr.flags['C_CONTIGUOUS']
+    return arr.ctypes.data_as(c_int_p)
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (None -> NULL). The tensor must live on the GPU and be contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EmposeError('the HIP path needs tensors on the GPU (got device {}); there is no CPU fallback'
+                          .format(t.device))
+    if not t.is_contiguous():
+        raise EmposeError('tensor must be contiguous')
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,732 @@
+// C ABI (include/empose_hip.h): model packing, workspace carving and the launch sequence of the LGD loop.
+#include "../../include/empose_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace empose;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(EMPOSE_EHIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+
+// A packed Linear(+BN)(+PReLU): device weight and the per-column epilogue (scale, shift).
+struct Dense {
+  int in_dim = 0, out_dim = 0;
+  float* w = nullptr;      // [out][in]
+  float* scale = nullptr;  // nullptr => 1
+  float* shift = nullptr;  // bias (and folded BN)
+  int act = 0;
+  float slope = 0.f;
+};
+
+struct Mlp {
+  int n_layers = 0, skip = 0;
+  Dense layers[EMPOSE_MAX_DENSE];
+};
+
+struct Lstm {
+  int num_layers = 0, input_size = 0, H = 0;
+  float* w_ih[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* w_hh[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* bias[4] = {nullptr, nullptr, nullptr, nullptr};  // b_ih + b_hh
+};
+
+}  // namespace
+
+struct empose_model {
+  std::vector<void*> allocs;
+  SmplTables tab;
+  int n_markers = 12;
+  int marker_idx[12];
+  int used_slot[12];
+  int N = 4;
+  float step = 0.1f;
+  int shape_avg = 1, use_gradient = 1, rnn_init = 1;
+  int d_in = 144, d_x = 296;
+  Lstm rnn;
+  Dense pose_head, shape_head;
+  Mlp pose_init, shape_init, pose_iter, shape_iter;
+  int hidden_max = 0;
+  int any_skip = 0;
+};
+
+struct empose_mesh {
+  std::vector<void*> allocs;
+  int V = 0, j_off = 0, ncp = 0, kb = 0;
+  float* wc = nullptr;
+  int* skin_idx = nullptr;
+  float* skin_w = nullptr;
+  int* parents = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload(std::vector<void*>& allocs, const T* host, size_t count, T** dev) {
+  *dev = nullptr;
+  if (count == 0) return EMPOSE_OK;
+  if (!host) return fail(EMPOSE_EINVAL, "null host pointer in model descriptor");
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+  allocs.push_back(p);
+  HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<T*>(p);
+  return EMPOSE_OK;
+}
+
+#define TRY(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != EMPOSE_OK) return rc_; \
+  } while (0)
+
+int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
+  if (d.in_dim <= 0 || d.out_dim <= 0 || !d.weight) return fail(EMPOSE_EINVAL, "dense layer: bad dims / null weight");
+  if (d.in_dim % 4 != 0) return fail(EMPOSE_EINVAL, "dense layer: in_dim %d must be a multiple of 4", d.in_dim);
+  out->in_dim = d.in_dim;
+  out->out_dim = d.out_dim;
+  TRY(upload(allocs, d.weight, (size_t)d.in_dim * d.out_dim, &out->w));
+  std::vector<float> shift(d.out_dim, 0.f), scale;
+  if (d.bn_weight) {
+    if (!d.bn_bias || !d.bn_mean || !d.bn_var) return fail(EMPOSE_EINVAL, "dense layer: incomplete batch norm");
+    scale.resize(d.out_dim);
+    for (int n = 0; n < d.out_dim; ++n) {
+      const double s = (double)d.bn_weight[n] / std::sqrt((double)d.bn_var[n] + (double)d.bn_eps);
+      const double b = d.bias ? (double)d.bias[n] : 0.0;
+      scale[n] = (float)s;
+      shift[n] = (float)((b - (double)d.bn_mean[n]) * s + (double)d.bn_bias[n]);
+    }
+    TRY(upload(allocs, scale.data(), scale.size(), &out->scale));
+  } else if (d.bias) {
+    for (int n = 0; n < d.out_dim; ++n) shift[n] = d.bias[n];
+  }
+  TRY(upload(allocs, shift.data(), shift.size(), &out->shift));
+  out->act = d.has_prelu ? 1 : 0;
+  out->slope = d.prelu;
+  return EMPOSE_OK;
+}
+
+int pack_mlp(std::vector<void*>& allocs, const empose_mlp_desc& d, Mlp* out, int* hidden_max, int* any_skip) {
+  out->n_layers = d.n_layers;
+  out->skip = d.skip;
+  if (d.n_layers == 0) return EMPOSE_OK;
+  if (d.skip) *any_skip = 1;
+  if (d.n_layers < 2 || d.n_layers > EMPOSE_MAX_DENSE || (d.n_layers % 2) != 0)
+    return fail(EMPOSE_EINVAL, "mlp: n_layers=%d unsupported", d.n_layers);
+  for (int i = 0; i < d.n_layers; ++i) {
+    TRY(pack_dense(allocs, d.layers[i], &out->layers[i]));
+    if (i > 0 && d.layers[i].in_dim != d.layers[i - 1].out_dim) return fail(EMPOSE_EINVAL, "mlp: layer dims do not chain");
+    if (i + 1 < d.n_layers && d.layers[i].out_dim > *hidden_max) *hidden_max = d.layers[i].out_dim;
+  }
+  return EMPOSE_OK;
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+  float* f(size_t count) {
+    float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align_up(count * sizeof(float));
+    return r;
+  }
+};
+
+// ---- workspace layouts ------------------------------------------------------------------------------------------
+struct SmplWs {
+  float *rot, *feat, *out, *d_out, *d_feat, *d_rot, *theta, *beta;
+};
+SmplWs carve_smpl(Carver& c, const empose_model* m, int T) {
+  SmplWs w;
+  w.rot = c.f((size_t)T * 198);
+  w.feat = c.f((size_t)T * 200);
+  w.out = c.f((size_t)T * m->tab.ncp);
+  w.d_out = c.f((size_t)T * m->tab.ncp);
+  w.d_feat = c.f((size_t)T * 200);
+  w.d_rot = c.f((size_t)T * 198);
+  w.theta = c.f((size_t)T * 66);
+  w.beta = c.f((size_t)T * 10);
+  return w;
+}
+
+struct UpdWs {
+  float* buf[3];  // [2 nets][T][hidden_max] each; buf[2] only when a net uses skip connections
+};
+UpdWs carve_upd(Carver& c, const empose_model* m, int T) {
+  UpdWs w;
+  w.buf[0] = c.f((size_t)2 * T * m->hidden_max);
+  w.buf[1] = c.f((size_t)2 * T * m->hidden_max);
+  w.buf[2] = m->any_skip ? c.f((size_t)2 * T * m->hidden_max) : nullptr;
+  return w;
+}
+
+struct LstmWs {
+  float *gin, *ya, *h[2], *c;
+};
+LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) {
+  LstmWs w;
+  const size_t T = (size_t)B * F;
+  const int H = m->rnn.H;
+  w.gin = c.f(T * 4 * H);
+  w.ya = c.f(T * H);
+  w.h[0] = c.f((size_t)B * H);
+  w.h[1] = c.f((size_t)B * H);
+  w.c = c.f((size_t)B * H);
+  return w;
+}
+
+GemmProb linear_prob(const float* A, int lda, const Dense& d, float* C, int ldc, int M) {
+  GemmProb p;
+  p.A = A; p.lda = lda; p.W = d.w; p.ldw = d.in_dim; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = d.out_dim; p.K = d.in_dim;
+  p.scale = d.scale; p.shift = d.shift; p.resid = nullptr; p.ldr = 0; p.act = d.act; p.slope = d.slope;
+  return p;
+}
+
+// Runs one or two MLPs that share the input x (the update nets / the init nets) layer by layer, both nets per launch.
+// Hidden blocks are layer pairs (1,2), (3,4), ...; with skip connections the block input is added to the block
+// output (reference layers.py:35-43), which needs the block input kept alive in a third buffer.
+int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2], const float* x, int ldx, int T,
+             const UpdWs& ws, int hidden_max, hipStream_t stream) {
+  const int L = nets[0]->n_layers;
+  for (int i = 1; i < n_nets; ++i)
+    if (nets[i]->n_layers != L) return fail(EMPOSE_EINVAL, "paired MLPs must have the same depth");
+  int cur[2] = {-1, -1}, block_in[2] = {-1, -1};
+  for (int l = 0; l < L; ++l) {
+    GemmBatch b;
+    b.count = n_nets;
+    int nxt[2] = {-1, -1};
+    for (int i = 0; i < n_nets; ++i) {
+      const Dense& d = nets[i]->layers[l];
+      auto buf = [&](int k) { return ws.buf[k] + (size_t)i * T * hidden_max; };
+      const float* in = (l == 0) ? x : buf(cur[i]);
+      const int ld_in = (l == 0) ? ldx : nets[i]->layers[l - 1].out_dim;
+      const bool block_first = (l >= 1) && (l % 2 == 1) && (l < L - 1);
+      const bool block_last = (l >= 2) && (l % 2 == 0) && (l < L - 1);
+      if (block_first) block_in[i] = cur[i];
+      float* out;
+      int ld_out;
+      if (l == L - 1) {
+        out = outs[i];
+        ld_out = out_ld[i];
+      } else {
+        int k = 0;
+        while (k == cur[i] || (nets[i]->skip && k == block_in[i])) ++k;
+        if (k > 2 || !ws.buf[k]) return fail(EMPOSE_EINVAL, "internal: MLP scratch buffers exhausted");
+        nxt[i] = k;
+        out = buf(k);
+        ld_out = d.out_dim;
+      }
+      b.p[i] = linear_prob(in, ld_in, d, out, ld_out, T);
+      if (block_last && nets[i]->skip) {
+        b.p[i].resid = buf(block_in[i]);
+        b.p[i].ldr = d.out_dim;
+      }
+    }
+    hipError_t e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "gemm launch: %s", hipGetErrorString(e));
+    for (int i = 0; i < n_nets; ++i) cur[i] = nxt[i];
+  }
+  return EMPOSE_OK;
+}
+
+int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const int* seq_lengths, const float* h0,
+             const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
+  const Lstm& r = m->rnn;
+  const int H = r.H;
+  const size_t T = (size_t)B * F;
+  const size_t bh = (size_t)B * H;
+  // Layer outputs alternate between ws.ya and y such that the LAST layer writes y; a layer reads its predecessor.
+  auto layer_out = [&](int l) -> float* { return (((r.num_layers - 1 - l) % 2) == 0) ? y : ws.ya; };
+  for (int l = 0; l < r.num_layers; ++l) {
+    const float* in = (l == 0) ? x : layer_out(l - 1);
+    const int ld_in = (l == 0) ? ldx : H;
+    const int k_in = (l == 0) ? r.input_size : H;
+    float* out = layer_out(l);
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& p = b.p[0];
+    p.A = in; p.lda = ld_in; p.W = r.w_ih[l]; p.ldw = k_in; p.C = ws.gin; p.ldc = 4 * H;
+    p.M = (int)T; p.N = 4 * H; p.K = k_in;
+    p.scale = nullptr; p.shift = r.bias[l]; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+    hipError_t e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm gemm: %s", hipGetErrorString(e));
+    if (h0) HIP_TRY(hipMemcpyAsync(ws.h[0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.h[0], 0, bh * sizeof(float), stream));
+    if (c0) HIP_TRY(hipMemcpyAsync(ws.c, c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.c, 0, bh * sizeof(float), stream));
+    for (int t = 0; t < F; ++t) {
+      LstmStepArgs a;
+      a.gin = ws.gin; a.w_hh = r.w_hh[l]; a.h_prev = ws.h[t & 1]; a.h_next = ws.h[(t + 1) & 1]; a.c = ws.c;
+      a.y = out; a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H; a.t = t;
+      e = launch_lstm_step(a, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+    }
+    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, ws.h[F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, ws.c, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  return EMPOSE_OK;
+}
+
+// One SMPL evaluation given rot/feat already produced by update_feat.
+int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const float* offset_r, const float* offset_t,
+                  const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori, float* joints,
+                  float* pos2, float* ori2, float* joints2, hipStream_t stream) {
+  GemmBatch b;
+  b.count = 1;
+  GemmProb& p = b.p[0];
+  p.A = ws.feat; p.lda = 200; p.W = m->tab.wc; p.ldw = 200; p.C = ws.out; p.ldc = m->tab.ncp;
+  p.M = T; p.N = m->tab.ncp; p.K = 200;
+  p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+  hipError_t e = launch_gemm(b, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm: %s", hipGetErrorString(e));
+  ChainArgs c;
+  c.tab = m->tab;
+  c.rot = ws.rot; c.out = ws.out; c.offset_r = offset_r; c.offset_t = offset_t;
+  c.tgt = tgt; c.ld_tgt = ld_tgt; c.frame_scale = frame_scale;
+  c.n_markers = m->n_markers;
+  for (int i = 0; i < 12; ++i) c.used_slot[i] = m->used_slot[i];
+  c.pos = pos; c.ori = ori; c.joints = joints; c.pos2 = pos2; c.ori2 = ori2; c.joints2 = joints2;
+  c.d_out = ws.d_out; c.d_rot = ws.d_rot; c.T = T; c.F = F;
+  e = launch_chain_sensors(c, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "chain kernel: %s", hipGetErrorString(e));
+  if (tgt) {
+    p.A = ws.d_out; p.lda = m->tab.ncp; p.W = m->tab.wct; p.ldw = m->tab.ncp; p.C = ws.d_feat; p.ldc = 200;
+    p.M = T; p.N = 200; p.K = m->tab.ncp;
+    e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm: %s", hipGetErrorString(e));
+  }
+  return EMPOSE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* empose_last_error(void) { return g_err.c_str(); }
+int empose_version(void) { return 1; }
+const char* empose_arch(void) { return "gfx950"; }
+
+void empose_model_destroy(empose_model_t* model) {
+  if (!model) return;
+  for (void* p : model->allocs) (void)hipFree(p);
+  delete model;
+}
+
+int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
+  if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
+  *out = nullptr;
+  const empose_smpl_desc& s = d->smpl;
+  if (s.n_sensors != EMPOSE_N_SENSORS) return fail(EMPOSE_EINVAL, "n_sensors must be 12");
+  if (s.nv <= 0 || s.ncp % 4 != 0 || s.j_off < s.nv * 3 || s.j_off + 66 > s.ncp || s.kb <= 0 || s.max_deg <= 0)
+    return fail(EMPOSE_EINVAL, "inconsistent SMPL table sizes");
+  if (d->n_markers != 6 && d->n_markers != 12) return fail(EMPOSE_EINVAL, "n_markers must be 6 or 12");
+  if (d->n_iterations < 0) return fail(EMPOSE_EINVAL, "n_iterations < 0");
+  empose_model* m = new empose_model();
+  auto bail = [&](int rc) { empose_model_destroy(m); return rc; };
+#define MTRY(expr) do { int rc_ = (expr); if (rc_ != EMPOSE_OK) return bail(rc_); } while (0)
+  SmplTables& t = m->tab;
+  t.n_sensors = s.n_sensors; t.nv = s.nv; t.j_off = s.j_off; t.ncp = s.ncp; t.kb = s.kb; t.max_deg = s.max_deg;
+  float* fp; int* ip;
+  MTRY(upload(m->allocs, s.wc, (size_t)s.ncp * 200, &fp)); t.wc = fp;
+  MTRY(upload(m->allocs, s.wct, (size_t)s.ncp * 200, &fp)); t.wct = fp;
+  MTRY(upload(m->allocs, s.parents, 22, &ip)); t.parents = ip;
+  MTRY(upload(m->allocs, s.skin_idx, (size_t)s.nv * s.kb, &ip)); t.skin_idx = ip;
+  MTRY(upload(m->allocs, s.skin_w, (size_t)s.nv * s.kb, &fp)); t.skin_w = fp;
+  if (!s.bone_ptr || !s.path_ptr || !s.sub_ptr) return bail(fail(EMPOSE_EINVAL, "null CSR pointer"));
+  MTRY(upload(m->allocs, s.bone_ptr, 23, &ip)); t.bone_ptr = ip;
+  MTRY(upload(m->allocs, s.bone_vert, (size_t)s.bone_ptr[22], &ip)); t.bone_vert = ip;
+  MTRY(upload(m->allocs, s.bone_w, (size_t)s.bone_ptr[22], &fp)); t.bone_w = fp;
+  MTRY(upload(m->allocs, s.s_center, 12, &ip)); t.s_center = ip;
+  MTRY(upload(m->allocs, s.s_helper, 12, &ip)); t.s_helper = ip;
+  MTRY(upload(m->allocs, s.s_deg, 12, &ip)); t.s_deg = ip;
+  MTRY(upload(m->allocs, s.s_faces, (size_t)12 * s.max_deg * 3, &ip)); t.s_faces = ip;
+  MTRY(upload(m->allocs, s.path_ptr, 23, &ip)); t.path_ptr = ip;
+  MTRY(upload(m->allocs, s.path, (size_t)s.path_ptr[22], &ip)); t.path = ip;
+  MTRY(upload(m->allocs, s.sub_ptr, 23, &ip)); t.sub_ptr = ip;
+  MTRY(upload(m->allocs, s.sub, (size_t)s.sub_ptr[22], &ip)); t.sub = ip;
+
+  m->n_markers = d->n_markers;
+  for (int i = 0; i < 12; ++i) { m->marker_idx[i] = 0; m->used_slot[i] = -1; }
+  for (int i = 0; i < d->n_markers; ++i) {
+    const int v = d->marker_idx[i];
+    if (v < 0 || v >= 12) return bail(fail(EMPOSE_EINVAL, "marker_idx out of range"));
+    m->marker_idx[i] = v;
+    m->used_slot[v] = i;
+  }
+  m->N = d->n_iterations; m->step = d->step_size; m->shape_avg = d->shape_avg; m->use_gradient = d->use_gradient;
+  m->rnn_init = d->rnn_init;
+  m->d_in = d->n_markers * 12;
+  m->d_x = m->d_in + 76 + (d->use_gradient ? 76 : 0);
+
+  if (d->rnn_init) {
+    const empose_lstm_desc& r = d->rnn;
+    if (r.num_layers < 1 || r.num_layers > 4 || r.input_size != m->d_in || r.hidden_size % 4 != 0)
+      return bail(fail(EMPOSE_EINVAL, "unsupported LSTM configuration"));
+    m->rnn.num_layers = r.num_layers; m->rnn.input_size = r.input_size; m->rnn.H = r.hidden_size;
+    for (int l = 0; l < r.num_layers; ++l) {
+      const int k_in = l == 0 ? r.input_size : r.hidden_size;
+      MTRY(upload(m->allocs, r.w_ih[l], (size_t)4 * r.hidden_size * k_in, &m->rnn.w_ih[l]));
+      MTRY(upload(m->allocs, r.w_hh[l], (size_t)4 * r.hidden_size * r.hidden_size, &m->rnn.w_hh[l]));
+      if (!r.b_ih[l] || !r.b_hh[l]) return bail(fail(EMPOSE_EINVAL, "null LSTM bias"));
+      std::vector<float> bias(4 * r.hidden_size);
+      for (int i = 0; i < 4 * r.hidden_size; ++i) bias[i] = r.b_ih[l][i] + r.b_hh[l][i];
+      MTRY(upload(m->allocs, bias.data(), bias.size(), &m->rnn.bias[l]));
+    }
+    MTRY(pack_dense(m->allocs, d->pose_head, &m->pose_head));
+    MTRY(pack_dense(m->allocs, d->shape_head, &m->shape_head));
+    if (m->pose_head.out_dim != 66 || m->shape_head.out_dim != 10 || m->pose_head.in_dim != r.hidden_size)
+      return bail(fail(EMPOSE_EINVAL, "init head dims"));
+  } else {
+    MTRY(pack_mlp(m->allocs, d->pose_init, &m->pose_init, &m->hidden_max, &m->any_skip));
+    MTRY(pack_mlp(m->allocs, d->shape_init, &m->shape_init, &m->hidden_max, &m->any_skip));
+    if (m->pose_init.n_layers == 0 || m->pose_init.layers[0].in_dim != m->d_in)
+      return bail(fail(EMPOSE_EINVAL, "init MLP dims"));
+  }
+  if (m->N > 0) {
+    MTRY(pack_mlp(m->allocs, d->pose_iter, &m->pose_iter, &m->hidden_max, &m->any_skip));
+    MTRY(pack_mlp(m->allocs, d->shape_iter, &m->shape_iter, &m->hidden_max, &m->any_skip));
+    if (m->pose_iter.n_layers == 0 || m->pose_iter.layers[0].in_dim != m->d_x ||
+        m->pose_iter.layers[m->pose_iter.n_layers - 1].out_dim != 66 ||
+        m->shape_iter.layers[m->shape_iter.n_layers - 1].out_dim != 10)
+      return bail(fail(EMPOSE_EINVAL, "update MLP dims (expected input %d)", m->d_x));
+  }
+  if (m->hidden_max == 0) m->hidden_max = 4;
+#undef MTRY
+  *out = m;
+  return EMPOSE_OK;
+}
+
+size_t empose_smpl_workspace_bytes(const empose_model_t* m, int T) {
+  Carver c(nullptr);
+  carve_smpl(c, m, T);
+  return c.off;
+}
+
+size_t empose_update_workspace_bytes(const empose_model_t* m, int T) {
+  Carver c(nullptr);
+  carve_upd(c, m, T);
+  return c.off;
+}
+
+size_t empose_lstm_workspace_bytes(const empose_model_t* m, int B, int F) {
+  Carver c(nullptr);
+  carve_lstm(c, m, B, F);
+  return c.off;
+}
+
+struct LgdWs {
+  float *x, *scale, *d_pose, *d_shape, *pos, *ori, *joints;
+  SmplWs smpl;
+  UpdWs upd;
+  LstmWs lstm;
+  float* y;
+};
+static LgdWs carve_lgd(Carver& c, const empose_model* m, int B, int F) {
+  LgdWs w;
+  const size_t T = (size_t)B * F;
+  w.x = c.f(T * m->d_x);
+  w.scale = c.f(T);
+  w.d_pose = c.f(T * 66);
+  w.d_shape = c.f(T * 10);
+  w.pos = c.f(T * 36);
+  w.ori = c.f(T * 108);
+  w.joints = c.f(T * 66);
+  w.smpl = carve_smpl(c, m, (int)T);
+  w.upd = carve_upd(c, m, (int)T);
+  if (m->rnn_init) {
+    w.lstm = carve_lstm(c, m, B, F);
+    w.y = c.f(T * m->rnn.H);
+  } else {
+    w.y = nullptr;
+  }
+  return w;
+}
+
+size_t empose_lgd_workspace_bytes(const empose_model_t* m, int B, int F) {
+  if (!m || B <= 0 || F <= 0) return 0;
+  Carver c(nullptr);
+  carve_lgd(c, m, B, F);
+  return c.off;
+}
+
+int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
+                       empose_stream_t stream_) {
+  if (!m || !io || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  const int B = io->B, F = io->F;
+  if (B <= 0 || F <= 0) return fail(EMPOSE_EINVAL, "B and F must be positive");
+  if (!io->marker_pos || !io->marker_oris || !io->offset_t || !io->offset_r || !io->pose_hat || !io->shape_hat ||
+      !io->joints_hat)
+    return fail(EMPOSE_EINVAL, "null input/output tensor");
+  if (workspace_bytes < empose_lgd_workspace_bytes(m, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int T = B * F;
+  Carver c(workspace);
+  LgdWs w = carve_lgd(c, m, B, F);
+  const int dx = m->d_x, din = m->d_in;
+  float* x_theta = w.x + din;
+  float* x_beta = w.x + din + 66;
+  float* x_gtheta = w.x + din + 76;
+  float* x_gbeta = w.x + din + 142;
+
+  PackArgs pa;
+  pa.marker_pos = io->marker_pos; pa.marker_oris = io->marker_oris; pa.marker_masks = io->marker_masks;
+  pa.seq_lengths = io->seq_lengths; pa.x = w.x; pa.ldx = dx; pa.frame_scale = w.scale;
+  pa.B = B; pa.F = F; pa.n_markers = m->n_markers;
+  for (int i = 0; i < 12; ++i) pa.marker_idx[i] = m->marker_idx[i];
+  hipError_t e = launch_pack_inputs(pa, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "pack kernel: %s", hipGetErrorString(e));
+
+  // ---- initial estimate (reference models.py:511-526)
+  if (m->rnn_init) {
+    TRY(run_lstm(m, B, F, w.x, dx, io->seq_lengths, io->h0, io->c0, w.y, io->h_n, io->c_n, w.lstm, stream));
+    GemmBatch b;
+    b.count = 2;
+    b.p[0] = linear_prob(w.y, m->rnn.H, m->pose_head, x_theta, dx, T);
+    b.p[1] = linear_prob(w.y, m->rnn.H, m->shape_head, w.d_shape, 10, T);
+    e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "head gemm: %s", hipGetErrorString(e));
+  } else {
+    const Mlp* nets[2] = {&m->pose_init, &m->shape_init};
+    float* outs[2] = {x_theta, w.d_shape};
+    const int lds[2] = {dx, 10};
+    TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream));
+  }
+
+  const int N = m->N;
+  auto hist = [&](float* base, int i, size_t width) -> float* { return base ? base + (size_t)i * T * width : nullptr; };
+  for (int i = 0; i <= N; ++i) {
+    FeatArgs fa;
+    fa.theta = x_theta; fa.ld_theta = dx; fa.beta = x_beta; fa.ld_beta = dx;
+    fa.shape_avg = m->shape_avg;
+    if (i == 0) {
+      fa.d_theta = nullptr; fa.theta_step = 0.f;
+      fa.d_beta = w.d_shape; fa.beta_keep = 0.f; fa.beta_step = 1.f;
+    } else {
+      fa.d_theta = w.d_pose; fa.theta_step = m->step;
+      fa.d_beta = w.d_shape; fa.beta_keep = 1.f; fa.beta_step = m->step;
+    }
+    fa.rot = w.smpl.rot; fa.feat = w.smpl.feat;
+    fa.out_theta = hist(io->hist_pose, i, 66); fa.out_beta = hist(io->hist_shape, i, 10);
+    fa.out_theta2 = (i == N) ? io->pose_hat : nullptr;
+    fa.out_beta2 = (i == N) ? io->shape_hat : nullptr;
+    fa.T = T; fa.F = F;
+    e = launch_update_feat(fa, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+
+    const bool need_grad = (i < N) && m->use_gradient;
+    float* hm = hist(io->hist_markers, i, 36);
+    float* ho = hist(io->hist_markers_ori, i, 108);
+    float* hj = hist(io->hist_joints, i, 66);
+    if ((hm == nullptr) != (ho == nullptr)) return fail(EMPOSE_EINVAL, "hist_markers and hist_markers_ori go together");
+    TRY(run_smpl_eval(m, T, F, w.smpl, io->offset_r, io->offset_t, need_grad ? w.x : nullptr, dx, w.scale,
+                      hm ? hm : w.pos, ho ? ho : w.ori, (i == N) ? io->joints_hat : (hj ? hj : w.joints),
+                      nullptr, nullptr, (i == N) ? hj : nullptr, stream));
+    if (i == N) break;
+    if (m->use_gradient) {
+      RodBwdArgs ra;
+      ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot = w.smpl.d_rot; ra.d_feat = w.smpl.d_feat;
+      ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
+      ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
+      ra.T = T;
+      e = launch_rodrigues_bwd(ra, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
+    }
+    const Mlp* nets[2] = {&m->pose_iter, &m->shape_iter};
+    float* outs[2] = {w.d_pose, w.d_shape};
+    const int lds[2] = {66, 10};
+    TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream));
+  }
+  return EMPOSE_OK;
+}
+
+int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const float* theta, int ld_theta,
+                                const float* beta, int ld_beta, const float* offset_r, const float* offset_t,
+                                const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori,
+                                float* joints, float* g_theta, int ld_g, float* g_beta, int ld_gb, void* workspace,
+                                size_t workspace_bytes, empose_stream_t stream_) {
+  if (!m || !theta || !beta || !offset_r || !offset_t || !pos || !ori || !joints || !workspace)
+    return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0 || F <= 0 || T % F != 0) return fail(EMPOSE_EINVAL, "T must be a positive multiple of F");
+  if (tgt && (!frame_scale || !g_theta || !g_beta)) return fail(EMPOSE_EINVAL, "gradient outputs missing");
+  if (workspace_bytes < empose_smpl_workspace_bytes(m, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Carver c(workspace);
+  SmplWs ws = carve_smpl(c, m, T);
+  HIP_TRY(hipMemcpy2DAsync(ws.theta, 66 * sizeof(float), theta, (size_t)ld_theta * sizeof(float), 66 * sizeof(float), T,
+                           hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemcpy2DAsync(ws.beta, 10 * sizeof(float), beta, (size_t)ld_beta * sizeof(float), 10 * sizeof(float), T,
+                           hipMemcpyDeviceToDevice, stream));
+  FeatArgs fa;
+  fa.theta = ws.theta; fa.ld_theta = 66; fa.beta = ws.beta; fa.ld_beta = 10;
+  fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
+  fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
+  fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
+  fa.T = T; fa.F = F;
+  hipError_t e = launch_update_feat(fa, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, tgt, ld_tgt, frame_scale, pos, ori, joints, nullptr, nullptr,
+                    nullptr, stream));
+  if (tgt) {
+    RodBwdArgs ra;
+    ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
+    ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
+    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T;
+    e = launch_rodrigues_bwd(ra, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
+  }
+  return EMPOSE_OK;
+}
+
+int empose_update_nets_fwd(const empose_model_t* m, int T, const float* x, int ldx, float* d_pose, float* d_shape,
+                           void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  if (!m || !x || !d_pose || !d_shape || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (m->pose_iter.n_layers == 0) return fail(EMPOSE_EINVAL, "model has no update nets");
+  if (ldx < m->d_x || ldx % 4 != 0) return fail(EMPOSE_EINVAL, "ldx must be >= %d and a multiple of 4", m->d_x);
+  if (workspace_bytes < empose_update_workspace_bytes(m, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  Carver c(workspace);
+  UpdWs ws = carve_upd(c, m, T);
+  const Mlp* nets[2] = {&m->pose_iter, &m->shape_iter};
+  float* outs[2] = {d_pose, d_shape};
+  const int lds[2] = {66, 10};
+  return run_mlps(nets, 2, outs, lds, x, ldx, T, ws, m->hidden_max, static_cast<hipStream_t>(stream_));
+}
+
+int empose_lstm_fwd(const empose_model_t* m, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                    const float* h0, const float* c0, float* y, float* h_n, float* c_n, void* workspace,
+                    size_t workspace_bytes, empose_stream_t stream_) {
+  if (!m || !x || !y || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (!m->rnn_init) return fail(EMPOSE_EINVAL, "model has no LSTM");
+  if (ldx % 4 != 0) return fail(EMPOSE_EINVAL, "ldx must be a multiple of 4");
+  if (workspace_bytes < empose_lstm_workspace_bytes(m, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  Carver c(workspace);
+  LstmWs ws = carve_lstm(c, m, B, F);
+  return run_lstm(m, B, F, x, ldx, seq_lengths, h0, c0, y, h_n, c_n, ws, static_cast<hipStream_t>(stream_));
+}
+
+int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                      const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream_) {
+  if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");
+  if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0) return fail(EMPOSE_EINVAL, "K, lda, ldw must be multiples of 4");
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return fail(EMPOSE_EINVAL, "A and W must be 16-byte aligned");
+  GemmBatch b;
+  b.count = 1;
+  GemmProb& p = b.p[0];
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.scale = scale; p.shift = shift; p.resid = nullptr; p.ldr = 0; p.act = prelu ? 1 : 0; p.slope = slope;
+  hipError_t e = launch_gemm(b, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "gemm launch: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+// ---- full mesh -----------------------------------------------------------------------------------------------
+void empose_mesh_destroy(empose_mesh_t* mesh) {
+  if (!mesh) return;
+  for (void* p : mesh->allocs) (void)hipFree(p);
+  delete mesh;
+}
+
+int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
+  if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
+  *out = nullptr;
+  if (d->n_vertices <= 0 || d->ncp % 4 != 0 || d->j_off < d->n_vertices * 3 || d->j_off + 66 > d->ncp || d->kb <= 0)
+    return fail(EMPOSE_EINVAL, "inconsistent mesh table sizes");
+  empose_mesh* m = new empose_mesh();
+  m->V = d->n_vertices; m->j_off = d->j_off; m->ncp = d->ncp; m->kb = d->kb;
+  int rc;
+  if ((rc = upload(m->allocs, d->wc, (size_t)d->ncp * 200, &m->wc)) ||
+      (rc = upload(m->allocs, d->skin_idx, (size_t)d->n_vertices * d->kb, &m->skin_idx)) ||
+      (rc = upload(m->allocs, d->skin_w, (size_t)d->n_vertices * d->kb, &m->skin_w)) ||
+      (rc = upload(m->allocs, d->parents, 22, &m->parents))) {
+    empose_mesh_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return EMPOSE_OK;
+}
+
+static const int MESH_SLAB = 2048;  // frames per pass: bounds the v_posed scratch to ~170 MB
+
+size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T) {
+  if (!mesh || T <= 0) return 0;
+  const size_t S = T < MESH_SLAB ? T : MESH_SLAB;
+  Carver c(nullptr);
+  c.f(S * 198); c.f(S * 200); c.f(S * mesh->ncp); c.f(S * 264); c.f(S * 66); c.f(S * 10);
+  return c.off;
+}
+
+int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                             const float* trans, float* vertices, float* joints, void* workspace,
+                             size_t workspace_bytes, empose_stream_t stream_) {
+  if (!mesh || !poses || !betas || !vertices || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
+  if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int S = T < MESH_SLAB ? T : MESH_SLAB;
+  Carver c(workspace);
+  float* rot = c.f((size_t)S * 198);
+  float* feat = c.f((size_t)S * 200);
+  float* outb = c.f((size_t)S * mesh->ncp);
+  float* xf = c.f((size_t)S * 264);
+  float* th = c.f((size_t)S * 66);
+  float* be = c.f((size_t)S * 10);
+  for (int t0 = 0; t0 < T; t0 += S) {
+    const int n = (T - t0) < S ? (T - t0) : S;
+    HIP_TRY(hipMemcpyAsync(th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    FeatArgs fa;
+    fa.theta = th; fa.ld_theta = 66; fa.beta = be; fa.ld_beta = 10;
+    fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
+    fa.shape_avg = 0; fa.rot = rot; fa.feat = feat;
+    fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
+    fa.T = n; fa.F = 1;
+    hipError_t e = launch_update_feat(fa, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& p = b.p[0];
+    p.A = feat; p.lda = 200; p.W = mesh->wc; p.ldw = 200; p.C = outb; p.ldc = mesh->ncp;
+    p.M = n; p.N = mesh->ncp; p.K = 200;
+    p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+    e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh gemm: %s", hipGetErrorString(e));
+    const float* tr = trans ? trans + (size_t)t0 * 3 : nullptr;
+    MeshChainArgs ca;
+    ca.rot = rot; ca.out = outb; ca.ncp = mesh->ncp; ca.j_off = mesh->j_off; ca.parents = mesh->parents;
+    ca.trans = tr; ca.xf = xf; ca.joints = joints + (size_t)t0 * 66; ca.T = n;
+    e = launch_mesh_chain(ca, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh chain: %s", hipGetErrorString(e));
+    MeshSkinArgs sa;
+    sa.out = outb; sa.ncp = mesh->ncp; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
+    sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
+    e = launch_mesh_skin(sa, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh skin: %s", hipGetErrorString(e));
+  }
+  return EMPOSE_OK;
+}
+
+}  // extern "C"

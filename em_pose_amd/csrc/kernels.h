@@ -1,0 +1,134 @@
+// Internal launch interfaces of the HIP kernels (gfx950 only). Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace empose {
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 matrix-core linear layer:  C[m][n] = act( (sum_k A[m][k] * W[n][k]) * scale[n] + shift[n] ) (+ resid[m][n])
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmProb {
+  const float* A; int lda;
+  const float* W; int ldw;
+  float* C; int ldc;
+  int M, N, K;              // K % 4 == 0, lda/ldw % 4 == 0, A/W 16-byte aligned
+  const float* scale;       // [N] or nullptr (=1)
+  const float* shift;       // [N] or nullptr (=0)
+  const float* resid; int ldr;  // added after the activation (skip connections) or nullptr
+  int act;                  // 0 none, 1 PReLU(slope)
+  float slope;
+};
+struct GemmBatch { GemmProb p[2]; int count; };
+
+// Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
+hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// LSTM
+// ---------------------------------------------------------------------------------------------------------------
+struct LstmStepArgs {
+  const float* gin;    // [B][F][4H] input projection incl. both biases
+  const float* w_hh;   // [4H][H]
+  const float* h_prev; // [B][H]
+  float* h_next;       // [B][H]
+  float* c;            // [B][H] updated in place
+  float* y;            // [B][F][H]
+  const int* seq_lengths;  // [B] or nullptr
+  int B, F, H, t;
+};
+hipError_t launch_lstm_step(const LstmStepArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// SMPL sub-mesh kernels
+// ---------------------------------------------------------------------------------------------------------------
+struct SmplTables {  // device pointers
+  int n_sensors, nv, j_off, ncp, kb, max_deg;
+  const float* wc; const float* wct;
+  const int* parents;
+  const int* skin_idx; const float* skin_w;
+  const int* bone_ptr; const int* bone_vert; const float* bone_w;
+  const int* s_center; const int* s_helper; const int* s_deg; const int* s_faces;
+  const int* path_ptr; const int* path; const int* sub_ptr; const int* sub;
+};
+
+// Pack the network input columns and the per-frame loss weight.
+struct PackArgs {
+  const float* marker_pos; const float* marker_oris;  // [T][36], [T][108]
+  const float* marker_masks;                           // [T][12] or nullptr
+  const int* seq_lengths;                              // [B] or nullptr
+  float* x; int ldx;                                   // cols [0, 12*n_markers)
+  float* frame_scale;                                  // [T]
+  int B, F, n_markers;
+  int marker_idx[12];
+};
+hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream);
+
+// theta/beta update (+ window mean of the shape), Rodrigues and the GEMM feature row.
+struct FeatArgs {
+  float* theta; int ld_theta;          // [T][>=66] updated in place
+  float* beta; int ld_beta;            // [T][>=10] updated in place
+  const float* d_theta;                // [T][66] or nullptr
+  const float* d_beta;                 // [T][10] or nullptr
+  float theta_step;                    // theta += theta_step * d_theta
+  float beta_keep, beta_step;          // beta = beta_keep * beta + beta_step * (shape_avg ? mean_F(d_beta) : d_beta)
+  int shape_avg;
+  float* rot;                          // [T][22][9]
+  float* feat;                         // [T][200]
+  float* out_theta; float* out_beta;   // optional dense copies [T][66], [T][10]
+  float* out_theta2; float* out_beta2; // optional second copy (history)
+  int T, F;
+};
+hipError_t launch_update_feat(const FeatArgs& a, hipStream_t stream);
+
+struct ChainArgs {
+  SmplTables tab;
+  const float* rot;        // [T][22][9]
+  const float* out;        // [T][ncp] = feat . wc^T
+  const float* offset_r;   // [T/F][12][9]
+  const float* offset_t;   // [T/F][12][3]
+  const float* tgt; int ld_tgt;   // network-input layout; nullptr => forward only
+  const float* frame_scale;       // [T]
+  int n_markers; int used_slot[12];  // used_slot[m] = column slot of virtual sensor m in tgt, or -1
+  float* pos; float* ori; float* joints;   // [T][36], [T][108], [T][66]
+  float* pos2; float* ori2; float* joints2;  // optional second copies
+  float* d_out;            // [T][ncp]
+  float* d_rot;            // [T][22][9]
+  int T, F;
+};
+size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block);
+hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream);
+
+struct RodBwdArgs {
+  const float* theta; int ld_theta;
+  const float* d_rot;      // [T][22][9]
+  const float* d_feat;     // [T][200]
+  float* g_theta; int ld_g;
+  float* g_beta; int ld_gb;
+  float* trace_g_theta; float* trace_g_beta;  // optional dense copies
+  int T;
+};
+hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream);
+
+// Full-mesh: chain only (joints + relative transforms) and dense skinning.
+struct MeshChainArgs {
+  const float* rot; const float* out; int ncp; int j_off;
+  const int* parents;
+  const float* trans;      // [T][3] or nullptr
+  float* xf;               // [T][22][12]: G^R (9) | A^t (3)
+  float* joints;           // [T][66]
+  int T;
+};
+hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream);
+struct MeshSkinArgs {
+  const float* out; int ncp;   // [T][ncp], first V*3 columns are v_posed
+  const float* xf;             // [T][22][12]
+  const int* skin_idx; const float* skin_w; int kb;
+  const float* trans;
+  float* vertices;             // [T][V][3]
+  int T, V;
+};
+hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream);
+
+}  // namespace empose

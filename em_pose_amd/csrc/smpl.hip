@@ -1,0 +1,626 @@
+// SMPL-H on the sensor sub-mesh: everything of one body-model evaluation that is not a matrix product.
+//
+//   update_feat    theta/beta update of the LGD step (reference models.py:588-592), Rodrigues per joint
+//                  (smplx convention: angle = ||r + 1e-8||), GEMM feature row [vec(R_j - I) | beta | 1]
+//   chain_sensors  22-joint kinematic chain, linear blend skinning of the ~84 needed vertices, vertex normals and
+//                  sensor frames (reference virtual_sensors.py:16-38, utils.py:126-146), sensor offsets
+//                  (reference models.py:478-479), the reconstruction residual (reference loss.py:23-41) and its
+//                  hand-derived reverse pass down to d v_posed, d J and d R (oracle/analytic_np.py is the blueprint)
+//   rodrigues_bwd  d R -> d theta, and the gradient features written into the network input row
+//
+// chain_sensors runs a small tile of frames per workgroup; all per-frame state (rotations, rest joints, global
+// transforms, skinned vertices and their cotangents, per-bone force/moment sums) lives in LDS and every phase is a
+// flat parallel-for over (frame, item) so that no lane idles on the serial structure of the skeleton: the forward
+// chain is a per-(joint,row) walk down the root path, the reverse chain uses the world-space form
+// dR_j = G_p^T (sum_subtree M_b - F_b (x) t_j) G_j, which needs subtree sums instead of a level-by-level sweep.
+#include "kernels.h"
+
+namespace empose {
+
+constexpr int NB = 22;
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void pack_inputs_kernel(PackArgs a) {
+  const int T = a.B * a.F;
+  const int d_in = a.n_markers * 12;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * (d_in + 1)) return;
+  const int t = idx / (d_in + 1), c = idx % (d_in + 1);
+  if (c == d_in) {
+    const int b = t / a.F, f = t % a.F;
+    const int len = a.seq_lengths ? a.seq_lengths[b] : a.F;
+    float s = (f < len) ? (float)a.F / (float)len : 0.f;
+    if (a.marker_masks) {
+      bool all = true;
+      for (int m = 0; m < 12; ++m) all = all && (a.marker_masks[(size_t)t * 12 + m] != 0.f);
+      if (!all) s = 0.f;
+    }
+    a.frame_scale[t] = s;
+    return;
+  }
+  float v;
+  if (c < a.n_markers * 3) {
+    const int mi = c / 3, k = c % 3;
+    v = a.marker_pos[(size_t)t * 36 + a.marker_idx[mi] * 3 + k];
+  } else {
+    const int cc = c - a.n_markers * 3;
+    const int mi = cc / 9, k = cc % 9;
+    v = a.marker_oris[(size_t)t * 108 + a.marker_idx[mi] * 9 + k];
+  }
+  a.x[(size_t)t * a.ldx + c] = v;
+}
+
+hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream) {
+  const long n = (long)a.B * a.F * (a.n_markers * 12 + 1);
+  hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Rod {
+  float ux, uy, uz, ang, dx, dy, dz, s, c;
+};
+
+__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, Rod& q, float (&R)[9]) {
+  q.ux = rx + 1e-8f; q.uy = ry + 1e-8f; q.uz = rz + 1e-8f;
+  q.ang = sqrtf(q.ux * q.ux + q.uy * q.uy + q.uz * q.uz);
+  q.dx = rx / q.ang; q.dy = ry / q.ang; q.dz = rz / q.ang;
+  sincosf(q.ang, &q.s, &q.c);
+  const float oc = 1.f - q.c;
+  // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  R = I + s K + (1-c) K K
+  R[0] = 1.f + oc * (-q.dz * q.dz - q.dy * q.dy);
+  R[1] = -q.s * q.dz + oc * (q.dx * q.dy);
+  R[2] = q.s * q.dy + oc * (q.dx * q.dz);
+  R[3] = q.s * q.dz + oc * (q.dx * q.dy);
+  R[4] = 1.f + oc * (-q.dz * q.dz - q.dx * q.dx);
+  R[5] = -q.s * q.dx + oc * (q.dy * q.dz);
+  R[6] = -q.s * q.dy + oc * (q.dx * q.dz);
+  R[7] = q.s * q.dx + oc * (q.dy * q.dz);
+  R[8] = 1.f + oc * (-q.dy * q.dy - q.dx * q.dx);
+}
+
+// One thread per (frame, slot): slots 0..21 are joints, 22..31 the ten shape coefficients.
+__global__ void update_feat_kernel(FeatArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = idx >> 5, slot = idx & 31;
+  if (t >= a.T) return;
+  if (slot < NB) {
+    float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
+    float r0 = th[0], r1 = th[1], r2 = th[2];
+    if (a.d_theta) {
+      const float* d = a.d_theta + (size_t)t * 66 + slot * 3;
+      r0 = r0 + d[0] * a.theta_step;
+      r1 = r1 + d[1] * a.theta_step;
+      r2 = r2 + d[2] * a.theta_step;
+      th[0] = r0; th[1] = r1; th[2] = r2;
+    }
+    if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
+    if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
+    Rod q; float R[9];
+    rodrigues(r0, r1, r2, q, R);
+    float* ro = a.rot + ((size_t)t * NB + slot) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) ro[e] = R[e];
+    if (slot >= 1) {
+      float* f = a.feat + (size_t)t * 200 + (slot - 1) * 9;
+      f[0] = R[0] - 1.f; f[1] = R[1]; f[2] = R[2];
+      f[3] = R[3]; f[4] = R[4] - 1.f; f[5] = R[5];
+      f[6] = R[6]; f[7] = R[7]; f[8] = R[8] - 1.f;
+    }
+  } else {
+    const int k = slot - NB;
+    float* be = a.beta + (size_t)t * a.ld_beta + k;
+    float v = a.beta_keep != 0.f ? *be * a.beta_keep : 0.f;
+    if (a.d_beta) {
+      float d;
+      if (a.shape_avg) {
+        // mean over ALL frames of the window incl. padded ones (reference models.py:529-532)
+        const int w0 = (t / a.F) * a.F;
+        float s = 0.f;
+        for (int f = 0; f < a.F; ++f) s += a.d_beta[(size_t)(w0 + f) * 10 + k];
+        d = s / (float)a.F;
+      } else {
+        d = a.d_beta[(size_t)t * 10 + k];
+      }
+      v = v + d * a.beta_step;
+    }
+    // Every (t,k) thread of a window reads d_beta of all its frames but writes only beta[t][k]: no hazard.
+    *be = v;
+    if (a.out_beta) a.out_beta[(size_t)t * 10 + k] = v;
+    if (a.out_beta2) a.out_beta2[(size_t)t * 10 + k] = v;
+    a.feat[(size_t)t * 200 + 189 + k] = v;
+    if (k == 0) a.feat[(size_t)t * 200 + 199] = 1.f;
+  }
+}
+
+hipError_t launch_update_feat(const FeatArgs& a, hipStream_t stream) {
+  const long n = (long)a.T * 32;
+  hipLaunchKernelGGL(update_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void rodrigues_bwd_kernel(RodBwdArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = idx >> 5, slot = idx & 31;
+  if (t >= a.T) return;
+  if (slot < NB) {
+    const float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
+    Rod q; float R[9];
+    rodrigues(th[0], th[1], th[2], q, R);
+    float dR[9];
+    const float* dr = a.d_rot + ((size_t)t * NB + slot) * 9;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) dR[e] = dr[e];
+    if (slot >= 1) {
+      const float* df = a.d_feat + (size_t)t * 200 + (slot - 1) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) dR[e] += df[e];
+    }
+    // K and K^2
+    const float K[9] = {0.f, -q.dz, q.dy, q.dz, 0.f, -q.dx, -q.dy, q.dx, 0.f};
+    const float KK[9] = {-q.dz * q.dz - q.dy * q.dy, q.dx * q.dy, q.dx * q.dz,
+                         q.dx * q.dy, -q.dz * q.dz - q.dx * q.dx, q.dy * q.dz,
+                         q.dx * q.dz, q.dy * q.dz, -q.dy * q.dy - q.dx * q.dx};
+    float ds = 0.f, dc1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { ds += dR[e] * K[e]; dc1 += dR[e] * KK[e]; }
+    const float oc = 1.f - q.c;
+    // dK = s dR + (1-c) (dR K^T + K^T dR)
+    float dK[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) m += dR[r * 3 + k] * K[c * 3 + k] + K[k * 3 + r] * dR[k * 3 + c];
+        dK[r * 3 + c] = q.s * dR[r * 3 + c] + oc * m;
+      }
+    const float ddx = dK[7] - dK[5], ddy = dK[2] - dK[6], ddz = dK[3] - dK[1];
+    float da = ds * q.c + dc1 * q.s;
+    da -= (ddx * q.dx + ddy * q.dy + ddz * q.dz) / q.ang;
+    const float g0 = ddx / q.ang + da * q.ux / q.ang;
+    const float g1 = ddy / q.ang + da * q.uy / q.ang;
+    const float g2 = ddz / q.ang + da * q.uz / q.ang;
+    float* g = a.g_theta + (size_t)t * a.ld_g + slot * 3;
+    g[0] = g0; g[1] = g1; g[2] = g2;
+    if (a.trace_g_theta) { float* o = a.trace_g_theta + (size_t)t * 66 + slot * 3; o[0] = g0; o[1] = g1; o[2] = g2; }
+  } else {
+    const int k = slot - NB;
+    const float v = a.d_feat[(size_t)t * 200 + 189 + k];
+    a.g_beta[(size_t)t * a.ld_gb + k] = v;
+    if (a.trace_g_beta) a.trace_g_beta[(size_t)t * 10 + k] = v;
+  }
+}
+
+hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream) {
+  const long n = (long)a.T * 32;
+  hipLaunchKernelGGL(rodrigues_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// chain + skinning + sensors (+ reverse)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CH_THREADS = 256;
+constexpr int CH_FRAMES = 4;
+
+struct ChainLds {  // per-frame float offsets
+  int rot, out, g, at, v, dv, m, x, total;
+};
+
+__host__ __device__ inline ChainLds chain_layout(int nv, int ncp) {
+  ChainLds l;
+  int o = 0;
+  l.rot = o; o += NB * 9;
+  l.out = o; o += ncp;
+  l.g = o; o += NB * 12;    // per joint: G^R (9, row-major) | G^t (3)
+  l.at = o; o += NB * 3;    // A^t = G^t - G^R J
+  l.v = o; o += nv * 3;
+  l.dv = o; o += nv * 3;
+  l.m = o; o += NB * 12;    // per bone: moment M (9) | force F (3)
+  l.x = o; o += NB * 12;    // per joint: X (9) | subtree force (3)
+  l.total = (o + 3) & ~3;
+  return l;
+}
+
+size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block) {
+  return (size_t)chain_layout(tab.nv, tab.ncp).total * frames_per_block * sizeof(float);
+}
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float norm3(const float* a) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+// y = x/|x|  ->  dx = (dy - y (y.dy)) / |x|
+__device__ __forceinline__ void unit_bwd(const float* dy, const float* y, float n, float* dx) {
+  const float d = dy[0] * y[0] + dy[1] * y[1] + dy[2] * y[2];
+  dx[0] = (dy[0] - y[0] * d) / n;
+  dx[1] = (dy[1] - y[1] * d) / n;
+  dx[2] = (dy[2] - y[2] * d) / n;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SmplTables& tb = a.tab;
+  const ChainLds L = chain_layout(tb.nv, tb.ncp);
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * CH_FRAMES;
+  const int nf = min(CH_FRAMES, a.T - t0);
+  const int nv3 = tb.nv * 3;
+  const bool bwd = a.tgt != nullptr;
+
+  // ---- P1: stage rotations and the GEMM output row (v_posed | J); clear the vertex cotangents
+  for (int i = tid; i < nf * L.total; i += CH_THREADS) {
+    const int f = i / L.total, o = i % L.total;
+    float v = 0.f;
+    if (o < L.out) v = a.rot[(size_t)(t0 + f) * (NB * 9) + o];
+    else if (o < L.g) v = a.out[(size_t)(t0 + f) * tb.ncp + (o - L.out)];
+    smem[f * L.total + o] = v;
+  }
+  __syncthreads();
+
+  // ---- P2: forward chain, one (joint,row) per lane walking the root path
+  for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
+    const int f = i / (NB * 3), jr = i % (NB * 3), j = jr / 3, r = jr % 3;
+    float* S = smem + f * L.total;
+    const float* sR = S + L.rot;
+    const float* sJ = S + L.out + tb.j_off;
+    const int p0 = tb.path_ptr[j], p1 = tb.path_ptr[j + 1];
+    float row0 = sR[r * 3 + 0], row1 = sR[r * 3 + 1], row2 = sR[r * 3 + 2];  // root rotation, row r
+    float tr = sJ[r];
+    int prev = 0;
+    for (int k = p0 + 1; k < p1; ++k) {
+      const int q = tb.path[k];
+      const float* Jq = sJ + q * 3;
+      const float* Jp = sJ + prev * 3;
+      tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;
+      const float* Rq = sR + q * 9;
+      const float n0 = row0 * Rq[0] + row1 * Rq[3] + row2 * Rq[6];
+      const float n1 = row0 * Rq[1] + row1 * Rq[4] + row2 * Rq[7];
+      const float n2 = row0 * Rq[2] + row1 * Rq[5] + row2 * Rq[8];
+      row0 = n0; row1 = n1; row2 = n2;
+      prev = q;
+    }
+    float* G = S + L.g + j * 12;
+    G[r * 3 + 0] = row0; G[r * 3 + 1] = row1; G[r * 3 + 2] = row2;
+    G[9 + r] = tr;
+    const float* Jj = sJ + j * 3;
+    S[L.at + j * 3 + r] = tr - (row0 * Jj[0] + row1 * Jj[1] + row2 * Jj[2]);
+    const size_t go = (size_t)(t0 + f) * 66 + j * 3 + r;
+    a.joints[go] = tr;
+    if (a.joints2) a.joints2[go] = tr;
+  }
+  __syncthreads();
+
+  // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
+  for (int i = tid; i < nf * nv3; i += CH_THREADS) {
+    const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
+    float* S = smem + f * L.total;
+    const float* vp = S + L.out + s * 3;
+    float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;  // row r of the blended 3x4 transform
+    for (int k = 0; k < tb.kb; ++k) {
+      const float w = tb.skin_w[s * tb.kb + k];
+      if (w == 0.f) continue;
+      const int b = tb.skin_idx[s * tb.kb + k];
+      const float* G = S + L.g + b * 12 + r * 3;
+      T0 += w * G[0]; T1 += w * G[1]; T2 += w * G[2];
+      T3 += w * S[L.at + b * 3 + r];
+    }
+    S[L.v + sr] = T0 * vp[0] + T1 * vp[1] + T2 * vp[2] + T3;
+  }
+  __syncthreads();
+
+  // ---- P4: sensors, one (frame, sensor) per lane: normals, frame, offsets, residual and its reverse to dv
+  for (int i = tid; i < nf * tb.n_sensors; i += CH_THREADS) {
+    const int f = i / tb.n_sensors, m = i % tb.n_sensors;
+    const int t = t0 + f;
+    float* S = smem + f * L.total;
+    const float* V = S + L.v;
+    const int c = tb.s_center[m], h = tb.s_helper[m], deg = tb.s_deg[m];
+    const int* faces = tb.s_faces + (size_t)m * tb.max_deg * 3;
+    float n[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < deg; ++k) {
+      const float* v0 = V + faces[k * 3 + 0] * 3;
+      const float* v1 = V + faces[k * 3 + 1] * 3;
+      const float* v2 = V + faces[k * 3 + 2] * 3;
+      const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+      const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+      float fn[3];
+      cross3(e1, e2, fn);
+      n[0] += fn[0]; n[1] += fn[1]; n[2] += fn[2];
+    }
+    const float fdeg = (float)deg;
+    n[0] /= fdeg; n[1] /= fdeg; n[2] /= fdeg;
+    const float nn = norm3(n);
+    const float nh[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+    const float* vc = V + c * 3;
+    const float* vh = V + h * 3;
+    const float e[3] = {vh[0] - vc[0], vh[1] - vc[1], vh[2] - vc[2]};
+    const float ne = norm3(e);
+    const float sv[3] = {e[0] / ne, e[1] / ne, e[2] / ne};
+    float bb[3];
+    cross3(nh, sv, bb);
+    const float nb = norm3(bb);
+    const float tv[3] = {bb[0] / nb, bb[1] / nb, bb[2] / nb};
+    float aa[3];
+    cross3(tv, nh, aa);
+    const float na = norm3(aa);
+    const float s2[3] = {aa[0] / na, aa[1] / na, aa[2] / na};
+    // R_m columns (s2, tv, nh)
+    const float Rm[9] = {s2[0], tv[0], nh[0], s2[1], tv[1], nh[1], s2[2], tv[2], nh[2]};
+    const int w = t / a.F;
+    const float* Ro = a.offset_r + ((size_t)w * 12 + m) * 9;
+    const float* to = a.offset_t + ((size_t)w * 12 + m) * 3;
+    float ori[9], pos[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        ori[r * 3 + cc] = Rm[r * 3 + 0] * Ro[cc] + Rm[r * 3 + 1] * Ro[3 + cc] + Rm[r * 3 + 2] * Ro[6 + cc];
+      pos[r] = vc[r] + (Rm[r * 3 + 0] * to[0] + Rm[r * 3 + 1] * to[1] + Rm[r * 3 + 2] * to[2]);
+    }
+    {
+      float* po = a.pos + ((size_t)t * 12 + m) * 3;
+      float* oo = a.ori + ((size_t)t * 12 + m) * 9;
+      po[0] = pos[0]; po[1] = pos[1]; po[2] = pos[2];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) oo[k] = ori[k];
+      if (a.pos2) {
+        float* p2 = a.pos2 + ((size_t)t * 12 + m) * 3;
+        float* o2 = a.ori2 + ((size_t)t * 12 + m) * 9;
+        p2[0] = pos[0]; p2[1] = pos[1]; p2[2] = pos[2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o2[k] = ori[k];
+      }
+    }
+    if (!bwd) continue;
+    const int slot = a.used_slot[m];
+    const float scale = a.frame_scale[t];
+    if (slot < 0 || scale == 0.f) continue;
+    const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
+    const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
+    float dpos[3], dori[9];
+    {
+      const float r0 = pos[0] - tp[0], r1 = pos[1] - tp[1], r2 = pos[2] - tp[2];
+      const float rn = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+      dpos[0] = r0 / rn * scale; dpos[1] = r1 / rn * scale; dpos[2] = r2 / rn * scale;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { dori[k] = ori[k] - tori[k]; q += dori[k] * dori[k]; }
+      q = sqrtf(q);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dori[k] = dori[k] / q * scale;
+    }
+    // dR_m = dori Ro^T + dpos (x) to
+    float dRm[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        dRm[r * 3 + cc] = dori[r * 3 + 0] * Ro[cc * 3 + 0] + dori[r * 3 + 1] * Ro[cc * 3 + 1] +
+                          dori[r * 3 + 2] * Ro[cc * 3 + 2] + dpos[r] * to[cc];
+    float ds2[3] = {dRm[0], dRm[3], dRm[6]};
+    float dt[3] = {dRm[1], dRm[4], dRm[7]};
+    float dnh[3] = {dRm[2], dRm[5], dRm[8]};
+    float da[3], tmp[3];
+    unit_bwd(ds2, s2, na, da);       // a = t x nh
+    cross3(nh, da, tmp); dt[0] += tmp[0]; dt[1] += tmp[1]; dt[2] += tmp[2];
+    cross3(da, tv, tmp); dnh[0] += tmp[0]; dnh[1] += tmp[1]; dnh[2] += tmp[2];
+    float db[3];
+    unit_bwd(dt, tv, nb, db);        // b = nh x s
+    cross3(sv, db, tmp); dnh[0] += tmp[0]; dnh[1] += tmp[1]; dnh[2] += tmp[2];
+    float dsv[3];
+    cross3(db, nh, dsv);
+    float de[3];
+    unit_bwd(dsv, sv, ne, de);
+    float dn[3];
+    unit_bwd(dnh, nh, nn, dn);
+    float* DV = S + L.dv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(DV + c * 3 + k, dpos[k] - de[k]);
+      atomicAdd(DV + h * 3 + k, de[k]);
+    }
+    const float dfn[3] = {dn[0] / fdeg, dn[1] / fdeg, dn[2] / fdeg};
+    for (int k = 0; k < deg; ++k) {
+      const int i0 = faces[k * 3 + 0], i1 = faces[k * 3 + 1], i2 = faces[k * 3 + 2];
+      const float* v0 = V + i0 * 3;
+      const float* v1 = V + i1 * 3;
+      const float* v2 = V + i2 * 3;
+      const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+      const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+      float de1[3], de2[3];
+      cross3(e2, dfn, de1);
+      cross3(dfn, e1, de2);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        atomicAdd(DV + i1 * 3 + q, de1[q]);
+        atomicAdd(DV + i2 * 3 + q, de2[q]);
+        atomicAdd(DV + i0 * 3 + q, -(de1[q] + de2[q]));
+      }
+    }
+  }
+  if (!bwd) return;
+  __syncthreads();
+
+  // ---- P5: d v_posed (to global) and the per-bone force / world-space moment sums
+  for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
+    const int f = i / tb.ncp, col = i % tb.ncp;
+    if (col >= tb.j_off && col < tb.j_off + NB * 3) continue;  // d J is written in P7
+    float acc = 0.f;
+    if (col < nv3) {
+      const int s = col / 3, cc = col % 3;
+      const float* S = smem + f * L.total;
+      const float* dv = S + L.dv + s * 3;
+      for (int k = 0; k < tb.kb; ++k) {
+        const float w = tb.skin_w[s * tb.kb + k];
+        if (w == 0.f) continue;
+        const float* G = S + L.g + tb.skin_idx[s * tb.kb + k] * 12;
+        acc += w * (G[0 + cc] * dv[0] + G[3 + cc] * dv[1] + G[6 + cc] * dv[2]);
+      }
+    }
+    a.d_out[(size_t)(t0 + f) * tb.ncp + col] = acc;
+  }
+  for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
+    const int f = i / (NB * 12), be = i % (NB * 12), b = be / 12, e = be % 12;
+    float* S = smem + f * L.total;
+    const float* G = S + L.g + b * 12;
+    float acc = 0.f;
+    const int q0 = tb.bone_ptr[b], q1 = tb.bone_ptr[b + 1];
+    if (e < 9) {
+      const int ar = e / 3, cc = e % 3;
+      const float at = S[L.at + b * 3 + cc];
+      for (int q = q0; q < q1; ++q) {
+        const int s = tb.bone_vert[q];
+        const float* vp = S + L.out + s * 3;
+        const float x = G[cc * 3 + 0] * vp[0] + G[cc * 3 + 1] * vp[1] + G[cc * 3 + 2] * vp[2] + at;
+        acc += tb.bone_w[q] * S[L.dv + s * 3 + ar] * x;
+      }
+    } else {
+      const int ar = e - 9;
+      for (int q = q0; q < q1; ++q) acc += tb.bone_w[q] * S[L.dv + tb.bone_vert[q] * 3 + ar];
+    }
+    S[L.m + be] = acc;
+  }
+  __syncthreads();
+
+  // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j
+  for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
+    const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
+    float* S = smem + f * L.total;
+    const int q0 = tb.sub_ptr[j], q1 = tb.sub_ptr[j + 1];
+    if (e < 9) {
+      const int ar = e / 3, cc = e % 3;
+      float ms = 0.f, fs = 0.f;
+      for (int q = q0; q < q1; ++q) {
+        const float* Mb = S + L.m + tb.sub[q] * 12;
+        ms += Mb[e];
+        fs += Mb[9 + ar];
+      }
+      S[L.x + je] = ms - fs * S[L.g + j * 12 + 9 + cc];
+    } else {
+      float fs = 0.f;
+      for (int q = q0; q < q1; ++q) fs += S[L.m + tb.sub[q] * 12 + e];
+      S[L.x + je] = fs;
+    }
+  }
+  __syncthreads();
+
+  // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
+  for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
+    const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
+    const float* S = smem + f * L.total;
+    const float* Gj = S + L.g + j * 12;
+    const float* X = S + L.x + j * 12;
+    const int p = tb.parents[j];
+    const float* Gp = S + L.g + (p < 0 ? 0 : p) * 12;
+    if (e < 9) {
+      const int r = e / 3, cc = e % 3;
+      float acc = 0.f;
+#pragma unroll
+      for (int ar = 0; ar < 3; ++ar) {
+        const float xg = X[ar * 3 + 0] * Gj[0 + cc] + X[ar * 3 + 1] * Gj[3 + cc] + X[ar * 3 + 2] * Gj[6 + cc];
+        const float gp = p < 0 ? (ar == r ? 1.f : 0.f) : Gp[ar * 3 + r];
+        acc += gp * xg;
+      }
+      a.d_rot[((size_t)(t0 + f) * NB + j) * 9 + e] = acc;
+    } else {
+      const int cc = e - 9;
+      float acc = 0.f;
+#pragma unroll
+      for (int ar = 0; ar < 3; ++ar) {
+        const float gp = p < 0 ? (ar == cc ? 1.f : 0.f) : Gp[ar * 3 + cc];
+        acc += (gp - Gj[ar * 3 + cc]) * X[9 + ar];
+      }
+      a.d_out[(size_t)(t0 + f) * tb.ncp + tb.j_off + j * 3 + cc] = acc;
+    }
+  }
+}
+
+hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream) {
+  const size_t lds = chain_lds_bytes(a.tab, CH_FRAMES);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int blocks = (a.T + CH_FRAMES - 1) / CH_FRAMES;
+  hipLaunchKernelGGL(chain_sensors_kernel, dim3(blocks), dim3(CH_THREADS), lds, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Full mesh (final vertices): chain to relative transforms, then dense skinning of all V vertices.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void mesh_chain_kernel(MeshChainArgs a) {
+  // one thread per (frame, joint, row): walks parents up to the root
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.T * NB * 3) return;
+  const int t = idx / (NB * 3), jr = idx % (NB * 3), j = jr / 3, r = jr % 3;
+  const float* R = a.rot + (size_t)t * NB * 9;
+  const float* J = a.out + (size_t)t * a.ncp + a.j_off;
+  int path[NB];
+  int n = 0;
+  for (int q = j; q >= 0; q = a.parents[q]) path[n++] = q;
+  float row0 = R[r * 3 + 0], row1 = R[r * 3 + 1], row2 = R[r * 3 + 2];
+  float tr = J[r];
+  int prev = 0;
+  for (int k = n - 2; k >= 0; --k) {
+    const int q = path[k];
+    const float* Jq = J + q * 3;
+    const float* Jp = J + prev * 3;
+    tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;
+    const float* Rq = R + q * 9;
+    const float n0 = row0 * Rq[0] + row1 * Rq[3] + row2 * Rq[6];
+    const float n1 = row0 * Rq[1] + row1 * Rq[4] + row2 * Rq[7];
+    const float n2 = row0 * Rq[2] + row1 * Rq[5] + row2 * Rq[8];
+    row0 = n0; row1 = n1; row2 = n2;
+    prev = q;
+  }
+  float* X = a.xf + ((size_t)t * NB + j) * 12;
+  X[r * 3 + 0] = row0; X[r * 3 + 1] = row1; X[r * 3 + 2] = row2;
+  const float* Jj = J + j * 3;
+  X[9 + r] = tr - (row0 * Jj[0] + row1 * Jj[1] + row2 * Jj[2]);
+  a.joints[(size_t)t * 66 + j * 3 + r] = tr + (a.trans ? a.trans[(size_t)t * 3 + r] : 0.f);
+}
+
+hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream) {
+  const long n = (long)a.T * NB * 3;
+  hipLaunchKernelGGL(mesh_chain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mesh_skin_kernel(MeshSkinArgs a) {
+  // blockIdx.y = frame; the frame's 22 relative transforms sit in LDS, lanes sweep vertex coordinates
+  __shared__ float xf[NB * 12];
+  const int t = blockIdx.y;
+  for (int i = threadIdx.x; i < NB * 12; i += 256) xf[i] = a.xf[(size_t)t * NB * 12 + i];
+  __syncthreads();
+  const int sr = blockIdx.x * 256 + threadIdx.x;
+  if (sr >= a.V * 3) return;
+  const int s = sr / 3, r = sr % 3;
+  const float* vp = a.out + (size_t)t * a.ncp + s * 3;
+  float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
+  for (int k = 0; k < a.kb; ++k) {
+    const float w = a.skin_w[(size_t)s * a.kb + k];
+    if (w == 0.f) continue;
+    const float* G = xf + a.skin_idx[(size_t)s * a.kb + k] * 12;
+    T0 += w * G[r * 3 + 0]; T1 += w * G[r * 3 + 1]; T2 += w * G[r * 3 + 2]; T3 += w * G[9 + r];
+  }
+  float v = T0 * vp[0] + T1 * vp[1] + T2 * vp[2] + T3;
+  if (a.trans) v += a.trans[(size_t)t * 3 + r];
+  a.vertices[((size_t)t * a.V) * 3 + sr] = v;
+}
+
+hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream) {
+  dim3 grid((a.V * 3 + 255) / 256, a.T);
+  hipLaunchKernelGGL(mesh_skin_kernel, grid, dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace empose

@@ -1,0 +1,123 @@
+"""
+Batch containers: the input contract of the models (reference empose/data/data.py:17-104,193-309).
+
+Only what the LGD path touches is restated: the attribute set of `ABatch`, `RealBatch` with its missing-sensor
+suppression, and `get_inputs(sf, ef)` yielding the dict the model reads.  Sample classes, LMDB / npz
+IO and collation from files are out of scope (host-side IO).
+"""
+import torch
+
+from em_pose_amd.helpers.configuration import CONSTANTS as C
+
+
+class ABatch(object):
+    def __init__(self, seq_ids, seq_lengths, poses, shapes, trans, joints_gt, offset_t=None, offset_r=None):
+        self.ids = seq_ids
+        self.seq_lengths = seq_lengths
+        self.poses = poses  # (N, F, 66)
+        self.shapes = shapes  # (N, 10)
+        self.trans = trans  # (N, F, 3)
+        self.joints_gt = joints_gt
+        self.offset_t = offset_t
+        self.offset_r = offset_r
+        self.joints_hat = None
+        self.vertices = None
+        self.marker_pos_real = self.marker_ori_real = self.marker_normal_real = None
+        self.marker_pos_synth = self.marker_ori_synth = self.marker_normal_synth = None
+        self.marker_pos_vertex = self.marker_ori_vertex = None
+        self.marker_masks = None
+        self.marker_pos_noisy = self.marker_ori_noisy = self.marker_normal_noisy = None
+        self.offset_t_augmented = self.offset_r_augmented = None
+
+    @property
+    def batch_size(self):
+        return self.poses.shape[0]
+
+    @property
+    def seq_length(self):
+        return self.poses.shape[1]
+
+    @property
+    def poses_body(self):
+        return self.poses[:, :, 3:]
+
+    @property
+    def poses_root(self):
+        return self.poses[:, :, :3]
+
+    def get_inputs(self, sf=None, ef=None, **kwargs):
+        raise NotImplementedError('Must be implemented by subclass.')
+
+
+class RealBatch(ABatch):
+    """Real sensor recordings with ground-truth SMPL parameters and per-subject offsets."""
+
+    def __init__(self, seq_ids, seq_lengths, smpl_poses, smpl_shape, smpl_trans, marker_pos, marker_ori,
+                 marker_masks, offset_t=None, offset_r=None):
+        super(RealBatch, self).__init__(seq_ids, seq_lengths, smpl_poses, smpl_shape, smpl_trans, joints_gt=None)
+        self.marker_pos_real = marker_pos
+        self.marker_ori_real = marker_ori
+        self.marker_masks = marker_masks
+        n_markers = marker_ori.shape[-1] // 9
+        m_ori = marker_ori.detach().clone().reshape(self.batch_size, self.seq_length, n_markers, 3, 3)
+        self.marker_normal_real = m_ori[..., 2].reshape(self.batch_size, self.seq_length, -1)
+        self.offset_t = torch.zeros((self.batch_size, n_markers, 3)) if offset_t is None else offset_t
+        self.offset_r = torch.eye(3).expand(self.batch_size, n_markers, 3, 3).clone() if offset_r is None else offset_r
+
+    @property
+    def n_markers(self):
+        return self.marker_pos_real.shape[-1] // 3
+
+    def to_gpu(self, device=None):
+        device = C.DEVICE if device is None else device
+        self.seq_lengths = self.seq_lengths.to(dtype=torch.int, device=device)
+        for name in ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes',
+                     'trans', 'offset_t', 'offset_r'):
+            setattr(self, name, getattr(self, name).to(dtype=C.DTYPE, device=device))
+        return self
+
+    def _suppress_missing_markers(self, mask_value):
+        """Missing sensors read `mask_value`, as in training with suppression noise (reference data.py:284-302)."""
+        valid = (self.marker_masks == 1.0).unsqueeze(-1)
+        n, f, m = self.batch_size, self.seq_length, self.n_markers
+
+        def _mask(x):
+            xr = x.reshape((n, f, m, -1))
+            return (xr * valid + (torch.zeros_like(xr) + mask_value) * ~valid).reshape((n, f, -1))
+
+        self.marker_pos_real = _mask(self.marker_pos_real)
+        self.marker_ori_real = _mask(self.marker_ori_real)
+        self.marker_normal_real = _mask(self.marker_normal_real)
+
+    def get_inputs(self, sf=None, ef=None, **kwargs):
+        self._suppress_missing_markers(kwargs.get('mask_value', 0.0))
+        joints = self.joints_hat[:, sf:ef] if self.joints_hat is not None else None
+        return {'marker_pos': self.marker_pos_real[:, sf:ef], 'marker_oris': self.marker_ori_real[:, sf:ef],
+                'marker_normals': self.marker_normal_real[:, sf:ef], 'joints': joints,
+                'offset_t': self.offset_t, 'offset_r': self.offset_r, 'marker_masks': self.marker_masks[:, sf:ef]}
+
+
+class SyntheticBatch(ABatch):
+    """Synthetic windows (the AMASS-batch contract: `marker_masks` is None, reference data.py:433-459)."""
+
+    def __init__(self, windows, seq_lengths=None, device=None):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+        poses = t(windows['poses'])
+        B, F = poses.shape[:2]
+        if seq_lengths is None:
+            seq_lengths = torch.full((B,), F, dtype=torch.int32, device=device)
+        super(SyntheticBatch, self).__init__(list(range(B)), seq_lengths, poses, t(windows['shapes']),
+                                             torch.zeros(B, F, 3, device=device), None)
+        self.marker_pos_synth = t(windows['marker_pos'])
+        self.marker_ori_synth = t(windows['marker_oris'])
+        self.offset_t_augmented = t(windows['offset_t'])
+        self.offset_r_augmented = t(windows['offset_r'])
+
+    @property
+    def n_markers(self):
+        return self.marker_pos_synth.shape[-1] // 3
+
+    def get_inputs(self, sf=None, ef=None, **kwargs):
+        return {'marker_pos': self.marker_pos_synth[:, sf:ef], 'marker_oris': self.marker_ori_synth[:, sf:ef],
+                'marker_normals': None, 'joints': None, 'offset_t': self.offset_t_augmented,
+                'offset_r': self.offset_r_augmented, 'marker_masks': None}

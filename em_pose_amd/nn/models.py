@@ -1,0 +1,441 @@
+"""
+Model construction and forward() for the LGD path (mirror of reference empose/nn/models.py).
+
+`create_model(config, smpl_model)`                       reference models.py:23-33
+`IterativeErrorFeedback.forward(batch, window_size, is_new_sequence)`   reference models.py:485-632
+`IterativeErrorFeedback.backward(batch, model_out, writer, global_step)` reference models.py:634-688 (loss values)
+`FeedForwardResNet`                                      reference models.py:166-262 (CPU plumbing config only)
+
+The module keeps the reference's parameter tree (same `state_dict` keys) but does none of the arithmetic itself:
+forward() packs the parameters once into an opaque HIP model (include/empose_hip.h) and then calls
+`empose_lgd_forward` -- LSTM / MLP GEMMs on the fp32 matrix cores, SMPL-H restricted to the sensor sub-mesh, and the
+residual gradient by a hand-derived reverse pass instead of autograd (so `torch.set_grad_enabled` is left alone,
+unlike reference models.py:487).  There is no CPU path: CPU tensors raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from em_pose_amd import _lib
+from em_pose_amd.bodymodels import tables as TB
+from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.nn.layers import MLP, FeedForwardResidualBlock, RNNLayer, fill_dense_desc
+
+
+def create_model(config, *args):
+    m_type = config.m_type
+    if m_type == 'resnet':
+        return FeedForwardResNet(config, *args)
+    elif m_type in ('ief', 'lgd'):
+        return IterativeErrorFeedback(config, *args)
+    elif m_type == 'rnn':
+        raise NotImplementedError("The BiRNN baseline ('rnn') is outside the LGD path (SURVEY.md 8f-3).")
+    raise ValueError("Model type '{}' unknown.".format(m_type))
+
+
+def mask_from_seq_lengths(seq_lengths, max_seq_len=None):
+    """reference helpers/utils.py:105-123"""
+    max_seq_len = int(seq_lengths.max()) if max_seq_len is None else max_seq_len
+    t = torch.arange(max_seq_len, device=seq_lengths.device, dtype=seq_lengths.dtype)
+    return t[None, :] < seq_lengths[:, None]
+
+
+def reconstruction_loss(markers_gt, markers_hat, seq_lengths=None, marker_mask=None):
+    """reference nn/loss.py:23-41 (used for reporting loss values only; the in-loop residual lives in the kernels)."""
+    diff = markers_hat - markers_gt
+    per = torch.sqrt((diff * diff).sum(dim=-1)).sum(dim=-1)
+    if marker_mask is not None:
+        per = per * marker_mask.logical_not().any(dim=-1).logical_not()
+    if seq_lengths is not None:
+        mask = mask_from_seq_lengths(seq_lengths, per.shape[1]).to(per.dtype)
+        per = (per * mask).sum(-1) / seq_lengths.to(per.dtype)
+    return per.mean()
+
+
+def padded_loss(gt, hat, loss_fn, seq_lengths):
+    """reference nn/loss.py:13-20"""
+    unreduced = loss_fn(gt, hat).mean(-1)
+    mask = mask_from_seq_lengths(seq_lengths, unreduced.shape[1]).to(unreduced.dtype)
+    return ((unreduced * mask).sum(-1) / seq_lengths.to(unreduced.dtype)).mean()
+
+
+class BaseModel(nn.Module):
+    def __init__(self, config, smpl_model=None):
+        super(BaseModel, self).__init__()
+        self.n_markers = config.n_markers if getattr(config, 'n_markers', -1) > -1 else CONST.N_TRACKERS_WO_ROOT
+        self.config = config
+        self.n_frames = config.window_size
+        self.smpl = smpl_model
+        self.estimate_shape = config.m_estimate_shape
+        self.shape_avg = config.m_average_shape
+        self.fk_loss_weight = config.m_fk_loss
+        self.do_fk = self.fk_loss_weight > 0.0
+        if self.do_fk:
+            assert self.smpl is not None
+            assert self.estimate_shape or isinstance(self, IterativeErrorFeedback)
+        self.shape_weight = getattr(config, 'm_shape_loss_weight', 1.0)
+        self.pose_weight = getattr(config, 'm_pose_loss_weight', 1.0)
+        self.set_input_output_size()
+        self.create_model()
+
+    def set_input_output_size(self):
+        input_size = 0
+        if self.config.use_marker_pos:
+            input_size += self.n_markers * 3
+        if self.config.use_marker_ori:
+            input_size += self.n_markers * 9
+            assert not self.config.use_marker_nor
+        if self.config.use_marker_nor:
+            input_size += self.n_markers * 3
+            assert not self.config.use_marker_ori
+        setattr(self.config, 'input_size', input_size)
+        setattr(self.config, 'output_size', (CONST.N_JOINTS + 1) * 3)
+        self.input_size = input_size
+        self.output_size = self.config.output_size
+
+    def create_model(self):
+        raise NotImplementedError('Must be implemented by subclass.')
+
+    def prepare_inputs(self, batch_inputs):
+        """(N,F,12*3) + (N,F,12*9) -> (N,F,D_in), 6-sensor subset if configured (reference models.py:106-125)."""
+        n, f = batch_inputs['marker_pos'].shape[0], batch_inputs['marker_pos'].shape[1]
+        m_pos = batch_inputs['marker_pos'].reshape((n, f, -1, 3))
+        m_ori = batch_inputs['marker_oris'].reshape((n, f, -1, 3, 3))
+        assert self.n_markers in [6, 12]
+        if self.n_markers == 6:
+            m_pos, m_ori = m_pos[:, :, CONST.S_CONFIG_6], m_ori[:, :, CONST.S_CONFIG_6]
+        model_in = []
+        if self.config.use_marker_pos:
+            model_in.append(m_pos.reshape((n, f, -1)))
+        if self.config.use_marker_ori:
+            model_in.append(m_ori.reshape((n, f, -1)))
+        if self.config.use_marker_nor:
+            raise ValueError('Normals currently not supported.')
+        return torch.cat(model_in, dim=-1)
+
+    def window_generator(self, batch, window_size):
+        """reference models.py:146-163 (the sliced branch is only valid for batch size 1, as in the reference)."""
+        if window_size is not None:
+            seq_len = batch.seq_length
+            n_windows = seq_len // window_size + int(seq_len % window_size > 0)
+            for i in range(n_windows):
+                sf, ef = i * window_size, min((i + 1) * window_size, seq_len)
+                batch_inputs = batch.get_inputs(sf=sf, ef=ef)
+                batch_inputs['seq_lengths'] = torch.tensor([ef - sf], dtype=batch.seq_lengths.dtype,
+                                                           device=batch.seq_lengths.device)
+                yield batch_inputs
+        else:
+            batch_inputs = batch.get_inputs()
+            batch_inputs['seq_lengths'] = batch.seq_lengths
+            yield batch_inputs
+
+    def log_loss_vals(self, loss_vals, writer, global_step):
+        mode_prefix = 'train' if self.training else 'valid'
+        for k in loss_vals:
+            writer.add_scalar('{}/{}'.format(k, mode_prefix), loss_vals[k], global_step)
+
+
+class FeedForwardResNet(BaseModel):
+    """
+    Frame-wise residual MLP baseline (reference models.py:166-262), pose only. Restated in plain PyTorch because
+    BASELINE.json's config 0 is "forward on PyTorch CPU ... plumbing, no GPU"; it is not on the accelerated path.
+    """
+
+    def create_model(self):
+        h = self.config.m_hidden_size
+        self.from_input = nn.Linear(self.input_size, h)
+        self.blocks = nn.Sequential(*[FeedForwardResidualBlock(h, h) for _ in range(self.config.m_num_layers)])
+        self.to_output = nn.Linear(h, self.output_size)
+
+    def model_name(self):
+        return 'ResNet-{}x{}-n{}-lr{}'.format(self.config.m_num_layers, self.config.m_hidden_size, self.n_markers,
+                                              self.config.lr)
+
+    def forward(self, batch, window_size=None, is_new_sequence=True):
+        inputs_ = self.prepare_inputs(batch.get_inputs())
+        pose = self.to_output(self.blocks(self.from_input(inputs_)))
+        return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3], 'shape_hat': None, 'joints_hat': None}
+
+
+class IterativeErrorFeedback(BaseModel):
+    """The LGD / LGD-RNN model."""
+
+    def __init__(self, config, smpl_model):
+        self.N = config.m_num_iterations
+        self.step_size = config.m_step_size
+        self.shape_avg = config.m_average_shape
+        self.r_weight = config.m_reprojection_loss_weight
+        self.use_gradient = config.m_use_gradient
+        self.skip_connections = config.m_skip_connections
+        self.rnn_init = config.m_rnn_init
+        super(IterativeErrorFeedback, self).__init__(config, smpl_model)
+        self.vertex_ids = list(CONST.VERTEX_IDS)
+        self.helper_ids = None  # optional explicit helper-vertex table (data of a trained model), else derived
+        assert self.n_markers in [6, 12]
+        self.marker_idxs = list(range(12)) if self.n_markers == 12 else list(CONST.S_CONFIG_6)
+        self.keep_history = True
+        self.keep_gradient_trace = False
+        self.gradient_trace = None
+        self.markers_hat_history = None
+        self.markers_ori_hat_history = None
+        self.pose_hat_history = None
+        self.shape_hat_history = None
+        self.joints_hat_history = None
+        self._handle = None      # opaque empose_model_t*
+        self._handle_key = None  # what it was built from
+        self._workspace = None
+
+    def set_input_output_size(self):
+        if self.config.use_marker_nor:
+            raise ValueError('Normals currently not supported.')
+        if not (self.config.use_marker_pos and self.config.use_marker_ori):
+            raise NotImplementedError('the HIP path implements the released configuration: positions + orientations')
+        self.pos_d_start, self.pos_d_end = 0, self.n_markers * 3
+        self.ori_d_start, self.ori_d_end = self.pos_d_end, self.pos_d_end + self.n_markers * 9
+        self.input_size = self.n_markers * 12
+        self.pose_size = (CONST.N_JOINTS + 1) * 3
+        self.shape_size = CONST.N_SHAPE_PARAMS
+        self.input_iter_size = self.input_size + self.pose_size + self.shape_size
+        if self.use_gradient:
+            self.input_iter_size += self.pose_size + self.shape_size
+        for k in ('input_size', 'pose_size', 'shape_size', 'input_iter_size'):
+            setattr(self.config, k, getattr(self, k))
+
+    def create_model(self):
+        cfg = self.config
+        if self.rnn_init:
+            if cfg.m_rnn_bidirectional:
+                raise NotImplementedError('bidirectional init RNN (the reference itself mis-sizes the heads for it)')
+            self.rnn = RNNLayer(self.input_size, cfg.m_rnn_hidden_size, cfg.m_rnn_num_layers, dropout=cfg.m_dropout)
+            self.pose_net_init = nn.Linear(cfg.m_rnn_hidden_size, self.pose_size)
+            self.shape_net_init = nn.Linear(cfg.m_rnn_hidden_size, self.shape_size)
+        else:
+            mk = lambda out: MLP(self.input_size, out, cfg.m_hidden_size, cfg.m_num_layers, cfg.m_dropout_hidden,
+                                 self.skip_connections, not cfg.m_no_batch_norm)
+            self.pose_net_init = mk(self.pose_size)
+            self.shape_net_init = mk(self.shape_size)
+        mk = lambda out: MLP(self.input_iter_size, out, cfg.m_hidden_size, cfg.m_num_layers, cfg.m_dropout_hidden,
+                             self.skip_connections, not cfg.m_no_batch_norm)
+        self.pose_net_iter = mk(self.pose_size)
+        self.shape_net_iter = mk(self.shape_size)
+        self.smpl_loss = nn.L1Loss(reduction='none')
+
+    def model_name(self):
+        cfg = self.config
+        name = 'IEF-{}x{}-N{}'.format(cfg.m_num_layers, cfg.m_hidden_size, cfg.m_num_iterations)
+        if self.rnn_init:
+            name += '-{}RNN-{}x{}'.format('Bi' if cfg.m_rnn_bidirectional else '', cfg.m_rnn_num_layers,
+                                          cfg.m_rnn_hidden_size)
+        name += '-r{}-ws{}-lr{}'.format(self.r_weight, cfg.window_size, cfg.lr)
+        name += '-grad' if self.use_gradient else ''
+        name += '-skip' if self.skip_connections else ''
+        name += '-n{}'.format(self.n_markers)
+        return name
+
+    # ---- HIP model handle ------------------------------------------------------------------------------------
+    def _own_parameters(self):
+        return [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
+               [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
+
+    def _state_key(self, device):
+        ps = self._own_parameters()
+        return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N,
+                tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+
+    def release(self):
+        if self._handle is not None:
+            _lib.lib().empose_model_destroy(self._handle)
+            self._handle, self._handle_key = None, None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def sub_mesh_tables(self):
+        return TB.build_lgd_tables(self.smpl.model, self.vertex_ids, self.helper_ids, CONST.N_SHAPE_PARAMS)
+
+    def _ensure_handle(self, device):
+        key = self._state_key(device)
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self.release()
+        keep = []
+        desc = _lib.ModelDesc()
+        tab = self.sub_mesh_tables()
+        s = desc.smpl
+        for k in ('n_sensors', 'nv', 'j_off', 'ncp', 'kb', 'max_deg'):
+            setattr(s, k, int(tab[k]))
+        for k in ('wc', 'wct', 'skin_w', 'bone_w'):
+            setattr(s, k, _lib.fptr(tab[k]))
+        for k in ('parents', 'skin_idx', 'bone_ptr', 'bone_vert', 's_center', 's_helper', 's_deg', 's_faces',
+                  'path_ptr', 'path', 'sub_ptr', 'sub'):
+            setattr(s, k, _lib.iptr(tab[k]))
+        keep.append(tab)
+        desc.n_markers = self.n_markers
+        for i, v in enumerate(self.marker_idxs):
+            desc.marker_idx[i] = v
+        desc.n_iterations = self.N
+        desc.step_size = float(self.step_size)
+        desc.shape_avg = int(bool(self.shape_avg))
+        desc.use_gradient = int(bool(self.use_gradient))
+        desc.rnn_init = int(bool(self.rnn_init))
+        if self.rnn_init:
+            self.rnn.fill_desc(desc.rnn, keep)
+            fill_dense_desc(desc.pose_head, self.pose_net_init, None, None, keep)
+            fill_dense_desc(desc.shape_head, self.shape_net_init, None, None, keep)
+        else:
+            self.pose_net_init.fill_desc(desc.pose_init, keep)
+            self.shape_net_init.fill_desc(desc.shape_init, keep)
+        self.pose_net_iter.fill_desc(desc.pose_iter, keep)
+        self.shape_net_iter.fill_desc(desc.shape_iter, keep)
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().empose_model_create(C.byref(desc), C.byref(handle)))
+        self._handle, self._handle_key = handle, key
+        return handle
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward_tensors(self, marker_pos, marker_oris, offset_t, offset_r, marker_masks=None, seq_lengths=None,
+                        state=None, keep_history=False, keep_gradient_trace=False):
+        """
+        One window batch through `empose_lgd_forward`. All tensors on the GPU, fp32.
+        :return: dict(pose (B,F,66), shape (B,F,10), joints (B,F,66), state (h_n,c_n) or None, hist {...} or None)
+        """
+        if self.training:
+            raise NotImplementedError('training through the HIP path (BASELINE config 5) is not implemented yet; '
+                                      'call .eval() for inference')
+        if not marker_pos.is_cuda:
+            raise _lib.EmposeError('IterativeErrorFeedback needs GPU tensors; there is no CPU fallback')
+        dev = marker_pos.device
+        B, F = marker_pos.shape[0], marker_pos.shape[1]
+        T = B * F
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+        marker_pos, marker_oris = f32(marker_pos).reshape(B, F, 36), f32(marker_oris).reshape(B, F, 108)
+        offset_t, offset_r = f32(offset_t), f32(offset_r)
+        if offset_t.shape[0] == 1 and B > 1:
+            offset_t, offset_r = offset_t.expand(B, 12, 3).contiguous(), offset_r.expand(B, 12, 3, 3).contiguous()
+        assert offset_t.shape == (B, 12, 3) and offset_r.shape == (B, 12, 3, 3)
+        marker_masks = f32(marker_masks)
+        if seq_lengths is not None:
+            seq_lengths = seq_lengths.to(device=dev, dtype=torch.int32).contiguous()
+            assert seq_lengths.numel() == B
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            handle = self._ensure_handle(dev)
+            new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            io = _lib.LgdIO()
+            io.B, io.F = B, F
+            io.marker_pos, io.marker_oris = _lib.dptr(marker_pos), _lib.dptr(marker_oris)
+            io.offset_t, io.offset_r = _lib.dptr(offset_t), _lib.dptr(offset_r)
+            io.marker_masks, io.seq_lengths = _lib.dptr(marker_masks), _lib.dptr(seq_lengths)
+            out = {'pose': new(B, F, 66), 'shape': new(B, F, 10), 'joints': new(B, F, 66), 'state': None,
+                   'hist': None, 'trace': None}
+            io.pose_hat, io.shape_hat, io.joints_hat = [_lib.dptr(out[k]) for k in ('pose', 'shape', 'joints')]
+            h0 = c0 = None
+            if self.rnn_init:
+                L, H = self.rnn.num_layers, self.rnn.hidden_size
+                if state is not None:
+                    h0, c0 = f32(state[0]), f32(state[1])
+                    assert h0.shape == (L, B, H) and c0.shape == (L, B, H)
+                h_n, c_n = new(L, B, H), new(L, B, H)
+                io.h0, io.c0, io.h_n, io.c_n = _lib.dptr(h0), _lib.dptr(c0), _lib.dptr(h_n), _lib.dptr(c_n)
+                out['state'] = (h_n, c_n)
+            if keep_history:
+                n1 = self.N + 1
+                hist = {'pose': new(n1, T, 66), 'shape': new(n1, T, 10), 'joints': new(n1, T, 66),
+                        'markers': new(n1, T, 36), 'markers_ori': new(n1, T, 108)}
+                io.hist_pose, io.hist_shape, io.hist_joints = [_lib.dptr(hist[k]) for k in ('pose', 'shape', 'joints')]
+                io.hist_markers, io.hist_markers_ori = _lib.dptr(hist['markers']), _lib.dptr(hist['markers_ori'])
+                out['hist'] = hist
+            if keep_gradient_trace and self.use_gradient and self.N > 0:
+                trace = {'g_pose': new(self.N, T, 66), 'g_shape': new(self.N, T, 10)}
+                io.trace_g_pose, io.trace_g_shape = _lib.dptr(trace['g_pose']), _lib.dptr(trace['g_shape'])
+                out['trace'] = trace
+            need = lib.empose_lgd_workspace_bytes(handle, B, F)
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_lgd_forward(handle, C.byref(io), _lib.dptr(self._workspace),
+                                              self._workspace.numel(), _lib.current_stream()))
+        return out
+
+    def forward(self, batch, window_size=None, is_new_sequence=True):
+        if self.rnn_init:
+            if is_new_sequence:
+                self.rnn.final_state = None
+            self.rnn.init_state = self.rnn.final_state
+        outs, hists, traces = [], [], []
+        for batch_inputs in self.window_generator(batch, window_size=window_size):
+            state = None
+            if self.rnn_init:
+                self.rnn.init_state = self.rnn.final_state
+                state = self.rnn.init_state
+            res = self.forward_tensors(batch_inputs['marker_pos'], batch_inputs['marker_oris'],
+                                       batch_inputs['offset_t'], batch_inputs['offset_r'],
+                                       batch_inputs['marker_masks'], batch_inputs['seq_lengths'], state=state,
+                                       keep_history=self.keep_history,
+                                       keep_gradient_trace=self.keep_gradient_trace)
+            if self.rnn_init:
+                self.rnn.final_state = res['state']
+            outs.append(res)
+            hists.append(res['hist'])
+            traces.append(res['trace'])
+
+        bsz = batch.batch_size
+        if self.keep_history:
+            # Same shapes as reference models.py:611-629: history entry h is (B, -1, last_dim of the flat tensor).
+            def merged(key, inner):
+                res = []
+                for h in range(self.N + 1):
+                    parts = [hw[key][h].reshape(bsz, -1, inner) for hw in hists]
+                    res.append(torch.cat(parts, dim=1))
+                return res
+            self.pose_hat_history = merged('pose', 66)
+            self.shape_hat_history = merged('shape', 10)
+            self.joints_hat_history = merged('joints', 3)
+            self.markers_hat_history = merged('markers', 3)
+            self.markers_ori_hat_history = merged('markers_ori', 3)
+        self.gradient_trace = traces if self.keep_gradient_trace else None
+        pose = torch.cat([o['pose'] for o in outs], dim=1)
+        return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3],
+                'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
+                'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
+
+    def backward(self, batch, model_out, writer=None, global_step=None):
+        """Loss values of reference models.py:634-688 from the recorded histories (evaluation mode only)."""
+        if self.training:
+            raise NotImplementedError('training through the HIP path is not implemented yet')
+        if self.pose_hat_history is None:
+            raise RuntimeError('backward() needs the histories of the preceding forward() (keep_history=True)')
+        bs, f = batch.batch_size, batch.seq_length
+        dev = model_out['pose_hat'].device
+        inputs_ = self.prepare_inputs(batch.get_inputs()).to(dev)
+        markers_in = inputs_[:, :, self.pos_d_start:self.pos_d_end].reshape(bs, f, -1, 3)
+        markers_ori_in = inputs_[:, :, self.ori_d_start:self.ori_d_end].reshape(bs, f, -1, 9)
+        sl = batch.seq_lengths.to(dev)
+        masks = batch.marker_masks.to(dev) if batch.marker_masks is not None else None
+        zero = lambda: torch.zeros(1, device=dev)
+        rec, shp, pos, fk = zero(), zero(), zero(), zero()
+        n_hist = len(self.pose_hat_history)
+        for i in range(n_hist):
+            pose_hat = self.pose_hat_history[i].reshape(bs, f, -1)
+            shape_hat = self.shape_hat_history[i].reshape(bs, f, -1)
+            pos += padded_loss(batch.poses.to(dev), pose_hat, self.smpl_loss, sl)
+            shp += padded_loss(batch.shapes.to(dev).unsqueeze(1).repeat(1, f, 1), shape_hat, self.smpl_loss, sl)
+            if self.do_fk:
+                joints_gt = batch.joints_gt.to(dev).reshape(bs, f, -1, 3)
+                fk += reconstruction_loss(joints_gt, model_out['joints_hat'].reshape(bs, f, -1, 3), sl, masks)
+            m_hat = self.markers_hat_history[i].reshape(bs, f, -1, 3)[:, :, self.marker_idxs]
+            o_hat = self.markers_ori_hat_history[i].reshape(bs, f, -1, 9)[:, :, self.marker_idxs]
+            rec += reconstruction_loss(markers_in, m_hat, sl, masks)
+            rec += reconstruction_loss(markers_ori_in, o_hat, sl, masks)
+        total = (self.pose_weight * pos + self.fk_loss_weight * fk + self.shape_weight * shp + self.r_weight * rec)
+        total = total / n_hist
+        loss_vals = {'pose': pos.item() / n_hist, 'shape': shp.item() / n_hist, 'reconstruction': rec.item() / n_hist,
+                     'fk': fk.item() / n_hist, 'total_loss': total.item()}
+        if writer is not None:
+            self.log_loss_vals(loss_vals, writer, global_step)
+        return total, loss_vals

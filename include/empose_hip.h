@@ -1,0 +1,225 @@
+/*
+ * empose_hip.h -- C ABI of the MI355X (gfx950) implementation of EM-POSE's learned-gradient-descent fitting loop.
+ *
+ * The reference (facebookresearch/em-pose) has no FFI/operator layer for this path: it sits behind Python objects
+ * (SURVEY.md 8b).  This header is the boundary the build introduces underneath those objects; every entry point
+ * names the reference interface it replaces.  Conventions:
+ *   - extern "C", plain C types only; every function returns 0 on success or a negative EMPOSE_E* code, and
+ *     empose_last_error() returns a thread-local description.  No exception crosses the boundary.
+ *   - All tensors are caller-owned DEVICE pointers, fp32, row-major contiguous unless a leading dimension is given;
+ *     index data is int32.  Model descriptors (empose_*_desc) hold HOST pointers and are consumed at create time.
+ *   - Every compute call takes a stream handle (a hipStream_t passed as void*; NULL = default stream), is
+ *     asynchronous and stream-ordered, and never allocates: scratch comes from the caller via
+ *     empose_lgd_workspace_bytes().  A model is immutable after creation, so concurrent calls on distinct streams
+ *     with distinct workspaces are safe.
+ */
+#ifndef EMPOSE_HIP_H_
+#define EMPOSE_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMPOSE_OK 0
+#define EMPOSE_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define EMPOSE_EHIP (-2)     /* a HIP runtime call failed */
+#define EMPOSE_ENOMEM (-3)   /* workspace too small / allocation failed */
+
+#define EMPOSE_N_BODY 22      /* root + 21 body joints, reference configuration.py:104 */
+#define EMPOSE_N_SENSORS 12   /* virtual sensors always evaluated, reference models.py:383,538 */
+#define EMPOSE_K_FEAT 200     /* 189 pose-feature + 10 shape + 1 */
+#define EMPOSE_MAX_DENSE 8
+
+typedef void* empose_stream_t;
+typedef struct empose_model empose_model_t;
+typedef struct empose_mesh empose_mesh_t;
+
+const char* empose_last_error(void);
+/* Library/ABI version and the offload architecture it was compiled for ("gfx950"). */
+int empose_version(void);
+const char* empose_arch(void);
+
+/* ---- model description (host pointers) ------------------------------------------------------------------------ */
+
+/* Packed SMPL-H constants for the sensor sub-mesh; produced by em_pose_amd/bodymodels/tables.py.
+ * Replaces what the reference keeps as BodyModel buffers + VirtualMarkerHelper index caches
+ * (reference bodymodels/smpl.py:42-67, data/virtual_sensors.py:47-75). */
+typedef struct {
+  int n_sensors;          /* 12 */
+  int nv;                 /* needed vertices */
+  int j_off;              /* column of the first rest-joint coordinate in `wc` rows */
+  int ncp;                /* padded row count of wc (multiple of 4) */
+  int kb;                 /* skinning weights per vertex (after folding the hands into the wrists) */
+  int max_deg;            /* faces per sensor vertex (padded) */
+  const float* wc;        /* [ncp][200] */
+  const float* wct;       /* [200][ncp] */
+  const int* parents;     /* [22] */
+  const int* skin_idx;    /* [nv][kb] */
+  const float* skin_w;    /* [nv][kb] */
+  const int* bone_ptr;    /* [23] CSR over bones */
+  const int* bone_vert;   /* [bone_ptr[22]] */
+  const float* bone_w;    /* [bone_ptr[22]] */
+  const int* s_center;    /* [12] local vertex of the sensor */
+  const int* s_helper;    /* [12] local helper vertex */
+  const int* s_deg;       /* [12] */
+  const int* s_faces;     /* [12][max_deg][3] local vertex ids */
+  const int* path_ptr;    /* [23] root->joint paths */
+  const int* path;
+  const int* sub_ptr;     /* [23] subtree member lists */
+  const int* sub;
+} empose_smpl_desc;
+
+/* One Linear (+ BatchNorm1d in eval mode) (+ PReLU): reference nn/layers.py:13-43,46-77. weight is [out][in]. */
+typedef struct {
+  int in_dim, out_dim;
+  const float* weight;
+  const float* bias;
+  const float* bn_weight; /* NULL => no batch norm */
+  const float* bn_bias;
+  const float* bn_mean;
+  const float* bn_var;
+  float bn_eps;
+  int has_prelu;
+  float prelu;            /* single shared slope, nn.PReLU() */
+} empose_dense_desc;
+
+/* reference nn/layers.py:46-77: layers[0]=input_to_hidden, then 2*num_blocks hidden layers, then hidden_to_output. */
+typedef struct {
+  int n_layers;           /* 2 + 2*num_blocks, <= EMPOSE_MAX_DENSE; 0 => MLP absent */
+  int skip;               /* m_skip_connections: residual around every 2-layer block */
+  empose_dense_desc layers[EMPOSE_MAX_DENSE];
+} empose_mlp_desc;
+
+/* reference nn/layers.py:114 (nn.LSTM, unidirectional, gate order i,f,g,o). */
+typedef struct {
+  int num_layers;         /* <= 4; 0 => absent */
+  int input_size, hidden_size;
+  const float* w_ih[4];   /* [4H][in] */
+  const float* w_hh[4];   /* [4H][H] */
+  const float* b_ih[4];
+  const float* b_hh[4];
+} empose_lstm_desc;
+
+/* reference nn/models.py:372-394,424-457 (IterativeErrorFeedback.__init__/create_model). */
+typedef struct {
+  empose_smpl_desc smpl;
+  int n_markers;          /* 6 or 12: sensors fed to the networks */
+  int marker_idx[12];     /* first n_markers entries: which of the 12 virtual sensors they are (S_CONFIG_6) */
+  int n_iterations;       /* N */
+  float step_size;
+  int shape_avg;
+  int use_gradient;
+  int rnn_init;
+  empose_lstm_desc rnn;           /* rnn_init */
+  empose_dense_desc pose_head;    /* rnn_init: Linear(H,66) */
+  empose_dense_desc shape_head;   /* rnn_init: Linear(H,10) */
+  empose_mlp_desc pose_init;      /* !rnn_init */
+  empose_mlp_desc shape_init;
+  empose_mlp_desc pose_iter;
+  empose_mlp_desc shape_iter;
+} empose_model_desc;
+
+/* Replaces IterativeErrorFeedback construction + load_state_dict (reference models.py:23-33, eval/helpers.py:131-137):
+ * copies and packs every constant to the current HIP device. */
+int empose_model_create(const empose_model_desc* desc, empose_model_t** out);
+void empose_model_destroy(empose_model_t* model);
+
+/* ---- the whole N-step loop ------------------------------------------------------------------------------------ */
+
+/* Inputs are what `batch.get_inputs()` yields (reference data/data.py:304-309,433-459). */
+typedef struct {
+  int B, F;                      /* windows x frames; T = B*F */
+  const float* marker_pos;       /* [B][F][12*3] */
+  const float* marker_oris;      /* [B][F][12*9] row-major 3x3 */
+  const float* offset_t;         /* [B][12][3] */
+  const float* offset_r;         /* [B][12][3][3] */
+  const float* marker_masks;     /* [B][F][12] 1=present, or NULL */
+  const int* seq_lengths;        /* [B] or NULL (= F everywhere) */
+  const float* h0;               /* [L][B][H] carried LSTM state or NULL (zeros): reference layers.py:149-150 */
+  const float* c0;
+  float* h_n;                    /* [L][B][H] out, may be NULL */
+  float* c_n;
+  /* outputs (reference models.py:602-609,631): pose_hat holds root+body (66); callers slice [..., :3] / [..., 3:] */
+  float* pose_hat;               /* [B][F][66] */
+  float* shape_hat;              /* [B][F][10] */
+  float* joints_hat;             /* [B][F][66] */
+  /* optional histories, N+1 entries each (reference models.py:620-629); NULL to skip */
+  float* hist_pose;              /* [N+1][T][66] */
+  float* hist_shape;             /* [N+1][T][10] */
+  float* hist_joints;            /* [N+1][T][66] */
+  float* hist_markers;           /* [N+1][T][12*3] */
+  float* hist_markers_ori;       /* [N+1][T][12*9] */
+  /* optional trace of the gradient features fed to the update nets (reference models.py:578-582); NULL to skip */
+  float* trace_g_pose;           /* [N][T][66] */
+  float* trace_g_shape;          /* [N][T][10] */
+} empose_lgd_io;
+
+size_t empose_lgd_workspace_bytes(const empose_model_t* model, int B, int F);
+
+/* Replaces IterativeErrorFeedback.forward for one window batch (reference models.py:485-632). */
+int empose_lgd_forward(const empose_model_t* model, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
+                       empose_stream_t stream);
+
+/* ---- building blocks (also what the unit tests drive) --------------------------------------------------------- */
+
+/* One SMPL-H evaluation restricted to the sensor sub-mesh and, optionally, the residual gradient.
+ * Replaces get_estimated_real_markers + reconstruction_loss + autograd.backward
+ * (reference models.py:471-483,560-579; loss.py:23-41; virtual_sensors.py:85-96).
+ *   theta [T][ld_theta] (66 used), beta [T][ld_beta] (10 used)
+ *   offset_r/offset_t per WINDOW ([T/F][12][3][3], [T/F][12][3]); F = frames per window
+ *   targets: tgt [T][ld_tgt] holding n_markers*3 positions then n_markers*9 orientations (the network input
+ *            layout of prepare_inputs, reference models.py:106-125); frame_scale [T] per-frame loss weight
+ *   outputs pos [T][36], ori [T][108], joints [T][66]; g_theta [T][ld_g] (66), g_beta [T][ld_gb] (10) or NULL.
+ * workspace: empose_smpl_workspace_bytes(model, T). */
+size_t empose_smpl_workspace_bytes(const empose_model_t* model, int T);
+int empose_smpl_sensors_fwd_bwd(const empose_model_t* model, int T, int F,
+                                const float* theta, int ld_theta, const float* beta, int ld_beta,
+                                const float* offset_r, const float* offset_t,
+                                const float* tgt, int ld_tgt, const float* frame_scale,
+                                float* pos, float* ori, float* joints,
+                                float* g_theta, int ld_g, float* g_beta, int ld_gb,
+                                void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+/* Both update networks on x [T][ldx]: d_pose [T][66], d_shape [T][10]
+ * (replaces pose_net_iter / shape_net_iter, reference models.py:586-587; layers.py:46-77). */
+size_t empose_update_workspace_bytes(const empose_model_t* model, int T);
+int empose_update_nets_fwd(const empose_model_t* model, int T, const float* x, int ldx, float* d_pose, float* d_shape,
+                           void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+/* The init LSTM over ragged windows: x [B][F][ldx] (input_size used) -> y [B][F][H]
+ * (replaces RNNLayer.forward, reference layers.py:133-157). */
+size_t empose_lstm_workspace_bytes(const empose_model_t* model, int B, int F);
+int empose_lstm_fwd(const empose_model_t* model, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                    const float* h0, const float* c0, float* y, float* h_n, float* c_n,
+                    void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+/* C[M][ldc] = act((A[M][lda] . W[N][ldw]^T) * scale[n] + shift[n]) on the fp32 matrix cores; scale/shift may be NULL.
+ * Exposed for tests and for host code that needs a plain fp32 linear layer. */
+int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                      const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream);
+
+/* ---- full-mesh evaluation (final vertices; ground-truth preprocessing) ---------------------------------------- */
+
+typedef struct {
+  int n_vertices, j_off, ncp, kb;
+  const float* wc;        /* [ncp][200] rows: V*3 vertex coordinates then 66 joint coordinates */
+  const int* skin_idx;    /* [V][kb] */
+  const float* skin_w;    /* [V][kb] */
+  const int* parents;     /* [22] */
+} empose_mesh_desc;
+
+int empose_mesh_create(const empose_mesh_desc* desc, empose_mesh_t** out);
+void empose_mesh_destroy(empose_mesh_t* mesh);
+size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T);
+/* Replaces SMPLLayer.forward/fk (reference bodymodels/smpl.py:81-147): poses [T][66] (root first), betas [T][10],
+ * trans [T][3] or NULL -> vertices [T][V][3], joints [T][22][3]. */
+int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                             const float* trans, float* vertices, float* joints,
+                             void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMPOSE_HIP_H_ */

@@ -1,0 +1,403 @@
+"""
+GPU parity tests (run with `-m gpu` on an MI355X): every HIP entry point of include/empose_hip.h against the oracle
+(oracle/torch_ref.py pinned to the reference; oracle/analytic_np.py for per-kernel intermediates) and against the
+golden vectors recorded from the reference itself.
+
+Tolerance: BASELINE.json north_star -- outputs (pose, shape, joints, vertices) within 1e-4 abs fp32 of the reference
+PyTorch-CPU path. Gradient features are O(10) so they carry a matching relative tolerance.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from em_pose_amd import _lib, synthetic
+from em_pose_amd.bodymodels import tables as TB
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.helpers.configuration import lgd_config
+from em_pose_amd.nn.models import create_model
+from oracle import analytic_np as A
+from oracle import torch_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+DEV = 'cuda:0'
+
+
+def gpu(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype).to(DEV).contiguous()
+
+
+@pytest.fixture(scope='module')
+def big_model():
+    return synthetic.make_model()
+
+
+def build_net(case_or_cfg, model, vids=None, sd=None):
+    smpl = SMPLLayer(model)
+    net = create_model(case_or_cfg, smpl)
+    if sd is not None:
+        missing, unexpected = net.load_state_dict(H.sd_to_torch(sd), strict=False)
+        assert not unexpected and all(k.startswith('smpl.') for k in missing)
+    if vids is not None:
+        net.vertex_ids = [int(v) for v in vids]
+    return net.to(DEV).eval()
+
+
+def cfg_of(meta, hidden=32):
+    return lgd_config(int(meta['n_markers']), bool(meta['rnn']), int(meta['N']), hidden=hidden, rnn_hidden=hidden)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_library_reports_gfx950():
+    lib = _lib.lib()
+    assert lib.empose_arch() == b'gfx950'
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 4, 4), (64, 64, 32), (100, 66, 296), (257, 10, 512), (1000, 512, 144),
+                                   (4096, 512, 512), (333, 200, 320), (130, 2048, 72)])
+def test_linear_f32(M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    lda = K + 8
+    a = rng.normal(size=(M, lda)).astype(np.float32)
+    w = rng.normal(size=(N, K)).astype(np.float32) / np.sqrt(K)
+    scale = rng.uniform(0.5, 1.5, size=N).astype(np.float32)
+    shift = rng.normal(size=N).astype(np.float32)
+    # asymmetric operands: catches transposed outputs
+    ref = (a[:, :K].astype(np.float64) @ w.astype(np.float64).T) * scale + shift
+    ref = np.where(ref >= 0, ref, 0.25 * ref)
+    A_, W_, out = gpu(a), gpu(w), torch.full((M, N + 3), -7.0, device=DEV)
+    _lib.check(_lib.lib().empose_linear_f32(_lib.dptr(A_), lda, _lib.dptr(W_), K, _lib.dptr(out), N + 3, M, N, K,
+                                            _lib.dptr(gpu(scale)), _lib.dptr(gpu(shift)), 1, 0.25,
+                                            _lib.current_stream()))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got[:, :N], ref, atol=2e-5 * np.sqrt(K / 32), rtol=1e-5)
+    assert (got[:, N:] == -7.0).all()  # never writes outside N
+
+
+def test_linear_f32_rejects_bad_arguments():
+    x = torch.zeros(8, 8, device=DEV)
+    rc = _lib.lib().empose_linear_f32(_lib.dptr(x), 8, _lib.dptr(x), 8, _lib.dptr(x), 8, 8, 8, 6, None, None, 0, 0.0,
+                                      None)
+    assert rc == -1 and b'multiples of 4' in _lib.lib().empose_last_error()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _smpl_case(model, vids, T, F, seed, n_markers):
+    rng = np.random.default_rng(seed)
+    theta = rng.normal(0, 0.25, size=(T, 66))
+    beta = rng.normal(0, 1.0, size=(T, 10))
+    W = T // F
+    off_t = rng.normal(0, 0.02, size=(W, 12, 3))
+    off_r = synthetic._exp_so3(rng.normal(0, 0.1, size=(W, 12, 3)))
+    idx = list(range(12)) if n_markers == 12 else list(CONST.S_CONFIG_6)
+    tab64 = TB.build_lgd_tables(model, vids, dtype=np.float64)
+    rep = lambda a: np.repeat(a, F, axis=0)
+    base = A.smpl_sensors(tab64, theta, beta, rep(off_r), rep(off_t))
+    tgt_pos = base['pos'][:, idx] + rng.normal(0, 0.01, size=(T, len(idx), 3))
+    tgt_ori = base['ori'][:, idx] @ synthetic._exp_so3(rng.normal(0, 0.05, size=(T, len(idx), 3)))
+    scale = rng.choice([0.0, 1.0, 1.0, 1.0, 32.0 / 20.0], size=T)
+    ref = A.smpl_sensors(tab64, theta, beta, rep(off_r), rep(off_t), tgt_pos, tgt_ori, idx, scale)
+    tgt = np.concatenate([tgt_pos.reshape(T, -1), tgt_ori.reshape(T, -1)], axis=1)
+    return theta, beta, off_r, off_t, tgt, scale, ref
+
+
+@pytest.mark.parametrize('which,n_markers', [('small', 12), ('small', 6), ('big', 12), ('big', 6)])
+def test_smpl_sensors_fwd_bwd(which, n_markers, big_model):
+    if which == 'small':
+        model, vids = H.small_model(), synthetic.small_vertex_ids(160)
+    else:
+        model, vids = big_model, CONST.VERTEX_IDS
+    T, F = 96, 8
+    theta, beta, off_r, off_t, tgt, scale, ref = _smpl_case(model, vids, T, F, 11, n_markers)
+    net = build_net(lgd_config(n_markers, False, 1, hidden=32), model, vids)
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    th, be = gpu(theta), gpu(beta)
+    pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
+    g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
+    nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    tg = gpu(tgt)
+    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10,
+                                               _lib.dptr(gpu(off_r)), _lib.dptr(gpu(off_t)), _lib.dptr(tg),
+                                               tg.shape[1], _lib.dptr(gpu(scale)), _lib.dptr(pos), _lib.dptr(ori),
+                                               _lib.dptr(joints), _lib.dptr(g_th), 66, _lib.dptr(g_be), 10,
+                                               _lib.dptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pos.cpu().numpy().reshape(T, 12, 3), ref['pos'], atol=1e-5)
+    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=2e-5)
+    np.testing.assert_allclose(joints.cpu().numpy().reshape(T, 22, 3), ref['joints'], atol=1e-5)
+    gmax = np.abs(ref['g_theta']).max()
+    np.testing.assert_allclose(g_th.cpu().numpy(), ref['g_theta'], atol=2e-4 * max(gmax, 1.0), rtol=1e-3)
+    np.testing.assert_allclose(g_be.cpu().numpy(), ref['g_beta'], atol=2e-4 * max(np.abs(ref['g_beta']).max(), 1.0),
+                               rtol=1e-3)
+    # frames with zero weight contribute an exactly-zero gradient
+    assert (g_th.cpu().numpy()[scale == 0] == 0).all()
+
+
+def test_smpl_forward_only_matches(big_model):
+    """tgt=NULL: positions/orientations/joints only (the final evaluation of the loop)."""
+    T, F = 64, 32
+    theta, beta, off_r, off_t, tgt, scale, ref = _smpl_case(big_model, CONST.VERTEX_IDS, T, F, 5, 12)
+    net = build_net(lgd_config(12, False, 1, hidden=32), big_model)
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
+    nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(gpu(theta)), 66, _lib.dptr(gpu(beta)), 10,
+                                               _lib.dptr(gpu(off_r)), _lib.dptr(gpu(off_t)), None, 0, None,
+                                               _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), None, 0, None, 0,
+                                               _lib.dptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pos.cpu().numpy().reshape(T, 12, 3), ref['pos'], atol=1e-5)
+    # rotation outputs are orthonormal frames times the offset rotation
+    o = ori.cpu().numpy().reshape(T, 12, 3, 3).astype(np.float64)
+    np.testing.assert_allclose(o @ np.swapaxes(o, -1, -2), np.broadcast_to(np.eye(3), o.shape), atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_update_nets_and_lstm_vs_oracle():
+    case = H.load_case('lgdrnn12_n4_carry')
+    model = H.small_model()
+    net = build_net(cfg_of(case['meta']), model, case['meta']['vertex_ids'], case['sd'])
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    sd = H.sd_to_torch(case['sd'])
+    rng = np.random.default_rng(0)
+    T = 200
+    x = rng.normal(size=(T, 296)).astype(np.float32)
+    want_p = R.mlp_forward(sd, 'pose_net_iter.', torch.from_numpy(x)).numpy()
+    want_s = R.mlp_forward(sd, 'shape_net_iter.', torch.from_numpy(x)).numpy()
+    dp, ds = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
+    nbytes = lib.empose_update_workspace_bytes(handle, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    xg = gpu(x)
+    _lib.check(lib.empose_update_nets_fwd(handle, T, _lib.dptr(xg), 296, _lib.dptr(dp), _lib.dptr(ds), _lib.dptr(ws),
+                                          nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dp.cpu().numpy(), want_p, atol=2e-5)
+    np.testing.assert_allclose(ds.cpu().numpy(), want_s, atol=2e-5)
+
+    # LSTM: ragged lengths + carried state
+    B, F, Hh = 5, 13, 32
+    xs = rng.normal(size=(B, F, 144)).astype(np.float32)
+    lens = np.array([13, 7, 1, 13, 4], dtype=np.int32)
+    h0 = rng.normal(size=(2, B, Hh)).astype(np.float32) * 0.3
+    c0 = rng.normal(size=(2, B, Hh)).astype(np.float32) * 0.3
+    want_y, (want_h, want_c) = R.lstm_forward(sd, 'rnn.lstm.', torch.from_numpy(xs), torch.from_numpy(lens).long(),
+                                              (torch.from_numpy(h0), torch.from_numpy(c0)))
+    y = torch.empty(B, F, Hh, device=DEV)
+    hn, cn = torch.empty(2, B, Hh, device=DEV), torch.empty(2, B, Hh, device=DEV)
+    nbytes = lib.empose_lstm_workspace_bytes(handle, B, F)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    xg = gpu(xs)
+    _lib.check(lib.empose_lstm_fwd(handle, B, F, _lib.dptr(xg), 144, _lib.dptr(gpu(lens, torch.int32)),
+                                   _lib.dptr(gpu(h0)), _lib.dptr(gpu(c0)), _lib.dptr(y), _lib.dptr(hn), _lib.dptr(cn),
+                                   _lib.dptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), want_y.numpy(), atol=1e-5)
+    np.testing.assert_allclose(hn.cpu().numpy(), want_h.numpy(), atol=1e-5)
+    np.testing.assert_allclose(cn.cpu().numpy(), want_c.numpy(), atol=1e-5)
+
+
+def test_mlp_module_forward_vs_oracle():
+    case = H.load_case('lgd12_n4')
+    net = build_net(cfg_of(case['meta']), H.small_model(), case['meta']['vertex_ids'], case['sd'])
+    x = torch.from_numpy(np.random.default_rng(3).normal(size=(7, 11, 144)).astype(np.float32))
+    want = R.mlp_forward(H.sd_to_torch(case['sd']), 'pose_net_init.', x.reshape(-1, 144)).reshape(7, 11, 66)
+    got = net.pose_net_init(x.to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _check_against_record(net, rec, res, B, F, N):
+    pose = res['pose'].cpu().numpy()
+    np.testing.assert_allclose(pose[:, :, 3:], rec['out_pose_hat'], atol=ATOL)
+    np.testing.assert_allclose(pose[:, :, :3], rec['out_root_ori_hat'], atol=ATOL)
+    np.testing.assert_allclose(res['shape'].cpu().numpy(), rec['out_shape_hat'], atol=ATOL)
+    np.testing.assert_allclose(res['joints'].cpu().numpy(), rec['out_joints_hat'], atol=ATOL)
+    for key, name in (('pose', 'pose'), ('shape', 'shape'), ('joints', 'joints'), ('markers', 'markers'),
+                      ('markers_ori', 'markers_ori')):
+        got = res['hist'][key].cpu().numpy().reshape(N + 1, B, F, -1)
+        np.testing.assert_allclose(got, rec['hist_' + name], atol=ATOL)
+    gp = res['trace']['g_pose'].cpu().numpy()
+    gs = res['trace']['g_shape'].cpu().numpy()
+    np.testing.assert_allclose(gp, rec['g_pose'], atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(gs, rec['g_shape'], atol=2e-3, rtol=2e-3)
+
+
+def _run_case(name, tags, sl_key=None):
+    case = H.load_case(name)
+    meta, w = case['meta'], case['in']
+    N = int(meta['N'])
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    state = None
+    for tag, (sf, ef) in tags:
+        rec = case[tag]
+        inp = H.oracle_inputs(w, sl=w[sl_key] if sl_key else None, sf=sf, ef=ef)
+        B, F = inp['marker_pos'].shape[:2]
+        res = net.forward_tensors(inp['marker_pos'].to(DEV), inp['marker_oris'].to(DEV), inp['offset_t'].to(DEV),
+                                  inp['offset_r'].to(DEV),
+                                  None if inp['marker_masks'] is None else inp['marker_masks'].to(DEV),
+                                  inp['seq_lengths'].to(DEV), state=state, keep_history=True,
+                                  keep_gradient_trace=True)
+        torch.cuda.synchronize()
+        _check_against_record(net, rec, res, B, F, N)
+        state = res['state']
+        if state is not None:
+            np.testing.assert_allclose(state[0].cpu().numpy(), rec['rnn_h'], atol=2e-5)
+            np.testing.assert_allclose(state[1].cpu().numpy(), rec['rnn_c'], atol=2e-5)
+
+
+def test_golden_lgd12_no_rnn():
+    _run_case('lgd12_n4', [('run', (None, None))])
+
+
+def test_golden_lgdrnn12_two_chunks_with_state_carry():
+    _run_case('lgdrnn12_n4_carry', [('chunk0', (0, 32)), ('chunk1', (32, 64))])
+
+
+def test_golden_lgdrnn6():
+    _run_case('lgdrnn6_n2', [('run', (None, None))])
+
+
+def test_golden_ragged_and_masked():
+    _run_case('lgdrnn12_n3_ragged_masked', [('run', (None, None))], sl_key='seq_lengths')
+
+
+def test_module_forward_mirrors_reference_interface():
+    """forward(batch) through the batch container: dict keys/shapes, history shapes, state carry (models.py:485-632)."""
+    from em_pose_amd.data.data import RealBatch
+    case = H.load_case('lgdrnn12_n4_carry')
+    meta, w = case['meta'], case['in']
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    for tag, (sf, ef), new in (('chunk0', (0, 32), True), ('chunk1', (32, 64), False)):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        b = RealBatch([0, 1], torch.tensor([32, 32]), t(w['poses'][:, sf:ef]), t(w['shapes']), torch.zeros(2, 32, 3),
+                      t(w['marker_pos'][:, sf:ef]), t(w['marker_oris'][:, sf:ef]), torch.ones(2, 32, 12),
+                      t(w['offset_t']), t(w['offset_r'])).to_gpu(torch.device(DEV))
+        out = net(b, is_new_sequence=new)
+        rec = case[tag]
+        for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+            assert out[k].shape == rec['out_' + k].shape
+            np.testing.assert_allclose(out[k].cpu().numpy(), rec['out_' + k], atol=ATOL)
+        assert len(net.pose_hat_history) == 5
+        assert net.markers_hat_history[0].shape == (2, 32 * 12, 3)
+        assert net.markers_ori_hat_history[0].shape == (2, 32 * 12 * 3, 3)
+        assert net.joints_hat_history[0].shape == (2, 32 * 22, 3)
+        _, loss_vals = net.backward(b, out)
+        assert set(loss_vals) == {'pose', 'shape', 'reconstruction', 'fk', 'total_loss'}
+
+
+def test_cpu_tensors_are_refused():
+    case = H.load_case('lgd12_n4')
+    net = build_net(cfg_of(case['meta']), H.small_model(), case['meta']['vertex_ids'], case['sd'])
+    w = case['in']
+    with pytest.raises(_lib.EmposeError):
+        net.forward_tensors(torch.from_numpy(w['marker_pos']), torch.from_numpy(w['marker_oris']),
+                            torch.from_numpy(w['offset_t']), torch.from_numpy(w['offset_r']))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _full_size_net(big_model, n_markers=12, rnn=True, N=4, seed=1615200973):
+    torch.manual_seed(seed)
+    net = create_model(lgd_config(n_markers, rnn, N), SMPLLayer(big_model))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    return net.eval()
+
+
+def _oracle_sensors(big_model):
+    bm = R.BodyModelTensors(big_model)
+    tables = R.sensor_tables(big_model['f'], CONST.VERTEX_IDS)
+
+    def fn(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, CONST.VERTEX_IDS, torch.from_numpy(poses),
+                                          torch.from_numpy(betas), torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    return bm, tables, fn
+
+
+@pytest.mark.parametrize('n_markers,rnn,N', [(12, True, 4), (12, False, 4), (6, True, 2)])
+def test_full_size_model_vs_oracle(big_model, n_markers, rnn, N):
+    """The released architectures (2x512 nets, 2x512 LSTM, V=6890 body model, real sensor vertex ids)."""
+    net = _full_size_net(big_model, n_markers, rnn, N)
+    bm, tables, fn = _oracle_sensors(big_model)
+    B, F = 3, 32
+    w = synthetic.make_windows(B, F, 1234 + n_markers, fn)
+    inp = H.oracle_inputs(w)
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    want, hist = R.ief_forward(sd, bm, tables, CONST.VERTEX_IDS, inp, n_markers=n_markers, N=N, rnn_init=rnn)
+    net = net.to(DEV)
+    res = net.forward_tensors(*(inp[k].to(DEV) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')),
+                              keep_history=True, keep_gradient_trace=True)
+    torch.cuda.synchronize()
+    pose = res['pose'].cpu().numpy()
+    np.testing.assert_allclose(pose[:, :, 3:], want['pose_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(pose[:, :, :3], want['root_ori_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['shape'].cpu().numpy(), want['shape_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['joints'].cpu().numpy(), want['joints_hat'].numpy(), atol=ATOL)
+    got_m = res['hist']['markers'].cpu().numpy().reshape(N + 1, B * F, 12, 3)
+    np.testing.assert_allclose(got_m, np.stack([t.numpy() for t in hist['markers']]), atol=ATOL)
+    # MPJPE between the two implementations, in millimetres (north_star: within 0.1 mm)
+    dj = (res['joints'].cpu().numpy() - want['joints_hat'].numpy()).reshape(B, F, 22, 3)
+    assert np.linalg.norm(dj, axis=-1).mean() * 1000.0 < 0.1
+
+
+def test_full_size_properties_shard_invariance_and_determinism(big_model):
+    """BASELINE config 3 size (B=1024, ws=32): results for a window do not depend on its position in the batch or on
+    which other windows share the launch (the multi-GPU sharding of SURVEY.md 8e relies on exactly this)."""
+    net = _full_size_net(big_model).to(DEV)
+    _, _, fn = _oracle_sensors(big_model)
+    w = synthetic.make_windows(16, 32, 99, fn)
+    rep = 64
+    big = {k: np.concatenate([w[k]] * rep, axis=0) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')}
+    args = lambda d, s: [torch.from_numpy(d[k][s]).to(DEV) for k in ('marker_pos', 'marker_oris', 'offset_t',
+                                                                      'offset_r')]
+    full = net.forward_tensors(*args(big, slice(None)))
+    torch.cuda.synchronize()
+    assert full['pose'].shape == (1024, 32, 66)
+    assert torch.isfinite(full['pose']).all() and torch.isfinite(full['joints']).all()
+    small = net.forward_tensors(*args(w, slice(None)))
+    for k in ('pose', 'shape', 'joints'):
+        a = full[k].cpu().numpy()
+        # every replica of the 16 windows gives the same answer, and equals the 16-window launch
+        np.testing.assert_allclose(a.reshape(rep, 16, 32, -1), np.broadcast_to(a[:16], (rep, 16, 32, a.shape[-1])),
+                                   atol=1e-6)
+        np.testing.assert_allclose(a[:16], small[k].cpu().numpy(), atol=1e-6)
+    # shape is constant inside a window (m_average_shape)
+    s = full['shape'].cpu().numpy()
+    np.testing.assert_allclose(s, np.broadcast_to(s[:, :1], s.shape), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_full_mesh_vertices_vs_oracle(big_model):
+    smpl = SMPLLayer(big_model).to(DEV)
+    rng = np.random.default_rng(2)
+    n = 70
+    pose = rng.normal(0, 0.3, size=(n, 63)).astype(np.float32)
+    root = rng.normal(0, 0.5, size=(n, 3)).astype(np.float32)
+    betas = rng.normal(0, 1, size=(n, 16)).astype(np.float32)
+    trans = rng.normal(0, 1, size=(n, 3)).astype(np.float32)
+    bm = R.BodyModelTensors(big_model)
+    v_ref, j_ref = R.smpl_fk(bm, torch.from_numpy(pose), torch.from_numpy(betas), torch.from_numpy(root),
+                             torch.from_numpy(trans))
+    v, j = smpl(poses_body=gpu(pose), betas=gpu(betas), poses_root=gpu(root), trans=gpu(trans))
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
+    np.testing.assert_allclose(j.cpu().numpy(), j_ref[:, :22].numpy(), atol=2e-5)
+    # zero pose / zero shape reproduces the template; broadcast of a single beta row
+    v0, j0 = smpl(poses_body=torch.zeros(2, 63, device=DEV), betas=torch.zeros(10, device=DEV))
+    np.testing.assert_allclose(v0[0].cpu().numpy(), big_model['v_template'], atol=1e-6)
+    np.testing.assert_allclose(v0[1].cpu().numpy(), v0[0].cpu().numpy(), atol=0)

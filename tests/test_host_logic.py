@@ -1,0 +1,122 @@
+"""Host-side logic of the package (CPU): configuration, model construction, packed tables, batch containers."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from em_pose_amd import synthetic
+from em_pose_amd.bodymodels import tables as TB
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.data.data import RealBatch
+from em_pose_amd.helpers.configuration import CONSTANTS as C
+from em_pose_amd.helpers.configuration import Configuration, lgd_config
+from em_pose_amd.nn.models import create_model, mask_from_seq_lengths, reconstruction_loss
+from tests import helpers as H
+
+
+def test_known_answers_of_released_configurations():
+    """Parameter counts / model names recorded from the reference (tests/golden/known_answers.json, README.md:228-229)."""
+    known = json.load(open(os.path.join(H.GOLDEN, 'known_answers.json')))
+    smpl = SMPLLayer(H.small_model())
+    for tag, cfg in (('lgd_rnn_6_N2', lgd_config(6, True, 2, lr=0.0005)),
+                     ('lgd_rnn_12_N4', lgd_config(12, True, 4)),
+                     ('lgd_12_N4', lgd_config(12, False, 4))):
+        net = create_model(cfg, smpl)
+        n = sum(p.numel() for k, p in net.named_parameters() if not k.startswith('smpl.'))
+        assert n == known[tag]['params_without_bodymodel']
+        assert net.model_name() == known[tag]['model_name']
+    net = create_model(lgd_config(6, True, 2, lr=0.0005), smpl)
+    assert sum(p.numel() for p in net.parameters()) == 5721419  # reference README.md:228
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    smpl = SMPLLayer(H.small_model())
+    for name, rnn in (('lgdrnn12_n4_carry', True), ('lgd12_n4', False)):
+        case = H.load_case(name)
+        net = create_model(lgd_config(12, rnn, 4, hidden=32, rnn_hidden=32), smpl)
+        mine = {k for k in net.state_dict() if not k.startswith('smpl.')}
+        assert mine == set(case['sd'])
+        for k, v in net.state_dict().items():
+            if not k.startswith('smpl.'):
+                assert tuple(v.shape) == case['sd'][k].shape, k
+    keys = {k for k in net.state_dict() if k.startswith('smpl.bm.')}
+    assert {'smpl.bm.f', 'smpl.bm.v_template', 'smpl.bm.shapedirs', 'smpl.bm.posedirs', 'smpl.bm.J_regressor',
+            'smpl.bm.weights'} <= keys
+    assert net.state_dict()['smpl.bm.posedirs'].shape == (459, 160 * 3)
+
+
+def test_configuration_roundtrip(tmp_path):
+    cfg = lgd_config(6, True, 2)
+    p = tmp_path / 'config.json'
+    cfg.to_json(str(p))
+    back = Configuration.from_json(str(p))
+    assert vars(back) == vars(cfg)
+    cli = Configuration.parse_cmd(['--m_type', 'ief', '--n_markers', '6', '--m_rnn_init', '--use_marker_pos'])
+    assert cli.m_type == 'ief' and cli.n_markers == 6 and cli.m_rnn_init and cli.m_step_size == 0.1
+    assert C.S_CONFIG_6 == [0, 1, 2, 6, 7, 11] and len(C.VERTEX_IDS) == 12 and len(C.SMPL_PARENTS) == 22
+
+
+def test_tables_match_reference_topology_vectors():
+    z = np.load(os.path.join(H.GOLDEN, 'components.npz'))
+    model = H.small_model()
+    vids = synthetic.small_vertex_ids(160)
+    sub_faces, vf_sub, helpers = TB.sensor_topology(model['f'], vids)
+    assert (sub_faces == z['vs_sub_faces']).all() and (vf_sub == z['vs_sub_vertex_faces']).all()
+    assert (helpers == z['vs_helpers']).all()
+    tab = TB.build_lgd_tables(model, vids)
+    # every sensor patch refers to needed vertices only, helper is part of the ring
+    assert tab['s_faces'].max() < tab['nv'] and (tab['s_deg'] == 6).all()
+    for m in range(12):
+        ring = set(tab['s_faces'][m, :tab['s_deg'][m]].reshape(-1).tolist())
+        assert tab['s_center'][m] in ring and tab['s_helper'][m] in ring
+    assert tab['needed'][tab['s_center']].tolist() == vids
+    # folded skinning weights stay convex; CSR by bone is the transpose of the per-vertex table
+    np.testing.assert_allclose(tab['skin_w'].sum(1), 1.0, atol=1e-6)
+    dense = np.zeros((tab['nv'], 22))
+    for s in range(tab['nv']):
+        for k in range(tab['kb']):
+            dense[s, tab['skin_idx'][s, k]] += tab['skin_w'][s, k]
+    dense2 = np.zeros_like(dense)
+    for b in range(22):
+        for q in range(tab['bone_ptr'][b], tab['bone_ptr'][b + 1]):
+            dense2[tab['bone_vert'][q], b] = tab['bone_w'][q]
+    np.testing.assert_allclose(dense, dense2, atol=0)
+    # tree walks
+    assert tab['path'][tab['path_ptr'][20]:tab['path_ptr'][21]].tolist() == [0, 3, 6, 9, 13, 16, 18, 20]
+    assert sorted(tab['sub'][tab['sub_ptr'][16]:tab['sub_ptr'][17]].tolist()) == [16, 18, 20]
+    assert tab['sub_ptr'][1] == 22  # the root's subtree is everything
+
+
+def test_loss_helpers_match_reference_vectors():
+    z = np.load(os.path.join(H.GOLDEN, 'components.npz'))
+    gt, hat = torch.from_numpy(z['rl_gt']), torch.from_numpy(z['rl_hat'])
+    sl, mm = torch.from_numpy(z['rl_len']), torch.from_numpy(z['rl_mask'])
+    np.testing.assert_allclose(reconstruction_loss(gt, hat, sl, mm).numpy(), z['rl_full'], rtol=1e-6)
+    np.testing.assert_allclose(reconstruction_loss(gt, hat).numpy(), z['rl_plain'], rtol=1e-6)
+    assert (mask_from_seq_lengths(sl).numpy() == z['mask_from_len']).all()
+
+
+def test_real_batch_suppresses_missing_sensors():
+    B, F = 2, 5
+    masks = torch.ones(B, F, 12)
+    masks[0, 2, 3] = 0
+    b = RealBatch([0, 1], torch.tensor([5, 5]), torch.zeros(B, F, 66), torch.zeros(B, 10), torch.zeros(B, F, 3),
+                  torch.ones(B, F, 36), torch.ones(B, F, 108), masks)
+    inp = b.get_inputs(sf=1, ef=4)
+    assert inp['marker_pos'].shape == (B, 3, 36) and inp['marker_masks'].shape == (B, 3, 12)
+    assert inp['marker_pos'].reshape(B, 3, 12, 3)[0, 1, 3].abs().sum() == 0
+    assert inp['marker_oris'].reshape(B, 3, 12, 9)[0, 1, 3].abs().sum() == 0
+    assert inp['marker_pos'].sum() == B * 3 * 36 - 3
+    assert inp['offset_r'].shape == (B, 12, 3, 3)
+
+
+def test_resnet_plumbing_on_cpu():
+    """BASELINE config 0: ResNet, one 32-frame 12-sensor window, forward on PyTorch CPU."""
+    cfg = Configuration.defaults(m_type='resnet', m_hidden_size=64, m_num_layers=3, use_marker_pos=True,
+                                 use_marker_ori=True, n_markers=12, window_size=32)
+    net = create_model(cfg, None).eval()
+    b = RealBatch([0], torch.tensor([32]), torch.zeros(1, 32, 66), torch.zeros(1, 10), torch.zeros(1, 32, 3),
+                  torch.randn(1, 32, 36), torch.randn(1, 32, 108), torch.ones(1, 32, 12))
+    out = net(b)
+    assert out['pose_hat'].shape == (1, 32, 63) and out['root_ori_hat'].shape == (1, 32, 3)
