@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""
+Headline benchmark: frames/sec of the LGD-RNN-12 inference forward (N=4 iterations, window size 32, 12 sensors,
+batch 1024 windows per GPU -- BASELINE.json configs[2], model 1615200973's architecture) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step is one call of IterativeErrorFeedback.forward_tensors -> empose_lgd_forward on a device-resident batch of
+synthetic 12-sensor windows (synthetic SMPL-H-shaped body model, V=6890; random-init weights of the released
+architecture, BatchNorm statistics randomised; the licensed SMPL-H asset and the released weights cannot be shipped).
+Windows are independent, so ranks shard them with no data-path collective (weak scaling); the only RCCL traffic is an
+all-gather of per-rank result checksums / counts at the end.
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline      the dominant kernel (the 2x(T x 512 x 512) hidden-layer GEMM launch of the update nets) against the
+                fp32 matrix-core peak, from HIP events recorded around every launch on the launch stream
+                (empose_profile_*), in a profiling pass of the same workload right after the timed region;
+  cpu_baseline  the oracle (oracle/torch_ref.py: dense full-mesh SMPL-H + autograd, the reference's algorithm) timed on
+                the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+MODEL_SEED = 1615200973  # the released LGD-RNN-12 model id (BASELINE.json configs[2])
+
+
+def build_net(n_markers, rnn, N):
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn.models import create_model
+    model = synthetic.make_model()
+    torch.manual_seed(MODEL_SEED)
+    net = create_model(lgd_config(n_markers, rnn, N), SMPLLayer(model))
+    g = torch.Generator().manual_seed(MODEL_SEED + 1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    return net.eval(), model
+
+
+def make_inputs(net, dev, B, F, seed):
+    """Synthetic windows; the sensor readings come from the HIP body model itself (+ 5 mm / 2 deg noise)."""
+    from em_pose_amd import synthetic
+
+    def sensors(poses, betas, o_r, o_t):
+        T = poses.shape[0]
+        pos, ori, _ = net.get_estimated_real_markers(torch.from_numpy(poses).to(dev), torch.from_numpy(betas).to(dev),
+                                                     torch.from_numpy(o_r[::F].copy()).to(dev),
+                                                     torch.from_numpy(o_t[::F].copy()).to(dev), frames_per_window=F)
+        return pos.cpu().numpy(), ori.cpu().numpy()
+    w = synthetic.make_windows(B, F, seed, sensors)
+    return w, [torch.from_numpy(w[k]).to(dev) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')]
+
+
+def flops_per_frame(net):
+    """Dense-contraction flops of one frame: LSTM + heads + N x two 6-layer MLPs + blend matrices."""
+    d_in, dx, N = net.input_size, net.input_iter_size, net.N
+    h = net.config.m_hidden_size
+    mlp = lambda i, o: 2 * (i * h + 4 * h * h + h * o)
+    fl = N * (mlp(dx, 66) + mlp(dx, 10))
+    if net.rnn_init:
+        H, L = net.rnn.hidden_size, net.rnn.num_layers
+        fl += 2 * 4 * H * (d_in + H) + (L - 1) * 2 * 4 * H * (H + H) + 2 * H * 76
+    else:
+        fl += mlp(d_in, 66) + mlp(d_in, 10)
+    return fl
+
+
+def cpu_baseline(net, model, w, seconds_target=20.0):
+    """Oracle (reference algorithm: dense full mesh + autograd) on the host cores, bounded sample."""
+    from em_pose_amd.helpers.configuration import CONSTANTS as C
+    from oracle import torch_ref as R
+    bm = R.BodyModelTensors(model)
+    tables = R.sensor_tables(model['f'], C.VERTEX_IDS)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    F = w['marker_pos'].shape[1]
+
+    def run(nb):
+        inp = {k: torch.from_numpy(w[k][:nb]) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')}
+        inp['marker_masks'] = None
+        inp['seq_lengths'] = torch.full((nb,), F, dtype=torch.int64)
+        t0 = time.perf_counter()
+        R.ief_forward(sd, bm, tables, C.VERTEX_IDS, inp, n_markers=net.n_markers, N=net.N, rnn_init=net.rnn_init)
+        return time.perf_counter() - t0
+
+    run(2)  # warm-up (thread pools, allocator)
+    nb = 8
+    t = run(nb)
+    reps = [t]
+    while sum(reps) < seconds_target and len(reps) < 5:
+        reps.append(run(nb))
+    best = float(np.median(reps))
+    return {'value': nb * F / best, 'unit': 'frames/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d windows x %d frames, median of %d runs of oracle/torch_ref.ief_forward (dense V=6890 '
+                      'SMPL-H + autograd, fp32, torch CPU); host has %d logical cores'
+                      % (nb, F, len(reps), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=1024, help='windows per GPU')
+    ap.add_argument('--frames', type=int, default=32)
+    ap.add_argument('--n_markers', type=int, default=12)
+    ap.add_argument('--iterations', type=int, default=4)
+    ap.add_argument('--no_rnn', action='store_true')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world > 1:
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} bench.py ...'
+                         .format(args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from em_pose_amd import _lib
+    net, model = build_net(args.n_markers, not args.no_rnn, args.iterations)
+    net = net.to(dev)
+    B, F = args.batch, args.frames
+    w, inputs = make_inputs(net, dev, B, F, seed=1000 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = net.forward_tensors(*inputs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net.forward_tensors(*inputs)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only data-path-adjacent collective: gather per-rank result checksums over RCCL
+        mine = torch.stack([out['pose'].double().sum(), out['joints'].double().sum(),
+                            torch.tensor(float(B * F), dtype=torch.float64, device=dev)])
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        frames_total = int(sum(m[2].item() for m in allm))
+        assert all(torch.isfinite(m).all() for m in allm)
+    else:
+        frames_total = B * F
+        assert torch.isfinite(out['pose']).all()
+    barrier()
+
+    result = None
+    if rank == 0:
+        T = B * F
+        value = frames_total * args.steps / elapsed
+        fpf = flops_per_frame(net)
+        result = {
+            'metric': 'frames/sec LGD-RNN N=4 12-sensor ws=32; MPJPE vs ref (mm)',
+            'value': value, 'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: LGD%s %d-sensor, N=%d, ws=%d, batch %d windows per GPU, '
+                                   '2x512 update MLPs, 2x512 LSTM init, synthetic SMPL-H-shaped body model (V=6890), '
+                                   'random-init weights' % ('-RNN' if net.rnn_init else '', args.n_markers, net.N, F, B),
+                       'windows_per_gpu': B, 'frames_per_window': F, 'parallelism': 'window-sharded x%d' % world,
+                       'dense_mflop_per_frame': fpf / 1e6,
+                       'whole_path_tflops': value * fpf / 1e12},
+        }
+    if rank == 0 and not args.no_profile:
+        lib = _lib.lib()
+        lib.empose_profile_enable(1)
+        psteps = 3
+        for _ in range(psteps):
+            net.forward_tensors(*inputs)
+        prof = _lib.profile_read()
+        lib.empose_profile_enable(0)
+        total = sum(v[0] for v in prof.values())
+        h = net.config.m_hidden_size
+        ms, cnt = prof['mlp_hidden_gemm']
+        avg_ms = ms / cnt
+        flops = 2 * 2.0 * (B * F) * h * h  # both update nets in one launch
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                              'kernel': 'gemm_tn_f32_kernel<2,2> (update-net hidden layer, both nets per launch)',
+                              'avg_launch_ms': avg_ms, 'launches_per_step': cnt / psteps,
+                              'flops_per_launch': flops,
+                              'hbm_frac_on_algorithmic_bytes': value * 1162.0 / 1e9 / PEAK_HBM_GBS}
+        result['breakdown_ms_per_step'] = {k: v[0] / psteps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        result['breakdown_ms_per_step']['sum_of_kernels'] = total / psteps
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(net, model, w)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -89,6 +89,10 @@ SIGNATURES = {
                                    C.c_void_p]),
     'empose_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    'empose_profile_enable': (C.c_int, [C.c_int]),
+    'empose_profile_ntags': (C.c_int, []),
+    'empose_profile_tag_name': (C.c_char_p, [C.c_int]),
+    'empose_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     'empose_mesh_create': (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
     'empose_mesh_destroy': (None, [C.c_void_p]),
     'empose_mesh_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
@@ -150,3 +154,13 @@ def dptr(t):
 def current_stream():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def profile_read():
+    """{tag name: (total_ms, launches)} since the last read; see empose_profile_read."""
+    l = lib()
+    n = l.empose_profile_ntags()
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    check(l.empose_profile_read(ms, cnt))
+    return {l.empose_profile_tag_name(i).decode(): (ms[i], cnt[i]) for i in range(n) if cnt[i] > 0}

@@ -31,6 +31,32 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(EMPOSE_EHIP, "%s: %s", #expr, hipGetErrorString(e_));       \
   } while (0)
 
+// ---- optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline numbers ---------
+enum ProfTag { P_PACK = 0, P_LSTM_PROJ, P_LSTM_STEP, P_HEADS, P_UPDATE_FEAT, P_BLEND_GEMM, P_CHAIN, P_BLEND_T_GEMM,
+               P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_INIT_MLP, P_COPY, P_END, P_NTAGS };
+const char* const kProfNames[P_NTAGS] = {"pack_inputs", "lstm_input_proj_gemm", "lstm_step", "init_heads_gemm",
+                                         "update_feat", "blend_gemm", "chain_sensors", "blend_T_gemm",
+                                         "rodrigues_bwd", "mlp_in_gemm", "mlp_hidden_gemm", "mlp_out_gemm",
+                                         "init_mlp_gemm", "copies", "end"};
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> tags;
+  size_t used = 0;
+};
+Profiler g_prof;
+
+void prof_mark(int tag, hipStream_t stream) {
+  if (!g_prof.on) return;
+  if (g_prof.used == g_prof.ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    g_prof.ev.push_back(e);
+  }
+  (void)hipEventRecord(g_prof.ev[g_prof.used++], stream);
+  g_prof.tags.push_back(tag);
+}
+
 // A packed Linear(+BN)(+PReLU): device weight and the per-column epilogue (scale, shift).
 struct Dense {
   int in_dim = 0, out_dim = 0;
@@ -211,7 +237,7 @@ GemmProb linear_prob(const float* A, int lda, const Dense& d, float* C, int ldc,
 // Hidden blocks are layer pairs (1,2), (3,4), ...; with skip connections the block input is added to the block
 // output (reference layers.py:35-43), which needs the block input kept alive in a third buffer.
 int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2], const float* x, int ldx, int T,
-             const UpdWs& ws, int hidden_max, hipStream_t stream) {
+             const UpdWs& ws, int hidden_max, hipStream_t stream, bool init_net = false) {
   const int L = nets[0]->n_layers;
   for (int i = 1; i < n_nets; ++i)
     if (nets[i]->n_layers != L) return fail(EMPOSE_EINVAL, "paired MLPs must have the same depth");
@@ -247,6 +273,7 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
         b.p[i].ldr = d.out_dim;
       }
     }
+    prof_mark(init_net ? P_INIT_MLP : (l == 0 ? P_MLP_IN : (l == L - 1 ? P_MLP_OUT : P_MLP_HIDDEN)), stream);
     hipError_t e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "gemm launch: %s", hipGetErrorString(e));
     for (int i = 0; i < n_nets; ++i) cur[i] = nxt[i];
@@ -273,8 +300,10 @@ int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const
     p.A = in; p.lda = ld_in; p.W = r.w_ih[l]; p.ldw = k_in; p.C = ws.gin; p.ldc = 4 * H;
     p.M = (int)T; p.N = 4 * H; p.K = k_in;
     p.scale = nullptr; p.shift = r.bias[l]; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+    prof_mark(P_LSTM_PROJ, stream);
     hipError_t e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm gemm: %s", hipGetErrorString(e));
+    prof_mark(P_COPY, stream);
     if (h0) HIP_TRY(hipMemcpyAsync(ws.h[0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
     else HIP_TRY(hipMemsetAsync(ws.h[0], 0, bh * sizeof(float), stream));
     if (c0) HIP_TRY(hipMemcpyAsync(ws.c, c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -283,9 +312,11 @@ int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const
       LstmStepArgs a;
       a.gin = ws.gin; a.w_hh = r.w_hh[l]; a.h_prev = ws.h[t & 1]; a.h_next = ws.h[(t + 1) & 1]; a.c = ws.c;
       a.y = out; a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H; a.t = t;
+      prof_mark(P_LSTM_STEP, stream);
       e = launch_lstm_step(a, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
     }
+    prof_mark(P_COPY, stream);
     if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, ws.h[F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, ws.c, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
@@ -302,6 +333,7 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
   p.A = ws.feat; p.lda = 200; p.W = m->tab.wc; p.ldw = 200; p.C = ws.out; p.ldc = m->tab.ncp;
   p.M = T; p.N = m->tab.ncp; p.K = 200;
   p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+  prof_mark(P_BLEND_GEMM, stream);
   hipError_t e = launch_gemm(b, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm: %s", hipGetErrorString(e));
   ChainArgs c;
@@ -312,11 +344,13 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
   for (int i = 0; i < 12; ++i) c.used_slot[i] = m->used_slot[i];
   c.pos = pos; c.ori = ori; c.joints = joints; c.pos2 = pos2; c.ori2 = ori2; c.joints2 = joints2;
   c.d_out = ws.d_out; c.d_rot = ws.d_rot; c.T = T; c.F = F;
+  prof_mark(P_CHAIN, stream);
   e = launch_chain_sensors(c, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "chain kernel: %s", hipGetErrorString(e));
   if (tgt) {
     p.A = ws.d_out; p.lda = m->tab.ncp; p.W = m->tab.wct; p.ldw = m->tab.ncp; p.C = ws.d_feat; p.ldc = 200;
     p.M = T; p.N = 200; p.K = m->tab.ncp;
+    prof_mark(P_BLEND_T_GEMM, stream);
     e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm: %s", hipGetErrorString(e));
   }
@@ -330,6 +364,35 @@ extern "C" {
 const char* empose_last_error(void) { return g_err.c_str(); }
 int empose_version(void) { return 1; }
 const char* empose_arch(void) { return "gfx950"; }
+
+int empose_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  g_prof.tags.clear();
+  return EMPOSE_OK;
+}
+
+int empose_profile_ntags(void) { return P_NTAGS; }
+
+const char* empose_profile_tag_name(int tag) { return (tag >= 0 && tag < P_NTAGS) ? kProfNames[tag] : ""; }
+
+int empose_profile_read(double* total_ms, long long* count) {
+  if (!total_ms || !count) return fail(EMPOSE_EINVAL, "null argument");
+  for (int i = 0; i < P_NTAGS; ++i) { total_ms[i] = 0.0; count[i] = 0; }
+  if (g_prof.used == 0) return EMPOSE_OK;
+  HIP_TRY(hipEventSynchronize(g_prof.ev[g_prof.used - 1]));
+  for (size_t i = 0; i + 1 < g_prof.used; ++i) {
+    const int tag = g_prof.tags[i];
+    if (tag == P_END) continue;  // gap between two forwards
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+    total_ms[tag] += ms;
+    count[tag] += 1;
+  }
+  g_prof.used = 0;
+  g_prof.tags.clear();
+  return EMPOSE_OK;
+}
 
 void empose_model_destroy(empose_model_t* model) {
   if (!model) return;
@@ -498,6 +561,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
   pa.seq_lengths = io->seq_lengths; pa.x = w.x; pa.ldx = dx; pa.frame_scale = w.scale;
   pa.B = B; pa.F = F; pa.n_markers = m->n_markers;
   for (int i = 0; i < 12; ++i) pa.marker_idx[i] = m->marker_idx[i];
+  prof_mark(P_PACK, stream);
   hipError_t e = launch_pack_inputs(pa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "pack kernel: %s", hipGetErrorString(e));
 
@@ -508,13 +572,14 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     b.count = 2;
     b.p[0] = linear_prob(w.y, m->rnn.H, m->pose_head, x_theta, dx, T);
     b.p[1] = linear_prob(w.y, m->rnn.H, m->shape_head, w.d_shape, 10, T);
+    prof_mark(P_HEADS, stream);
     e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "head gemm: %s", hipGetErrorString(e));
   } else {
     const Mlp* nets[2] = {&m->pose_init, &m->shape_init};
     float* outs[2] = {x_theta, w.d_shape};
     const int lds[2] = {dx, 10};
-    TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream));
+    TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream, true));
   }
 
   const int N = m->N;
@@ -535,6 +600,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     fa.out_theta2 = (i == N) ? io->pose_hat : nullptr;
     fa.out_beta2 = (i == N) ? io->shape_hat : nullptr;
     fa.T = T; fa.F = F;
+    prof_mark(P_UPDATE_FEAT, stream);
     e = launch_update_feat(fa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
 
@@ -553,6 +619,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
       ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
       ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
       ra.T = T;
+      prof_mark(P_ROD_BWD, stream);
       e = launch_rodrigues_bwd(ra, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
     }
@@ -561,6 +628,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     const int lds[2] = {66, 10};
     TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream));
   }
+  prof_mark(P_END, stream);
   return EMPOSE_OK;
 }
 

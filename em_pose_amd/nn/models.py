@@ -298,6 +298,35 @@ class IterativeErrorFeedback(BaseModel):
         self._handle, self._handle_key = handle, key
         return handle
 
+    def get_estimated_real_markers(self, poses, shapes, offset_r, offset_t, vertex_ids=None, frames_per_window=1):
+        """
+        Virtual sensors (with offsets applied) and body joints for given pose/shape (reference models.py:471-483).
+        poses (T,66), shapes (T,10); offsets per window: offset_r (T/F,12,3,3), offset_t (T/F,12,3).
+        :return: pos (T,12,3), ori (T,12,3,3), joints (T,22,3)
+        """
+        if vertex_ids is not None and list(vertex_ids) != list(self.vertex_ids):
+            raise ValueError('the sensor sub-mesh is baked for self.vertex_ids; set it before the first call')
+        if not poses.is_cuda:
+            raise _lib.EmposeError('needs GPU tensors; there is no CPU fallback')
+        dev, T, F = poses.device, poses.shape[0], int(frames_per_window)
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        poses, shapes, offset_r, offset_t = f32(poses), f32(shapes), f32(offset_r), f32(offset_t)
+        assert T % F == 0 and offset_r.shape[0] == T // F and offset_t.shape[0] == T // F
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            handle = self._ensure_handle(dev)
+            pos = torch.empty(T, 12, 3, dtype=torch.float32, device=dev)
+            ori = torch.empty(T, 12, 3, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(T, 22, 3, dtype=torch.float32, device=dev)
+            nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(poses), 66, _lib.dptr(shapes), 10,
+                                                       _lib.dptr(offset_r), _lib.dptr(offset_t), None, 0, None,
+                                                       _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), None, 0,
+                                                       None, 0, _lib.dptr(ws), nbytes, _lib.current_stream()))
+            torch.cuda.current_stream().synchronize()  # `ws` and the fp32 copies die with this frame
+        return pos, ori, joints
+
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward_tensors(self, marker_pos, marker_oris, offset_t, offset_r, marker_masks=None, seq_lengths=None,
                         state=None, keep_history=False, keep_gradient_trace=False):

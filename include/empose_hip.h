@@ -200,6 +200,16 @@ int empose_lstm_fwd(const empose_model_t* model, int B, int F, const float* x, i
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream);
 
+/* ---- optional per-launch timing ------------------------------------------------------------------------------- */
+/* While enabled, every kernel launch issued by the entry points above is bracketed by HIP events on the launch stream
+ * and attributed to one of empose_profile_ntags() categories (GEMMs by role, LSTM step, chain kernel, ...).
+ * empose_profile_read() waits for the recorded events, returns per-category total milliseconds and launch counts, and
+ * clears the log. New in this library (the reference only has wall-clock prints, scripts/train.py:136-173). */
+int empose_profile_enable(int on);
+int empose_profile_ntags(void);
+const char* empose_profile_tag_name(int tag);
+int empose_profile_read(double* total_ms, long long* count);
+
 /* ---- full-mesh evaluation (final vertices; ground-truth preprocessing) ---------------------------------------- */
 
 typedef struct {

@@ -71,9 +71,9 @@ def test_linear_f32(M, N, K):
     ref = (a[:, :K].astype(np.float64) @ w.astype(np.float64).T) * scale + shift
     ref = np.where(ref >= 0, ref, 0.25 * ref)
     A_, W_, out = gpu(a), gpu(w), torch.full((M, N + 3), -7.0, device=DEV)
+    sc_, sh_ = gpu(scale), gpu(shift)  # keep every device tensor alive across the asynchronous call
     _lib.check(_lib.lib().empose_linear_f32(_lib.dptr(A_), lda, _lib.dptr(W_), K, _lib.dptr(out), N + 3, M, N, K,
-                                            _lib.dptr(gpu(scale)), _lib.dptr(gpu(shift)), 1, 0.25,
-                                            _lib.current_stream()))
+                                            _lib.dptr(sc_), _lib.dptr(sh_), 1, 0.25, _lib.current_stream()))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     np.testing.assert_allclose(got[:, :N], ref, atol=2e-5 * np.sqrt(K / 32), rtol=1e-5)
@@ -123,10 +123,10 @@ def test_smpl_sensors_fwd_bwd(which, n_markers, big_model):
     g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
     nbytes = lib.empose_smpl_workspace_bytes(handle, T)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    tg = gpu(tgt)
+    tg, o_r, o_t, sc = gpu(tgt), gpu(off_r), gpu(off_t), gpu(scale)
     _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10,
-                                               _lib.dptr(gpu(off_r)), _lib.dptr(gpu(off_t)), _lib.dptr(tg),
-                                               tg.shape[1], _lib.dptr(gpu(scale)), _lib.dptr(pos), _lib.dptr(ori),
+                                               _lib.dptr(o_r), _lib.dptr(o_t), _lib.dptr(tg),
+                                               tg.shape[1], _lib.dptr(sc), _lib.dptr(pos), _lib.dptr(ori),
                                                _lib.dptr(joints), _lib.dptr(g_th), 66, _lib.dptr(g_be), 10,
                                                _lib.dptr(ws), nbytes, _lib.current_stream()))
     torch.cuda.synchronize()
@@ -151,8 +151,9 @@ def test_smpl_forward_only_matches(big_model):
     pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
     nbytes = lib.empose_smpl_workspace_bytes(handle, T)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(gpu(theta)), 66, _lib.dptr(gpu(beta)), 10,
-                                               _lib.dptr(gpu(off_r)), _lib.dptr(gpu(off_t)), None, 0, None,
+    th, be, o_r, o_t = gpu(theta), gpu(beta), gpu(off_r), gpu(off_t)
+    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10,
+                                               _lib.dptr(o_r), _lib.dptr(o_t), None, 0, None,
                                                _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), None, 0, None, 0,
                                                _lib.dptr(ws), nbytes, _lib.current_stream()))
     torch.cuda.synchronize()
@@ -197,9 +198,9 @@ def test_update_nets_and_lstm_vs_oracle():
     hn, cn = torch.empty(2, B, Hh, device=DEV), torch.empty(2, B, Hh, device=DEV)
     nbytes = lib.empose_lstm_workspace_bytes(handle, B, F)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    xg = gpu(xs)
-    _lib.check(lib.empose_lstm_fwd(handle, B, F, _lib.dptr(xg), 144, _lib.dptr(gpu(lens, torch.int32)),
-                                   _lib.dptr(gpu(h0)), _lib.dptr(gpu(c0)), _lib.dptr(y), _lib.dptr(hn), _lib.dptr(cn),
+    xg, lg, h0g, c0g = gpu(xs), gpu(lens, torch.int32), gpu(h0), gpu(c0)
+    _lib.check(lib.empose_lstm_fwd(handle, B, F, _lib.dptr(xg), 144, _lib.dptr(lg),
+                                   _lib.dptr(h0g), _lib.dptr(c0g), _lib.dptr(y), _lib.dptr(hn), _lib.dptr(cn),
                                    _lib.dptr(ws), nbytes, _lib.current_stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(y.cpu().numpy(), want_y.numpy(), atol=1e-5)
@@ -283,6 +284,7 @@ def test_module_forward_mirrors_reference_interface():
         b = RealBatch([0, 1], torch.tensor([32, 32]), t(w['poses'][:, sf:ef]), t(w['shapes']), torch.zeros(2, 32, 3),
                       t(w['marker_pos'][:, sf:ef]), t(w['marker_oris'][:, sf:ef]), torch.ones(2, 32, 12),
                       t(w['offset_t']), t(w['offset_r'])).to_gpu(torch.device(DEV))
+        b.joints_gt = torch.zeros(2, 32, 66, device=DEV)  # set by the SMPLFK transform in the reference's flow
         out = net(b, is_new_sequence=new)
         rec = case[tag]
         for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
