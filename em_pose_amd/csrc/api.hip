@@ -211,17 +211,19 @@ UpdWs carve_upd(Carver& c, const empose_model* m, int T) {
 }
 
 struct LstmWs {
-  float *gin, *ya, *h[2], *c;
+  float* h[4][2];
+  float* c[4];
 };
 LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) {
   LstmWs w;
-  const size_t T = (size_t)B * F;
+  (void)F;
   const int H = m->rnn.H;
-  w.gin = c.f(T * 4 * H);
-  w.ya = c.f(T * H);
-  w.h[0] = c.f((size_t)B * H);
-  w.h[1] = c.f((size_t)B * H);
-  w.c = c.f((size_t)B * H);
+  for (int l = 0; l < 4; ++l) {
+    const bool used = l < m->rnn.num_layers;
+    w.h[l][0] = used ? c.f((size_t)B * H) : nullptr;
+    w.h[l][1] = used ? c.f((size_t)B * H) : nullptr;
+    w.c[l] = used ? c.f((size_t)B * H) : nullptr;
+  }
   return w;
 }
 
@@ -273,6 +275,7 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
         b.p[i].ldr = d.out_dim;
       }
     }
+    b.role = (!init_net && l > 0 && l < L - 1) ? 1 : 0;
     prof_mark(init_net ? P_INIT_MLP : (l == 0 ? P_MLP_IN : (l == L - 1 ? P_MLP_OUT : P_MLP_HIDDEN)), stream);
     hipError_t e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "gemm launch: %s", hipGetErrorString(e));
@@ -284,41 +287,35 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
 int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const int* seq_lengths, const float* h0,
              const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
   const Lstm& r = m->rnn;
-  const int H = r.H;
-  const size_t T = (size_t)B * F;
+  const int H = r.H, L = r.num_layers;
   const size_t bh = (size_t)B * H;
-  // Layer outputs alternate between ws.ya and y such that the LAST layer writes y; a layer reads its predecessor.
-  auto layer_out = [&](int l) -> float* { return (((r.num_layers - 1 - l) % 2) == 0) ? y : ws.ya; };
-  for (int l = 0; l < r.num_layers; ++l) {
-    const float* in = (l == 0) ? x : layer_out(l - 1);
-    const int ld_in = (l == 0) ? ldx : H;
-    const int k_in = (l == 0) ? r.input_size : H;
-    float* out = layer_out(l);
-    GemmBatch b;
-    b.count = 1;
-    GemmProb& p = b.p[0];
-    p.A = in; p.lda = ld_in; p.W = r.w_ih[l]; p.ldw = k_in; p.C = ws.gin; p.ldc = 4 * H;
-    p.M = (int)T; p.N = 4 * H; p.K = k_in;
-    p.scale = nullptr; p.shift = r.bias[l]; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
-    prof_mark(P_LSTM_PROJ, stream);
-    hipError_t e = launch_gemm(b, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm gemm: %s", hipGetErrorString(e));
-    prof_mark(P_COPY, stream);
-    if (h0) HIP_TRY(hipMemcpyAsync(ws.h[0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    else HIP_TRY(hipMemsetAsync(ws.h[0], 0, bh * sizeof(float), stream));
-    if (c0) HIP_TRY(hipMemcpyAsync(ws.c, c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    else HIP_TRY(hipMemsetAsync(ws.c, 0, bh * sizeof(float), stream));
-    for (int t = 0; t < F; ++t) {
-      LstmStepArgs a;
-      a.gin = ws.gin; a.w_hh = r.w_hh[l]; a.h_prev = ws.h[t & 1]; a.h_next = ws.h[(t + 1) & 1]; a.c = ws.c;
-      a.y = out; a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H; a.t = t;
-      prof_mark(P_LSTM_STEP, stream);
-      e = launch_lstm_step(a, stream);
-      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
-    }
-    prof_mark(P_COPY, stream);
-    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, ws.h[F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, ws.c, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  prof_mark(P_COPY, stream);
+  for (int l = 0; l < L; ++l) {
+    if (h0) HIP_TRY(hipMemcpyAsync(ws.h[l][0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.h[l][0], 0, bh * sizeof(float), stream));
+    if (c0) HIP_TRY(hipMemcpyAsync(ws.c[l], c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.c[l], 0, bh * sizeof(float), stream));
+  }
+  LstmWaveArgs a;
+  a.num_layers = L; a.x = x; a.ldx = ldx; a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H;
+  for (int l = 0; l < 4; ++l) {
+    LstmLayerArgs& la = a.layer[l];
+    la.w_ih = r.w_ih[l]; la.w_hh = r.w_hh[l]; la.bias = r.bias[l];
+    la.in_k = (l == 0) ? r.input_size : H;
+    la.h[0] = ws.h[l][0]; la.h[1] = ws.h[l][1]; la.c = ws.c[l];
+    la.y = (l == L - 1) ? y : nullptr;
+  }
+  // Wavefront over (layer, time): launch s advances layer l by its step s - l.
+  for (int s = 0; s < F + L - 1; ++s) {
+    a.s = s;
+    prof_mark(P_LSTM_STEP, stream);
+    hipError_t e = launch_lstm_wave(a, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+  }
+  prof_mark(P_COPY, stream);
+  for (int l = 0; l < L; ++l) {
+    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, ws.h[l][F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, ws.c[l], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   return EMPOSE_OK;
 }

@@ -45,7 +45,9 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const float4 (&r
   }
 }
 
-template <int WM, int WN>
+// ROLE only separates instantiations by name so that profilers report the update-net hidden layers (ROLE 1) apart
+// from the other users of the same tile configuration.
+template <int WM, int WN, int ROLE>
 __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmBatch batch) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * LDT];
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(GemmBatch batch) {
   }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int ROLE = 0>
 static hipError_t launch_cfg(const GemmBatch& batch, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   int blocks = 0;
@@ -144,7 +146,7 @@ static hipError_t launch_cfg(const GemmBatch& batch, hipStream_t stream) {
     blocks = t > blocks ? t : blocks;
   }
   if (blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL((gemm_tn_f32_kernel<WM, WN>), dim3(blocks, batch.count), dim3(256), 0, stream, batch);
+  hipLaunchKernelGGL((gemm_tn_f32_kernel<WM, WN, ROLE>), dim3(blocks, batch.count), dim3(256), 0, stream, batch);
   return hipGetLastError();
 }
 
@@ -167,7 +169,7 @@ hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream) {
   if (shortm && narrow) return launch_cfg<1, 1>(batch, stream);
   if (shortm) return launch_cfg<1, 2>(batch, stream);
   if (narrow) return launch_cfg<2, 1>(batch, stream);
-  if (nblocks(128, 128) >= 512) return launch_cfg<2, 2>(batch, stream);
+  if (nblocks(128, 128) >= 512) return batch.role == 1 ? launch_cfg<2, 2, 1>(batch, stream) : launch_cfg<2, 2>(batch, stream);
   if (nblocks(64, 128) >= 256) return launch_cfg<1, 2>(batch, stream);
   return launch_cfg<1, 1>(batch, stream);
 }

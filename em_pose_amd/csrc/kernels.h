@@ -20,7 +20,7 @@ struct GemmProb {
   int act;                  // 0 none, 1 PReLU(slope)
   float slope;
 };
-struct GemmBatch { GemmProb p[2]; int count; };
+struct GemmBatch { GemmProb p[2]; int count; int role = 0; };  // role 1 = update-net hidden layer (profiling name only)
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
@@ -28,17 +28,24 @@ hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------------------------
 // LSTM
 // ---------------------------------------------------------------------------------------------------------------
-struct LstmStepArgs {
-  const float* gin;    // [B][F][4H] input projection incl. both biases
+struct LstmLayerArgs {
+  const float* w_ih;   // [4H][in_k]
   const float* w_hh;   // [4H][H]
-  const float* h_prev; // [B][H]
-  float* h_next;       // [B][H]
+  const float* bias;   // [4H] = b_ih + b_hh
+  int in_k;            // width of the layer input
+  float* h[2];         // [B][H] ping-pong: step t reads h[t & 1], writes h[(t + 1) & 1]
   float* c;            // [B][H] updated in place
-  float* y;            // [B][F][H]
-  const int* seq_lengths;  // [B] or nullptr
-  int B, F, H, t;
+  float* y;            // [B][F][H] layer output or nullptr (only the last layer's is kept)
 };
-hipError_t launch_lstm_step(const LstmStepArgs& a, hipStream_t stream);
+struct LstmWaveArgs {
+  LstmLayerArgs layer[4];
+  int num_layers;
+  const float* x; int ldx;   // [B][F][ldx] network input rows
+  const int* seq_lengths;    // [B] or nullptr
+  int B, F, H;
+  int s;                     // wavefront index: layer l runs time step s - l
+};
+hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // SMPL sub-mesh kernels

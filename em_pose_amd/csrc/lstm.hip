@@ -1,108 +1,169 @@
-// One time step of an LSTM layer on the fp32 matrix cores (reference nn/layers.py:133-157, nn.LSTM gate order
-// i,f,g,o).  The input projection x_t . W_ih^T + b_ih + b_hh for ALL steps is one plain GEMM (gemm_f32.hip); this
-// kernel adds the recurrent term h_{t-1} . W_hh^T and applies the cell non-linearities in its epilogue.
+// LSTM time steps on the fp32 matrix cores (reference nn/layers.py:133-157: nn.LSTM, gate order i,f,g,o, stacked
+// layers, pack_padded_sequence semantics).
 //
-// Tiling: a wave owns 32 batch rows x 32 hidden units and keeps FOUR 32x32 accumulators, one per gate, so that
-// i/f/g/o of one (row, unit) land in the same lane and the cell update needs no cross-lane traffic.  A block is
-// 2x2 waves = 64 rows x 64 units (x 4 gates = 256 W_hh rows staged per K tile).
-// Ragged windows (pack_padded_sequence semantics): rows with t >= seq_length keep (h, c) and emit zeros.
+// One launch advances the whole layer stack by one "wavefront" step s: layer l processes time step t = s - l, so
+// all layers run concurrently (layer l at step t only needs layer l-1 at step t, produced by the previous launch,
+// and its own state after step t-1).  For every (layer, step) the gate pre-activations are
+//     gates = in_t . W_ih^T + h_{t-1} . W_hh^T + (b_ih + b_hh)
+// i.e. one GEMM whose K dimension is the concatenation of two operand "segments"; the cell non-linearities are the
+// epilogue.  Nothing but h, c and the last layer's output ever touches memory (no gate buffer, no separate input
+// projection).
+//
+// Tiling: v_mfma_f32_16x16x4_f32.  A wave owns 32 batch rows x 16 hidden units and keeps 2 x 4 accumulators
+// (row half x gate), so i/f/g/o of one (row, unit) sit in the same lane.  A block is 2x2 waves = 64 rows x 32 units
+// (128 weight rows per K tile) -> for B=1024, H=512: 256 blocks per layer, one wave per SIMD and layer.
+// K tiles (32 wide) are register-prefetched one tile ahead; since a dot product does not care about the order of k,
+// each 16-lane group takes 4 consecutive k of a 16-wide chunk so that one ds_read_b128 feeds four MFMAs.
 #include "kernels.h"
 
 namespace empose {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LBK = 32;
 constexpr int LLD = LBK + 4;
+constexpr int LROWS = 64;   // batch rows per block
+constexpr int LUNITS = 32;  // hidden units per block
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[(64 + 256) * LLD];
-  float* As = lds;             // [64 rows][LLD]
-  float* Bs = lds + 64 * LLD;  // [4 gates][64 units][LLD]
+struct Seg {
+  const float* a; int lda;   // [B][lda]
+  const float* w; int ldw;   // [4H][ldw]
+  int K;
+};
 
-  const int H = a.H;
-  const int m0 = blockIdx.x * 64;
-  const int j0 = blockIdx.y * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = wave >> 1, wcol = wave & 1;
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  f32x16 acc[4];
+__device__ __forceinline__ void lstm_load(const Seg& sg, int k0, int m0, int j0, int B, int H, int tid,
+                                          float4 (&ra)[2], float4 (&rb)[4]) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-
-  const int nk = (H + LBK - 1) / LBK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int k0 = kt * LBK;
-    // stage h_prev rows (64 x 32) and the 4 x 64 W_hh rows of this unit tile
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int slot = tid + i * 256;
-      const int r = slot >> 3, c4 = (slot & 7) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m0 + r < a.B && k0 + c4 < H) v = *reinterpret_cast<const float4*>(a.h_prev + (size_t)(m0 + r) * H + k0 + c4);
-      *reinterpret_cast<float4*>(As + r * LLD + c4) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int slot = tid + i * 256;
-      const int r = slot >> 3, c4 = (slot & 7) * 4;  // r in [0,256): gate = r >> 6, unit = r & 63
-      const int unit = j0 + (r & 63);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (unit < H && k0 + c4 < H)
-        v = *reinterpret_cast<const float4*>(a.w_hh + (size_t)((r >> 6) * H + unit) * H + k0 + c4);
-      *reinterpret_cast<float4*>(Bs + r * LLD + c4) = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < LBK / 8; ++kk) {
-      const float4 av = *reinterpret_cast<const float4*>(As + (wrow * 32 + l31) * LLD + kk * 8 + lh * 4);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(Bs + (g * 64 + wcol * 32 + l31) * LLD + kk * 8 + lh * 4);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[g], 0, 0, 0);
-      }
-    }
-    __syncthreads();
+  for (int i = 0; i < 2; ++i) {
+    const int slot = tid + i * 256;
+    const int r = slot >> 3, c4 = (slot & 7) * 4;
+    ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + r < B && k0 + c4 < sg.K) ra[i] = *reinterpret_cast<const float4*>(sg.a + (size_t)(m0 + r) * sg.lda + k0 + c4);
   }
-
-  const int unit = j0 + wcol * 32 + l31;
-  if (unit >= H) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (row >= a.B) continue;
-    const size_t hc = (size_t)row * H + unit;
-    const size_t yo = ((size_t)row * a.F + a.t) * H + unit;
-    const bool live = a.seq_lengths ? (a.t < a.seq_lengths[row]) : true;
-    if (!live) {
-      a.h_next[hc] = a.h_prev[hc];
-      a.y[yo] = 0.f;
-      continue;
-    }
-    const float* gin = a.gin + ((size_t)row * a.F + a.t) * 4 * H + unit;
-    const float gi = acc[0][r] + gin[0];
-    const float gf = acc[1][r] + gin[H];
-    const float gg = acc[2][r] + gin[2 * H];
-    const float go = acc[3][r] + gin[3 * H];
-    const float c_new = sigmoidf_(gf) * a.c[hc] + sigmoidf_(gi) * tanhf(gg);
-    const float h_new = sigmoidf_(go) * tanhf(c_new);
-    a.c[hc] = c_new;
-    a.h_next[hc] = h_new;
-    a.y[yo] = h_new;
+  for (int i = 0; i < 4; ++i) {
+    const int slot = tid + i * 256;
+    const int r = slot >> 3, c4 = (slot & 7) * 4;  // r in [0,128): gate = r >> 5, unit = r & 31
+    const int unit = j0 + (r & 31);
+    rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (unit < H && k0 + c4 < sg.K)
+      rb[i] = *reinterpret_cast<const float4*>(sg.w + (size_t)((r >> 5) * H + unit) * sg.ldw + k0 + c4);
   }
 }
 
-hipError_t launch_lstm_step(const LstmStepArgs& a, hipStream_t stream) {
-  dim3 grid((a.B + 63) / 64, (a.H + 63) / 64);
-  hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, stream, a);
+__device__ __forceinline__ void lstm_store(float* As, float* Bs, int tid, const float4 (&ra)[2], const float4 (&rb)[4]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = tid + i * 256;
+    *reinterpret_cast<float4*>(As + (slot >> 3) * LLD + (slot & 7) * 4) = ra[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int slot = tid + i * 256;
+    *reinterpret_cast<float4*>(Bs + (slot >> 3) * LLD + (slot & 7) * 4) = rb[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[(LROWS + 4 * LUNITS) * LLD];
+  float* As = lds;
+  float* Bs = lds + LROWS * LLD;
+
+  const int l = blockIdx.z;
+  const int t = a.s - l;
+  if (t < 0 || t >= a.F) return;
+  const LstmLayerArgs& L = a.layer[l];
+  const int H = a.H, B = a.B;
+  const int m0 = blockIdx.x * LROWS, j0 = blockIdx.y * LUNITS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave >> 1, wcol = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  Seg segs[2];
+  // segment 0: the layer input at step t (x_t for layer 0, the previous layer's h after ITS step t otherwise)
+  if (l == 0) { segs[0].a = a.x + (size_t)t * a.ldx; segs[0].lda = a.F * a.ldx; }
+  else { segs[0].a = a.layer[l - 1].h[(t + 1) & 1]; segs[0].lda = H; }
+  segs[0].w = L.w_ih; segs[0].ldw = L.in_k; segs[0].K = L.in_k;
+  // segment 1: own hidden state after step t-1
+  segs[1].a = L.h[t & 1]; segs[1].lda = H; segs[1].w = L.w_hh; segs[1].ldw = H; segs[1].K = H;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[i][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk0 = (segs[0].K + LBK - 1) / LBK, nk1 = (segs[1].K + LBK - 1) / LBK;
+  const int nk = nk0 + nk1;
+  float4 ra[2], rb[4];
+  lstm_load(segs[0], 0, m0, j0, B, H, tid, ra, rb);
+  lstm_store(As, Bs, tid, ra, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      const int nx = kt + 1;
+      if (nx < nk0) lstm_load(segs[0], nx * LBK, m0, j0, B, H, tid, ra, rb);
+      else lstm_load(segs[1], (nx - nk0) * LBK, m0, j0, B, H, tid, ra, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < LBK / 16; ++kk) {
+      float4 av[2], bv[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        av[i] = *reinterpret_cast<const float4*>(As + (wrow * 32 + i * 16 + l15) * LLD + kk * 16 + lq * 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bv[g] = *reinterpret_cast<const float4*>(Bs + (g * LUNITS + wcol * 16 + l15) * LLD + kk * 16 + lq * 4);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[g].x, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[g].y, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[g].z, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[g].w, acc[i][g], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstm_store(As, Bs, tid, ra, rb);
+      __syncthreads();
+    }
+  }
+
+  // Epilogue. C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r.
+  const int unit = j0 + wcol * 16 + l15;
+  if (unit >= H) return;
+  const float bi = L.bias[unit], bf = L.bias[H + unit], bg = L.bias[2 * H + unit], bo = L.bias[3 * H + unit];
+  const float* h_prev = L.h[t & 1];
+  float* h_next = L.h[(t + 1) & 1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wrow * 32 + i * 16 + lq * 4 + r;
+      if (row >= B) continue;
+      const size_t hc = (size_t)row * H + unit;
+      const bool live = a.seq_lengths ? (t < a.seq_lengths[row]) : true;
+      float h_new;
+      if (live) {
+        const float c_new = sigmoidf_(acc[i][1][r] + bf) * L.c[hc] + sigmoidf_(acc[i][0][r] + bi) * tanhf(acc[i][2][r] + bg);
+        h_new = sigmoidf_(acc[i][3][r] + bo) * tanhf(c_new);
+        L.c[hc] = c_new;
+        h_next[hc] = h_new;
+      } else {
+        h_next[hc] = h_prev[hc];
+        h_new = 0.f;
+      }
+      if (L.y) L.y[((size_t)row * a.F + t) * H + unit] = h_new;
+    }
+}
+
+hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream) {
+  dim3 grid((a.B + LROWS - 1) / LROWS, (a.H + LUNITS - 1) / LUNITS, a.num_layers);
+  hipLaunchKernelGGL(lstm_wave_kernel, grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
