@@ -103,6 +103,7 @@ struct ChainArgs {
   float* d_out;            // [T][ncp]
   float* d_rot;            // [T][22][9]
   int T, F;
+  int debug_stop = 0;      // timing aid: return after phase k (0 = run everything)
 };
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block);
 hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream);

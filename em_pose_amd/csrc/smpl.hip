@@ -15,6 +15,8 @@
 // dR_j = G_p^T (sum_subtree M_b - F_b (x) t_j) G_j, which needs subtree sums instead of a level-by-level sweep.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace empose {
 
 constexpr int NB = 22;
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     smem[f * L.total + o] = v;
   }
   __syncthreads();
+  if (a.debug_stop == 1) return;
 
   // ---- P2: forward chain, one (joint,row) per lane walking the root path
   for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     if (a.joints2) a.joints2[go] = tr;
   }
   __syncthreads();
+  if (a.debug_stop == 2) return;
 
   // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.v + sr] = T0 * vp[0] + T1 * vp[1] + T2 * vp[2] + T3;
   }
   __syncthreads();
+  if (a.debug_stop == 3) return;
 
   // ---- P4: sensors, one (frame, sensor) per lane: normals, frame, offsets, residual and its reverse to dv
   for (int i = tid; i < nf * tb.n_sensors; i += CH_THREADS) {
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   }
   if (!bwd) return;
   __syncthreads();
+  if (a.debug_stop == 4) return;
 
   // ---- P5: d v_posed (to global) and the per-bone force / world-space moment sums
   for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
@@ -487,6 +493,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.m + be] = acc;
   }
   __syncthreads();
+  if (a.debug_stop == 5) return;
 
   // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -509,6 +516,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     }
   }
   __syncthreads();
+  if (a.debug_stop == 6) return;
 
   // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -541,7 +549,10 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   }
 }
 
-hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream) {
+hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
+  ChainArgs a = a_in;
+  static const int dbg = getenv("EMPOSE_CHAIN_STOP") ? atoi(getenv("EMPOSE_CHAIN_STOP")) : 0;  // timing aid only
+  a.debug_stop = dbg;
   const size_t lds = chain_lds_bytes(a.tab, CH_FRAMES);
   static bool attr_set = false;
   if (!attr_set && lds > 48 * 1024) {
