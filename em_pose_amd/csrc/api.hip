@@ -2,6 +2,7 @@
 #include "../../include/empose_hip.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -127,6 +128,72 @@ int upload(std::vector<void*>& allocs, const T* host, size_t count, T** dev) {
     int rc_ = (expr);        \
     if (rc_ != EMPOSE_OK) return rc_; \
   } while (0)
+
+// Packs every index/weight table the chain kernel needs into one array of 32-bit words (staged into LDS per block).
+void build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, ChainTabs& off, int* n_chunks) {
+  auto put_i = [&](const std::vector<int>& v) { int o = (int)blob.size(); for (int x : v) blob.push_back((uint32_t)x); return o; };
+  auto put_f = [&](const float* p, size_t n) {
+    int o = (int)blob.size();
+    for (size_t i = 0; i < n; ++i) { uint32_t u; std::memcpy(&u, p + i, 4); blob.push_back(u); }
+    return o;
+  };
+  std::vector<int> path_mask(22, 0), sub_mask(22, 0), parents(s.parents, s.parents + 22);
+  for (int j = 0; j < 22; ++j) {
+    for (int q = s.path_ptr[j]; q < s.path_ptr[j + 1]; ++q) path_mask[j] |= 1 << s.path[q];
+    for (int q = s.sub_ptr[j]; q < s.sub_ptr[j + 1]; ++q) sub_mask[j] |= 1 << s.sub[q];
+  }
+  off.path_mask = put_i(path_mask);
+  off.sub_mask = put_i(sub_mask);
+  off.parents = put_i(parents);
+  off.skin_idx = put_i(std::vector<int>(s.skin_idx, s.skin_idx + (size_t)s.nv * s.kb));
+  off.skin_w = put_f(s.skin_w, (size_t)s.nv * s.kb);
+  // per-bone (vertex, weight) lists cut into chunks of CHAIN_CHUNK pairs, each chunk padded with (vertex 0, weight 0)
+  std::vector<int> cb, cbeg, bcp(23, 0), pv;
+  std::vector<float> pw;
+  for (int b = 0; b < 22; ++b) {
+    bcp[b] = (int)cb.size();
+    for (int q = s.bone_ptr[b]; q < s.bone_ptr[b + 1]; q += CHAIN_CHUNK) {
+      cb.push_back(b);
+      cbeg.push_back((int)pv.size());
+      for (int k = 0; k < CHAIN_CHUNK; ++k) {
+        const bool in = q + k < s.bone_ptr[b + 1];
+        pv.push_back(in ? s.bone_vert[q + k] : 0);
+        pw.push_back(in ? s.bone_w[q + k] : 0.f);
+      }
+    }
+  }
+  bcp[22] = (int)cb.size();
+  *n_chunks = (int)cb.size();
+  off.chunk_bone = put_i(cb); off.chunk_beg = put_i(cbeg);
+  off.bone_chunk_ptr = put_i(bcp);
+  off.bone_vert = put_i(pv);
+  off.bone_w = put_f(pw.data(), pw.size());
+  off.s_center = put_i(std::vector<int>(s.s_center, s.s_center + 12));
+  off.s_helper = put_i(std::vector<int>(s.s_helper, s.s_helper + 12));
+  off.s_deg = put_i(std::vector<int>(s.s_deg, s.s_deg + 12));
+  {
+    std::vector<int> faces(s.s_faces, s.s_faces + (size_t)12 * s.max_deg * 3);
+    for (int m = 0; m < 12; ++m)
+      for (int k = s.s_deg[m]; k < s.max_deg; ++k)
+        for (int c = 0; c < 3; ++c) faces[((size_t)m * s.max_deg + k) * 3 + c] = s.s_center[m];
+    off.s_faces = put_i(faces);
+  }
+  std::vector<int> inc_ptr(s.nv + 1, 0), inc_code;
+  for (int v = 0; v < s.nv; ++v) {
+    inc_ptr[v] = (int)inc_code.size();
+    for (int m = 0; m < 12; ++m) {
+      if (s.s_center[m] == v) inc_code.push_back((m << 3) | 3);
+      if (s.s_helper[m] == v) inc_code.push_back((m << 3) | 4);
+      for (int k = 0; k < s.s_deg[m]; ++k)
+        for (int c = 0; c < 3; ++c)
+          if (s.s_faces[((size_t)m * s.max_deg + k) * 3 + c] == v) inc_code.push_back(((m * s.max_deg + k) << 3) | c);
+    }
+  }
+  inc_ptr[s.nv] = (int)inc_code.size();
+  off.inc_ptr = put_i(inc_ptr);
+  off.inc_code = put_i(inc_code);
+  off.total = (int)blob.size();
+}
 
 int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
   if (d.in_dim <= 0 || d.out_dim <= 0 || !d.weight) return fail(EMPOSE_EINVAL, "dense layer: bad dims / null weight");
@@ -429,6 +496,15 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
   MTRY(upload(m->allocs, s.path, (size_t)s.path_ptr[22], &ip)); t.path = ip;
   MTRY(upload(m->allocs, s.sub_ptr, 23, &ip)); t.sub_ptr = ip;
   MTRY(upload(m->allocs, s.sub, (size_t)s.sub_ptr[22], &ip)); t.sub = ip;
+  {
+    for (int i = 0; i < 12; ++i)
+      if (s.s_deg[i] < 1 || s.s_deg[i] > s.max_deg) return bail(fail(EMPOSE_EINVAL, "sensor degree out of range"));
+    std::vector<uint32_t> blob;
+    build_chain_blob(s, blob, t.off, &t.n_chunks);
+    uint32_t* bp;
+    MTRY(upload(m->allocs, blob.data(), blob.size(), &bp));
+    t.blob = bp;
+  }
 
   m->n_markers = d->n_markers;
   for (int i = 0; i < 12; ++i) { m->marker_idx[i] = 0; m->used_slot[i] = -1; }

@@ -50,8 +50,25 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------------------------
 // SMPL sub-mesh kernels
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int CHAIN_CHUNK = 8;  // pairs per partial-sum chunk of the per-bone (vertex, weight) lists
+
+// Word offsets into the packed table blob that chain_sensors_kernel stages into LDS (all entries are 32-bit).
+struct ChainTabs {
+  int path_mask, sub_mask, parents;       // [22] each: ancestors-or-self mask, subtree mask, parent index
+  int skin_idx, skin_w;                   // [nv*kb]
+  int chunk_bone, chunk_beg;              // [n_chunks]: CHAIN_CHUNK-pair slices of the per-bone (vertex, weight) lists
+  int bone_chunk_ptr;                     // [23]
+  int bone_vert, bone_w;                  // [nnz]
+  int s_center, s_helper, s_deg, s_faces; // [12], [12], [12], [12*max_deg*3]
+  int inc_ptr, inc_code;                  // [nv+1], [n_inc]: per vertex, what contributes to its cotangent
+  int total;
+};
+
 struct SmplTables {  // device pointers
   int n_sensors, nv, j_off, ncp, kb, max_deg;
+  int n_chunks;
+  const uint32_t* blob;
+  ChainTabs off;
   const float* wc; const float* wct;
   const int* parents;
   const int* skin_idx; const float* skin_w;

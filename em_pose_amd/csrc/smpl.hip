@@ -204,15 +204,29 @@ hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // chain + skinning + sensors (+ reverse)
+//
+// Workgroup = CH_FRAMES frames.  Phase list (each a flat parallel-for over (frame, item), barrier in between):
+//   P0  stage the packed index/weight tables (once per block) and each frame's rot | out row into LDS
+//   P2  forward chain: (joint,row) walks the root path given as a bit mask (joints are topologically ordered)
+//   P3  skinning of the needed vertices
+//   P4a face normals, one (sensor,face) per lane      P4b per sensor: normal sum (in face order, as the reference),
+//       frame, offsets, outputs, residual and its reverse down to (d centre, d helper, d face-normal)
+//   P4c per (sensor,face): d e1, d e2                 P4d per vertex coordinate: gather its incident contributions
+//   P5  d v_posed -> global;  per-bone force/moment partial sums over chunks of <= 16 (vertex,weight) pairs
+//   P5c combine chunks per bone                       P6 subtree sums (bit mask)      P7 d R, d J -> global
+// Every accumulation is a gather in a fixed order: results are bitwise reproducible and independent of the batch.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CH_THREADS = 256;
-constexpr int CH_FRAMES = 4;
+constexpr int CH_THREADS = 192;
+constexpr int CH_FRAMES = 2;
+constexpr int CHUNK = CHAIN_CHUNK;  // (vertex, weight) pairs per partial-sum chunk, lists padded with weight 0
 
 struct ChainLds {  // per-frame float offsets
-  int rot, out, g, at, v, dv, m, x, total;
+  int rot, out, g, at, v, dv, u, total;
+  // inside u (time-shared): fn | fg | scr   then   part | m | x
+  int fn, fg, scr, part, m, x;
 };
 
-__host__ __device__ inline ChainLds chain_layout(int nv, int ncp) {
+__host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, int n_chunks) {
   ChainLds l;
   int o = 0;
   l.rot = o; o += NB * 9;
@@ -221,14 +235,20 @@ __host__ __device__ inline ChainLds chain_layout(int nv, int ncp) {
   l.at = o; o += NB * 3;    // A^t = G^t - G^R J
   l.v = o; o += nv * 3;
   l.dv = o; o += nv * 3;
-  l.m = o; o += NB * 12;    // per bone: moment M (9) | force F (3)
-  l.x = o; o += NB * 12;    // per joint: X (9) | subtree force (3)
+  l.u = o;
+  const int nf = 12 * max_deg;
+  l.fn = l.u; l.fg = l.fn + nf * 3; l.scr = l.fg + nf * 6;
+  const int sz1 = nf * 9 + 12 * 9;
+  l.part = l.u; l.m = l.part + n_chunks * 12; l.x = l.m + NB * 12;
+  const int sz2 = n_chunks * 12 + 2 * NB * 12;
+  o += sz1 > sz2 ? sz1 : sz2;
   l.total = (o + 3) & ~3;
   return l;
 }
 
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block) {
-  return (size_t)chain_layout(tab.nv, tab.ncp).total * frames_per_block * sizeof(float);
+  const ChainLds l = chain_layout(tab.nv, tab.ncp, tab.max_deg, tab.n_chunks);
+  return ((size_t)l.total * frames_per_block + ((tab.off.total + 3) & ~3)) * sizeof(float);
 }
 
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
@@ -248,36 +268,65 @@ __device__ __forceinline__ void unit_bwd(const float* dy, const float* y, float 
 __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SmplTables& tb = a.tab;
-  const ChainLds L = chain_layout(tb.nv, tb.ncp);
+  const ChainTabs& O = tb.off;
+  const ChainLds L = chain_layout(tb.nv, tb.ncp, tb.max_deg, tb.n_chunks);
   const int tid = threadIdx.x;
   const int t0 = blockIdx.x * CH_FRAMES;
   const int nf = min(CH_FRAMES, a.T - t0);
   const int nv3 = tb.nv * 3;
+  const int md = tb.max_deg;
   const bool bwd = a.tgt != nullptr;
+  float* frames = smem;
+  const uint32_t* TI = reinterpret_cast<const uint32_t*>(smem + (size_t)L.total * CH_FRAMES);  // tables (ints)
+  const float* TF = reinterpret_cast<const float*>(TI);                                        // tables (floats)
 
-  // ---- P1: stage rotations and the GEMM output row (v_posed | J); clear the vertex cotangents
-  for (int i = tid; i < nf * L.total; i += CH_THREADS) {
-    const int f = i / L.total, o = i % L.total;
-    float v = 0.f;
-    if (o < L.out) v = a.rot[(size_t)(t0 + f) * (NB * 9) + o];
-    else if (o < L.g) v = a.out[(size_t)(t0 + f) * tb.ncp + (o - L.out)];
-    smem[f * L.total + o] = v;
+  // ---- P0: tables + per-frame rot | out.  Loads are issued in batches of 4 before the first LDS store so that the
+  // round trips overlap (a plain strided copy loop serialises one global latency per iteration).
+  {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)L.total * CH_FRAMES);
+    for (int i0 = tid; i0 < O.total; i0 += 4 * CH_THREADS) {
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CH_THREADS; v[u] = i < O.total ? tb.blob[i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CH_THREADS; if (i < O.total) dst[i] = v[u]; }
+    }
+    const int row = NB * 9 + tb.ncp;
+    const int n = nf * row;
+    for (int i0 = tid; i0 < n; i0 += 4 * CH_THREADS) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * CH_THREADS;
+        v[u] = 0.f;
+        if (i < n) {
+          const int f = i / row, o = i % row;
+          v[u] = o < NB * 9 ? a.rot[(size_t)(t0 + f) * (NB * 9) + o] : a.out[(size_t)(t0 + f) * tb.ncp + (o - NB * 9)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * CH_THREADS;
+        if (i < n) frames[(i / row) * L.total + (i % row)] = v[u];
+      }
+    }
   }
   __syncthreads();
   if (a.debug_stop == 1) return;
 
-  // ---- P2: forward chain, one (joint,row) per lane walking the root path
+  // ---- P2: forward chain
   for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
     const int f = i / (NB * 3), jr = i % (NB * 3), j = jr / 3, r = jr % 3;
-    float* S = smem + f * L.total;
+    float* S = frames + f * L.total;
     const float* sR = S + L.rot;
     const float* sJ = S + L.out + tb.j_off;
-    const int p0 = tb.path_ptr[j], p1 = tb.path_ptr[j + 1];
     float row0 = sR[r * 3 + 0], row1 = sR[r * 3 + 1], row2 = sR[r * 3 + 2];  // root rotation, row r
     float tr = sJ[r];
     int prev = 0;
-    for (int k = p0 + 1; k < p1; ++k) {
-      const int q = tb.path[k];
+    uint32_t pm = TI[O.path_mask + j] & ~1u;
+    while (pm) {
+      const int q = __ffs(pm) - 1;
+      pm &= pm - 1;
       const float* Jq = sJ + q * 3;
       const float* Jp = sJ + prev * 3;
       tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;
@@ -303,13 +352,13 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
     const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
-    float* S = smem + f * L.total;
+    float* S = frames + f * L.total;
     const float* vp = S + L.out + s * 3;
     float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;  // row r of the blended 3x4 transform
-    for (int k = 0; k < tb.kb; ++k) {
-      const float w = tb.skin_w[s * tb.kb + k];
-      if (w == 0.f) continue;
-      const int b = tb.skin_idx[s * tb.kb + k];
+#pragma unroll 4
+    for (int k = 0; k < tb.kb; ++k) {  // padding entries have weight 0 / bone 0: no branch, loads can be batched
+      const float w = TF[O.skin_w + s * tb.kb + k];
+      const int b = TI[O.skin_idx + s * tb.kb + k];
       const float* G = S + L.g + b * 12 + r * 3;
       T0 += w * G[0]; T1 += w * G[1]; T2 += w * G[2];
       T3 += w * S[L.at + b * 3 + r];
@@ -319,23 +368,31 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   __syncthreads();
   if (a.debug_stop == 3) return;
 
-  // ---- P4: sensors, one (frame, sensor) per lane: normals, frame, offsets, residual and its reverse to dv
-  for (int i = tid; i < nf * tb.n_sensors; i += CH_THREADS) {
-    const int f = i / tb.n_sensors, m = i % tb.n_sensors;
-    const int t = t0 + f;
-    float* S = smem + f * L.total;
+  // ---- P4a: un-normalised face normals
+  for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
+    const int f = i / (12 * md), mk = i % (12 * md);
+    float* S = frames + f * L.total;
     const float* V = S + L.v;
-    const int c = tb.s_center[m], h = tb.s_helper[m], deg = tb.s_deg[m];
-    const int* faces = tb.s_faces + (size_t)m * tb.max_deg * 3;
+    const uint32_t* fc = TI + O.s_faces + mk * 3;  // padding faces are (c,c,c): zero normal, zero cotangent
+    const float* v0 = V + fc[0] * 3;
+    const float* v1 = V + fc[1] * 3;
+    const float* v2 = V + fc[2] * 3;
+    const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    cross3(e1, e2, S + L.fn + mk * 3);
+  }
+  __syncthreads();
+
+  // ---- P4b: per sensor
+  for (int i = tid; i < nf * 12; i += CH_THREADS) {
+    const int f = i / 12, m = i % 12;
+    const int t = t0 + f;
+    float* S = frames + f * L.total;
+    const float* V = S + L.v;
+    const int c = TI[O.s_center + m], h = TI[O.s_helper + m], deg = TI[O.s_deg + m];
     float n[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < deg; ++k) {
-      const float* v0 = V + faces[k * 3 + 0] * 3;
-      const float* v1 = V + faces[k * 3 + 1] * 3;
-      const float* v2 = V + faces[k * 3 + 2] * 3;
-      const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
-      const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
-      float fn[3];
-      cross3(e1, e2, fn);
+      const float* fn = S + L.fn + (m * md + k) * 3;
       n[0] += fn[0]; n[1] += fn[1]; n[2] += fn[2];
     }
     const float fdeg = (float)deg;
@@ -383,9 +440,14 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
       }
     }
     if (!bwd) continue;
+    float* scr = S + L.scr + m * 9;  // d face-normal (3) | d centre (3) | d helper (3)
     const int slot = a.used_slot[m];
     const float scale = a.frame_scale[t];
-    if (slot < 0 || scale == 0.f) continue;
+    if (slot < 0 || scale == 0.f) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) scr[k] = 0.f;
+      continue;
+    }
     const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
     const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
     float dpos[3], dori[9];
@@ -424,72 +486,111 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     unit_bwd(dsv, sv, ne, de);
     float dn[3];
     unit_bwd(dnh, nh, nn, dn);
-    float* DV = S + L.dv;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      atomicAdd(DV + c * 3 + k, dpos[k] - de[k]);
-      atomicAdd(DV + h * 3 + k, de[k]);
-    }
-    const float dfn[3] = {dn[0] / fdeg, dn[1] / fdeg, dn[2] / fdeg};
-    for (int k = 0; k < deg; ++k) {
-      const int i0 = faces[k * 3 + 0], i1 = faces[k * 3 + 1], i2 = faces[k * 3 + 2];
-      const float* v0 = V + i0 * 3;
-      const float* v1 = V + i1 * 3;
-      const float* v2 = V + i2 * 3;
-      const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
-      const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
-      float de1[3], de2[3];
-      cross3(e2, dfn, de1);
-      cross3(dfn, e1, de2);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        atomicAdd(DV + i1 * 3 + q, de1[q]);
-        atomicAdd(DV + i2 * 3 + q, de2[q]);
-        atomicAdd(DV + i0 * 3 + q, -(de1[q] + de2[q]));
-      }
+      scr[k] = dn[k] / fdeg;
+      scr[3 + k] = dpos[k] - de[k];
+      scr[6 + k] = de[k];
     }
   }
   if (!bwd) return;
   __syncthreads();
+
+  // ---- P4c: per (sensor, face): cotangents of the two edge vectors
+  for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
+    const int f = i / (12 * md), mk = i % (12 * md), m = mk / md;
+    float* S = frames + f * L.total;
+    const float* V = S + L.v;
+    const uint32_t* fc = TI + O.s_faces + mk * 3;
+    const float* v0 = V + fc[0] * 3;
+    const float* v1 = V + fc[1] * 3;
+    const float* v2 = V + fc[2] * 3;
+    const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    const float* dfn = S + L.scr + m * 9;
+    float* fg = S + L.fg + mk * 6;
+    cross3(e2, dfn, fg);      // d e1
+    cross3(dfn, e1, fg + 3);  // d e2
+  }
+  __syncthreads();
+
+  // ---- P4d: gather the vertex cotangents (fixed order => deterministic)
+  for (int i = tid; i < nf * nv3; i += CH_THREADS) {
+    const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
+    float* S = frames + f * L.total;
+    float acc = 0.f;
+    const int q0 = TI[O.inc_ptr + s], q1 = TI[O.inc_ptr + s + 1];
+    for (int q = q0; q < q1; ++q) {
+      const uint32_t code = TI[O.inc_code + q];
+      const int slot = code >> 3, type = code & 7;
+      if (type == 0) acc -= S[L.fg + slot * 6 + r] + S[L.fg + slot * 6 + 3 + r];
+      else if (type == 1) acc += S[L.fg + slot * 6 + r];
+      else if (type == 2) acc += S[L.fg + slot * 6 + 3 + r];
+      else if (type == 3) acc += S[L.scr + slot * 9 + 3 + r];
+      else acc += S[L.scr + slot * 9 + 6 + r];
+    }
+    S[L.dv + sr] = acc;
+  }
+  __syncthreads();
   if (a.debug_stop == 4) return;
 
-  // ---- P5: d v_posed (to global) and the per-bone force / world-space moment sums
+  // ---- P5: d v_posed (to global) and per-chunk force / world-space moment partial sums
   for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
     const int f = i / tb.ncp, col = i % tb.ncp;
     if (col >= tb.j_off && col < tb.j_off + NB * 3) continue;  // d J is written in P7
     float acc = 0.f;
     if (col < nv3) {
       const int s = col / 3, cc = col % 3;
-      const float* S = smem + f * L.total;
+      const float* S = frames + f * L.total;
       const float* dv = S + L.dv + s * 3;
+#pragma unroll 4
       for (int k = 0; k < tb.kb; ++k) {
-        const float w = tb.skin_w[s * tb.kb + k];
-        if (w == 0.f) continue;
-        const float* G = S + L.g + tb.skin_idx[s * tb.kb + k] * 12;
+        const float w = TF[O.skin_w + s * tb.kb + k];
+        const float* G = S + L.g + TI[O.skin_idx + s * tb.kb + k] * 12;
         acc += w * (G[0 + cc] * dv[0] + G[3 + cc] * dv[1] + G[6 + cc] * dv[2]);
       }
     }
     a.d_out[(size_t)(t0 + f) * tb.ncp + col] = acc;
   }
+  for (int i = tid; i < nf * tb.n_chunks; i += CH_THREADS) {
+    const int f = i / tb.n_chunks, ch = i % tb.n_chunks;
+    float* S = frames + f * L.total;
+    const int b = TI[O.chunk_bone + ch];
+    const int q0 = TI[O.chunk_beg + ch];
+    float G[12];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G[k] = S[L.g + b * 12 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) G[9 + k] = S[L.at + b * 3 + k];
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < CHUNK; ++q) {  // chunks are padded to CHUNK pairs with weight 0
+      const int sidx = TI[O.bone_vert + q0 + q];
+      const float wq = TF[O.bone_w + q0 + q];
+      const float* vp = S + L.out + sidx * 3;
+      const float* dv = S + L.dv + sidx * 3;
+      const float d0 = wq * dv[0], d1 = wq * dv[1], d2 = wq * dv[2];
+      const float x0 = G[0] * vp[0] + G[1] * vp[1] + G[2] * vp[2] + G[9];
+      const float x1 = G[3] * vp[0] + G[4] * vp[1] + G[5] * vp[2] + G[10];
+      const float x2 = G[6] * vp[0] + G[7] * vp[1] + G[8] * vp[2] + G[11];
+      acc[0] += d0 * x0; acc[1] += d0 * x1; acc[2] += d0 * x2;
+      acc[3] += d1 * x0; acc[4] += d1 * x1; acc[5] += d1 * x2;
+      acc[6] += d2 * x0; acc[7] += d2 * x1; acc[8] += d2 * x2;
+      acc[9] += d0; acc[10] += d1; acc[11] += d2;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) S[L.part + ch * 12 + k] = acc[k];
+  }
+  __syncthreads();
+
+  // ---- P5c: per bone: sum its chunks (chunks of a bone are contiguous)
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
     const int f = i / (NB * 12), be = i % (NB * 12), b = be / 12, e = be % 12;
-    float* S = smem + f * L.total;
-    const float* G = S + L.g + b * 12;
+    float* S = frames + f * L.total;
     float acc = 0.f;
-    const int q0 = tb.bone_ptr[b], q1 = tb.bone_ptr[b + 1];
-    if (e < 9) {
-      const int ar = e / 3, cc = e % 3;
-      const float at = S[L.at + b * 3 + cc];
-      for (int q = q0; q < q1; ++q) {
-        const int s = tb.bone_vert[q];
-        const float* vp = S + L.out + s * 3;
-        const float x = G[cc * 3 + 0] * vp[0] + G[cc * 3 + 1] * vp[1] + G[cc * 3 + 2] * vp[2] + at;
-        acc += tb.bone_w[q] * S[L.dv + s * 3 + ar] * x;
-      }
-    } else {
-      const int ar = e - 9;
-      for (int q = q0; q < q1; ++q) acc += tb.bone_w[q] * S[L.dv + tb.bone_vert[q] * 3 + ar];
-    }
+    for (int ch = TI[O.bone_chunk_ptr + b]; ch < (int)TI[O.bone_chunk_ptr + b + 1]; ++ch) acc += S[L.part + ch * 12 + e];
     S[L.m + be] = acc;
   }
   __syncthreads();
@@ -498,20 +599,26 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
     const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
-    float* S = smem + f * L.total;
-    const int q0 = tb.sub_ptr[j], q1 = tb.sub_ptr[j + 1];
+    float* S = frames + f * L.total;
+    uint32_t sm = TI[O.sub_mask + j];
     if (e < 9) {
       const int ar = e / 3, cc = e % 3;
       float ms = 0.f, fs = 0.f;
-      for (int q = q0; q < q1; ++q) {
-        const float* Mb = S + L.m + tb.sub[q] * 12;
+      while (sm) {
+        const int d = __ffs(sm) - 1;
+        sm &= sm - 1;
+        const float* Mb = S + L.m + d * 12;
         ms += Mb[e];
         fs += Mb[9 + ar];
       }
       S[L.x + je] = ms - fs * S[L.g + j * 12 + 9 + cc];
     } else {
       float fs = 0.f;
-      for (int q = q0; q < q1; ++q) fs += S[L.m + tb.sub[q] * 12 + e];
+      while (sm) {
+        const int d = __ffs(sm) - 1;
+        sm &= sm - 1;
+        fs += S[L.m + d * 12 + e];
+      }
       S[L.x + je] = fs;
     }
   }
@@ -521,10 +628,10 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
     const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
-    const float* S = smem + f * L.total;
+    const float* S = frames + f * L.total;
     const float* Gj = S + L.g + j * 12;
     const float* X = S + L.x + j * 12;
-    const int p = tb.parents[j];
+    const int p = (int)TI[O.parents + j];
     const float* Gp = S + L.g + (p < 0 ? 0 : p) * 12;
     if (e < 9) {
       const int r = e / 3, cc = e % 3;
@@ -554,11 +661,12 @@ hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
   static const int dbg = getenv("EMPOSE_CHAIN_STOP") ? atoi(getenv("EMPOSE_CHAIN_STOP")) : 0;  // timing aid only
   a.debug_stop = dbg;
   const size_t lds = chain_lds_bytes(a.tab, CH_FRAMES);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
   }
   const int blocks = (a.T + CH_FRAMES - 1) / CH_FRAMES;
   hipLaunchKernelGGL(chain_sensors_kernel, dim3(blocks), dim3(CH_THREADS), lds, stream, a);
