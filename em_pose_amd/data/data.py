@@ -5,7 +5,9 @@ Only what the LGD path touches is restated: the attribute set of `ABatch`, `Real
 suppression, and `get_inputs(sf, ef)` yielding the dict the model reads.  Sample classes, LMDB / npz
 IO and collation from files are out of scope (host-side IO).
 """
+import numpy as np
 import torch
+from torch.nn.utils.rnn import pad_sequence
 
 from em_pose_amd.helpers.configuration import CONSTANTS as C
 
@@ -49,6 +51,38 @@ class ABatch(object):
         raise NotImplementedError('Must be implemented by subclass.')
 
 
+class RealSample(object):
+    """One recording: real sensor data aligned with ground-truth SMPL parameters (reference data.py:106-190)."""
+
+    def __init__(self, seq_id, marker_pos, marker_ori, marker_masks, smpl_poses, smpl_shape, smpl_trans, offset_data):
+        assert marker_pos.shape[0] == smpl_poses.shape[0]
+        f = marker_pos.shape[0]
+        self.id = seq_id
+        self.marker_pos_real = marker_pos.reshape(f, -1)
+        self.marker_ori_real = marker_ori.reshape(f, -1)
+        self.marker_masks = marker_masks
+        self.smpl_poses, self.smpl_shape, self.smpl_trans = smpl_poses, smpl_shape, smpl_trans
+        self.offset_means, self.offset_covs, self.offset_r = offset_data['means'], offset_data['covs'], offset_data['r']
+
+    @classmethod
+    def from_npz_clean(cls, npz_file):
+        """The `*_clean.npz` layout of the EM-POSE data release (reference data.py:161-171)."""
+        assert npz_file.endswith('_clean.npz')
+        d = np.load(npz_file)
+        return cls(d['id'].tolist(), d['sensor_pos'], d['sensor_oris'], d['sensor_masks'], d['smpl_poses'],
+                   d['smpl_shape'], d['smpl_trans'],
+                   {'means': d['offset_means'], 'covs': d['offset_covs'], 'r': d['offset_r']})
+
+    @property
+    def n_frames(self):
+        return self.marker_pos_real.shape[0]
+
+    def to_tensor(self):
+        for name in ('marker_pos_real', 'marker_ori_real', 'marker_masks', 'smpl_poses', 'smpl_shape', 'smpl_trans',
+                     'offset_means', 'offset_covs', 'offset_r'):
+            setattr(self, name, torch.from_numpy(np.asarray(getattr(self, name))).to(dtype=C.DTYPE))
+
+
 class RealBatch(ABatch):
     """Real sensor recordings with ground-truth SMPL parameters and per-subject offsets."""
 
@@ -67,6 +101,17 @@ class RealBatch(ABatch):
     @property
     def n_markers(self):
         return self.marker_pos_real.shape[-1] // 3
+
+    @staticmethod
+    def from_sample_list(samples):
+        """Collate `RealSample`s (already tensors) with zero padding (reference data.py:239-268)."""
+        seq_lengths = torch.tensor([s.smpl_poses.shape[0] for s in samples])
+        pad = lambda xs: pad_sequence(xs, batch_first=True)
+        return RealBatch([s.id for s in samples], seq_lengths, pad([s.smpl_poses[:, :66] for s in samples]),
+                         torch.stack([s.smpl_shape[:C.N_SHAPE_PARAMS] for s in samples]),
+                         pad([s.smpl_trans for s in samples]), pad([s.marker_pos_real for s in samples]),
+                         pad([s.marker_ori_real for s in samples]), pad([s.marker_masks for s in samples]),
+                         torch.stack([s.offset_means for s in samples]), torch.stack([s.offset_r for s in samples]))
 
     def to_gpu(self, device=None):
         device = C.DEVICE if device is None else device

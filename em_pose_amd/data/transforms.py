@@ -1,0 +1,75 @@
+"""
+The few transforms `evaluate_real` needs before the model sees a recording (reference empose/data/transforms.py):
+
+  NormalizeRealMarkers   reference transforms.py:99-129  sensor readings into the frame of the first SMPL root pose
+  ToTensor               reference transforms.py:51-56
+  NormalizeRoot          reference transforms.py:229-256 first root orientation := identity, translation := 0
+
+Host-side NumPy/PyTorch-CPU code, once per recording; not on the accelerated path.  Training-time transforms
+(SMPLFK ground truth, SampleMarkersWithOffsets, noise) are out of scope of this round.
+"""
+import numpy as np
+import torch
+
+from em_pose_amd.eval.metrics import rotvec_to_matrix
+
+
+def matrix_to_rotvec(R):
+    """(...,3,3) -> (...,3) log map, float64, robust near 0 and pi."""
+    R = np.asarray(R, dtype=np.float64)
+    tr = np.clip((np.trace(R, axis1=-2, axis2=-1) - 1.0) * 0.5, -1.0, 1.0)
+    theta = np.arccos(tr)
+    w = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1)
+    s = np.sin(theta)
+    small = theta < 1e-6
+    near_pi = (np.pi - theta) < 1e-4
+    scale = np.where(small, 0.5 + theta ** 2 / 12.0, theta / (2.0 * np.where(np.abs(s) < 1e-12, 1.0, s)))
+    out = w * scale[..., None]
+    if np.any(near_pi):
+        # axis from the symmetric part: R + I = 2 n n^T at theta = pi
+        B = (R + np.eye(3)) * 0.5
+        k = np.argmax(np.diagonal(B, axis1=-2, axis2=-1), axis=-1)
+        col = np.take_along_axis(B, k[..., None, None], axis=-1)[..., 0]
+        axis = col / np.linalg.norm(col, axis=-1, keepdims=True)
+        axis = axis * np.where((axis * w).sum(-1, keepdims=True) < 0, -1.0, 1.0)
+        out = np.where(near_pi[..., None], axis * theta[..., None], out)
+    return out
+
+
+class NormalizeRealMarkers(object):
+    def __call__(self, sample):
+        n_markers = sample.marker_pos_real.shape[-1] // 3
+        R0 = rotvec_to_matrix(np.asarray(sample.smpl_poses[0, :3], dtype=np.float64))  # (3,3)
+        trans = np.asarray(sample.smpl_trans, dtype=np.float64)[:, None, :]
+        pos = np.asarray(sample.marker_pos_real, dtype=np.float64).reshape(-1, n_markers, 3) - trans
+        pos = pos @ R0  # R0^T p for row vectors
+        ori = R0.T @ np.asarray(sample.marker_ori_real, dtype=np.float64).reshape(-1, n_markers, 3, 3)
+        sample.marker_pos_real = pos.reshape(-1, n_markers * 3).astype(np.float32)
+        sample.marker_ori_real = ori.reshape(-1, n_markers * 9).astype(np.float32)
+        return sample
+
+
+class ToTensor(object):
+    def __call__(self, sample):
+        sample.to_tensor()
+        return sample
+
+
+class NormalizeRoot(object):
+    def __init__(self, normalize_root_ori=True, remove_root_trans=True):
+        self.normalize_root_ori = normalize_root_ori
+        self.remove_root_trans = remove_root_trans
+
+    def __call__(self, batch):
+        with torch.no_grad():
+            batch.trans_source = batch.trans.clone()
+            batch.root_pose_source = batch.poses[:, :, :3].clone()
+            if self.remove_root_trans:
+                batch.trans = torch.zeros_like(batch.trans)
+            if self.normalize_root_ori:
+                root = batch.poses[:, :, :3].detach().cpu().numpy().astype(np.float64)
+                R = rotvec_to_matrix(root)  # (N,F,3,3)
+                Rn = np.swapaxes(R[:, :1], -1, -2) @ R
+                batch.poses = batch.poses.clone()
+                batch.poses[:, :, :3] = torch.from_numpy(matrix_to_rotvec(Rn)).to(batch.poses)
+        return batch

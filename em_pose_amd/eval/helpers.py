@@ -1,0 +1,109 @@
+"""
+Evaluation driver (mirror of reference empose/eval/helpers.py:30-200 and scripts/evaluate_real.py:24-101).
+
+  window_generator        256-frame chunks of one recording (reference helpers.py:30-48)
+  load_model              config.json + model.pth of a released model id (reference helpers.py:131-164)
+  partition_sequences     NEW: whole recordings -> ranks, longest-processing-time-first (chunks of one
+                          recording are serially dependent through the LSTM state and must stay on one GPU)
+  evaluate_sequences      the per-recording loop of evaluate_real.py (state carry, first chunk's shape for the whole
+                          recording, metrics on all frames / per recording)
+"""
+import glob
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from em_pose_amd.data.data import RealBatch
+from em_pose_amd.eval.metrics import MetricsEngine
+from em_pose_amd.helpers.configuration import CONSTANTS as C
+from em_pose_amd.helpers.configuration import Configuration
+
+
+def window_generator(batch, window_size):
+    if window_size is None:
+        yield batch
+        return
+    assert isinstance(batch, RealBatch)
+    seq_len = batch.seq_length
+    n_windows = seq_len // window_size + int(seq_len % window_size > 0)
+    for i in range(n_windows):
+        sf, ef = i * window_size, min((i + 1) * window_size, seq_len)
+        lengths = torch.tensor([ef - sf], dtype=batch.seq_lengths.dtype, device=batch.seq_lengths.device)
+        yield RealBatch(batch.ids, lengths, batch.poses[:, sf:ef], batch.shapes, batch.trans[:, sf:ef],
+                        batch.marker_pos_real[:, sf:ef], batch.marker_ori_real[:, sf:ef], batch.marker_masks[:, sf:ef],
+                        batch.offset_t, batch.offset_r)
+
+
+def get_model_dir(experiment_dir, model_id):
+    hits = glob.glob(os.path.join(experiment_dir, str(model_id) + '-*'))
+    if len(hits) != 1:
+        raise ValueError('expected exactly one model directory for id {} under {}, found {}'
+                         .format(model_id, experiment_dir, len(hits)))
+    return hits[0]
+
+
+def load_model_weights(checkpoint_file, net, state_key='model_state_dict'):
+    if not os.path.exists(checkpoint_file):
+        raise ValueError('Could not find model checkpoint {}.'.format(checkpoint_file))
+    ckpt = torch.load(checkpoint_file, map_location='cpu')[state_key]
+    missing, unexpected = net.load_state_dict(ckpt, strict=False)
+    bad = [k for k in list(missing) + list(unexpected) if not k.startswith('smpl.')]
+    if bad:
+        raise ValueError('checkpoint does not match the model: {}'.format(bad[:8]))
+
+
+def load_model(model_id, device=None):
+    from em_pose_amd.bodymodels.smpl import create_default_smpl_model
+    from em_pose_amd.nn.models import create_model
+    device = C.DEVICE if device is None else device
+    model_dir = get_model_dir(C.EXPERIMENT_DIR, model_id)
+    config = Configuration.from_json(os.path.join(model_dir, 'config.json'))
+    smpl = create_default_smpl_model(device)
+    net = create_model(config, smpl)
+    load_model_weights(os.path.join(model_dir, 'model.pth'), net)
+    return net.to(device).eval(), config, model_dir
+
+
+def partition_sequences(lengths, world_size):
+    """
+    Longest-processing-time-first assignment of recordings to ranks.
+    :return: list (per rank) of sorted recording indices; deterministic for equal lengths.
+    """
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world_size
+    parts = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(p) for p in parts]
+
+
+def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=None):
+    """
+    :param batches: iterable of single-recording `RealBatch`es (root already normalised), on the CPU.
+    :return: (overall MetricsEngine, [(recording id, metrics dict)], frames processed)
+    """
+    from em_pose_amd.nn.models import IterativeErrorFeedback
+    me_all, me_ind = MetricsEngine(smpl_model), MetricsEngine(smpl_model)
+    per_sequence, frames = [], 0
+    is_lgd = isinstance(net, IterativeErrorFeedback)
+    ws = window_size if is_lgd else None
+    for batch in batches:
+        if log:
+            log('Evaluate {} ({} frames)'.format(batch.ids[0], int(batch.seq_lengths[0])))
+        first_shape_hat = None
+        me_ind.reset()
+        for c, chunk in enumerate(window_generator(batch, ws)):
+            chunk = chunk.to_gpu(device)
+            out = net(chunk, is_new_sequence=(c == 0))
+            if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
+                first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
+            for me in (me_all, me_ind):
+                me.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
+                           chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
+            frames += int(chunk.seq_lengths.sum())
+        per_sequence.append((batch.ids[0], me_ind.get_metrics()))
+    return me_all, per_sequence, frames

@@ -166,3 +166,22 @@ def make_windows(n_windows, n_frames, seed, sensors_fn=None):
         out['marker_pos'] = pos.reshape(B, F, 36).astype(np.float32)
         out['marker_oris'] = ori.reshape(B, F, 108).astype(np.float32)
     return out
+
+
+# Frame counts of the 36 recordings of the EM-POSE test set (reference README.md:107-142), used to shape the synthetic
+# stand-in of BASELINE.json configs[3] (sum = 54 030 frames).
+README_SEQUENCE_LENGTHS = [3460, 1937, 688, 2213, 490, 1630, 801, 1945, 1875, 2916, 1311, 745, 1796, 246, 1423, 1331,
+                           1647, 1569, 2931, 596, 1421, 1846, 296, 1191, 560, 1736, 1677, 2458, 779, 1269, 2002, 504,
+                           1600, 1191, 2303, 1647]
+
+
+def make_sequence(n_frames, seed, sensors_fn, missing_rate=0.002):
+    """One synthetic recording in the shape of a `*_clean.npz` file (reference data.py:161-171)."""
+    w = make_windows(1, n_frames, seed, sensors_fn)
+    rng = np.random.default_rng(seed + 17)
+    masks = (rng.uniform(size=(n_frames, 12)) > missing_rate)
+    return {'id': np.asarray('synthetic_%05d' % seed), 'sensor_pos': w['marker_pos'][0].reshape(n_frames, 12, 3),
+            'sensor_oris': w['marker_oris'][0].reshape(n_frames, 12, 3, 3), 'sensor_masks': masks,
+            'smpl_poses': w['poses'][0], 'smpl_shape': w['shapes'][0], 'smpl_trans': np.zeros((n_frames, 3), np.float32),
+            'offset_means': w['offset_t'][0], 'offset_covs': np.tile(np.eye(3, dtype=np.float32) * 1e-4, (12, 1, 1)),
+            'offset_r': w['offset_r'][0]}

@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""
+Evaluate an end-to-end model on the EM-POSE recordings (mirror of reference scripts/evaluate_real.py:24-110).
+
+    python scripts/evaluate_real.py --model_id 1615631737 [--cross_subject]
+
+needs the assets the reference needs (EM_EXPERIMENTS, EM_DATA_REAL, SMPL_MODELS: released weights, recordings and the
+licensed SMPL-H model); they cannot be shipped with this repository.  Without them,
+
+    python scripts/evaluate_real.py --synthetic [--n_markers 6 --iterations 2]
+
+runs the same driver on the stand-in of BASELINE.json configs[3]: 36 synthetic recordings with the frame counts of
+the real test set (README.md:107-142, 54 030 frames), a synthetic SMPL-H-shaped body model and random-init weights of
+the released LGD-RNN-6 architecture, streamed in 256-frame chunks with LSTM state carry.
+
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N scripts/evaluate_real.py ...`; whole
+recordings are assigned to ranks longest-first (chunks of one recording are serially dependent), and the per-rank metric
+accumulators are combined with one all_gather over RCCL.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from tabulate import tabulate  # noqa: E402
+
+from em_pose_amd.data.data import RealBatch, RealSample  # noqa: E402
+from em_pose_amd.data.transforms import NormalizeRealMarkers, NormalizeRoot, ToTensor  # noqa: E402
+from em_pose_amd.eval.helpers import evaluate_sequences, load_model, partition_sequences  # noqa: E402
+from em_pose_amd.helpers.configuration import CONSTANTS as C  # noqa: E402
+
+
+def sample_to_batch(sample):
+    sample = ToTensor()(NormalizeRealMarkers()(sample))
+    return NormalizeRoot()(RealBatch.from_sample_list([sample]))
+
+
+def synthetic_setup(args, device):
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn.models import create_model
+    model = synthetic.make_model()
+    torch.manual_seed(args.model_id)
+    cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, lr=0.0005)
+    net = create_model(cfg, SMPLLayer(model)).to(device).eval()
+    smpl = SMPLLayer(model).to(device)
+
+    def sensors(poses, betas, o_r, o_t):
+        n = poses.shape[0]
+        pos, ori, _ = net.get_estimated_real_markers(torch.from_numpy(poses).to(device),
+                                                     torch.from_numpy(betas).to(device),
+                                                     torch.from_numpy(o_r[:1].copy()).to(device),
+                                                     torch.from_numpy(o_t[:1].copy()).to(device), frames_per_window=n)
+        return pos.cpu().numpy(), ori.cpu().numpy()
+
+    lengths = synthetic.README_SEQUENCE_LENGTHS[:args.max_sequences] if args.max_sequences else \
+        synthetic.README_SEQUENCE_LENGTHS
+
+    def load(i):
+        d = synthetic.make_sequence(lengths[i], 100 + i, sensors)
+        s = RealSample(str(d['id']), d['sensor_pos'], d['sensor_oris'], d['sensor_masks'].astype(np.float32),
+                       d['smpl_poses'], d['smpl_shape'], d['smpl_trans'],
+                       {'means': d['offset_means'], 'covs': d['offset_covs'], 'r': d['offset_r']})
+        return sample_to_batch(s)
+    return net, smpl, lengths, load, 'synthetic-%d' % args.model_id
+
+
+def real_setup(args, device):
+    from em_pose_amd.bodymodels.smpl import create_default_smpl_model
+    for var in ('EM_EXPERIMENTS', 'EM_DATA_REAL', 'SMPL_MODELS'):
+        if not os.environ.get(var):
+            raise SystemExit('{} is not set. The real evaluation needs the released weights, the recordings and the '
+                             'licensed SMPL-H model; use --synthetic to run the driver without them.'.format(var))
+    net, config, _ = load_model(args.model_id, device)
+    smpl = create_default_smpl_model(device)
+    base = os.path.join(C.DATA_DIR_TEST, 'hold_out') if args.cross_subject else C.DATA_DIR_TEST
+    files = sorted(glob.glob(os.path.join(base, '*_clean.npz')))
+    if not files:
+        raise SystemExit('no *_clean.npz recordings under ' + base)
+    lengths = [int(np.load(f)['smpl_poses'].shape[0]) for f in files]
+    return net, smpl, lengths, (lambda i: sample_to_batch(RealSample.from_npz_clean(files[i]))), str(args.model_id)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--model_id', type=int, default=1615631737, help='Which end-to-end model to evaluate.')
+    p.add_argument('--visualize', type=int, default=-1, help='(accepted for compatibility; not implemented)')
+    p.add_argument('--cross_subject', action='store_true', help='Evaluate on hold-out subject 0715.')
+    p.add_argument('--synthetic', action='store_true', help='Synthetic recordings / body model / weights.')
+    p.add_argument('--n_markers', type=int, default=6)
+    p.add_argument('--iterations', type=int, default=2)
+    p.add_argument('--no_rnn', action='store_true')
+    p.add_argument('--max_sequences', type=int, default=0)
+    p.add_argument('--json', action='store_true', help='Also print one machine-readable JSON line.')
+    args = p.parse_args()
+
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('evaluate_real.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=device)
+
+    net, smpl, lengths, load, name = (synthetic_setup if args.synthetic else real_setup)(args, device)
+    mine = partition_sequences(lengths, world)[rank]
+    batches = [load(i) for i in mine]  # data preparation is outside the timed region
+    net.keep_history = False
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    log = print if world == 1 else None
+    me_all, per_seq, frames = evaluate_sequences(net, batches, smpl, device, window_size=256, log=log)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]
+    if dist is not None:
+        me_all.gather(device=device)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rows, frames, elapsed))
+        rows = sorted(r for g in gathered for r in g[0])
+        frames = sum(g[1] for g in gathered)
+        elapsed = max(g[2] for g in gathered)
+    if rank == 0:
+        metrics = me_all.get_metrics()
+        table = [[i, sid] + list(m.values()) for i, sid, m in rows]
+        table.append([len(table), 'Overall average'] + list(metrics.values()))
+        print(tabulate(table, headers=['Nr', 'E2E {}'.format(name)] + list(metrics.keys())))
+        print('{} frames in {:.3f} s on {} GPU(s): {:.0f} frames/s (model forward + metrics)'
+              .format(frames, elapsed, world, frames / elapsed))
+        if args.json:
+            print(json.dumps({'frames': frames, 'seconds': elapsed, 'n_gpus': world, 'frames_per_sec': frames / elapsed,
+                              'metrics': metrics}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

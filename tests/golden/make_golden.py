@@ -264,6 +264,19 @@ def main():
     v2, j2 = smpl(poses_body=p, betas=bt[0])
     comp.update({'fk_pose': p.numpy(), 'fk_betas': bt.numpy(), 'fk_root': rt.numpy(), 'fk_v': v1.numpy(),
                  'fk_j': j1.numpy(), 'fk_v_noroot_bcast': v2.numpy(), 'fk_j_noroot_bcast': j2.numpy()})
+    # MetricsEngine (reference eval/metrics.py:243-263,289-330): joint-distance part (needs no numpy-quaternion)
+    from empose.eval.metrics import MetricsEngine
+    me = MetricsEngine(smpl)
+    mj = torch.randn(3, 9, 66, generator=g)
+    mjh = mj + 0.05 * torch.randn(3, 9, 66, generator=g)
+    mlen = torch.tensor([9, 5, 2])
+    mmask = (torch.rand(3, 9, 12, generator=g) > 0.05).float()
+    me.compute_joint_dist(mj, mjh, mlen, mmask)
+    mm_ = me.get_metrics()
+    comp.update({'me_joints': mj.numpy(), 'me_joints_hat': mjh.numpy(), 'me_len': mlen.numpy(),
+                 'me_mask': mmask.numpy(), 'me_MPJPE': mm_['MPJPE [mm]'], 'me_MPJPE_STD': mm_['MPJPE STD'],
+                 'me_PA-MPJPE': mm_['PA-MPJPE [mm]'], 'me_PA-MPJPE_STD': mm_['PA-MPJPE STD'],
+                 'me_n_rows': np.concatenate(me.eucl_dists).shape[0]})
     np.savez_compressed(os.path.join(HERE, 'components.npz'), **comp)
     print('wrote components.npz')
 

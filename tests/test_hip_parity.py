@@ -403,3 +403,66 @@ def test_full_mesh_vertices_vs_oracle(big_model):
     v0, j0 = smpl(poses_body=torch.zeros(2, 63, device=DEV), betas=torch.zeros(10, device=DEV))
     np.testing.assert_allclose(v0[0].cpu().numpy(), big_model['v_template'], atol=1e-6)
     np.testing.assert_allclose(v0[1].cpu().numpy(), v0[0].cpu().numpy(), atol=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_streaming_evaluation_driver_matches_oracle_chunk_by_chunk():
+    """evaluate_real's loop: one 600-frame recording, 256-frame chunks, LSTM state carried chunk to chunk, missing
+    sensors; the model outputs equal the oracle run chunk by chunk, and the metrics equal a NumPy recomputation."""
+    from em_pose_amd.data.data import RealBatch, RealSample
+    from em_pose_amd.data.transforms import NormalizeRealMarkers, NormalizeRoot, ToTensor
+    from em_pose_amd.eval.helpers import evaluate_sequences, window_generator
+    from em_pose_amd.eval.metrics import MetricsEngine
+    case = H.load_case('lgdrnn6_n2')
+    meta = case['meta']
+    model = H.small_model()
+    vids = [int(v) for v in meta['vertex_ids']]
+    net = build_net(cfg_of(meta), model, vids, case['sd'])
+    net.keep_history = False
+    smpl = SMPLLayer(model).to(DEV)
+    bm = R.BodyModelTensors(model)
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    d = synthetic.make_sequence(600, 5, sensors, missing_rate=0.01)
+    s = RealSample('rec', d['sensor_pos'], d['sensor_oris'], d['sensor_masks'].astype(np.float32), d['smpl_poses'],
+                   d['smpl_shape'], d['smpl_trans'], {'means': d['offset_means'], 'covs': d['offset_covs'],
+                                                      'r': d['offset_r']})
+    batch = NormalizeRoot()(RealBatch.from_sample_list([ToTensor()(NormalizeRealMarkers()(s))]))
+
+    # oracle, chunk by chunk with state carry
+    sd = H.sd_to_torch(case['sd'])
+    state, want = None, []
+    for chunk in window_generator(batch, 256):
+        inp = chunk.get_inputs()
+        inp['seq_lengths'] = chunk.seq_lengths.long()
+        out, hist = R.ief_forward(sd, bm, tables, vids, inp, n_markers=6, N=int(meta['N']), rnn_init=True,
+                                  rnn_state=state)
+        state = hist['rnn_state']
+        want.append(out)
+    me, per_seq, frames = evaluate_sequences(net, [batch], smpl, torch.device(DEV), window_size=256)
+    assert frames == 600 and len(per_seq) == 1
+    # re-run the model chunks to compare raw outputs
+    for c, chunk in enumerate(window_generator(batch, 256)):
+        out = net(chunk.to_gpu(torch.device(DEV)), is_new_sequence=(c == 0))
+        for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+            np.testing.assert_allclose(out[k].cpu().numpy(), want[c][k].numpy(), atol=ATOL)
+    m = me.get_metrics()
+    assert all(np.isfinite(v) for v in m.values()) and m['MPJPE [mm]'] > 0
+    # the frames with a missing sensor are excluded from the metrics (frame_mask semantics of metrics.py:166-181)
+    n_valid = int((d['sensor_masks'].all(axis=1)).sum())
+    assert np.concatenate(me.eucl_dists).shape[0] == n_valid
+    # MPJPE recomputed with the oracle's FK on the same predictions
+    pose = torch.cat([w['pose_hat'] for w in want], 1)[0]
+    root = torch.cat([w['root_ori_hat'] for w in want], 1)[0]
+    shape0 = want[0]['shape_hat'][0, :1].expand(600, 10)
+    valid = torch.from_numpy(d['sensor_masks'].all(axis=1))
+    _, j_hat = R.smpl_fk(bm, pose, shape0, root)
+    _, j_gt = R.smpl_fk(bm, batch.poses[0, :, 3:], batch.shapes.expand(600, 10), batch.poses[0, :, :3])
+    e = np.linalg.norm((j_hat[:, :22] - j_gt[:, :22]).numpy()[valid.numpy()], axis=-1)
+    want_mpjpe = float(np.mean(np.mean(e, axis=0)[me.eucl_idxs]) * 1000.0)
+    assert m['MPJPE [mm]'] == pytest.approx(want_mpjpe, rel=1e-3)
