@@ -89,6 +89,8 @@ SIGNATURES = {
                                    C.c_void_p]),
     'empose_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    'empose_virtual_sensors_fwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_profile_enable': (C.c_int, [C.c_int]),
     'empose_profile_ntags': (C.c_int, []),
     'empose_profile_tag_name': (C.c_char_p, [C.c_int]),

@@ -784,6 +784,19 @@ int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C
   return EMPOSE_OK;
 }
 
+int empose_virtual_sensors_fwd(int T, int V, const float* vertices, int M, int max_deg, const int* center,
+                               const int* helper, const int* deg, const int* faces, float* pos, float* ori,
+                               float* normals, empose_stream_t stream_) {
+  if (!vertices || !center || !helper || !deg || !faces || !pos || !ori) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0 || V <= 0 || M <= 0 || max_deg <= 0) return fail(EMPOSE_EINVAL, "sizes must be positive");
+  VirtualSensorArgs a;
+  a.vertices = vertices; a.center = center; a.helper = helper; a.deg = deg; a.faces = faces;
+  a.pos = pos; a.ori = ori; a.normals = normals; a.T = T; a.V = V; a.M = M; a.max_deg = max_deg;
+  hipError_t e = launch_virtual_sensors(a, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "virtual sensors kernel: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
 // ---- full mesh -----------------------------------------------------------------------------------------------
 void empose_mesh_destroy(empose_mesh_t* mesh) {
   if (!mesh) return;

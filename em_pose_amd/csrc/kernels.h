@@ -156,4 +156,12 @@ struct MeshSkinArgs {
 };
 hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream);
 
+struct VirtualSensorArgs {
+  const float* vertices;   // [T][V][3]
+  const int* center; const int* helper; const int* deg; const int* faces;  // [M], [M], [M], [M][max_deg][3] (mesh ids)
+  float* pos; float* ori; float* normals;   // [T][M][3], [T][M][9], [T][M][3] (un-normalised) or nullptr
+  int T, V, M, max_deg;
+};
+hipError_t launch_virtual_sensors(const VirtualSensorArgs& a, hipStream_t stream);
+
 }  // namespace empose

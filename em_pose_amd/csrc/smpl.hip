@@ -742,4 +742,60 @@ hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Virtual sensors from arbitrary full-mesh vertices (reference virtual_sensors.py:16-38,77-96; utils.py:126-146):
+// one lane per (frame, sensor).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void virtual_sensors_kernel(VirtualSensorArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.T * a.M) return;
+  const int t = idx / a.M, m = idx % a.M;
+  const float* V = a.vertices + (size_t)t * a.V * 3;
+  const int deg = a.deg[m];
+  const int* faces = a.faces + (size_t)m * a.max_deg * 3;
+  float n[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < deg; ++k) {
+    const float* v0 = V + (size_t)faces[k * 3 + 0] * 3;
+    const float* v1 = V + (size_t)faces[k * 3 + 1] * 3;
+    const float* v2 = V + (size_t)faces[k * 3 + 2] * 3;
+    const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    float fn[3];
+    cross3(e1, e2, fn);
+    n[0] += fn[0]; n[1] += fn[1]; n[2] += fn[2];
+  }
+  const float fdeg = (float)deg;
+  n[0] /= fdeg; n[1] /= fdeg; n[2] /= fdeg;
+  const float nn = norm3(n);
+  const float nh[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+  const float* vc = V + (size_t)a.center[m] * 3;
+  const float* vh = V + (size_t)a.helper[m] * 3;
+  const float e[3] = {vh[0] - vc[0], vh[1] - vc[1], vh[2] - vc[2]};
+  const float ne = norm3(e);
+  const float sv[3] = {e[0] / ne, e[1] / ne, e[2] / ne};
+  float bb[3];
+  cross3(nh, sv, bb);
+  const float nb = norm3(bb);
+  const float tv[3] = {bb[0] / nb, bb[1] / nb, bb[2] / nb};
+  float aa[3];
+  cross3(tv, nh, aa);
+  const float na = norm3(aa);
+  float* po = a.pos + (size_t)idx * 3;
+  float* oo = a.ori + (size_t)idx * 9;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    po[r] = vc[r];
+    oo[r * 3 + 0] = aa[r] / na;
+    oo[r * 3 + 1] = tv[r];
+    oo[r * 3 + 2] = nh[r];
+    if (a.normals) a.normals[(size_t)idx * 3 + r] = n[r];
+  }
+}
+
+hipError_t launch_virtual_sensors(const VirtualSensorArgs& a, hipStream_t stream) {
+  const long n = (long)a.T * a.M;
+  hipLaunchKernelGGL(virtual_sensors_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, a);
+  return hipGetLastError();
+}
+
 }  // namespace empose

@@ -200,6 +200,15 @@ int empose_lstm_fwd(const empose_model_t* model, int B, int F, const float* x, i
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream);
 
+/* Virtual sensor positions and local frames from full-mesh vertices [T][V][3]
+ * (replaces VirtualMarkerHelper.get_virtual_pos_and_rot, reference data/virtual_sensors.py:85-96, and
+ * compute_vertex_and_face_normals restricted to the sensor vertices, helpers/utils.py:126-146).
+ * Index tables are DEVICE int32 arrays in mesh numbering: center/helper/deg [M], faces [M][max_deg][3].
+ * Outputs pos [T][M][3], ori [T][M][3][3] (columns tangent, bitangent, normal), normals [T][M][3] un-normalised or NULL. */
+int empose_virtual_sensors_fwd(int T, int V, const float* vertices, int M, int max_deg, const int* center,
+                               const int* helper, const int* deg, const int* faces, float* pos, float* ori,
+                               float* normals, empose_stream_t stream);
+
 /* ---- optional per-launch timing ------------------------------------------------------------------------------- */
 /* While enabled, every kernel launch issued by the entry points above is bracketed by HIP events on the launch stream
  * and attributed to one of empose_profile_ntags() categories (GEMMs by role, LSTM step, chain kernel, ...).
