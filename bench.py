@@ -213,7 +213,7 @@ def main():
         ach = flops / (avg_ms * 1e-3) / 1e12
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
-                              'kernel': 'gemm_tn_f32_kernel<2,2> (update-net hidden layer, both nets per launch)',
+                              'kernel': 'gemm_tn_f32_kernel<Cfg<4,2,2,2,32>,1> (update-net hidden layer, both nets per launch)',
                               'avg_launch_ms': avg_ms, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,
                               'hbm_frac_on_algorithmic_bytes': value * 1162.0 / 1e9 / PEAK_HBM_GBS}
