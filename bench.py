@@ -112,6 +112,22 @@ def cpu_baseline(net, model, w, seconds_target=20.0):
                       % (nb, F, len(reps), os.cpu_count())}
 
 
+def pmc_traffic(T, hidden):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes). Only valid for the workload
+    the counters were collected on; otherwise null."""
+    import glob
+    if (T, hidden) != (32768, 512):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_hbm_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        ks = json.load(f)['kernels']
+    hit = [v for k, v in ks.items() if 'gemm_tn_f32_kernel' in k and ', 1>(' in k]
+    return hit[0]['hbm_bytes_per_launch_corrected'] if hit else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -212,7 +228,7 @@ def main():
         flops = 2 * 2.0 * (B * F) * h * h  # both update nets in one launch
         ach = flops / (avg_ms * 1e-3) / 1e12
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(B * F, h),
                               'kernel': 'gemm_tn_f32_kernel<Cfg<4,2,2,2,32>,1> (update-net hidden layer, both nets per launch)',
                               'avg_launch_ms': avg_ms, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,
