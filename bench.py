@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--no_rnn', action='store_true')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
+    ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -155,9 +156,12 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', device_id=dev)
 
     from em_pose_amd import _lib

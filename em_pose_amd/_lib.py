@@ -80,6 +80,10 @@ SIGNATURES = {
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_smpl_vjp_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_smpl_sensors_vjp': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_update_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'empose_update_nets_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -97,6 +97,7 @@ struct empose_model {
   Mlp pose_init, shape_init, pose_iter, shape_iter;
   int hidden_max = 0;
   int any_skip = 0;
+  int smpl_only = 0;
 };
 
 struct empose_mesh {
@@ -390,7 +391,8 @@ int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const
 // One SMPL evaluation given rot/feat already produced by update_feat.
 int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const float* offset_r, const float* offset_t,
                   const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori, float* joints,
-                  float* pos2, float* ori2, float* joints2, hipStream_t stream) {
+                  float* pos2, float* ori2, float* joints2, hipStream_t stream, const float* cot_pos = nullptr,
+                  const float* cot_ori = nullptr, const float* cot_joints = nullptr) {
   GemmBatch b;
   b.count = 1;
   GemmProb& p = b.p[0];
@@ -408,10 +410,11 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
   for (int i = 0; i < 12; ++i) c.used_slot[i] = m->used_slot[i];
   c.pos = pos; c.ori = ori; c.joints = joints; c.pos2 = pos2; c.ori2 = ori2; c.joints2 = joints2;
   c.d_out = ws.d_out; c.d_rot = ws.d_rot; c.T = T; c.F = F;
+  c.cot_pos = cot_pos; c.cot_ori = cot_ori; c.cot_joints = cot_joints;
   prof_mark(P_CHAIN, stream);
   e = launch_chain_sensors(c, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "chain kernel: %s", hipGetErrorString(e));
-  if (tgt) {
+  if (tgt || cot_pos) {
     p.A = ws.d_out; p.lda = m->tab.ncp; p.W = m->tab.wct; p.ldw = m->tab.ncp; p.C = ws.d_feat; p.ldc = 200;
     p.M = T; p.N = 200; p.K = m->tab.ncp;
     prof_mark(P_BLEND_T_GEMM, stream);
@@ -537,6 +540,9 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
     MTRY(pack_dense(m->allocs, d->shape_head, &m->shape_head));
     if (m->pose_head.out_dim != 66 || m->shape_head.out_dim != 10 || m->pose_head.in_dim != r.hidden_size)
       return bail(fail(EMPOSE_EINVAL, "init head dims"));
+  } else if (d->pose_init.n_layers == 0 && d->n_iterations == 0) {
+    // body-model-only handle: serves empose_smpl_sensors_fwd_bwd / _vjp (training path), not empose_lgd_forward
+    m->smpl_only = 1;
   } else {
     MTRY(pack_mlp(m->allocs, d->pose_init, &m->pose_init, &m->hidden_max, &m->any_skip));
     MTRY(pack_mlp(m->allocs, d->shape_init, &m->shape_init, &m->hidden_max, &m->any_skip));
@@ -613,6 +619,7 @@ size_t empose_lgd_workspace_bytes(const empose_model_t* m, int B, int F) {
 int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
                        empose_stream_t stream_) {
   if (!m || !io || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (m->smpl_only) return fail(EMPOSE_EINVAL, "this handle holds the body model only (no networks)");
   const int B = io->B, F = io->F;
   if (B <= 0 || F <= 0) return fail(EMPOSE_EINVAL, "B and F must be positive");
   if (!io->marker_pos || !io->marker_oris || !io->offset_t || !io->offset_r || !io->pose_hat || !io->shape_hat ||
@@ -741,6 +748,48 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
+}
+
+int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* theta, int ld_theta, const float* beta,
+                            int ld_beta, const float* offset_r, const float* offset_t, const float* d_pos,
+                            const float* d_ori, const float* d_joints, float* g_theta, float* g_beta, void* workspace,
+                            size_t workspace_bytes, empose_stream_t stream_) {
+  if (!m || !theta || !beta || !offset_r || !offset_t || !d_pos || !d_ori || !g_theta || !g_beta || !workspace)
+    return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0 || F <= 0 || T % F != 0) return fail(EMPOSE_EINVAL, "T must be a positive multiple of F");
+  if (workspace_bytes < empose_smpl_workspace_bytes(m, T) + (size_t)T * (36 + 108 + 66) * sizeof(float) + 1024)
+    return fail(EMPOSE_ENOMEM, "workspace too small (need empose_smpl_vjp_workspace_bytes)");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Carver c(workspace);
+  SmplWs ws = carve_smpl(c, m, T);
+  float* pos = c.f((size_t)T * 36);
+  float* ori = c.f((size_t)T * 108);
+  float* joints = c.f((size_t)T * 66);
+  HIP_TRY(hipMemcpy2DAsync(ws.theta, 66 * sizeof(float), theta, (size_t)ld_theta * sizeof(float), 66 * sizeof(float), T,
+                           hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemcpy2DAsync(ws.beta, 10 * sizeof(float), beta, (size_t)ld_beta * sizeof(float), 10 * sizeof(float), T,
+                           hipMemcpyDeviceToDevice, stream));
+  FeatArgs fa;
+  fa.theta = ws.theta; fa.ld_theta = 66; fa.beta = ws.beta; fa.ld_beta = 10;
+  fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
+  fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
+  fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
+  fa.T = T; fa.F = F;
+  hipError_t e = launch_update_feat(fa, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, pos, ori, joints, nullptr, nullptr, nullptr,
+                    stream, d_pos, d_ori, d_joints));
+  RodBwdArgs ra;
+  ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
+  ra.g_theta = g_theta; ra.ld_g = 66; ra.g_beta = g_beta; ra.ld_gb = 10;
+  ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T;
+  e = launch_rodrigues_bwd(ra, stream);
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+size_t empose_smpl_vjp_workspace_bytes(const empose_model_t* m, int T) {
+  return empose_smpl_workspace_bytes(m, T) + (size_t)T * (36 + 108 + 66) * sizeof(float) + 1024;
 }
 
 int empose_update_nets_fwd(const empose_model_t* m, int T, const float* x, int ldx, float* d_pose, float* d_shape,

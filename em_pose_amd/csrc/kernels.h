@@ -120,6 +120,9 @@ struct ChainArgs {
   float* d_out;            // [T][ncp]
   float* d_rot;            // [T][22][9]
   int T, F;
+  const float* cot_pos = nullptr;    // [T][36]  external cotangents (vector-Jacobian product for training);
+  const float* cot_ori = nullptr;    // [T][108] when set they replace the residual of `tgt`
+  const float* cot_joints = nullptr; // [T][66]  optional
   int debug_stop = 0;      // timing aid: return after phase k (0 = run everything)
 };
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block);

@@ -275,7 +275,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   const int nf = min(CH_FRAMES, a.T - t0);
   const int nv3 = tb.nv * 3;
   const int md = tb.max_deg;
-  const bool bwd = a.tgt != nullptr;
+  const bool cot = a.cot_pos != nullptr;          // external cotangents (training) instead of the residual
+  const bool bwd = a.tgt != nullptr || cot;
   float* frames = smem;
   const uint32_t* TI = reinterpret_cast<const uint32_t*>(smem + (size_t)L.total * CH_FRAMES);  // tables (ints)
   const float* TF = reinterpret_cast<const float*>(TI);                                        // tables (floats)
@@ -441,17 +442,23 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     }
     if (!bwd) continue;
     float* scr = S + L.scr + m * 9;  // d face-normal (3) | d centre (3) | d helper (3)
-    const int slot = a.used_slot[m];
-    const float scale = a.frame_scale[t];
-    if (slot < 0 || scale == 0.f) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) scr[k] = 0.f;
-      continue;
-    }
-    const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
-    const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
     float dpos[3], dori[9];
-    {
+    if (cot) {
+      const float* cp = a.cot_pos + ((size_t)t * 12 + m) * 3;
+      const float* co = a.cot_ori + ((size_t)t * 12 + m) * 9;
+      dpos[0] = cp[0]; dpos[1] = cp[1]; dpos[2] = cp[2];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) dori[k] = co[k];
+    } else {
+      const int slot = a.used_slot[m];
+      const float scale = a.frame_scale[t];
+      if (slot < 0 || scale == 0.f) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) scr[k] = 0.f;
+        continue;
+      }
+      const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
+      const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
       const float r0 = pos[0] - tp[0], r1 = pos[1] - tp[1], r2 = pos[2] - tp[2];
       const float rn = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
       dpos[0] = r0 / rn * scale; dpos[1] = r1 / rn * scale; dpos[2] = r2 / rn * scale;
@@ -591,6 +598,15 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     float* S = frames + f * L.total;
     float acc = 0.f;
     for (int ch = TI[O.bone_chunk_ptr + b]; ch < (int)TI[O.bone_chunk_ptr + b + 1]; ++ch) acc += S[L.part + ch * 12 + e];
+    if (a.cot_joints) {
+      // joint j (position G_j^t) moves rigidly with its parent's frame: force d_j at point t_j on bone parent(j)
+      const float* dj = a.cot_joints + (size_t)(t0 + f) * 66;
+      for (int j = 1; j < NB; ++j) {
+        if ((int)TI[O.parents + j] != b) continue;
+        if (e < 9) acc += dj[j * 3 + e / 3] * S[L.g + j * 12 + 9 + e % 3];
+        else acc += dj[j * 3 + (e - 9)];
+      }
+    }
     S[L.m + be] = acc;
   }
   __syncthreads();
@@ -650,6 +666,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
       for (int ar = 0; ar < 3; ++ar) {
         const float gp = p < 0 ? (ar == cc ? 1.f : 0.f) : Gp[ar * 3 + cc];
         acc += (gp - Gj[ar * 3 + cc]) * X[9 + ar];
+        if (a.cot_joints) acc += gp * a.cot_joints[(size_t)(t0 + f) * 66 + j * 3 + ar];
       }
       a.d_out[(size_t)(t0 + f) * tb.ncp + tb.j_off + j * 3 + cc] = acc;
     }

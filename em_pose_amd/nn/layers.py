@@ -82,6 +82,15 @@ class MLP(nn.Module):
         specs.append((self.hidden_to_output, None, None))
         return specs
 
+    def forward_torch(self, x):
+        """The same network as PyTorch-ROCm ops with autograd (training path only: train-mode BatchNorm statistics,
+        parameter gradients). Layer order as reference nn/layers.py:69-77."""
+        y = self.dropout(self.activation_fn(self.batch_norm(self.input_to_hidden(x))))
+        for block in self.hidden_layers:
+            z = block.layers(y)
+            y = y + z if block.use_skip else z
+        return self.hidden_to_output(y)
+
     def fill_desc(self, desc, keep):
         """Fill an `_lib.MlpDesc` from the current parameters; host arrays are appended to `keep`."""
         specs = self.dense_specs()
@@ -164,6 +173,14 @@ class RNNLayer(nn.Module):
                     for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
             keep += arrs
             desc.w_ih[l], desc.w_hh[l], desc.b_ih[l], desc.b_hh[l] = [_lib.fptr(a) for a in arrs]
+
+    def forward_torch(self, x, seq_lengths):
+        """Training path only: nn.LSTM over packed sequences with the carried state (reference layers.py:133-157)."""
+        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        packed = pack_padded_sequence(x, seq_lengths.cpu(), batch_first=True, enforce_sorted=False)
+        out, self.final_state = self.lstm(packed, self.init_state)
+        out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])
+        return out
 
     def forward(self, x, seq_lengths):
         raise NotImplementedError('RNNLayer runs inside IterativeErrorFeedback.forward on the HIP path')

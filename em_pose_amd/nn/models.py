@@ -61,6 +61,39 @@ def padded_loss(gt, hat, loss_fn, seq_lengths):
     return ((unreduced * mask).sum(-1) / seq_lengths.to(unreduced.dtype)).mean()
 
 
+class _SmplSensorsFn(torch.autograd.Function):
+    """Differentiable `get_estimated_real_markers` for the training path: forward and vector-Jacobian product are the
+    HIP sub-mesh kernels (empose_smpl_sensors_fwd_bwd / empose_smpl_sensors_vjp); no autograd graph through SMPL."""
+
+    @staticmethod
+    def forward(ctx, net, pose, shape, offset_r, offset_t, frames_per_window):
+        pos, ori, joints = net.get_estimated_real_markers(pose.detach(), shape.detach(), offset_r, offset_t,
+                                                          frames_per_window=frames_per_window)
+        ctx.net, ctx.F = net, frames_per_window
+        ctx.save_for_backward(pose.detach(), shape.detach(), offset_r, offset_t)
+        return pos, ori, joints
+
+    @staticmethod
+    def backward(ctx, d_pos, d_ori, d_joints):
+        pose, shape, offset_r, offset_t = ctx.saved_tensors
+        net, dev, T = ctx.net, pose.device, pose.shape[0]
+        f32 = lambda t: t.to(dtype=torch.float32).contiguous()
+        pose, shape, d_pos, d_ori, d_joints = f32(pose), f32(shape), f32(d_pos), f32(d_ori), f32(d_joints)
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            handle = net._ensure_handle(dev)
+            g_pose = torch.empty(T, 66, dtype=torch.float32, device=dev)
+            g_shape = torch.empty(T, 10, dtype=torch.float32, device=dev)
+            nbytes = lib.empose_smpl_vjp_workspace_bytes(handle, T)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_smpl_sensors_vjp(handle, T, ctx.F, _lib.dptr(pose), 66, _lib.dptr(shape), 10,
+                                                   _lib.dptr(offset_r), _lib.dptr(offset_t), _lib.dptr(d_pos),
+                                                   _lib.dptr(d_ori), _lib.dptr(d_joints), _lib.dptr(g_pose),
+                                                   _lib.dptr(g_shape), _lib.dptr(ws), nbytes, _lib.current_stream()))
+            torch.cuda.current_stream().synchronize()
+        return None, g_pose, g_shape, None, None, None
+
+
 class BaseModel(nn.Module):
     def __init__(self, config, smpl_model=None):
         super(BaseModel, self).__init__()
@@ -185,6 +218,8 @@ class IterativeErrorFeedback(BaseModel):
         self.joints_hat_history = None
         self._handle = None      # opaque empose_model_t*
         self._handle_key = None  # what it was built from
+        self._smpl_handle = None      # body-model-only handle used by the training path
+        self._smpl_handle_key = None
         self._workspace = None
 
     def set_input_output_size(self):
@@ -249,9 +284,15 @@ class IterativeErrorFeedback(BaseModel):
             _lib.lib().empose_model_destroy(self._handle)
             self._handle, self._handle_key = None, None
 
+    def release_all(self):
+        self.release()
+        if getattr(self, '_smpl_handle', None) is not None:
+            _lib.lib().empose_model_destroy(self._smpl_handle)
+            self._smpl_handle, self._smpl_handle_key = None, None
+
     def __del__(self):
         try:
-            self.release()
+            self.release_all()
         except Exception:
             pass
 
@@ -259,10 +300,26 @@ class IterativeErrorFeedback(BaseModel):
         return TB.build_lgd_tables(self.smpl.model, self.vertex_ids, self.helper_ids, CONST.N_SHAPE_PARAMS)
 
     def _ensure_handle(self, device):
+        if self.training:
+            return self._ensure_smpl_handle(device)
         key = self._state_key(device)
         if self._handle is not None and key == self._handle_key:
             return self._handle
         self.release()
+        return self._build_handle(device, key, smpl_only=False)
+
+    def _ensure_smpl_handle(self, device):
+        """Body-model-only handle for the training path: its key ignores the network parameters, which change with
+        every optimiser step."""
+        key = (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()))
+        if self._smpl_handle is not None and key == self._smpl_handle_key:
+            return self._smpl_handle
+        if self._smpl_handle is not None:
+            _lib.lib().empose_model_destroy(self._smpl_handle)
+        self._smpl_handle, self._smpl_handle_key = None, None
+        return self._build_handle(device, key, smpl_only=True)
+
+    def _build_handle(self, device, key, smpl_only):
         keep = []
         desc = _lib.ModelDesc()
         tab = self.sub_mesh_tables()
@@ -278,24 +335,30 @@ class IterativeErrorFeedback(BaseModel):
         desc.n_markers = self.n_markers
         for i, v in enumerate(self.marker_idxs):
             desc.marker_idx[i] = v
-        desc.n_iterations = self.N
         desc.step_size = float(self.step_size)
         desc.shape_avg = int(bool(self.shape_avg))
         desc.use_gradient = int(bool(self.use_gradient))
-        desc.rnn_init = int(bool(self.rnn_init))
-        if self.rnn_init:
-            self.rnn.fill_desc(desc.rnn, keep)
-            fill_dense_desc(desc.pose_head, self.pose_net_init, None, None, keep)
-            fill_dense_desc(desc.shape_head, self.shape_net_init, None, None, keep)
+        if smpl_only:
+            desc.n_iterations, desc.rnn_init = 0, 0
         else:
-            self.pose_net_init.fill_desc(desc.pose_init, keep)
-            self.shape_net_init.fill_desc(desc.shape_init, keep)
-        self.pose_net_iter.fill_desc(desc.pose_iter, keep)
-        self.shape_net_iter.fill_desc(desc.shape_iter, keep)
+            desc.n_iterations = self.N
+            desc.rnn_init = int(bool(self.rnn_init))
+            if self.rnn_init:
+                self.rnn.fill_desc(desc.rnn, keep)
+                fill_dense_desc(desc.pose_head, self.pose_net_init, None, None, keep)
+                fill_dense_desc(desc.shape_head, self.shape_net_init, None, None, keep)
+            else:
+                self.pose_net_init.fill_desc(desc.pose_init, keep)
+                self.shape_net_init.fill_desc(desc.shape_init, keep)
+            self.pose_net_iter.fill_desc(desc.pose_iter, keep)
+            self.shape_net_iter.fill_desc(desc.shape_iter, keep)
         handle = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().empose_model_create(C.byref(desc), C.byref(handle)))
-        self._handle, self._handle_key = handle, key
+        if smpl_only:
+            self._smpl_handle, self._smpl_handle_key = handle, key
+        else:
+            self._handle, self._handle_key = handle, key
         return handle
 
     def get_estimated_real_markers(self, poses, shapes, offset_r, offset_t, vertex_ids=None, frames_per_window=1):
@@ -335,8 +398,7 @@ class IterativeErrorFeedback(BaseModel):
         :return: dict(pose (B,F,66), shape (B,F,10), joints (B,F,66), state (h_n,c_n) or None, hist {...} or None)
         """
         if self.training:
-            raise NotImplementedError('training through the HIP path (BASELINE config 5) is not implemented yet; '
-                                      'call .eval() for inference')
+            raise RuntimeError('forward_tensors is the inference entry point; in training mode call forward(batch)')
         if not marker_pos.is_cuda:
             raise _lib.EmposeError('IterativeErrorFeedback needs GPU tensors; there is no CPU fallback')
         dev = marker_pos.device
@@ -391,11 +453,103 @@ class IterativeErrorFeedback(BaseModel):
                                               self._workspace.numel(), _lib.current_stream()))
         return out
 
+    # ---- training path (BASELINE configs[4]) -------------------------------------------------------------------
+    def residual_gradient(self, pose, shape, inputs_flat, offset_r, offset_t, frame_scale, F):
+        """g_pose, g_shape of the in-loop reconstruction energy (reference models.py:560-579) from the HIP kernel."""
+        dev, T = pose.device, pose.shape[0]
+        lib = _lib.lib()
+        f32 = lambda t: t.detach().to(dtype=torch.float32).contiguous()
+        pose, shape, tgt = f32(pose), f32(shape), f32(inputs_flat)
+        with torch.cuda.device(dev):
+            handle = self._ensure_handle(dev)
+            new = lambda n: torch.empty(T, n, dtype=torch.float32, device=dev)
+            pos, ori, joints, g_pose, g_shape = new(36), new(108), new(66), new(66), new(10)
+            nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(pose), 66, _lib.dptr(shape), 10,
+                                                       _lib.dptr(offset_r), _lib.dptr(offset_t), _lib.dptr(tgt),
+                                                       tgt.shape[1], _lib.dptr(frame_scale), _lib.dptr(pos),
+                                                       _lib.dptr(ori), _lib.dptr(joints), _lib.dptr(g_pose), 66,
+                                                       _lib.dptr(g_shape), 10, _lib.dptr(ws), nbytes,
+                                                       _lib.current_stream()))
+            torch.cuda.current_stream().synchronize()
+        return g_pose, g_shape
+
+    def _forward_train(self, batch_inputs):
+        """
+        One window batch WITH an autograd graph (reference models.py:501-609 in training mode).  The SMPL evaluation
+        and its reverse are the HIP kernels (custom autograd Function); the LSTM / MLPs run as PyTorch-ROCm ops so
+        that autograd provides their backward (train-mode BatchNorm statistics included).  The reference's quirk is
+        kept: every in-loop residual gradient is also back-propagated into the parameters that produced the current
+        estimate (`E.backward(retain_graph=True)`, models.py:576).
+        """
+        inputs_ = self.prepare_inputs(batch_inputs)
+        if not inputs_.is_cuda:
+            raise _lib.EmposeError('IterativeErrorFeedback needs GPU tensors; there is no CPU fallback')
+        dev = inputs_.device
+        B, F = inputs_.shape[0], inputs_.shape[1]
+        T = B * F
+        seq_lengths = batch_inputs['seq_lengths'].to(dev)
+        masks = batch_inputs['marker_masks']
+        offset_r = batch_inputs['offset_r'].to(dev, torch.float32).contiguous()
+        offset_t = batch_inputs['offset_t'].to(dev, torch.float32).contiguous()
+        live = (torch.arange(F, device=dev)[None, :] < seq_lengths[:, None]).float()
+        scale = live * (float(F) / seq_lengths.float())[:, None]
+        if masks is not None:
+            scale = scale * masks.to(dev).ne(0).all(dim=-1).float()
+        scale = scale.reshape(T).contiguous()
+        inputs_flat = inputs_.reshape(T, -1)
+        if self.rnn_init:
+            self.rnn.init_state = self.rnn.final_state
+            lstm_out = self.rnn.forward_torch(inputs_, seq_lengths)
+            pose = self.pose_net_init(lstm_out).reshape(T, -1)
+            shape = self.shape_net_init(lstm_out).reshape(T, -1)
+        else:
+            pose = self.pose_net_init.forward_torch(inputs_flat)
+            shape = self.shape_net_init.forward_torch(inputs_flat)
+
+        def single_shape(s):
+            return s.reshape(B, F, -1).mean(dim=1, keepdim=True).repeat(1, F, 1).reshape(T, -1)
+        if self.shape_avg:
+            shape = single_shape(shape)
+        hist = {'pose': [pose], 'shape': [shape], 'joints': [], 'markers': [], 'markers_ori': []}
+
+        def evaluate(p, s):
+            pos, ori, joints = _SmplSensorsFn.apply(self, p, s, offset_r, offset_t, F)
+            hist['markers'].append(pos)
+            hist['markers_ori'].append(ori)
+            hist['joints'].append(joints)
+        evaluate(pose, shape)
+        for i in range(self.N):
+            feats = [inputs_flat, pose.detach(), shape.detach()]
+            if self.use_gradient:
+                g_pose, g_shape = self.residual_gradient(pose, shape, inputs_flat, offset_r, offset_t, scale, F)
+                # reference quirk: E.backward() also reaches the parameters behind the current estimate
+                if pose.requires_grad:
+                    torch.autograd.backward([pose, shape], [g_pose / float(T), g_shape / float(T)], retain_graph=True)
+                feats += [g_pose, g_shape]
+            x = torch.cat(feats, dim=-1)
+            d_pose = self.pose_net_iter.forward_torch(x)
+            d_shape = self.shape_net_iter.forward_torch(x)
+            if self.shape_avg:
+                d_shape = single_shape(d_shape)
+            pose = pose + d_pose * self.step_size
+            shape = shape + d_shape * self.step_size
+            hist['pose'].append(pose)
+            hist['shape'].append(shape)
+            evaluate(pose, shape)
+        pose_f = pose.reshape(B, F, -1)
+        out = {'pose': pose_f, 'shape': shape.reshape(B, F, -1), 'joints': hist['joints'][-1].reshape(B, F, -1)}
+        return out, hist
+
     def forward(self, batch, window_size=None, is_new_sequence=True):
         if self.rnn_init:
             if is_new_sequence:
                 self.rnn.final_state = None
             self.rnn.init_state = self.rnn.final_state
+        if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and \
+                getattr(self, 'differentiable', False):
+            return self._forward_with_graph(batch, window_size)
         outs, hists, traces = [], [], []
         for batch_inputs in self.window_generator(batch, window_size=window_size):
             state = None
@@ -433,10 +587,29 @@ class IterativeErrorFeedback(BaseModel):
                 'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
                 'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
 
+    def _forward_with_graph(self, batch, window_size):
+        outs, hists = [], []
+        for batch_inputs in self.window_generator(batch, window_size=window_size):
+            out, hist = self._forward_train(batch_inputs)
+            outs.append(out)
+            hists.append(hist)
+        bsz = batch.batch_size
+
+        def merged(key, inner):
+            return [torch.cat([hw[key][h].reshape(bsz, -1, inner) for hw in hists], dim=1) for h in range(self.N + 1)]
+        self.pose_hat_history = merged('pose', 66)
+        self.shape_hat_history = merged('shape', 10)
+        self.joints_hat_history = merged('joints', 3)
+        self.markers_hat_history = merged('markers', 3)
+        self.markers_ori_hat_history = merged('markers_ori', 3)
+        pose = torch.cat([o['pose'] for o in outs], dim=1)
+        return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3],
+                'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
+                'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
+
     def backward(self, batch, model_out, writer=None, global_step=None):
-        """Loss values of reference models.py:634-688 from the recorded histories (evaluation mode only)."""
-        if self.training:
-            raise NotImplementedError('training through the HIP path is not implemented yet')
+        """Losses of reference models.py:634-688 from the recorded histories; in training mode also
+        `total_loss.backward()` (the histories then carry the autograd graph of `_forward_train`)."""
         if self.pose_hat_history is None:
             raise RuntimeError('backward() needs the histories of the preceding forward() (keep_history=True)')
         bs, f = batch.batch_size, batch.seq_length
@@ -467,4 +640,6 @@ class IterativeErrorFeedback(BaseModel):
                      'fk': fk.item() / n_hist, 'total_loss': total.item()}
         if writer is not None:
             self.log_loss_vals(loss_vals, writer, global_step)
+        if self.training:
+            total.backward()
         return total, loss_vals

@@ -182,6 +182,16 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* model, int T, int F,
                                 float* g_theta, int ld_g, float* g_beta, int ld_gb,
                                 void* workspace, size_t workspace_bytes, empose_stream_t stream);
 
+/* Vector-Jacobian product of the same evaluation for training: given cotangents of the outputs
+ * d_pos [T][36], d_ori [T][108], d_joints [T][66] (or NULL) returns g_theta [T][66], g_beta [T][10].
+ * This is the backward of `get_estimated_real_markers` that the reference gets from autograd when
+ * IterativeErrorFeedback.backward calls total_loss.backward() (reference models.py:634-688). */
+size_t empose_smpl_vjp_workspace_bytes(const empose_model_t* model, int T);
+int empose_smpl_sensors_vjp(const empose_model_t* model, int T, int F, const float* theta, int ld_theta,
+                            const float* beta, int ld_beta, const float* offset_r, const float* offset_t,
+                            const float* d_pos, const float* d_ori, const float* d_joints, float* g_theta,
+                            float* g_beta, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
 /* Both update networks on x [T][ldx]: d_pose [T][66], d_shape [T][10]
  * (replaces pose_net_iter / shape_net_iter, reference models.py:586-587; layers.py:46-77). */
 size_t empose_update_workspace_bytes(const empose_model_t* model, int T);

@@ -234,6 +234,38 @@ def main():
     save_case('lgdrnn12_n3_ragged_masked', net, w2, {'run': rec},
               {'n_markers': 12, 'N': 3, 'rnn': 1, 'vertex_ids': vids})
 
+    # ---- case E: TRAINING step (reference models.py:485-688 in train mode): forward, backward, parameter gradients
+    for tag, rnn, nm, N, seed in (('train_lgdrnn12_n2', True, 12, 2, 31), ('train_lgd6_n2', False, 6, 2, 32)):
+        net, smpl = make_net(lgd_flags(nm, rnn, N, H, H), seed, vids)
+        w = synthetic.make_windows(3, 16, seed, sensors_from_reference(net, smpl))
+        lengths = torch.tensor([16, 16, 11])
+        with torch.no_grad():
+            _, jgt = smpl(poses_body=torch.from_numpy(w['poses'].reshape(48, 66)[:, 3:]),
+                          betas=torch.from_numpy(np.repeat(w['shapes'], 16, axis=0)),
+                          poses_root=torch.from_numpy(w['poses'].reshape(48, 66)[:, :3]))
+        w['joints_gt'] = jgt[:, :22].reshape(3, 16, 66).numpy()
+        batch = _SynthBatch(w, lengths)
+        batch.joints_gt = torch.from_numpy(w['joints_gt'])
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        net.train()
+        net.zero_grad()
+        out = net(batch)
+        total, loss_vals = net.backward(batch, out)
+        rec = {'out_' + k: v.detach().numpy() for k, v in out.items()}
+        rec['total_loss'] = total.detach().numpy()
+        for k, v in loss_vals.items():
+            rec['loss_' + k] = np.asarray(v)
+        for k, p_ in net.named_parameters():
+            if not k.startswith('smpl.') and p_.grad is not None:
+                rec['grad/' + k] = p_.grad.detach().numpy()
+        for k, v in net.state_dict().items():
+            if 'running_' in k:
+                rec['after/' + k] = v.numpy()
+        net.load_state_dict(sd0)  # fixtures store the state BEFORE the step
+        w2 = dict(w)
+        w2['seq_lengths'] = lengths.numpy()
+        save_case(tag, net, w2, {'run': rec}, {'n_markers': nm, 'N': N, 'rnn': int(rnn), 'vertex_ids': vids})
+
     # ---- component vectors straight from reference functions
     from empose.nn.loss import reconstruction_loss
     from empose.helpers.utils import mask_from_seq_lengths, compute_vertex_and_face_normals

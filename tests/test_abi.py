@@ -75,6 +75,12 @@ def test_cpu_tensors_raise_instead_of_falling_back():
         net.forward_tensors(x, torch.zeros(1, 4, 108), torch.zeros(1, 12, 3), torch.eye(3).expand(1, 12, 3, 3))
     with pytest.raises(_lib.EmposeError):
         smpl(poses_body=torch.zeros(2, 63), betas=torch.zeros(2, 10))
-    with pytest.raises(NotImplementedError):
-        net.train()
+    net.train()
+    with pytest.raises(RuntimeError):  # the inference entry point refuses training mode ...
         net.forward_tensors(x, x, x, x)
+    from em_pose_amd.data.data import SyntheticBatch
+    w = {'poses': np.zeros((1, 4, 66), np.float32), 'shapes': np.zeros((1, 10), np.float32),
+         'marker_pos': np.zeros((1, 4, 36), np.float32), 'marker_oris': np.zeros((1, 4, 108), np.float32),
+         'offset_t': np.zeros((1, 12, 3), np.float32), 'offset_r': np.tile(np.eye(3, dtype=np.float32), (1, 12, 1, 1))}
+    with pytest.raises(_lib.EmposeError):  # ... and the training path refuses CPU tensors as well
+        net(SyntheticBatch(w))

@@ -480,3 +480,82 @@ def test_virtual_marker_helper_vs_reference_vectors():
     np.testing.assert_allclose(ori.cpu().numpy(), z['vs_ori'], atol=5e-6)
     np.testing.assert_allclose(nor.cpu().numpy(), z['vs_nor'], atol=1e-8)
     assert helper.get_vertex_helpers(vids) == z['vs_helpers'].tolist()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training path (BASELINE configs[4])
+# ----------------------------------------------------------------------------------------------------------------------
+def test_smpl_sensors_vjp_vs_autograd(big_model):
+    """Vector-Jacobian product of (pos, ori, joints) w.r.t. (pose, shape) for arbitrary cotangents."""
+    T, F = 40, 8
+    rng = np.random.default_rng(21)
+    theta = rng.normal(0, 0.25, size=(T, 66)).astype(np.float32)
+    beta = rng.normal(0, 1.0, size=(T, 10)).astype(np.float32)
+    off_t = rng.normal(0, 0.02, size=(T // F, 12, 3)).astype(np.float32)
+    off_r = synthetic._exp_so3(rng.normal(0, 0.1, size=(T // F, 12, 3))).astype(np.float32)
+    d_pos = rng.normal(size=(T, 12, 3)).astype(np.float32)
+    d_ori = rng.normal(size=(T, 12, 3, 3)).astype(np.float32)
+    d_j = rng.normal(size=(T, 22, 3)).astype(np.float32)
+    bm = R.BodyModelTensors(big_model, dtype=torch.float64)
+    tables = R.sensor_tables(big_model['f'], CONST.VERTEX_IDS)
+    th = torch.from_numpy(theta).double().requires_grad_(True)
+    be = torch.from_numpy(beta).double().requires_grad_(True)
+    rep = lambda a: torch.from_numpy(np.repeat(a, F, axis=0)).double()
+    pos, ori, joints = R.estimated_markers(bm, tables, CONST.VERTEX_IDS, th, be, rep(off_r), rep(off_t))
+    obj = (pos * torch.from_numpy(d_pos)).sum() + (ori * torch.from_numpy(d_ori)).sum() + \
+        (joints * torch.from_numpy(d_j)).sum()
+    want_th, want_be = torch.autograd.grad(obj, [th, be])
+
+    from em_pose_amd.nn.models import _SmplSensorsFn
+    net = build_net(lgd_config(12, False, 1, hidden=32), big_model)
+    net.train()
+    p = gpu(theta).requires_grad_(True)
+    s = gpu(beta).requires_grad_(True)
+    o_r, o_t = gpu(off_r), gpu(off_t)
+    got_pos, got_ori, got_j = _SmplSensorsFn.apply(net, p, s, o_r, o_t, F)
+    np.testing.assert_allclose(got_pos.detach().cpu().numpy(), pos.detach().numpy(), atol=1e-5)
+    (got_pos * gpu(d_pos)).sum().add((got_ori * gpu(d_ori)).sum()).add((got_j * gpu(d_j)).sum()).backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), want_th.numpy(), atol=2e-4 * want_th.abs().max().item(), rtol=1e-3)
+    np.testing.assert_allclose(s.grad.cpu().numpy(), want_be.numpy(), atol=2e-4 * want_be.abs().max().item(), rtol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['train_lgdrnn12_n2', 'train_lgd6_n2'])
+def test_training_step_matches_reference_gradients(name):
+    """forward (train mode) + backward: losses and EVERY parameter gradient against the reference's own training
+    step recorded in tests/golden (incl. the in-forward E.backward() deposits, ragged lengths, train-mode BatchNorm)."""
+    from em_pose_amd.data.data import SyntheticBatch
+    case = H.load_case(name)
+    meta, w, rec = case['meta'], case['in'], case['run']
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    net.train()
+    batch = SyntheticBatch(w, torch.from_numpy(w['seq_lengths']).to(DEV), device=DEV)
+    batch.joints_gt = gpu(w['joints_gt'])
+    net.zero_grad()
+    out = net(batch)
+    total, loss_vals = net.backward(batch, out)
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), rec['out_' + k], atol=ATOL)
+    for k in ('pose', 'shape', 'reconstruction', 'fk', 'total_loss'):
+        assert loss_vals[k] == pytest.approx(float(rec['loss_' + k]), rel=2e-4, abs=1e-6), k
+    checked = 0
+    for k, p in net.named_parameters():
+        if k.startswith('smpl.'):
+            continue
+        want = rec.get('grad/' + k)
+        if want is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        got = p.grad.detach().cpu().numpy()
+        tol = 2e-3 * max(np.abs(want).max(), 1e-6)
+        np.testing.assert_allclose(got, want, atol=tol, rtol=2e-3, err_msg=k)
+        checked += 1
+    assert checked >= 20
+    for k, v in net.state_dict().items():
+        if 'running_' in k:  # BatchNorm running statistics were updated like the reference's
+            np.testing.assert_allclose(v.cpu().numpy(), rec['after/' + k], atol=1e-5, err_msg=k)
+    # an optimiser step invalidates nothing: the body-model handle is independent of the network weights
+    h1 = net._smpl_handle.value
+    torch.optim.Adam([p for n, p in net.named_parameters() if not n.startswith('smpl.')], lr=1e-3).step()
+    net.zero_grad()
+    net.backward(batch, net(batch))
+    assert net._smpl_handle.value == h1
