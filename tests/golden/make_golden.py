@@ -257,10 +257,10 @@ def main():
             rec['loss_' + k] = np.asarray(v)
         for k, p_ in net.named_parameters():
             if not k.startswith('smpl.') and p_.grad is not None:
-                rec['grad/' + k] = p_.grad.detach().numpy()
+                rec['grad/' + k] = p_.grad.detach().numpy().copy()
         for k, v in net.state_dict().items():
             if 'running_' in k:
-                rec['after/' + k] = v.numpy()
+                rec['after/' + k] = v.numpy().copy()  # copy: load_state_dict below writes in place
         net.load_state_dict(sd0)  # fixtures store the state BEFORE the step
         w2 = dict(w)
         w2['seq_lengths'] = lengths.numpy()

@@ -538,6 +538,9 @@ def test_training_step_matches_reference_gradients(name):
     for k in ('pose', 'shape', 'reconstruction', 'fk', 'total_loss'):
         assert loss_vals[k] == pytest.approx(float(rec['loss_' + k]), rel=2e-4, abs=1e-6), k
     checked = 0
+    # biases in front of a train-mode BatchNorm have a mathematically zero gradient (pure round-off in both
+    # implementations), so the absolute tolerance is tied to the overall gradient scale, not to each tensor's own
+    gmax = max(np.abs(v).max() for kk, v in rec.items() if kk.startswith('grad/'))
     for k, p in net.named_parameters():
         if k.startswith('smpl.'):
             continue
@@ -546,10 +549,14 @@ def test_training_step_matches_reference_gradients(name):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         got = p.grad.detach().cpu().numpy()
-        tol = 2e-3 * max(np.abs(want).max(), 1e-6)
+        pre_bn_bias = k.endswith('.bias') and ('input_to_hidden' in k or '.layers.0.' in k or '.layers.4.' in k)
+        if pre_bn_bias:  # mathematically zero in both implementations: only check that it is round-off
+            assert np.abs(got).max() < 1e-4 * gmax and np.abs(want).max() < 1e-4 * gmax, k
+            continue
+        tol = 2e-3 * max(np.abs(want).max(), 1e-4 * gmax)
         np.testing.assert_allclose(got, want, atol=tol, rtol=2e-3, err_msg=k)
         checked += 1
-    assert checked >= 20
+    assert checked >= 14
     for k, v in net.state_dict().items():
         if 'running_' in k:  # BatchNorm running statistics were updated like the reference's
             np.testing.assert_allclose(v.cpu().numpy(), rec['after/' + k], atol=1e-5, err_msg=k)
