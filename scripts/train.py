@@ -1,0 +1,122 @@
+#!/usr/bin/env python
+"""
+Training driver for the LGD models (mirror of the loop in reference scripts/train.py:125-152: zero_grad -> forward ->
+model.backward -> optimizer.step, Adam, per-step loss line) on SYNTHETIC windows -- AMASS / 3DPW are not available here
+(SURVEY.md 8c), so ground-truth poses are random-walk windows and the sensor readings come from the HIP body model
+(the role of SMPLFK + SampleMarkersWithOffsets in the reference).  BASELINE.json configs[4].
+
+    python scripts/train.py --steps 20                       # LGD-RNN-12, N=4, ws=32, 12 windows per GPU
+    python -m torch.distributed.run --nproc-per-node 8 scripts/train.py --steps 20
+
+Data parallel over windows; gradients averaged with bucketed RCCL all-reduces (em_pose_amd/helpers/distributed.py).
+SMPL forward / reverse are the HIP kernels; the LSTM / MLP forward+backward of the training path run as PyTorch-ROCm
+autograd ops (the inference path does not use them).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from em_pose_amd import synthetic  # noqa: E402
+from em_pose_amd.bodymodels.smpl import SMPLLayer  # noqa: E402
+from em_pose_amd.data.data import SyntheticBatch  # noqa: E402
+from em_pose_amd.helpers.configuration import lgd_config  # noqa: E402
+from em_pose_amd.helpers.distributed import allreduce_gradients, init_from_env  # noqa: E402
+from em_pose_amd.nn.models import create_model  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--bs_train', type=int, default=12, help='windows per GPU (reference README.md:221: 12)')
+    p.add_argument('--window_size', type=int, default=32)
+    p.add_argument('--n_markers', type=int, default=12)
+    p.add_argument('--iterations', type=int, default=4)
+    p.add_argument('--no_rnn', action='store_true')
+    p.add_argument('--lr', type=float, default=0.0005)
+    p.add_argument('--seed', type=int, default=1615200973)
+    p.add_argument('--json', action='store_true')
+    args = p.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit('train.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    rank, world = init_from_env(dev)
+
+    model = synthetic.make_model()
+    torch.manual_seed(args.seed)  # identical initial replicas on every rank
+    cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, window_size=args.window_size, lr=args.lr)
+    net = create_model(cfg, SMPLLayer(model)).to(dev)
+    params = [q for n, q in net.named_parameters() if not n.startswith('smpl.')]
+    opt = torch.optim.Adam(params, lr=args.lr)
+    if rank == 0:
+        print('Model created with {} trainable parameters'.format(sum(q.numel() for q in net.parameters())))
+
+    B, F = args.bs_train, args.window_size
+    net.eval()
+
+    def sensors(poses, betas, o_r, o_t):
+        pos, ori, _ = net.get_estimated_real_markers(torch.from_numpy(poses).to(dev), torch.from_numpy(betas).to(dev),
+                                                     torch.from_numpy(o_r[::F].copy()).to(dev),
+                                                     torch.from_numpy(o_t[::F].copy()).to(dev), frames_per_window=F)
+        return pos.cpu().numpy(), ori.cpu().numpy()
+
+    def make_batch(step):
+        w = synthetic.make_windows(B, F, 7919 * step + rank, sensors)
+        b = SyntheticBatch(w, device=dev)
+        with torch.no_grad():
+            _, _, joints = net.get_estimated_real_markers(b.poses.reshape(B * F, 66),
+                                                          b.shapes[:, None].expand(B, F, 10).reshape(B * F, 10),
+                                                          b.offset_r_augmented, b.offset_t_augmented,
+                                                          frames_per_window=F)
+        b.joints_gt = joints.reshape(B, F, 66)
+        return b
+    batches = [make_batch(s) for s in range(4)]  # data preparation is not part of the measured step
+    net.train()
+    times = []
+    for step in range(args.warmup + args.steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        batch = batches[step % len(batches)]
+        opt.zero_grad()
+        out = net(batch)
+        loss, vals = net.backward(batch, out)
+        allreduce_gradients(params)
+        opt.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if step >= args.warmup:
+            times.append(dt)
+        if rank == 0:
+            print('[TRAIN {:0>5d}] '.format(step + 1) + ' '.join('{}: {:.6f}'.format(k, v) for k, v in vals.items()) +
+                  ' elapsed: {:.3f} secs'.format(dt))
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([float(np.median(times))], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med = float(t.item())
+    else:
+        med = float(np.median(times))
+    if rank == 0:
+        res = {'steps_per_sec': 1.0 / med, 'frames_per_sec': world * B * F / med, 'n_gpus': world,
+               'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3}
+        print(json.dumps(res) if args.json else res)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

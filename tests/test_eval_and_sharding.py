@@ -146,3 +146,52 @@ def test_metric_gather_world_size_2_equals_single_process():
         assert n_rows == sum(lengths)
         for k in want:
             assert got[k] == pytest.approx(want[k], rel=1e-12, abs=1e-12), (rank, k)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
+    from em_pose_amd.helpers.distributed import allreduce_gradients, init_from_env
+    init_from_env(torch.device('cpu'))
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Linear(300, 7))
+        frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+        x = torch.full((4, 40), float(rank + 1))
+        net(x).sum().backward()
+        net[1].bias.grad = None if rank == 1 else net[1].bias.grad  # a parameter without gradient on one rank
+        n_buckets = allreduce_gradients(list(net.parameters()) + [frozen], bucket_bytes=16 << 10)
+        q.put((rank, n_buckets, [p.grad.clone() for p in net.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_size_2():
+    """Bucketed gradient averaging over gloo equals the mean of the per-rank gradients."""
+    from em_pose_amd.helpers.distributed import shard_range
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.Linear(300, 7))
+    want = []
+    for rank in range(2):
+        net.zero_grad()
+        net(torch.full((4, 40), float(rank + 1))).sum().backward()
+        g = [p.grad.clone() for p in net.parameters()]
+        if rank == 1:
+            g[3] = torch.zeros_like(g[3])
+        want.append(g)
+    mean = [(a + b) / 2 for a, b in zip(*want)]
+    assert res[0][1] == res[1][1] >= 2  # several buckets, same number on every rank
+    for rank, _, grads in res:
+        for got, w in zip(grads, mean):
+            torch.testing.assert_close(got, w, rtol=1e-6, atol=1e-6)
