@@ -128,6 +128,53 @@ def pmc_traffic(T, hidden):
     return hit[0]['hbm_bytes_per_launch_corrected'] if hit else None
 
 
+def run_vertices(args, dev):
+    """Secondary workload: stand-alone full-mesh SMPL-H evaluation `smpl_vertices_fwd`
+    (SMPLLayer.forward -> empose_mesh_vertices_fwd), the only piece of the path whose algorithmic traffic is large:
+    83 842 B/frame (82 680 B of vertices written)."""
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    smpl = SMPLLayer(synthetic.make_model()).to(dev)
+    T = args.batch * args.frames
+    g = torch.Generator().manual_seed(3)
+    pose = (torch.randn(T, 63, generator=g) * 0.3).to(dev)
+    root = (torch.randn(T, 3, generator=g) * 0.3).to(dev)
+    betas = torch.randn(T, 10, generator=g).to(dev)
+    for _ in range(args.warmup):
+        v, j = smpl(poses_body=pose, betas=betas, poses_root=root)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        v, j = smpl(poses_body=pose, betas=betas, poses_root=root)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    V = smpl.n_vertices
+    bytes_frame = 66 * 4 + 10 * 4 + V * 3 * 4 + 66 * 4
+    flops_frame = 2.0 * 200 * (V * 3 + 66) + V * 3 * (4 * 8 + 8)
+    fps = T * args.steps / wall
+    hbm = bytes_frame * T / (dev_ms * 1e-3) / 1e9
+    tfl = flops_frame * T / (dev_ms * 1e-3) / 1e12
+    bound = 'mfma' if tfl / PEAK_FP32_MFMA_TFLOPS > hbm / PEAK_HBM_GBS else 'hbm'
+    print(json.dumps({
+        'metric': 'frames/sec SMPL-H full-mesh vertices (smpl_vertices_fwd)', 'value': fps, 'unit': 'frames/sec',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * wall / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SMPLLayer.forward: %d frames per step, V=%d vertices + 22 joints, synthetic SMPL-H-shaped '
+                               'model' % (T, V), 'frames_per_step': T},
+        'roofline': {'bound': bound, 'achieved': tfl if bound == 'mfma' else hbm,
+                     'peak': PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS,
+                     'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                     'frac': tfl / PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else hbm / PEAK_HBM_GBS, 'traffic': None,
+                     'kernel': 'update_feat + rest-joint gemm + mesh_chain + mesh_fused_kernel (device time of the call)',
+                     'device_ms_per_step': dev_ms, 'hbm_GBs_on_algorithmic_bytes': hbm,
+                     'hbm_frac': hbm / PEAK_HBM_GBS, 'fp32_mfma_TFLOPs': tfl, 'mfma_frac': tfl / PEAK_FP32_MFMA_TFLOPS,
+                     'algorithmic_bytes_per_frame': bytes_frame, 'flops_per_frame': flops_frame}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,6 +185,8 @@ def main():
     ap.add_argument('--n_markers', type=int, default=12)
     ap.add_argument('--iterations', type=int, default=4)
     ap.add_argument('--no_rnn', action='store_true')
+    ap.add_argument('--workload', default='lgd', choices=['lgd', 'vertices'],
+                    help="'lgd' = the headline LGD forward; 'vertices' = stand-alone full-mesh SMPL-H evaluation")
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
     ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
@@ -155,6 +204,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    if args.workload == 'vertices':
+        if world > 1:
+            raise SystemExit('the vertices workload is a single-GPU micro-benchmark')
+        return run_vertices(args, dev)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist

@@ -856,7 +856,8 @@ void empose_mesh_destroy(empose_mesh_t* mesh) {
 int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
   *out = nullptr;
-  if (d->n_vertices <= 0 || d->ncp % 4 != 0 || d->j_off < d->n_vertices * 3 || d->j_off + 66 > d->ncp || d->kb <= 0)
+  if (d->n_vertices <= 0 || d->ncp % 4 != 0 || d->j_off != d->n_vertices * 3 || d->j_off + 66 > d->ncp ||
+      d->ncp - d->j_off > 68 || d->kb <= 0)
     return fail(EMPOSE_EINVAL, "inconsistent mesh table sizes");
   empose_mesh* m = new empose_mesh();
   m->V = d->n_vertices; m->j_off = d->j_off; m->ncp = d->ncp; m->kb = d->kb;
@@ -872,13 +873,13 @@ int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   return EMPOSE_OK;
 }
 
-static const int MESH_SLAB = 2048;  // frames per pass: bounds the v_posed scratch to ~170 MB
+static const int MESH_SLAB = 16384;  // frames per pass: bounds the scratch (rot, feat, rest joints, transforms)
 
 size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T) {
   if (!mesh || T <= 0) return 0;
   const size_t S = T < MESH_SLAB ? T : MESH_SLAB;
   Carver c(nullptr);
-  c.f(S * 198); c.f(S * 200); c.f(S * mesh->ncp); c.f(S * 264); c.f(S * 66); c.f(S * 10);
+  c.f(S * 198); c.f(S * 200); c.f(S * 68); c.f(S * 264); c.f(S * 66); c.f(S * 10);
   return c.off;
 }
 
@@ -893,7 +894,7 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
   Carver c(workspace);
   float* rot = c.f((size_t)S * 198);
   float* feat = c.f((size_t)S * 200);
-  float* outb = c.f((size_t)S * mesh->ncp);
+  float* jrest = c.f((size_t)S * 68);
   float* xf = c.f((size_t)S * 264);
   float* th = c.f((size_t)S * 66);
   float* be = c.f((size_t)S * 10);
@@ -909,25 +910,26 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
     fa.T = n; fa.F = 1;
     hipError_t e = launch_update_feat(fa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+    // rest joints: the last 66 (+2 padding) rows of wc
     GemmBatch b;
     b.count = 1;
     GemmProb& p = b.p[0];
-    p.A = feat; p.lda = 200; p.W = mesh->wc; p.ldw = 200; p.C = outb; p.ldc = mesh->ncp;
-    p.M = n; p.N = mesh->ncp; p.K = 200;
+    p.A = feat; p.lda = 200; p.W = mesh->wc + (size_t)mesh->j_off * 200; p.ldw = 200; p.C = jrest; p.ldc = 68;
+    p.M = n; p.N = mesh->ncp - mesh->j_off; p.K = 200;
     p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
     e = launch_gemm(b, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh gemm: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rest-joint gemm: %s", hipGetErrorString(e));
     const float* tr = trans ? trans + (size_t)t0 * 3 : nullptr;
     MeshChainArgs ca;
-    ca.rot = rot; ca.out = outb; ca.ncp = mesh->ncp; ca.j_off = mesh->j_off; ca.parents = mesh->parents;
+    ca.rot = rot; ca.out = jrest; ca.ncp = 68; ca.j_off = 0; ca.parents = mesh->parents;
     ca.trans = tr; ca.xf = xf; ca.joints = joints + (size_t)t0 * 66; ca.T = n;
     e = launch_mesh_chain(ca, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh chain: %s", hipGetErrorString(e));
     MeshSkinArgs sa;
-    sa.out = outb; sa.ncp = mesh->ncp; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
+    sa.feat = feat; sa.wc = mesh->wc; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     e = launch_mesh_skin(sa, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh skin: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
 }

@@ -144,14 +144,15 @@ struct MeshChainArgs {
   const float* rot; const float* out; int ncp; int j_off;
   const int* parents;
   const float* trans;      // [T][3] or nullptr
-  float* xf;               // [T][22][12]: G^R (9) | A^t (3)
+  float* xf;               // [T][22][3][4]: per bone and row (G^R[r][0..2], A^t[r])
   float* joints;           // [T][66]
   int T;
 };
 hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream);
 struct MeshSkinArgs {
-  const float* out; int ncp;   // [T][ncp], first V*3 columns are v_posed
-  const float* xf;             // [T][22][12]
+  const float* feat;           // [T][200]
+  const float* wc;             // [V*3 (+66)][200]: row 3s+c = coefficients of coordinate c of vertex s
+  const float* xf;             // [T][22][3][4]: row r of bone b = (G^R[r][0..2], A^t[r])
   const int* skin_idx; const float* skin_w; int kb;
   const float* trans;
   float* vertices;             // [T][V][3]
