@@ -116,15 +116,16 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         bv[g] = *reinterpret_cast<const float4*>(Bs + (g * LUNITS + wcol * 16 + l15) * LLD + kk * 16 + lq * 4);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[g].x, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[g].y, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[g].z, acc[i][g], 0, 0, 0);
-          acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[g].w, acc[i][g], 0, 0, 0);
-        }
+      // k-element outermost: consecutive MFMAs go to 8 different accumulators, so the 40-cycle dependent latency of
+      // v_mfma_f32_16x16x4_f32 (issue interval 32) never stalls the pipe.
+#define LSTM_MFMA_STEP(E)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int g = 0; g < 4; ++g)                  \
+      acc[i][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].E, bv[g].E, acc[i][g], 0, 0, 0);
+      LSTM_MFMA_STEP(x)
+      LSTM_MFMA_STEP(y)
+      LSTM_MFMA_STEP(z)
+      LSTM_MFMA_STEP(w)
+#undef LSTM_MFMA_STEP
     }
     __syncthreads();
     if (kt + 1 < nk) {

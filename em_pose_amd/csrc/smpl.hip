@@ -757,24 +757,41 @@ __global__ __launch_bounds__(256) void mesh_fused_kernel(MeshSkinArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += MF_BK) {
-    // stage: 64 feature rows, and for each coordinate plane the 64 weight rows (vertex s, coordinate c) -> row 3s+c
+  // operand staging with a one-tile register prefetch (as in gemm_f32.hip)
+  float4 ra[2], rb[6];
+  auto load = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int slot = tid + i * 256, r = slot >> 3, c4 = (slot & 7) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f0 + r < a.T && k0 + c4 < K) v = *reinterpret_cast<const float4*>(a.feat + (size_t)(f0 + r) * K + k0 + c4);
-      *reinterpret_cast<float4*>(As + r * MF_LD + c4) = v;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f0 + r < a.T && k0 + c4 < K) ra[i] = *reinterpret_cast<const float4*>(a.feat + (size_t)(f0 + r) * K + k0 + c4);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int slot = tid + i * 256, r = slot >> 3, c4 = (slot & 7) * 4;  // r = c * 64 + v
-      const int c = r >> 6, s = s0 + (r & 63);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s < a.V && k0 + c4 < K) v = *reinterpret_cast<const float4*>(a.wc + ((size_t)s * 3 + c) * K + k0 + c4);
-      *reinterpret_cast<float4*>(Bs + r * MF_LD + c4) = v;
+      const int c = r >> 6, sv = s0 + (r & 63);
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sv < a.V && k0 + c4 < K) rb[i] = *reinterpret_cast<const float4*>(a.wc + ((size_t)sv * 3 + c) * K + k0 + c4);
     }
-    __syncthreads();
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int slot = tid + i * 256;
+      *reinterpret_cast<float4*>(As + (slot >> 3) * MF_LD + (slot & 7) * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int slot = tid + i * 256;
+      *reinterpret_cast<float4*>(Bs + (slot >> 3) * MF_LD + (slot & 7) * 4) = rb[i];
+    }
+  };
+  load(0);
+  store();
+  __syncthreads();
+  for (int k0 = 0; k0 < K; k0 += MF_BK) {
+    const bool more = k0 + MF_BK < K;
+    if (more) load(k0 + MF_BK);
 #pragma unroll
     for (int kk = 0; kk < MF_BK / 8; ++kk) {
       const float4 av = *reinterpret_cast<const float4*>(As + (wrow * 32 + l31) * MF_LD + kk * 8 + lh * 4);
@@ -788,6 +805,10 @@ __global__ __launch_bounds__(256) void mesh_fused_kernel(MeshSkinArgs a) {
       }
     }
     __syncthreads();
+    if (more) {
+      store();
+      __syncthreads();
+    }
   }
 
   // relative transforms of the block's frames -> LDS (operand tiles are dead now)

@@ -101,9 +101,68 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
             out = net(chunk, is_new_sequence=(c == 0))
             if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
                 first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
-            for me in (me_all, me_ind):
-                me.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
+            # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once, merge twice
+            me_tmp = MetricsEngine(smpl_model)
+            me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
                            chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
+            st = me_tmp.state()
+            me_all.merge(st)
+            me_ind.merge(st)
             frames += int(chunk.seq_lengths.sum())
         per_sequence.append((batch.ids[0], me_ind.get_metrics()))
+    return me_all, per_sequence, frames
+
+
+def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256):
+    """
+    Same results as `evaluate_sequences`, but chunk c of ALL recordings runs as one ragged batch (rows = recordings
+    that still have frames, `seq_lengths` = frames left in this chunk, LSTM state carried per row).  Windows are
+    independent of each other in the model, so this only changes how much work one launch carries:
+    36 recordings need 14 launches of the loop instead of 211.
+    """
+    from em_pose_amd.nn.models import IterativeErrorFeedback
+    assert isinstance(net, IterativeErrorFeedback)
+    n = len(batches)
+    lengths = [int(b.seq_lengths[0]) for b in batches]
+    engines = [MetricsEngine(smpl_model) for _ in range(n)]
+    first_shape = [None] * n
+    state = None       # (h, c) for the rows of `rows_prev`
+    rows_prev = []
+    n_chunks = (max(lengths) + window_size - 1) // window_size
+    frames = 0
+    pad = lambda t, f: torch.nn.functional.pad(t, (0, 0, 0, f - t.shape[1]))
+    for c in range(n_chunks):
+        sf = c * window_size
+        rows = [i for i in range(n) if lengths[i] > sf]
+        lens = [min(window_size, lengths[i] - sf) for i in rows]
+        f = max(lens)
+        cut = lambda name, i: pad(getattr(batches[i], name)[:, sf:sf + f], f)
+        chunk = RealBatch([batches[i].ids[0] for i in rows], torch.tensor(lens),
+                          torch.cat([cut('poses', i) for i in rows]), torch.cat([batches[i].shapes for i in rows]),
+                          torch.cat([cut('trans', i) for i in rows]),
+                          torch.cat([cut('marker_pos_real', i) for i in rows]),
+                          torch.cat([cut('marker_ori_real', i) for i in rows]),
+                          torch.cat([cut('marker_masks', i) for i in rows]),
+                          torch.cat([batches[i].offset_t for i in rows]),
+                          torch.cat([batches[i].offset_r for i in rows])).to_gpu(device)
+        if net.rnn_init and c > 0:
+            keep = torch.tensor([rows_prev.index(i) for i in rows], device=device)
+            net.rnn.final_state = (state[0].index_select(1, keep).contiguous(),
+                                   state[1].index_select(1, keep).contiguous())
+        out = net(chunk, is_new_sequence=(c == 0))
+        if net.rnn_init:
+            state, rows_prev = net.rnn.final_state, rows
+        for k, i in enumerate(rows):
+            if c == 0:
+                first_shape[i] = out['shape_hat'][k:k + 1, 0]
+            sl = slice(k, k + 1)
+            engines[i].compute(chunk.poses_body[sl], chunk.shapes[sl], out['pose_hat'][sl], first_shape[i],
+                               chunk.seq_lengths[sl], chunk.poses_root[sl], out['root_ori_hat'][sl],
+                               frame_mask=chunk.marker_masks[sl])
+        frames += sum(lens)
+    me_all = MetricsEngine(smpl_model)
+    per_sequence = []
+    for i in range(n):  # recording order, exactly as the sequential driver accumulates
+        me_all.merge(engines[i].state())
+        per_sequence.append((batches[i].ids[0], engines[i].get_metrics()))
     return me_all, per_sequence, frames

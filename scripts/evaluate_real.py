@@ -35,7 +35,8 @@ from tabulate import tabulate  # noqa: E402
 
 from em_pose_amd.data.data import RealBatch, RealSample  # noqa: E402
 from em_pose_amd.data.transforms import NormalizeRealMarkers, NormalizeRoot, ToTensor  # noqa: E402
-from em_pose_amd.eval.helpers import evaluate_sequences, load_model, partition_sequences  # noqa: E402
+from em_pose_amd.eval.helpers import (evaluate_sequences, evaluate_sequences_batched, load_model,  # noqa: E402
+                                      partition_sequences)
 from em_pose_amd.helpers.configuration import CONSTANTS as C  # noqa: E402
 
 
@@ -102,6 +103,8 @@ def main():
     p.add_argument('--no_rnn', action='store_true')
     p.add_argument('--max_sequences', type=int, default=0)
     p.add_argument('--json', action='store_true', help='Also print one machine-readable JSON line.')
+    p.add_argument('--sequential', action='store_true',
+                   help='One recording at a time like the reference; default: chunk c of all recordings as one batch.')
     args = p.parse_args()
 
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
@@ -125,7 +128,11 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     log = print if world == 1 else None
-    me_all, per_seq, frames = evaluate_sequences(net, batches, smpl, device, window_size=256, log=log)
+    from em_pose_amd.nn.models import IterativeErrorFeedback
+    if args.sequential or not isinstance(net, IterativeErrorFeedback):
+        me_all, per_seq, frames = evaluate_sequences(net, batches, smpl, device, window_size=256, log=log)
+    else:
+        me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]

@@ -566,3 +566,40 @@ def test_training_step_matches_reference_gradients(name):
     net.zero_grad()
     net.backward(batch, net(batch))
     assert net._smpl_handle.value == h1
+
+
+def test_batched_streaming_equals_sequential():
+    """Chunk c of all recordings as one ragged batch (state carried per row) gives the per-recording results of the
+    one-recording-at-a-time driver."""
+    from em_pose_amd.data.data import RealBatch, RealSample
+    from em_pose_amd.data.transforms import NormalizeRealMarkers, NormalizeRoot, ToTensor
+    from em_pose_amd.eval.helpers import evaluate_sequences, evaluate_sequences_batched
+    case = H.load_case('lgdrnn6_n2')
+    meta = case['meta']
+    model = H.small_model()
+    vids = [int(v) for v in meta['vertex_ids']]
+    net = build_net(cfg_of(meta), model, vids, case['sd'])
+    net.keep_history = False
+    smpl = SMPLLayer(model).to(DEV)
+
+    def sensors(poses, betas, o_r, o_t):
+        n = poses.shape[0]
+        p, o, _ = net.get_estimated_real_markers(gpu(poses), gpu(betas), gpu(o_r[:1]), gpu(o_t[:1]),
+                                                 frames_per_window=n)
+        return p.cpu().numpy(), o.cpu().numpy()
+    batches = []
+    for i, n in enumerate((300, 700, 256, 40)):
+        d = synthetic.make_sequence(n, 50 + i, sensors, missing_rate=0.01)
+        s = RealSample('r%d' % i, d['sensor_pos'], d['sensor_oris'], d['sensor_masks'].astype(np.float32),
+                       d['smpl_poses'], d['smpl_shape'], d['smpl_trans'],
+                       {'means': d['offset_means'], 'covs': d['offset_covs'], 'r': d['offset_r']})
+        batches.append(NormalizeRoot()(RealBatch.from_sample_list([ToTensor()(NormalizeRealMarkers()(s))])))
+    a_all, a_seq, a_frames = evaluate_sequences(net, batches, smpl, torch.device(DEV))
+    b_all, b_seq, b_frames = evaluate_sequences_batched(net, batches, smpl, torch.device(DEV))
+    assert a_frames == b_frames == 1296
+    for (ida, ma), (idb, mb) in zip(a_seq, b_seq):
+        assert ida == idb
+        for k in ma:
+            assert mb[k] == pytest.approx(ma[k], rel=1e-5, abs=1e-4), (ida, k)
+    for k, v in a_all.get_metrics().items():
+        assert b_all.get_metrics()[k] == pytest.approx(v, rel=1e-5, abs=1e-4)
