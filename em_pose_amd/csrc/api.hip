@@ -640,6 +640,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
   pa.marker_pos = io->marker_pos; pa.marker_oris = io->marker_oris; pa.marker_masks = io->marker_masks;
   pa.seq_lengths = io->seq_lengths; pa.x = w.x; pa.ldx = dx; pa.frame_scale = w.scale;
   pa.B = B; pa.F = F; pa.n_markers = m->n_markers;
+  pa.rows_as_unpadded = (m->shape_avg == 2) ? 1 : 0;
   for (int i = 0; i < 12; ++i) pa.marker_idx[i] = m->marker_idx[i];
   prof_mark(P_PACK, stream);
   hipError_t e = launch_pack_inputs(pa, stream);
@@ -668,6 +669,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     FeatArgs fa;
     fa.theta = x_theta; fa.ld_theta = dx; fa.beta = x_beta; fa.ld_beta = dx;
     fa.shape_avg = m->shape_avg;
+    fa.seq_lengths = io->seq_lengths;
     if (i == 0) {
       fa.d_theta = nullptr; fa.theta_step = 0.f;
       fa.d_beta = w.d_shape; fa.beta_keep = 0.f; fa.beta_step = 1.f;

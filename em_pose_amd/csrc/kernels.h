@@ -86,6 +86,7 @@ struct PackArgs {
   float* frame_scale;                                  // [T]
   int B, F, n_markers;
   int marker_idx[12];
+  int rows_as_unpadded = 0;   // 1: a ragged row counts as an unpadded window of its own length
 };
 hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream);
 
@@ -97,7 +98,8 @@ struct FeatArgs {
   const float* d_beta;                 // [T][10] or nullptr
   float theta_step;                    // theta += theta_step * d_theta
   float beta_keep, beta_step;          // beta = beta_keep * beta + beta_step * (shape_avg ? mean_F(d_beta) : d_beta)
-  int shape_avg;
+  int shape_avg;                       // 0 none, 1 mean over all F frames, 2 mean over the valid frames
+  const int* seq_lengths = nullptr;    // [T/F], only read when shape_avg == 2
   float* rot;                          // [T][22][9]
   float* feat;                         // [T][200]
   float* out_theta; float* out_beta;   // optional dense copies [T][66], [T][10]

@@ -31,7 +31,9 @@ __global__ void pack_inputs_kernel(PackArgs a) {
   if (c == d_in) {
     const int b = t / a.F, f = t % a.F;
     const int len = a.seq_lengths ? a.seq_lengths[b] : a.F;
-    float s = (f < len) ? (float)a.F / (float)len : 0.f;
+    // reference: loss / n_frames, then grad * B * F  ->  F / len per valid frame (models.py:578-579, loss.py:36-39);
+    // unpadded mode: every row is treated as a window of its own length (F == len), i.e. weight 1
+    float s = (f < len) ? (a.rows_as_unpadded ? 1.f : (float)a.F / (float)len) : 0.f;
     if (a.marker_masks) {
       bool all = true;
       for (int m = 0; m < 12; ++m) all = all && (a.marker_masks[(size_t)t * 12 + m] != 0.f);
@@ -116,11 +118,14 @@ __global__ void update_feat_kernel(FeatArgs a) {
     if (a.d_beta) {
       float d;
       if (a.shape_avg) {
-        // mean over ALL frames of the window incl. padded ones (reference models.py:529-532)
+        // shape_avg == 1: mean over ALL frames of the window incl. padded ones (reference models.py:529-532);
+        // shape_avg == 2: mean over the valid frames only (what an unpadded window of that length would give; used
+        // by the batched streaming driver so that ragged batches reproduce one-recording-at-a-time results)
         const int w0 = (t / a.F) * a.F;
+        const int n = (a.shape_avg == 2 && a.seq_lengths) ? max(1, min(a.F, a.seq_lengths[t / a.F])) : a.F;
         float s = 0.f;
-        for (int f = 0; f < a.F; ++f) s += a.d_beta[(size_t)(w0 + f) * 10 + k];
-        d = s / (float)a.F;
+        for (int f = 0; f < n; ++f) s += a.d_beta[(size_t)(w0 + f) * 10 + k];
+        d = s / (float)n;
       } else {
         d = a.d_beta[(size_t)t * 10 + k];
       }

@@ -122,6 +122,9 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
     """
     from em_pose_amd.nn.models import IterativeErrorFeedback
     assert isinstance(net, IterativeErrorFeedback)
+    # rows shorter than the chunk are padded: average the shape over their valid frames only, which is what the
+    # unpadded one-recording chunk of the sequential driver averages over
+    net.shape_avg_valid_only = True
     n = len(batches)
     lengths = [int(b.seq_lengths[0]) for b in batches]
     engines = [MetricsEngine(smpl_model) for _ in range(n)]
@@ -160,6 +163,7 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
                                chunk.seq_lengths[sl], chunk.poses_root[sl], out['root_ori_hat'][sl],
                                frame_mask=chunk.marker_masks[sl])
         frames += sum(lens)
+    net.shape_avg_valid_only = False
     me_all = MetricsEngine(smpl_model)
     per_sequence = []
     for i in range(n):  # recording order, exactly as the sequential driver accumulates

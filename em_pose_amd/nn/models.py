@@ -209,6 +209,8 @@ class IterativeErrorFeedback(BaseModel):
         assert self.n_markers in [6, 12]
         self.marker_idxs = list(range(12)) if self.n_markers == 12 else list(CONST.S_CONFIG_6)
         self.keep_history = True
+        # False: per-window shape mean over all F frames incl. padding, as the reference; True: over valid frames only
+        self.shape_avg_valid_only = False
         self.keep_gradient_trace = False
         self.gradient_trace = None
         self.markers_hat_history = None
@@ -276,7 +278,7 @@ class IterativeErrorFeedback(BaseModel):
 
     def _state_key(self, device):
         ps = self._own_parameters()
-        return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N,
+        return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N, self.shape_avg_valid_only,
                 tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def release(self):
@@ -336,7 +338,7 @@ class IterativeErrorFeedback(BaseModel):
         for i, v in enumerate(self.marker_idxs):
             desc.marker_idx[i] = v
         desc.step_size = float(self.step_size)
-        desc.shape_avg = int(bool(self.shape_avg))
+        desc.shape_avg = (2 if self.shape_avg_valid_only else 1) if self.shape_avg else 0
         desc.use_gradient = int(bool(self.use_gradient))
         if smpl_only:
             desc.n_iterations, desc.rnn_init = 0, 0

@@ -109,7 +109,9 @@ typedef struct {
   int marker_idx[12];     /* first n_markers entries: which of the 12 virtual sensors they are (S_CONFIG_6) */
   int n_iterations;       /* N */
   float step_size;
-  int shape_avg;
+  int shape_avg;          /* 0 off; 1 mean over all F frames incl. padding (reference models.py:529-532);
+                             2 ragged rows behave as unpadded windows of their own length: shape mean over the
+                               valid frames and residual weight 1 instead of F/len (batched streaming evaluation) */
   int use_gradient;
   int rnn_init;
   empose_lstm_desc rnn;           /* rnn_init */
