@@ -20,7 +20,7 @@ struct GemmProb {
   int act;                  // 0 none, 1 PReLU(slope)
   float slope;
 };
-struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
+struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; int ablate_loads = 0; };  // role 1 = update-net hidden layer (profiling name only)
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);

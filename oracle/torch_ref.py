@@ -16,7 +16,7 @@ Parity status
   dependency `human-body-prior` (fork github.com/totomobile43/human_body_prior @ 821a0e7, reference
   requirements.txt:9; call sites reference empose/bodymodels/smpl.py:42,121-122) whose source is not available.
   It restates the published SMPL / smplx `lbs` algorithm (Loper et al. 2015; smplx lbs.py) and is anchored on the
-  reference's call sites and on analytic invariants (tests/test_oracle_invariants.py).
+  reference's call sites and on analytic invariants (tests/test_analytic_vs_autograd.py::test_invariants).
 """
 import numpy as np
 import torch
@@ -284,7 +284,8 @@ S_CONFIG_6 = [0, 1, 2, 6, 7, 11]  # reference configuration.py:89
 
 
 def ief_forward(sd, bm, tables, vertex_ids, inputs, n_markers=12, N=4, step_size=0.1, rnn_init=True,
-                shape_avg=True, use_gradient=True, num_layers=2, batch_norm=True, skip=False, rnn_state=None):
+                shape_avg=True, use_gradient=True, num_layers=2, batch_norm=True, skip=False, rnn_state=None,
+                rnn_layers=2):
     """
     :param sd: state_dict (reference key names) of tensors in the working dtype.
     :param inputs: dict with marker_pos (B,F,36), marker_oris (B,F,108), offset_t (B,12,3), offset_r (B,12,3,3),
@@ -310,7 +311,7 @@ def ief_forward(sd, bm, tables, vertex_ids, inputs, n_markers=12, N=4, step_size
 
     new_state = None
     if rnn_init:
-        y, new_state = lstm_forward(sd, 'rnn.lstm.', x_in, seq_lengths, rnn_state)
+        y, new_state = lstm_forward(sd, 'rnn.lstm.', x_in, seq_lengths, rnn_state, num_layers=rnn_layers)
         pose = (y @ sd['pose_net_init.weight'].t() + sd['pose_net_init.bias']).reshape(T, -1)
         shape = (y @ sd['shape_net_init.weight'].t() + sd['shape_net_init.bias']).reshape(T, -1)
     else:

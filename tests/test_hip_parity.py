@@ -603,3 +603,112 @@ def test_batched_streaming_equals_sequential():
             assert mb[k] == pytest.approx(ma[k], rel=1e-5, abs=1e-4), (ida, k)
     for k, v in a_all.get_metrics().items():
         assert b_all.get_metrics()[k] == pytest.approx(v, rel=1e-5, abs=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configuration flags and edge shapes (reference configuration.py:171-185; models.py:372-380,424-454)
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('flags', [
+    dict(m_use_gradient=False),
+    dict(m_average_shape=False),
+    dict(m_skip_connections=True),
+    dict(m_no_batch_norm=True),
+    dict(m_num_iterations=0),
+    dict(m_num_layers=1),
+    dict(m_num_layers=3, m_skip_connections=True),
+    dict(m_rnn_num_layers=1),
+    dict(m_rnn_num_layers=3),
+    dict(m_step_size=0.25, m_num_iterations=1),
+], ids=lambda f: ','.join('%s=%s' % kv for kv in f.items()))
+@pytest.mark.parametrize('rnn', [True, False], ids=['rnn', 'mlp'])
+def test_configuration_flags_vs_oracle(flags, rnn):
+    if not rnn and any(k.startswith('m_rnn') for k in flags):
+        pytest.skip('LSTM flag without LSTM')
+    model = H.small_model()
+    vids = synthetic.small_vertex_ids(160)
+    cfg = lgd_config(12, rnn, 2, hidden=32, rnn_hidden=32, **{k: v for k, v in flags.items() if k != 'm_num_iterations'})
+    if 'm_num_iterations' in flags:
+        cfg.m_num_iterations = flags['m_num_iterations']
+    torch.manual_seed(5)
+    net = create_model(cfg, SMPLLayer(model))
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    net.vertex_ids = vids
+    net = net.eval()
+    bm = R.BodyModelTensors(model)
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    B, F = 3, 7
+    w = synthetic.make_windows(B, F, 77, sensors)
+    inp = H.oracle_inputs(w, sl=[7, 4, 1])
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    want, hist = R.ief_forward(sd, bm, tables, vids, inp, n_markers=12, N=cfg.m_num_iterations,
+                               step_size=cfg.m_step_size, rnn_init=rnn, shape_avg=cfg.m_average_shape,
+                               use_gradient=cfg.m_use_gradient, num_layers=cfg.m_num_layers,
+                               batch_norm=not cfg.m_no_batch_norm, skip=cfg.m_skip_connections,
+                               rnn_layers=cfg.m_rnn_num_layers)
+    net = net.to(DEV)
+    res = net.forward_tensors(*(inp[k].to(DEV) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')),
+                              seq_lengths=inp['seq_lengths'].to(DEV), keep_history=True)
+    pose = res['pose'].cpu().numpy()
+    np.testing.assert_allclose(pose[:, :, 3:], want['pose_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(pose[:, :, :3], want['root_ori_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['shape'].cpu().numpy(), want['shape_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['joints'].cpu().numpy(), want['joints_hat'].numpy(), atol=ATOL)
+    assert res['hist']['pose'].shape[0] == cfg.m_num_iterations + 1
+
+
+@pytest.mark.parametrize('B,F', [(1, 1), (1, 2), (5, 3), (1, 257), (2, 1000)])
+def test_edge_shapes_vs_oracle(B, F):
+    """Tiny and long windows (the reference slices SMPL work at 1000 frames, smpl.py:124-144; evaluate_real feeds up
+    to 256 frames per call): frame counts that are not multiples of any tile size."""
+    case = H.load_case('lgdrnn12_n4_carry')
+    model = H.small_model()
+    vids = [int(v) for v in case['meta']['vertex_ids']]
+    net = build_net(cfg_of(case['meta']), model, vids, case['sd'])
+    bm = R.BodyModelTensors(model)
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    w = synthetic.make_windows(B, F, 3 + F, sensors)
+    inp = H.oracle_inputs(w)
+    want, _ = R.ief_forward(H.sd_to_torch(case['sd']), bm, tables, vids, inp, n_markers=12, N=4, rnn_init=True)
+    res = net.forward_tensors(*(inp[k].to(DEV) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')))
+    pose = res['pose'].cpu().numpy()
+    np.testing.assert_allclose(pose[:, :, 3:], want['pose_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['shape'].cpu().numpy(), want['shape_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['joints'].cpu().numpy(), want['joints_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['state'][0].cpu().numpy(), _['rnn_state'][0].numpy(), atol=2e-5)
+
+
+def test_invalid_calls_are_rejected():
+    case = H.load_case('lgd12_n4')
+    net = build_net(cfg_of(case['meta']), H.small_model(), case['meta']['vertex_ids'], case['sd'])
+    lib = _lib.lib()
+    h = net._ensure_handle(torch.device(DEV))
+    io = _lib.LgdIO()
+    io.B, io.F = 0, 4
+    assert lib.empose_lgd_forward(h, C.byref(io), None, 0, None) == -1
+    io.B = 2
+    ws = torch.empty(16, dtype=torch.uint8, device=DEV)
+    x = torch.zeros(2, 4, 108, device=DEV)
+    io.marker_pos = io.marker_oris = io.offset_t = io.offset_r = _lib.dptr(x)
+    io.pose_hat = io.shape_hat = io.joints_hat = _lib.dptr(x)
+    assert lib.empose_lgd_forward(h, C.byref(io), _lib.dptr(ws), 16, None) == -3  # workspace too small
+    assert b'workspace' in lib.empose_last_error()
+    assert lib.empose_smpl_sensors_fwd_bwd(h, 5, 2, _lib.dptr(x), 66, _lib.dptr(x), 10, _lib.dptr(x), _lib.dptr(x), None,
+                                           0, None, _lib.dptr(x), _lib.dptr(x), _lib.dptr(x), None, 0, None, 0,
+                                           _lib.dptr(ws), 16, None) == -1  # T not a multiple of F
