@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collect the numbers committed under profiles/ for one round (run on the GPU box from the repo root).
+set -u
+TAG=${1:-r01}
+export TMPDIR=/tmp
+R=$PWD
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.log
+python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
+python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
+python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
+python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
+python scripts/evaluate_real.py --synthetic --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
+python scripts/evaluate_real.py --synthetic --sequential --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
+python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 5 --warmup 1 --no_cpu_baseline --no_profile > $OUT.log 2>&1 )
+cp $OUT/lgd_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_lgdrnn12_b1024.csv
+rm -rf $OUT
+ls -la gpurun_out | grep $TAG
