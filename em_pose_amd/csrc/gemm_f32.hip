@@ -106,7 +106,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
   for (int kt = 0; kt < nk; ++kt) {
     const float* As = lds + (C::DB ? (kt & 1) * C::STAGE : 0);
     const float* Bs = As + BM * LDT;
-    if (kt + 1 < nk && !batch.ablate_loads) {
+    if (kt + 1 < nk) {
       load_tile<C>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
       load_tile<C>(p.W, p.ldw, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
     }
@@ -219,8 +219,6 @@ hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
   GemmBatch batch = batch_in;
   static const int swz = getenv("EMPOSE_GEMM_SWIZZLE") ? atoi(getenv("EMPOSE_GEMM_SWIZZLE")) : 1;  // dev A/B only
   batch.xcd_swizzle = swz;
-  static const int abl = getenv("EMPOSE_GEMM_ABLATE") ? atoi(getenv("EMPOSE_GEMM_ABLATE")) : 0;  // timing experiments only
-  batch.ablate_loads = abl;
   int maxM = 0, maxN = 0;
   for (int i = 0; i < batch.count; ++i) {
     maxM = batch.p[i].M > maxM ? batch.p[i].M : maxM;

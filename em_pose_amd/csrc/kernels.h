@@ -20,7 +20,7 @@ struct GemmProb {
   int act;                  // 0 none, 1 PReLU(slope)
   float slope;
 };
-struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; int ablate_loads = 0; };  // role 1 = update-net hidden layer (profiling name only)
+struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
@@ -125,7 +125,6 @@ struct ChainArgs {
   const float* cot_pos = nullptr;    // [T][36]  external cotangents (vector-Jacobian product for training);
   const float* cot_ori = nullptr;    // [T][108] when set they replace the residual of `tgt`
   const float* cot_joints = nullptr; // [T][66]  optional
-  int debug_stop = 0;      // timing aid: return after phase k (0 = run everything)
 };
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block);
 hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream);

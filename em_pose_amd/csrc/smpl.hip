@@ -318,7 +318,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     }
   }
   __syncthreads();
-  if (a.debug_stop == 1) return;
 
   // ---- P2: forward chain
   for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
@@ -353,7 +352,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     if (a.joints2) a.joints2[go] = tr;
   }
   __syncthreads();
-  if (a.debug_stop == 2) return;
 
   // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
@@ -372,7 +370,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.v + sr] = T0 * vp[0] + T1 * vp[1] + T2 * vp[2] + T3;
   }
   __syncthreads();
-  if (a.debug_stop == 3) return;
 
   // ---- P4a: un-normalised face normals
   for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
@@ -544,7 +541,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.dv + sr] = acc;
   }
   __syncthreads();
-  if (a.debug_stop == 4) return;
 
   // ---- P5: d v_posed (to global) and per-chunk force / world-space moment partial sums
   for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
@@ -615,7 +611,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.m + be] = acc;
   }
   __syncthreads();
-  if (a.debug_stop == 5) return;
 
   // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -644,7 +639,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     }
   }
   __syncthreads();
-  if (a.debug_stop == 6) return;
 
   // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -680,8 +674,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
 hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
   ChainArgs a = a_in;
-  static const int dbg = getenv("EMPOSE_CHAIN_STOP") ? atoi(getenv("EMPOSE_CHAIN_STOP")) : 0;  // timing aid only
-  a.debug_stop = dbg;
   const size_t lds = chain_lds_bytes(a.tab, CH_FRAMES);
   static size_t attr_set = 0;
   if (lds > attr_set) {

@@ -712,3 +712,46 @@ def test_invalid_calls_are_rejected():
     assert lib.empose_smpl_sensors_fwd_bwd(h, 5, 2, _lib.dptr(x), 66, _lib.dptr(x), 10, _lib.dptr(x), _lib.dptr(x), None,
                                            0, None, _lib.dptr(x), _lib.dptr(x), _lib.dptr(x), None, 0, None, 0,
                                            _lib.dptr(ws), 16, None) == -1  # T not a multiple of F
+
+
+def test_smpl_degenerate_rotations(big_model):
+    """Exactly-zero and tiny joint rotations (the smplx Rodrigues has no small-angle branch: angle = ||r + 1e-8||),
+    large rotations close to pi, and extreme shapes: forward and residual gradient against the float64 blueprint."""
+    T, F = 64, 8
+    theta, beta, off_r, off_t, tgt, scale, _ = _smpl_case(big_model, CONST.VERTEX_IDS, T, F, 3, 12)
+    theta[0:8, :] = 0.0                      # the rest pose, every joint exactly zero
+    theta[8:16, 3:30] = 0.0                  # some joints exactly zero
+    theta[16:24, :] *= 1e-4                  # tiny angles
+    theta[24:32, 6:9] = np.array([3.1, 0.2, -0.1])  # close to pi
+    theta[32:40, :] *= 4.0                   # large everywhere
+    beta[40:48] = 4.0                        # far outside the usual +-2 range
+    tab64 = TB.build_lgd_tables(big_model, CONST.VERTEX_IDS, dtype=np.float64)
+    rep = lambda a: np.repeat(a, F, axis=0)
+    idx = list(range(12))
+    ref = A.smpl_sensors(tab64, theta, beta, rep(off_r), rep(off_t), tgt[:, :36].reshape(T, 12, 3),
+                         tgt[:, 36:].reshape(T, 12, 3, 3), idx, scale)
+    net = build_net(lgd_config(12, False, 1, hidden=32), big_model)
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    th, be, tg, o_r, o_t, sc = gpu(theta), gpu(beta), gpu(tgt), gpu(off_r), gpu(off_t), gpu(scale)
+    pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
+    g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
+    nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10, _lib.dptr(o_r),
+                                               _lib.dptr(o_t), _lib.dptr(tg), 144, _lib.dptr(sc), _lib.dptr(pos),
+                                               _lib.dptr(ori), _lib.dptr(joints), _lib.dptr(g_th), 66, _lib.dptr(g_be),
+                                               10, _lib.dptr(ws), nbytes, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(g_th).all() and torch.isfinite(pos).all()
+    np.testing.assert_allclose(pos.cpu().numpy().reshape(T, 12, 3), ref['pos'], atol=2e-5)
+    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=5e-5)
+    np.testing.assert_allclose(joints.cpu().numpy().reshape(T, 22, 3), ref['joints'], atol=2e-5)
+    # the rest pose reproduces the regressed template joints exactly
+    rest = big_model['J_regressor'][:22].astype(np.float64) @ (
+        big_model['v_template'].astype(np.float64) +
+        np.einsum('vkl,l->vk', big_model['shapedirs'][:, :, :10].astype(np.float64), beta[0]))
+    np.testing.assert_allclose(joints.cpu().numpy().reshape(T, 22, 3)[0], rest, atol=2e-6)
+    gmax = np.abs(ref['g_theta']).max()
+    np.testing.assert_allclose(g_th.cpu().numpy(), ref['g_theta'], atol=5e-4 * gmax, rtol=2e-3)
+    np.testing.assert_allclose(g_be.cpu().numpy(), ref['g_beta'], atol=5e-4 * np.abs(ref['g_beta']).max(), rtol=2e-3)
