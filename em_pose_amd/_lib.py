@@ -158,6 +158,9 @@ def dptr(t):
 
 
 def current_stream():
+    """Handle of torch's current stream.  Every launch of this package goes onto it, which is also what makes
+    temporaries safe without host synchronisation: the caching allocator hands a freed block only to later work on
+    the same stream, i.e. to work that is ordered after the kernels still reading it."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -59,5 +59,4 @@ class VirtualMarkerHelper(object):
                                                              _lib.dptr(helper), _lib.dptr(deg), _lib.dptr(faces),
                                                              _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(nor),
                                                              _lib.current_stream()))
-            torch.cuda.current_stream().synchronize()  # `v` may be a temporary copy
         return pos, ori, nor

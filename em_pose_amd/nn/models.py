@@ -90,7 +90,6 @@ class _SmplSensorsFn(torch.autograd.Function):
                                                    _lib.dptr(offset_r), _lib.dptr(offset_t), _lib.dptr(d_pos),
                                                    _lib.dptr(d_ori), _lib.dptr(d_joints), _lib.dptr(g_pose),
                                                    _lib.dptr(g_shape), _lib.dptr(ws), nbytes, _lib.current_stream()))
-            torch.cuda.current_stream().synchronize()
         return None, g_pose, g_shape, None, None, None
 
 
@@ -389,7 +388,6 @@ class IterativeErrorFeedback(BaseModel):
                                                        _lib.dptr(offset_r), _lib.dptr(offset_t), None, 0, None,
                                                        _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), None, 0,
                                                        None, 0, _lib.dptr(ws), nbytes, _lib.current_stream()))
-            torch.cuda.current_stream().synchronize()  # `ws` and the fp32 copies die with this frame
         return pos, ori, joints
 
     # ---- forward ---------------------------------------------------------------------------------------------
@@ -474,7 +472,6 @@ class IterativeErrorFeedback(BaseModel):
                                                        _lib.dptr(ori), _lib.dptr(joints), _lib.dptr(g_pose), 66,
                                                        _lib.dptr(g_shape), 10, _lib.dptr(ws), nbytes,
                                                        _lib.current_stream()))
-            torch.cuda.current_stream().synchronize()
         return g_pose, g_shape
 
     def _forward_train(self, batch_inputs):
