@@ -2,11 +2,10 @@
 Data-parallel helpers (new: the reference is single-process).
 
 Training is plain data parallelism over windows: every rank holds a full replica (5.9 M fp32 parameters), computes
-its own loss/gradients and the gradients are averaged with RCCL all-reduces over flat buckets.  DistributedDataParallel
-is not used because the model back-propagates several times per step (the in-forward `E.backward()` deposits of
-reference models.py:576 plus the final `total_loss.backward()`), which violates DDP's one-backward-per-forward rule;
-averaging after the last backward is equivalent and needs no hooks.  BatchNorm statistics stay per-rank, as in the
-reference (there is no SyncBN there).
+its own loss/gradients and the gradients are averaged with RCCL all-reduces over flat buckets after the backward
+pass.  The model object is driven through `net(batch)` / `net.backward(batch, out)` like the reference's training
+loop (scripts/train.py:146-150) rather than through a wrapped `forward`, so the averaging is an explicit call instead
+of DistributedDataParallel hooks.  BatchNorm statistics stay per-rank, as in the reference (there is no SyncBN).
 """
 import torch
 

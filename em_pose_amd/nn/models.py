@@ -93,6 +93,23 @@ class _SmplSensorsFn(torch.autograd.Function):
         return None, g_pose, g_shape, None, None, None
 
 
+class _InjectGrad(torch.autograd.Function):
+    """Identity whose backward adds a constant cotangent.  The reference calls `E_i.backward(retain_graph=True)` inside
+    forward (models.py:576), which deposits dE_i/dparams through the producers of the current estimate.  Backward is
+    linear, so adding dE_i/dpose_i (= the gradient feature / (B*F)) to whatever flows into pose_i during the single
+    final backward gives the same parameter gradients without N extra backward passes."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        ctx.save_for_backward(g)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (g,) = ctx.saved_tensors
+        return dy + g, None
+
+
 class BaseModel(nn.Module):
     def __init__(self, config, smpl_model=None):
         super(BaseModel, self).__init__()
@@ -511,22 +528,24 @@ class IterativeErrorFeedback(BaseModel):
             return s.reshape(B, F, -1).mean(dim=1, keepdim=True).repeat(1, F, 1).reshape(T, -1)
         if self.shape_avg:
             shape = single_shape(shape)
-        hist = {'pose': [pose], 'shape': [shape], 'joints': [], 'markers': [], 'markers_ori': []}
+        hist = {'pose': [], 'shape': [], 'joints': [], 'markers': [], 'markers_ori': []}
 
-        def evaluate(p, s):
+        def record(p, s):
             pos, ori, joints = _SmplSensorsFn.apply(self, p, s, offset_r, offset_t, F)
+            hist['pose'].append(p)
+            hist['shape'].append(s)
             hist['markers'].append(pos)
             hist['markers_ori'].append(ori)
             hist['joints'].append(joints)
-        evaluate(pose, shape)
         for i in range(self.N):
             feats = [inputs_flat, pose.detach(), shape.detach()]
             if self.use_gradient:
                 g_pose, g_shape = self.residual_gradient(pose, shape, inputs_flat, offset_r, offset_t, scale, F)
-                # reference quirk: E.backward() also reaches the parameters behind the current estimate
-                if pose.requires_grad:
-                    torch.autograd.backward([pose, shape], [g_pose / float(T), g_shape / float(T)], retain_graph=True)
+                # reference quirk (E.backward() inside forward) folded into the one final backward pass
+                pose = _InjectGrad.apply(pose, g_pose / float(T))
+                shape = _InjectGrad.apply(shape, g_shape / float(T))
                 feats += [g_pose, g_shape]
+            record(pose, shape)
             x = torch.cat(feats, dim=-1)
             d_pose = self.pose_net_iter.forward_torch(x)
             d_shape = self.shape_net_iter.forward_torch(x)
@@ -534,9 +553,7 @@ class IterativeErrorFeedback(BaseModel):
                 d_shape = single_shape(d_shape)
             pose = pose + d_pose * self.step_size
             shape = shape + d_shape * self.step_size
-            hist['pose'].append(pose)
-            hist['shape'].append(shape)
-            evaluate(pose, shape)
+        record(pose, shape)
         pose_f = pose.reshape(B, F, -1)
         out = {'pose': pose_f, 'shape': shape.reshape(B, F, -1), 'joints': hist['joints'][-1].reshape(B, F, -1)}
         return out, hist
