@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
   if (t < 0 || t >= a.F) return;
   const LstmLayerArgs& L = a.layer[l];
   const int H = a.H, B = a.B;
-  const int m0 = blockIdx.x * LROWS, j0 = blockIdx.y * LUNITS;
+  // blockIdx.x (the fast index, which also selects the XCD: workgroup b runs on XCD b % 8) walks the UNIT tiles, so
+  // one XCD's L2 holds the W_ih/W_hh rows of two unit tiles and streams the (smaller) h/x rows of all batch tiles.
+  const int j0 = blockIdx.x * LUNITS, m0 = blockIdx.y * LROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = wave >> 1, wcol = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
 }
 
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream) {
-  dim3 grid((a.B + LROWS - 1) / LROWS, (a.H + LUNITS - 1) / LUNITS, a.num_layers);
+  dim3 grid((a.H + LUNITS - 1) / LUNITS, (a.B + LROWS - 1) / LROWS, a.num_layers);
   hipLaunchKernelGGL(lstm_wave_kernel, grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
