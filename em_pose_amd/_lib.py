@@ -102,6 +102,10 @@ SIGNATURES = {
     'empose_mesh_create': (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
     'empose_mesh_destroy': (None, [C.c_void_p]),
     'empose_mesh_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_mesh_joints_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p]),
+    'empose_metrics_rows': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
+                                       C.c_void_p, C.c_void_p]),
     'empose_mesh_vertices_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -137,6 +137,28 @@ class SMPLLayer(nn.Module):
                                                     _lib.current_stream()))
         return vertices, joints
 
+    def fk_joints(self, poses_body, betas, poses_root=None, trans=None):
+        """The 22 posed body joints only (no vertices): forward kinematics for the metrics, (N,22,3)."""
+        if not poses_body.is_cuda:
+            raise _lib.EmposeError('SMPLLayer needs GPU tensors; there is no CPU fallback')
+        n, dev = poses_body.shape[0], poses_body.device
+        if poses_root is None:
+            poses_root = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+        if betas.dim() == 1 or betas.shape[0] == 1:
+            betas = betas.reshape(1, -1).repeat(n, 1)
+        betas = betas[:, :self.num_betas].contiguous().float()
+        poses = torch.cat([poses_root.float(), poses_body[:, :C.N_JOINTS * 3].float()], dim=1).contiguous()
+        trans = trans.contiguous().float() if trans is not None else None
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            handle = self._mesh_handle(dev)
+            joints = torch.empty(n, 22, 3, dtype=torch.float32, device=dev)
+            ws_bytes = lib.empose_mesh_workspace_bytes(handle, n)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_mesh_joints_fwd(handle, n, _lib.dptr(poses), _lib.dptr(betas), _lib.dptr(trans),
+                                                  _lib.dptr(joints), _lib.dptr(ws), ws_bytes, _lib.current_stream()))
+        return joints
+
     def fk(self, poses_body, betas, poses_root=None, trans=None, normalize_root=False, window_size=None):
         # The reference slices long inputs into windows to bound memory (smpl.py:124-144); the HIP entry point already
         # processes slabs of 2048 frames internally, so `window_size` only has to be accepted.

@@ -848,6 +848,22 @@ int empose_virtual_sensors_fwd(int T, int V, const float* vertices, int M, int m
   return EMPOSE_OK;
 }
 
+int empose_metrics_rows(int T, const float* joints_gt, const float* joints_hat, const float* pose_gt,
+                        const float* pose_hat, const int* parents_host, double* rows, empose_stream_t stream_) {
+  if (!joints_gt || !joints_hat || !parents_host || !rows) return fail(EMPOSE_EINVAL, "null argument");
+  if ((pose_gt == nullptr) != (pose_hat == nullptr)) return fail(EMPOSE_EINVAL, "pose_gt and pose_hat go together");
+  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
+  MetricsArgs a;
+  a.joints_gt = joints_gt; a.joints_hat = joints_hat; a.pose_gt = pose_gt; a.pose_hat = pose_hat; a.rows = rows; a.T = T;
+  for (int j = 0; j < 22; ++j) {
+    if (parents_host[j] >= j) return fail(EMPOSE_EINVAL, "parents must be topologically ordered");
+    a.parents[j] = parents_host[j] < 0 ? 0 : parents_host[j];
+  }
+  hipError_t e = launch_metrics_rows(a, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "metrics kernel: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
 // ---- full mesh -----------------------------------------------------------------------------------------------
 void empose_mesh_destroy(empose_mesh_t* mesh) {
   if (!mesh) return;
@@ -932,6 +948,50 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     e = launch_mesh_skin(sa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
+  }
+  return EMPOSE_OK;
+}
+
+int empose_mesh_joints_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                           const float* trans, float* joints, void* workspace, size_t workspace_bytes,
+                           empose_stream_t stream_) {
+  if (!mesh || !poses || !betas || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
+  if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int S = T < MESH_SLAB ? T : MESH_SLAB;
+  Carver c(workspace);
+  float* rot = c.f((size_t)S * 198);
+  float* feat = c.f((size_t)S * 200);
+  float* jrest = c.f((size_t)S * 68);
+  float* xf = c.f((size_t)S * 264);
+  float* th = c.f((size_t)S * 66);
+  float* be = c.f((size_t)S * 10);
+  for (int t0 = 0; t0 < T; t0 += S) {
+    const int n = (T - t0) < S ? (T - t0) : S;
+    HIP_TRY(hipMemcpyAsync(th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    FeatArgs fa;
+    fa.theta = th; fa.ld_theta = 66; fa.beta = be; fa.ld_beta = 10;
+    fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
+    fa.shape_avg = 0; fa.rot = rot; fa.feat = feat;
+    fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
+    fa.T = n; fa.F = 1;
+    hipError_t e = launch_update_feat(fa, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& p = b.p[0];
+    p.A = feat; p.lda = 200; p.W = mesh->wc + (size_t)mesh->j_off * 200; p.ldw = 200; p.C = jrest; p.ldc = 68;
+    p.M = n; p.N = mesh->ncp - mesh->j_off; p.K = 200;
+    p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
+    e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rest-joint gemm: %s", hipGetErrorString(e));
+    MeshChainArgs ca;
+    ca.rot = rot; ca.out = jrest; ca.ncp = 68; ca.j_off = 0; ca.parents = mesh->parents;
+    ca.trans = trans ? trans + (size_t)t0 * 3 : nullptr; ca.xf = xf; ca.joints = joints + (size_t)t0 * 66; ca.T = n;
+    e = launch_mesh_chain(ca, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh chain: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
 }

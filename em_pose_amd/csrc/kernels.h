@@ -169,4 +169,13 @@ struct VirtualSensorArgs {
 };
 hipError_t launch_virtual_sensors(const VirtualSensorArgs& a, hipStream_t stream);
 
+struct MetricsArgs {
+  const float* joints_gt; const float* joints_hat;   // [T][22][3]
+  const float* pose_gt; const float* pose_hat;       // [T][63] body axis-angles (no root) or nullptr
+  double* rows;                                      // [T][65] = 22 distances | 22 aligned distances | 21 angles (deg)
+  int parents[22];
+  int T;
+};
+hipError_t launch_metrics_rows(const MetricsArgs& a, hipStream_t stream);
+
 }  // namespace empose

@@ -104,6 +104,25 @@ class MetricsEngine(object):
             mask = torch.logical_and(mask, fm)
         return mask
 
+    def _add_device_rows(self, kp3d, kp3d_hat, pose=None, pose_hat=None):
+        """Euclidean / Procrustes / angle rows from the HIP kernel (empose_metrics_rows); one device->host copy."""
+        import ctypes
+        from em_pose_amd import _lib
+        n, dev = kp3d.shape[0], kp3d.device
+        f32 = lambda t: None if t is None else t.to(dtype=torch.float32).contiguous()
+        kp3d, kp3d_hat, pose, pose_hat = f32(kp3d), f32(kp3d_hat), f32(pose), f32(pose_hat)
+        rows = torch.empty(n, 65, dtype=torch.float64, device=dev)
+        parents = (ctypes.c_int * 22)(*C.SMPL_PARENTS)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().empose_metrics_rows(n, _lib.dptr(kp3d), _lib.dptr(kp3d_hat), _lib.dptr(pose),
+                                                      _lib.dptr(pose_hat), parents, _lib.dptr(rows),
+                                                      _lib.current_stream()))
+        rows = rows.cpu().numpy()
+        self.eucl_dists.append(rows[:, :22])
+        self.eucl_dists_pa.append(rows[:, 22:44])
+        if pose is not None:
+            self.angle_diffs.append(rows[:, 44:])
+
     def _add_eucl(self, kp3d, kp3d_hat):
         gt = kp3d.detach().cpu().numpy().astype(np.float64)
         hat = kp3d_hat.detach().cpu().numpy().astype(np.float64)
@@ -117,7 +136,10 @@ class MetricsEngine(object):
             return
         js = joints[mask].reshape(-1, joints.shape[-1] // 3, 3)[:, :C.N_JOINTS + 1]
         js_hat = joints_hat[mask].reshape(-1, joints_hat.shape[-1] // 3, 3)[:, :C.N_JOINTS + 1]
-        self._add_eucl(js, js_hat)
+        if js.is_cuda:
+            self._add_device_rows(js, js_hat)
+        else:
+            self._add_eucl(js, js_hat)
 
     def compute(self, pose, shape, pose_hat, shape_hat=None, seq_lengths=None, pose_root=None, pose_root_hat=None,
                 frame_mask=None):
@@ -137,6 +159,12 @@ class MetricsEngine(object):
             root_hat_f = torch.zeros_like(root_f)
         else:
             root_f, root_hat_f = pose_root[mask], pose_root_hat[mask]
+        if pose_f.is_cuda and self.angle_glob and hasattr(self.smpl_model, 'fk_joints'):
+            # device path: joints-only forward kinematics + one metrics kernel
+            kp3d = self.smpl_model.fk_joints(pose_f, shape_f, poses_root=root_f)
+            kp3d_hat = self.smpl_model.fk_joints(pose_hat_f, shape_hat_f, poses_root=root_hat_f)
+            self._add_device_rows(kp3d, kp3d_hat, pose_f, pose_hat_f)
+            return
         _, kp3d = self.smpl_model.fk(pose_f.contiguous(), shape_f.contiguous(), poses_root=root_f.contiguous(),
                                      window_size=1000)
         _, kp3d_hat = self.smpl_model.fk(pose_hat_f.contiguous(), shape_hat_f.contiguous(),

@@ -250,6 +250,21 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
                              const float* trans, float* vertices, float* joints,
                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
 
+/* Joints only (forward kinematics without the mesh): what MetricsEngine needs from `smpl_model.fk`
+ * (reference eval/metrics.py:223-228 keeps `kp3d[:, :22]` and discards the vertices). Same workspace as above. */
+int empose_mesh_joints_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                           const float* trans, float* joints, void* workspace, size_t workspace_bytes,
+                           empose_stream_t stream);
+
+/* ---- evaluation metrics ------------------------------------------------------------------------ */
+/* Per frame: 22 Euclidean joint distances, 22 distances after similarity-Procrustes alignment of the prediction onto
+ * the ground truth, and 21 geodesic angles (degrees) between global joint orientations with the root fixed to the
+ * identity. Replaces MetricsEngine._compute_eucl_dist / _procrustes / _compute_angular_dist + local_to_global
+ * (reference eval/metrics.py:18-66,110-162; helpers/utils.py:165-199). joints_* [T][22][3], pose_* [T][63] (body
+ * axis-angles, no root) or NULL (angles reported as 0), parents: HOST int[22]; rows: device double [T][65]. */
+int empose_metrics_rows(int T, const float* joints_gt, const float* joints_hat, const float* pose_gt,
+                        const float* pose_hat, const int* parents_host, double* rows, empose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
