@@ -73,3 +73,66 @@ class NormalizeRoot(object):
                 batch.poses = batch.poses.clone()
                 batch.poses[:, :, :3] = torch.from_numpy(matrix_to_rotvec(Rn)).to(batch.poses)
         return batch
+
+
+class SMPLFK(object):
+    """Ground-truth joints and vertices for a batch (reference transforms.py:259-282) through the HIP full-mesh layer."""
+
+    def __init__(self, smpl_model):
+        self.smpl_model = smpl_model
+        self.max_window_size = 1000
+
+    def __call__(self, batch):
+        n, f = batch.batch_size, batch.seq_length
+        p = batch.poses_body.reshape(n * f, -1)
+        s = batch.shapes.unsqueeze(1).repeat(1, f, 1).reshape(n * f, -1)
+        r = batch.poses_root.reshape(n * f, -1)
+        t = batch.trans.reshape(n * f, -1)
+        vertices, joints = self.smpl_model(poses_body=p, betas=s, poses_root=r, trans=t,
+                                           window_size=self.max_window_size)
+        batch.joints_gt = joints[:, :22].reshape(n, f, -1)
+        batch.vertices = vertices.reshape(n, f, -1)
+        batch.joints_hat = batch.joints_gt.clone().detach()
+        return batch
+
+
+class SampleMarkersWithOffsets(object):
+    """
+    Virtual sensors sampled from the ground-truth mesh with per-subject offsets applied
+    (reference transforms.py:132-226, the deterministic branch used at evaluation time: `noise_level=-1`, offsets =
+    the stored means).  `offset_sets` is a list of dicts with `means` (M,3), `r` (M,3,3) and `vertex_ids` (M,) -- the
+    content of the reference's `*_offsets.npz` files; one set is drawn per batch entry with the reference's seeded
+    RandomState(6273).
+    """
+
+    def __init__(self, smpl_model, offset_sets):
+        from em_pose_amd.data.virtual_sensors import VirtualMarkerHelper
+        if isinstance(offset_sets, dict):
+            offset_sets = [offset_sets]
+        self.n_offsets = len(offset_sets)
+        self.offset_means = np.stack([np.asarray(o['means'], dtype=np.float32) for o in offset_sets])
+        self.r = np.stack([np.asarray(o['r'], dtype=np.float32) for o in offset_sets])
+        self.vertex_ids = [int(v) for v in np.asarray(offset_sets[-1]['vertex_ids']).tolist()]
+        self.virtual_helper = VirtualMarkerHelper(smpl_model)
+        self.offset_rng = np.random.RandomState(6273)
+
+    def __call__(self, batch):
+        n, f = batch.batch_size, batch.seq_length
+        vs = batch.vertices.reshape(n * f, -1, 3)
+        markers, oris, normals = self.virtual_helper.get_virtual_pos_and_rot(vs, self.vertex_ids)
+        dev = markers.device
+        batch.marker_pos_vertex = markers.reshape(n, f, -1)
+        batch.marker_ori_vertex = oris.reshape(n, f, -1)
+        batch.marker_normal_vertex = normals.reshape(n, f, -1)
+        s_idxs = self.offset_rng.randint(0, self.n_offsets, n)
+        means = torch.from_numpy(self.offset_means[s_idxs]).to(dev)  # (n, M, 3)
+        r = torch.from_numpy(self.r[s_idxs]).to(dev)  # (n, M, 3, 3)
+        ori = oris.reshape(n, f, -1, 3, 3)
+        pos = markers.reshape(n, f, -1, 3) + torch.matmul(ori, means[:, None, :, :, None]).squeeze(-1)
+        ori = torch.matmul(ori, r[:, None])
+        batch.marker_pos_synth = pos.reshape(n, f, -1)
+        batch.marker_ori_synth = ori.reshape(n, f, -1)
+        batch.marker_normal_synth = ori[..., 2].reshape(n, f, -1)
+        batch.offset_t_augmented = means
+        batch.offset_r_augmented = r
+        return batch

@@ -3,15 +3,16 @@ Evaluation metrics (mirror of reference empose/eval/metrics.py:18-346): MPJPE, P
 global joint-angle error, accumulated per frame and reduced exactly like the reference (`get_metrics`,
 metrics.py:289-330: mean over frames per joint, then mean over the evaluated joints; std over all selected entries).
 
-This is host-side code in the reference (NumPy SVD loop, numpy-quaternion) and it stays host-side NumPy here
-(SURVEY.md 8f-1 lists a device version as the first item after the hot path).  What is new is that the accumulator is
-a mergeable value: `state()` / `merge()` / `gather()` let every rank of a sequence-sharded evaluation keep its own
+This is host-side code in the reference (a NumPy SVD per frame in a Python loop, numpy-quaternion).  Here GPU tensors
+take the device path: joints-only forward kinematics (`SMPLLayer.fk_joints`) and ONE kernel per call
+that produces the per-frame Euclidean / Procrustes / global-angle rows (`empose_metrics_rows`, csrc/metrics.hip); CPU
+tensors take the NumPy path below (same algorithm, used by the CPU tests).  The accumulator is a mergeable value: `state()` / `merge()` / `gather()` let every rank of a sequence-sharded evaluation keep its own
 engine and combine them with ONE all_gather at the end -- the raw per-frame rows are exchanged so that
 the reference's `np.std` is reproduced exactly, not approximated from moments.
 
-Joint positions come from `smpl_model.fk` (the HIP full-mesh layer) exactly as in the reference (metrics.py:223-224).
 The geodesic joint-angle distance is computed from rotation matrices, acos((tr(R1^T R2) - 1) / 2), which equals
-numpy-quaternion's `rotation_intrinsic_distance` used by the reference (metrics.py:158).
+numpy-quaternion's `rotation_intrinsic_distance` used by the reference (metrics.py:158); the device kernel builds the
+global orientations with the reference's clamped exponential map (helpers/so3.py:86-128).
 """
 import numpy as np
 import torch

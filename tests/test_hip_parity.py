@@ -801,3 +801,28 @@ def test_device_metrics_vs_reference_vectors_and_numpy(big_model):
     j, jh = j[:, :22].numpy().astype(np.float64), jh[:, :22].numpy().astype(np.float64)
     np.testing.assert_allclose(rows['eucl'], np.linalg.norm(j - jh, axis=-1), atol=5e-6)
     np.testing.assert_allclose(rows['eucl_pa'], np.linalg.norm(j - procrustes_align(j, jh), axis=-1), atol=5e-6)
+
+
+def test_ground_truth_preprocessing_round_trip(big_model):
+    """SMPLFK + SampleMarkersWithOffsets: sensors sampled from the full ground-truth mesh with offsets
+    equal what the LGD sub-mesh path predicts for the same pose/shape/offsets (two independent HIP routes)."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.data.transforms import SMPLFK, SampleMarkersWithOffsets
+    smpl = SMPLLayer(big_model).to(DEV)
+    w = synthetic.make_windows(3, 5, 8)
+    w['marker_pos'] = np.zeros((3, 5, 36), np.float32)
+    w['marker_oris'] = np.zeros((3, 5, 108), np.float32)
+    batch = SyntheticBatch(w, device=DEV)
+    sets = [{'means': w['offset_t'][i], 'r': w['offset_r'][i], 'vertex_ids': np.asarray(CONST.VERTEX_IDS)}
+            for i in range(3)]
+    tr = SampleMarkersWithOffsets(smpl, sets)
+    batch = tr(SMPLFK(smpl)(batch))
+    assert batch.vertices.shape == (3, 5, 6890 * 3) and batch.joints_gt.shape == (3, 5, 66)
+    net = build_net(lgd_config(12, False, 1, hidden=32), big_model)
+    pos, ori, joints = net.get_estimated_real_markers(batch.poses.reshape(15, 66),
+                                                      batch.shapes[:, None].expand(3, 5, 10).reshape(15, 10),
+                                                      batch.offset_r_augmented, batch.offset_t_augmented,
+                                                      frames_per_window=5)
+    np.testing.assert_allclose(batch.marker_pos_synth.cpu().numpy().reshape(15, 12, 3), pos.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(batch.marker_ori_synth.cpu().numpy().reshape(15, 12, 3, 3), ori.cpu().numpy(), atol=5e-5)
+    np.testing.assert_allclose(batch.joints_gt.cpu().numpy().reshape(15, 22, 3), joints.cpu().numpy(), atol=2e-5)
