@@ -42,6 +42,11 @@ class LstmDesc(C.Structure):
                 ('w_ih', c_float_p * 4), ('w_hh', c_float_p * 4), ('b_ih', c_float_p * 4), ('b_hh', c_float_p * 4)]
 
 
+class RnnDesc(C.Structure):
+    _fields_ = [('num_layers', C.c_int), ('input_size', C.c_int), ('hidden_size', C.c_int), ('bidirectional', C.c_int),
+                ('w_ih', c_float_p * 8), ('w_hh', c_float_p * 8), ('b_ih', c_float_p * 8), ('b_hh', c_float_p * 8)]
+
+
 class ModelDesc(C.Structure):
     _fields_ = [('smpl', SmplDesc), ('n_markers', C.c_int), ('marker_idx', C.c_int * 12),
                 ('n_iterations', C.c_int), ('step_size', C.c_float), ('shape_avg', C.c_int),
@@ -93,6 +98,14 @@ SIGNATURES = {
                                    C.c_void_p]),
     'empose_linear_f32': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    'empose_linear_f32_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p]),
+    'empose_rnn_create': (C.c_int, [C.POINTER(RnnDesc), C.POINTER(C.c_void_p)]),
+    'empose_rnn_destroy': (None, [C.c_void_p]),
+    'empose_rnn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    'empose_rnn_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_virtual_sensors_fwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_profile_enable': (C.c_int, [C.c_int]),

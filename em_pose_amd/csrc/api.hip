@@ -73,11 +73,11 @@ struct Mlp {
   Dense layers[EMPOSE_MAX_DENSE];
 };
 
-struct Lstm {
-  int num_layers = 0, input_size = 0, H = 0;
-  float* w_ih[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* w_hh[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* bias[4] = {nullptr, nullptr, nullptr, nullptr};  // b_ih + b_hh
+struct Lstm {   // unit u = layer * dirs + direction
+  int num_layers = 0, input_size = 0, H = 0, dirs = 1;
+  float* w_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* w_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* bias[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // b_ih + b_hh
 };
 
 }  // namespace
@@ -98,6 +98,11 @@ struct empose_model {
   int hidden_max = 0;
   int any_skip = 0;
   int smpl_only = 0;
+};
+
+struct empose_rnn {
+  std::vector<void*> allocs;
+  Lstm rnn;
 };
 
 struct empose_mesh {
@@ -279,21 +284,25 @@ UpdWs carve_upd(Carver& c, const empose_model* m, int T) {
 }
 
 struct LstmWs {
-  float* h[4][2];
-  float* c[4];
+  float* h[8][2];
+  float* c[8];
+  float* yb[2];   // [B][F][2H] ping-pong between the layers of a bidirectional stack
 };
-LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) {
+LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
-  (void)F;
-  const int H = m->rnn.H;
-  for (int l = 0; l < 4; ++l) {
-    const bool used = l < m->rnn.num_layers;
-    w.h[l][0] = used ? c.f((size_t)B * H) : nullptr;
-    w.h[l][1] = used ? c.f((size_t)B * H) : nullptr;
-    w.c[l] = used ? c.f((size_t)B * H) : nullptr;
+  const int H = r.H, U = r.num_layers * r.dirs;
+  for (int u = 0; u < 8; ++u) {
+    const bool used = u < U;
+    w.h[u][0] = used ? c.f((size_t)B * H) : nullptr;
+    w.h[u][1] = used ? c.f((size_t)B * H) : nullptr;
+    w.c[u] = used ? c.f((size_t)B * H) : nullptr;
   }
+  const bool need_y = r.dirs == 2 && r.num_layers > 1;
+  w.yb[0] = need_y ? c.f((size_t)B * F * 2 * H) : nullptr;
+  w.yb[1] = (need_y && r.num_layers > 2) ? c.f((size_t)B * F * 2 * H) : nullptr;
   return w;
 }
+LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) { return carve_lstm_of(c, m->rnn, B, F); }
 
 GemmProb linear_prob(const float* A, int lda, const Dense& d, float* C, int ldc, int M) {
   GemmProb p;
@@ -352,39 +361,94 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
   return EMPOSE_OK;
 }
 
-int run_lstm(const empose_model* m, int B, int F, const float* x, int ldx, const int* seq_lengths, const float* h0,
+void fill_unit(LstmUnitArgs& ua, const Lstm& r, const LstmWs& ws, int u) {
+  ua.w_ih = r.w_ih[u]; ua.w_hh = r.w_hh[u]; ua.bias = r.bias[u];
+  ua.h[0] = ws.h[u][0]; ua.h[1] = ws.h[u][1]; ua.c = ws.c[u];
+  ua.in_seq = nullptr; ua.in_ld = 0; ua.in_from = -1; ua.t_offset = 0; ua.reverse = 0;
+  ua.y = nullptr; ua.y_ld = 0; ua.y_col = 0;
+}
+
+// State layout of h0/c0/h_n/c_n: [num_layers * dirs][B][H], unit u = layer * dirs + direction (PyTorch's order).
+int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* seq_lengths, const float* h0,
              const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
-  const Lstm& r = m->rnn;
-  const int H = r.H, L = r.num_layers;
+  const int H = r.H, L = r.num_layers, D = r.dirs, U = L * D;
   const size_t bh = (size_t)B * H;
   prof_mark(P_COPY, stream);
-  for (int l = 0; l < L; ++l) {
-    if (h0) HIP_TRY(hipMemcpyAsync(ws.h[l][0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    else HIP_TRY(hipMemsetAsync(ws.h[l][0], 0, bh * sizeof(float), stream));
-    if (c0) HIP_TRY(hipMemcpyAsync(ws.c[l], c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    else HIP_TRY(hipMemsetAsync(ws.c[l], 0, bh * sizeof(float), stream));
+  for (int u = 0; u < U; ++u) {
+    if (h0) HIP_TRY(hipMemcpyAsync(ws.h[u][0], h0 + u * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.h[u][0], 0, bh * sizeof(float), stream));
+    if (c0) HIP_TRY(hipMemcpyAsync(ws.c[u], c0 + u * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ws.c[u], 0, bh * sizeof(float), stream));
   }
   LstmWaveArgs a;
-  a.num_layers = L; a.x = x; a.ldx = ldx; a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H;
-  for (int l = 0; l < 4; ++l) {
-    LstmLayerArgs& la = a.layer[l];
-    la.w_ih = r.w_ih[l]; la.w_hh = r.w_hh[l]; la.bias = r.bias[l];
-    la.in_k = (l == 0) ? r.input_size : H;
-    la.h[0] = ws.h[l][0]; la.h[1] = ws.h[l][1]; la.c = ws.c[l];
-    la.y = (l == L - 1) ? y : nullptr;
-  }
-  // Wavefront over (layer, time): launch s advances layer l by its step s - l.
-  for (int s = 0; s < F + L - 1; ++s) {
-    a.s = s;
-    prof_mark(P_LSTM_STEP, stream);
-    hipError_t e = launch_lstm_wave(a, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+  a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H;
+  if (D == 1) {
+    // Stacked uni-directional layers: wavefront over (layer, time), launch s advances layer l by its step s - l.
+    if (L > 4) return fail(EMPOSE_EINVAL, "at most 4 stacked layers per wavefront");
+    a.n_units = L;
+    for (int l = 0; l < L; ++l) {
+      LstmUnitArgs& ua = a.unit[l];
+      fill_unit(ua, r, ws, l);
+      ua.in_k = (l == 0) ? r.input_size : H;
+      if (l == 0) { ua.in_seq = x; ua.in_ld = ldx; }
+      else ua.in_from = l - 1;
+      ua.t_offset = l;
+      if (l == L - 1) { ua.y = y; ua.y_ld = H; }
+    }
+    for (int s = 0; s < F + L - 1; ++s) {
+      a.s = s;
+      prof_mark(P_LSTM_STEP, stream);
+      hipError_t e = launch_lstm_wave(a, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+    }
+  } else {
+    // Bidirectional: a layer needs the whole output sequence of the layer below, so layers run one after the other;
+    // the two directions of a layer share each launch.
+    if (!seq_lengths) return fail(EMPOSE_EINVAL, "bidirectional LSTM needs seq_lengths");
+    a.n_units = 2;
+    for (int l = 0; l < L; ++l) {
+      const float* in = (l == 0) ? x : ws.yb[(l - 1) & 1];
+      const int in_ld = (l == 0) ? ldx : 2 * H;
+      float* out = (l == L - 1) ? y : ws.yb[l & 1];
+      for (int d = 0; d < 2; ++d) {
+        LstmUnitArgs& ua = a.unit[d];
+        fill_unit(ua, r, ws, l * 2 + d);
+        ua.in_k = (l == 0) ? r.input_size : 2 * H;
+        ua.in_seq = in; ua.in_ld = in_ld; ua.reverse = d;
+        ua.y = out; ua.y_ld = 2 * H; ua.y_col = d * H;
+      }
+      for (int s = 0; s < F; ++s) {
+        a.s = s;
+        prof_mark(P_LSTM_STEP, stream);
+        hipError_t e = launch_lstm_wave(a, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+      }
+    }
   }
   prof_mark(P_COPY, stream);
-  for (int l = 0; l < L; ++l) {
-    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, ws.h[l][F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, ws.c[l], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  for (int u = 0; u < U; ++u) {
+    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + u * bh, ws.h[u][F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + u * bh, ws.c[u], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
+  return EMPOSE_OK;
+}
+
+int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, const float* const* w_ih,
+              const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, Lstm* out) {
+  if (r.num_layers < 1 || r.num_layers * dirs > 8 || r.hidden_size % 4 != 0 || r.input_size % 4 != 0)
+    return fail(EMPOSE_EINVAL, "unsupported LSTM configuration");
+  out->num_layers = r.num_layers; out->input_size = r.input_size; out->H = r.hidden_size; out->dirs = dirs;
+  for (int l = 0; l < r.num_layers; ++l)
+    for (int d = 0; d < dirs; ++d) {
+      const int u = l * dirs + d;
+      const int k_in = l == 0 ? r.input_size : r.hidden_size * dirs;
+      if (!w_ih[u] || !w_hh[u] || !b_ih[u] || !b_hh[u]) return fail(EMPOSE_EINVAL, "null LSTM parameter");
+      TRY(upload(allocs, w_ih[u], (size_t)4 * r.hidden_size * k_in, &out->w_ih[u]));
+      TRY(upload(allocs, w_hh[u], (size_t)4 * r.hidden_size * r.hidden_size, &out->w_hh[u]));
+      std::vector<float> bias(4 * r.hidden_size);
+      for (int i = 0; i < 4 * r.hidden_size; ++i) bias[i] = b_ih[u][i] + b_hh[u][i];
+      TRY(upload(allocs, bias.data(), bias.size(), &out->bias[u]));
+    }
   return EMPOSE_OK;
 }
 
@@ -524,18 +588,8 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
 
   if (d->rnn_init) {
     const empose_lstm_desc& r = d->rnn;
-    if (r.num_layers < 1 || r.num_layers > 4 || r.input_size != m->d_in || r.hidden_size % 4 != 0)
-      return bail(fail(EMPOSE_EINVAL, "unsupported LSTM configuration"));
-    m->rnn.num_layers = r.num_layers; m->rnn.input_size = r.input_size; m->rnn.H = r.hidden_size;
-    for (int l = 0; l < r.num_layers; ++l) {
-      const int k_in = l == 0 ? r.input_size : r.hidden_size;
-      MTRY(upload(m->allocs, r.w_ih[l], (size_t)4 * r.hidden_size * k_in, &m->rnn.w_ih[l]));
-      MTRY(upload(m->allocs, r.w_hh[l], (size_t)4 * r.hidden_size * r.hidden_size, &m->rnn.w_hh[l]));
-      if (!r.b_ih[l] || !r.b_hh[l]) return bail(fail(EMPOSE_EINVAL, "null LSTM bias"));
-      std::vector<float> bias(4 * r.hidden_size);
-      for (int i = 0; i < 4 * r.hidden_size; ++i) bias[i] = r.b_ih[l][i] + r.b_hh[l][i];
-      MTRY(upload(m->allocs, bias.data(), bias.size(), &m->rnn.bias[l]));
-    }
+    if (r.num_layers > 4 || r.input_size != m->d_in) return bail(fail(EMPOSE_EINVAL, "unsupported LSTM configuration"));
+    MTRY(pack_lstm(m->allocs, r, 1, r.w_ih, r.w_hh, r.b_ih, r.b_hh, &m->rnn));
     MTRY(pack_dense(m->allocs, d->pose_head, &m->pose_head));
     MTRY(pack_dense(m->allocs, d->shape_head, &m->shape_head));
     if (m->pose_head.out_dim != 66 || m->shape_head.out_dim != 10 || m->pose_head.in_dim != r.hidden_size)
@@ -648,7 +702,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
 
   // ---- initial estimate (reference models.py:511-526)
   if (m->rnn_init) {
-    TRY(run_lstm(m, B, F, w.x, dx, io->seq_lengths, io->h0, io->c0, w.y, io->h_n, io->c_n, w.lstm, stream));
+    TRY(run_lstm(m->rnn, B, F, w.x, dx, io->seq_lengths, io->h0, io->c0, w.y, io->h_n, io->c_n, w.lstm, stream));
     GemmBatch b;
     b.count = 2;
     b.p[0] = linear_prob(w.y, m->rnn.H, m->pose_head, x_theta, dx, T);
@@ -817,7 +871,62 @@ int empose_lstm_fwd(const empose_model_t* m, int B, int F, const float* x, int l
   if (workspace_bytes < empose_lstm_workspace_bytes(m, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
   Carver c(workspace);
   LstmWs ws = carve_lstm(c, m, B, F);
-  return run_lstm(m, B, F, x, ldx, seq_lengths, h0, c0, y, h_n, c_n, ws, static_cast<hipStream_t>(stream_));
+  return run_lstm(m->rnn, B, F, x, ldx, seq_lengths, h0, c0, y, h_n, c_n, ws, static_cast<hipStream_t>(stream_));
+}
+
+void empose_rnn_destroy(empose_rnn_t* rnn) {
+  if (!rnn) return;
+  for (void* p : rnn->allocs) (void)hipFree(p);
+  delete rnn;
+}
+
+int empose_rnn_create(const empose_rnn_desc* d, empose_rnn_t** out) {
+  if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
+  *out = nullptr;
+  empose_rnn* r = new empose_rnn();
+  empose_lstm_desc base;
+  base.num_layers = d->num_layers; base.input_size = d->input_size; base.hidden_size = d->hidden_size;
+  const int rc = pack_lstm(r->allocs, base, d->bidirectional ? 2 : 1, d->w_ih, d->w_hh, d->b_ih, d->b_hh, &r->rnn);
+  if (rc != EMPOSE_OK) { empose_rnn_destroy(r); return rc; }
+  if (!d->bidirectional && d->num_layers > 4) { empose_rnn_destroy(r); return fail(EMPOSE_EINVAL, "at most 4 stacked layers"); }
+  *out = r;
+  return EMPOSE_OK;
+}
+
+size_t empose_rnn_workspace_bytes(const empose_rnn_t* rnn, int B, int F) {
+  if (!rnn || B <= 0 || F <= 0) return 0;
+  Carver c(nullptr);
+  carve_lstm_of(c, rnn->rnn, B, F);
+  return c.off;
+}
+
+int empose_rnn_fwd(const empose_rnn_t* rnn, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                   const float* h0, const float* c0, float* y, float* h_n, float* c_n, void* workspace,
+                   size_t workspace_bytes, empose_stream_t stream_) {
+  if (!rnn || !x || !y || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0) return fail(EMPOSE_EINVAL, "B and F must be positive");
+  if (ldx % 4 != 0 || ldx < rnn->rnn.input_size) return fail(EMPOSE_EINVAL, "ldx must be a multiple of 4 and >= input_size");
+  if (workspace_bytes < empose_rnn_workspace_bytes(rnn, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  Carver c(workspace);
+  LstmWs ws = carve_lstm_of(c, rnn->rnn, B, F);
+  return run_lstm(rnn->rnn, B, F, x, ldx, seq_lengths, h0, c0, y, h_n, c_n, ws, static_cast<hipStream_t>(stream_));
+}
+
+int empose_linear_f32_ex(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* scale, const float* shift, const float* resid, int ldr, int act, float slope,
+                         empose_stream_t stream_) {
+  if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");
+  if (K % 4 != 0 || lda % 4 != 0 || ldw % 4 != 0) return fail(EMPOSE_EINVAL, "K, lda, ldw must be multiples of 4");
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return fail(EMPOSE_EINVAL, "A and W must be 16-byte aligned");
+  if (act < 0 || act > 2) return fail(EMPOSE_EINVAL, "act must be 0 (none), 1 (PReLU, residual added after) or 2 (residual, then ReLU)");
+  GemmBatch b;
+  b.count = 1;
+  GemmProb& p = b.p[0];
+  p.A = A; p.lda = lda; p.W = W; p.ldw = ldw; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  p.scale = scale; p.shift = shift; p.resid = resid; p.ldr = ldr; p.act = act; p.slope = slope;
+  hipError_t e = launch_gemm(b, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "gemm launch: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
 }
 
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,

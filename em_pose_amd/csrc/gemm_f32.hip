@@ -161,8 +161,13 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
         const int m = m0 + wrow * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= p.M) continue;
         float y = acc[i][j][r] * sc + sh;
-        if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
-        if (p.resid) y += p.resid[(size_t)m * p.ldr + n];
+        if (p.act == 2) {  // residual block of the ResNet baseline: relu(W x + b + x), reference layers.py:170-182
+          if (p.resid) y += p.resid[(size_t)m * p.ldr + n];
+          y = y > 0.f ? y : 0.f;
+        } else {
+          if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
+          if (p.resid) y += p.resid[(size_t)m * p.ldr + n];  // skip connection around a block (after the activation)
+        }
         p.C[(size_t)m * p.ldc + n] = y;
       }
     }

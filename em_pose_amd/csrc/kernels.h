@@ -17,7 +17,7 @@ struct GemmProb {
   const float* scale;       // [N] or nullptr (=1)
   const float* shift;       // [N] or nullptr (=0)
   const float* resid; int ldr;  // added after the activation (skip connections) or nullptr
-  int act;                  // 0 none, 1 PReLU(slope)
+  int act;                  // 0 none, 1 PReLU(slope) then + resid, 2 + resid then ReLU
   float slope;
 };
 struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
@@ -28,22 +28,25 @@ hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
 // ---------------------------------------------------------------------------------------------------------------
 // LSTM
 // ---------------------------------------------------------------------------------------------------------------
-struct LstmLayerArgs {
+struct LstmUnitArgs {        // one (layer, direction), selected by blockIdx.z
   const float* w_ih;   // [4H][in_k]
   const float* w_hh;   // [4H][H]
   const float* bias;   // [4H] = b_ih + b_hh
-  int in_k;            // width of the layer input
-  float* h[2];         // [B][H] ping-pong: step t reads h[t & 1], writes h[(t + 1) & 1]
+  int in_k;            // width of the unit's input
+  const float* in_seq; int in_ld;  // stored input sequence [B][F][in_ld] (used when in_from < 0)
+  int in_from;         // >= 0: the input is the hidden state of unit `in_from` after its step (stacked wavefront)
+  int t_offset;        // the unit processes step k = s - t_offset
+  int reverse;         // 1: at step k row b visits time len_b - 1 - k
+  float* h[2];         // [B][H] ping-pong: step k reads h[k & 1], writes h[(k + 1) & 1]
   float* c;            // [B][H] updated in place
-  float* y;            // [B][F][H] layer output or nullptr (only the last layer's is kept)
+  float* y; int y_ld; int y_col;   // output sequence [B][F][y_ld], columns [y_col, y_col + H), or nullptr
 };
 struct LstmWaveArgs {
-  LstmLayerArgs layer[4];
-  int num_layers;
-  const float* x; int ldx;   // [B][F][ldx] network input rows
-  const int* seq_lengths;    // [B] or nullptr
+  LstmUnitArgs unit[4];
+  int n_units;
+  const int* seq_lengths;    // [B] or nullptr (required for reverse units)
   int B, F, H;
-  int s;                     // wavefront index: layer l runs time step s - l
+  int s;                     // launch index
 };
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 

@@ -9,6 +9,11 @@
 // epilogue.  Nothing but h, c and the last layer's output ever touches memory (no gate buffer, no separate input
 // projection).
 //
+// Every blockIdx.z is one "unit" = one (layer, direction). Units either read a stored input sequence (layer 0, and the
+// layers of a bidirectional stack, whose input is the concatenated output sequence of the previous layer) or the hidden
+// state another unit produced in the previous launch (uni-directional stacks: the wavefront above).  A reverse unit
+// visits, at its step k, time len_b-1-k of every row b (packed-sequence semantics for ragged batches).
+//
 // Tiling: v_mfma_f32_16x16x4_f32.  A wave owns 32 batch rows x 16 hidden units and keeps 2 x 4 accumulators
 // (row half x gate), so i/f/g/o of one (row, unit) sit in the same lane.  A block is 2x2 waves = 64 rows x 32 units
 // (128 weight rows per K tile) -> for B=1024, H=512: 256 blocks per layer, one wave per SIMD and layer.
@@ -31,6 +36,8 @@ struct Seg {
   const float* a; int lda;   // [B][lda]
   const float* w; int ldw;   // [4H][ldw]
   int K;
+  // per-row time offset (reverse units): row b reads a + b*lda + trow(b)*tstride; tstride == 0 => none
+  const int* lens; int k; int tstride;
 };
 
 __device__ __forceinline__ void lstm_load(const Seg& sg, int k0, int m0, int j0, int B, int H, int tid,
@@ -40,7 +47,14 @@ __device__ __forceinline__ void lstm_load(const Seg& sg, int k0, int m0, int j0,
     const int slot = tid + i * 256;
     const int r = slot >> 3, c4 = (slot & 7) * 4;
     ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + r < B && k0 + c4 < sg.K) ra[i] = *reinterpret_cast<const float4*>(sg.a + (size_t)(m0 + r) * sg.lda + k0 + c4);
+    if (m0 + r < B && k0 + c4 < sg.K) {
+      size_t off = (size_t)(m0 + r) * sg.lda + k0 + c4;
+      if (sg.tstride) {
+        const int tr = sg.lens[m0 + r] - 1 - sg.k;   // reverse unit: time visited by this row
+        off += (size_t)(tr > 0 ? tr : 0) * sg.tstride;
+      }
+      ra[i] = *reinterpret_cast<const float4*>(sg.a + off);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -71,10 +85,9 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
   float* As = lds;
   float* Bs = lds + LROWS * LLD;
 
-  const int l = blockIdx.z;
-  const int t = a.s - l;
+  const LstmUnitArgs& L = a.unit[blockIdx.z];
+  const int t = a.s - L.t_offset;     // step index k of this unit (time index for forward units)
   if (t < 0 || t >= a.F) return;
-  const LstmLayerArgs& L = a.layer[l];
   const int H = a.H, B = a.B;
   // blockIdx.x (the fast index, which also selects the XCD: workgroup b runs on XCD b % 8) walks the UNIT tiles, so
   // one XCD's L2 holds the W_ih/W_hh rows of two unit tiles and streams the (smaller) h/x rows of all batch tiles.
@@ -82,14 +95,22 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wrow = wave >> 1, wcol = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
+  const bool rev = L.reverse != 0;
 
   Seg segs[2];
-  // segment 0: the layer input at step t (x_t for layer 0, the previous layer's h after ITS step t otherwise)
-  if (l == 0) { segs[0].a = a.x + (size_t)t * a.ldx; segs[0].lda = a.F * a.ldx; }
-  else { segs[0].a = a.layer[l - 1].h[(t + 1) & 1]; segs[0].lda = H; }
+  // segment 0: the unit's input at this step
+  segs[0].lens = a.seq_lengths; segs[0].k = t; segs[0].tstride = 0;
+  if (L.in_from < 0) {
+    segs[0].lda = a.F * L.in_ld;
+    if (rev) { segs[0].a = L.in_seq; segs[0].tstride = L.in_ld; }
+    else segs[0].a = L.in_seq + (size_t)t * L.in_ld;
+  } else {
+    segs[0].a = a.unit[L.in_from].h[(t + 1) & 1]; segs[0].lda = H;
+  }
   segs[0].w = L.w_ih; segs[0].ldw = L.in_k; segs[0].K = L.in_k;
-  // segment 1: own hidden state after step t-1
+  // segment 1: own hidden state after the previous step
   segs[1].a = L.h[t & 1]; segs[1].lda = H; segs[1].w = L.w_hh; segs[1].ldw = H; segs[1].K = H;
+  segs[1].lens = nullptr; segs[1].k = 0; segs[1].tstride = 0;
 
   f32x4 acc[2][4];
 #pragma unroll
@@ -149,7 +170,9 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
       const int row = m0 + wrow * 32 + i * 16 + lq * 4 + r;
       if (row >= B) continue;
       const size_t hc = (size_t)row * H + unit;
-      const bool live = a.seq_lengths ? (t < a.seq_lengths[row]) : true;
+      const int len = a.seq_lengths ? a.seq_lengths[row] : a.F;
+      const bool live = t < len;
+      const int t_out = (rev && live) ? len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
       float h_new;
       if (live) {
         const float c_new = sigmoidf_(acc[i][1][r] + bf) * L.c[hc] + sigmoidf_(acc[i][0][r] + bi) * tanhf(acc[i][2][r] + bg);
@@ -160,12 +183,12 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
         h_next[hc] = h_prev[hc];
         h_new = 0.f;
       }
-      if (L.y) L.y[((size_t)row * a.F + t) * H + unit] = h_new;
+      if (L.y) L.y[((size_t)row * a.F + t_out) * L.y_ld + L.y_col + unit] = h_new;
     }
 }
 
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream) {
-  dim3 grid((a.H + LUNITS - 1) / LUNITS, (a.B + LROWS - 1) / LROWS, a.num_layers);
+  dim3 grid((a.H + LUNITS - 1) / LUNITS, (a.B + LROWS - 1) / LROWS, a.n_units);
   hipLaunchKernelGGL(lstm_wave_kernel, grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -105,25 +105,31 @@ class MLP(nn.Module):
         """Eval-mode forward on the GPU through the fp32 matrix-core linear kernel (one launch per layer)."""
         if self.training:
             raise NotImplementedError('training mode of MLP is not available on the HIP path yet')
-        if self.skip_connection:
-            raise NotImplementedError('stand-alone MLP.forward does not implement skip connections')
         lib = _lib.lib()
         y = x.contiguous().float()
         lead = y.shape[:-1]
         y = y.reshape(-1, y.shape[-1])
-        for lin, bn, act in self.dense_specs():
+        specs = self.dense_specs()
+        block_in = None
+        for i, (lin, bn, act) in enumerate(specs):
             w = lin.weight.detach().contiguous()
             if bn is not None:
                 scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().contiguous()
                 shift = ((lin.bias - bn.running_mean) * scale + bn.bias).detach().contiguous()
             else:
                 scale, shift = None, lin.bias.detach().contiguous()
+            # hidden block h = dense layers 1+2h, 2+2h; with skip connections its output is block_in + block(block_in)
+            in_block = 0 < i < len(specs) - 1
+            if in_block and (i - 1) % 2 == 0:
+                block_in = y
+            resid = block_in if (self.skip_connection and in_block and (i - 1) % 2 == 1) else None
             out = torch.empty(y.shape[0], lin.out_features, device=y.device, dtype=torch.float32)
             slope = float(act.weight.item()) if act is not None else 0.0
-            _lib.check(lib.empose_linear_f32(_lib.dptr(y), y.shape[1], _lib.dptr(w), w.shape[1], _lib.dptr(out),
-                                             out.shape[1], y.shape[0], lin.out_features, lin.in_features,
-                                             _lib.dptr(scale), _lib.dptr(shift), int(act is not None), slope,
-                                             _lib.current_stream()))
+            _lib.check(lib.empose_linear_f32_ex(_lib.dptr(y), y.shape[1], _lib.dptr(w), w.shape[1], _lib.dptr(out),
+                                                out.shape[1], y.shape[0], lin.out_features, lin.in_features,
+                                                _lib.dptr(scale), _lib.dptr(shift), _lib.dptr(resid),
+                                                0 if resid is None else resid.shape[1], int(act is not None), slope,
+                                                _lib.current_stream()))
             y = out
         return y.reshape(lead + (y.shape[-1],))
 
@@ -149,30 +155,139 @@ def fill_dense_desc(d, lin, bn, act, keep):
         d.has_prelu, d.prelu = 0, 0.0
 
 
+def linear_hip(x2d, lin, resid=None, act=0, slope=0.0):
+    """y = act(x W^T + b (+ resid)) on the fp32 matrix-core kernel; x2d (M,K) fp32 contiguous on the GPU."""
+    w = lin.weight.detach().contiguous()
+    b = lin.bias.detach().contiguous()
+    out = torch.empty(x2d.shape[0], lin.out_features, device=x2d.device, dtype=torch.float32)
+    _lib.check(_lib.lib().empose_linear_f32_ex(_lib.dptr(x2d), x2d.shape[1], _lib.dptr(w), w.shape[1], _lib.dptr(out),
+                                               out.shape[1], x2d.shape[0], lin.out_features, lin.in_features, None,
+                                               _lib.dptr(b), _lib.dptr(resid),
+                                               0 if resid is None else resid.shape[1], act, slope,
+                                               _lib.current_stream()))
+    return out
+
+
 class RNNLayer(nn.Module):
-    """LSTM parameter container + carried state (reference nn/layers.py:80-167)."""
+    """
+    (Bi)LSTM parameter container + carried state (reference nn/layers.py:80-167).  Inside IterativeErrorFeedback the
+    LSTM runs as part of `empose_lgd_forward`; stand-alone (`forward`, used by the BiRNN baseline) it runs through its
+    own `empose_rnn_*` handle.
+    """
 
     def __init__(self, input_size, hidden_size, num_layers, output_size=None, bidirectional=False, dropout=0.0,
                  learn_init_state=False):
         super(RNNLayer, self).__init__()
-        if bidirectional or learn_init_state or output_size is not None or dropout > 0.0:
-            raise NotImplementedError('the LGD init RNN is a plain unidirectional LSTM (reference models.py:427-430)')
+        if dropout > 0.0:
+            raise NotImplementedError('input dropout is a training-time feature; the HIP path is inference')
+        if bidirectional and learn_init_state:
+            raise NotImplementedError('the reference reshapes the learned state to (B, L, H) (layers.py:125-130), which '
+                                      'does not fit a bidirectional LSTM')
         self.input_size = input_size
         self.hidden_size = hidden_size
         self.num_layers = num_layers
-        self.is_bidirectional = False
-        self.num_directions = 1
+        self.learn_init_state = learn_init_state
+        self.is_bidirectional = bidirectional
+        self.num_directions = 2 if bidirectional else 1
+        self.input_drop = nn.Identity()
         self.init_state = None
         self.final_state = None
-        self.lstm = nn.LSTM(input_size, hidden_size, num_layers, bidirectional=False)
+        if self.learn_init_state:
+            self.to_init_state_h = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
+            self.to_init_state_c = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
+        self.lstm = nn.LSTM(input_size, hidden_size, num_layers, bidirectional=bidirectional)
+        self.to_out = nn.Linear(hidden_size * self.num_directions, output_size) if output_size is not None \
+            else nn.Identity()
+        self._handle, self._handle_key = None, None
+
+    def _unit_params(self):
+        for l in range(self.num_layers):
+            for suffix in ([''] if not self.is_bidirectional else ['', '_reverse']):
+                yield [getattr(self.lstm, '{}_l{}{}'.format(n, l, suffix))
+                       for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
 
     def fill_desc(self, desc, keep):
+        """Fill the LSTM part of an `_lib.ModelDesc` (uni-directional init RNN of the LGD model)."""
+        assert not self.is_bidirectional
         desc.num_layers, desc.input_size, desc.hidden_size = self.num_layers, self.input_size, self.hidden_size
-        for l in range(self.num_layers):
-            arrs = [_np32(getattr(self.lstm, '{}_l{}'.format(n, l)))
-                    for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+        for l, params in enumerate(self._unit_params()):
+            arrs = [_np32(p) for p in params]
             keep += arrs
             desc.w_ih[l], desc.w_hh[l], desc.b_ih[l], desc.b_hh[l] = [_lib.fptr(a) for a in arrs]
+
+    def _ensure_handle(self, device):
+        ps = [p for unit in self._unit_params() for p in unit]
+        key = (device.index, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+        if self._handle is not None and key == self._handle_key:
+            return self._handle
+        self.release()
+        keep = []
+        desc = _lib.RnnDesc()
+        desc.num_layers, desc.input_size, desc.hidden_size = self.num_layers, self.input_size, self.hidden_size
+        desc.bidirectional = int(self.is_bidirectional)
+        for u, params in enumerate(self._unit_params()):
+            arrs = [_np32(p) for p in params]
+            keep += arrs
+            desc.w_ih[u], desc.w_hh[u], desc.b_ih[u], desc.b_hh[u] = [_lib.fptr(a) for a in arrs]
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().empose_rnn_create(C.byref(desc), C.byref(handle)))
+        self._handle, self._handle_key = handle, key
+        return handle
+
+    def release(self):
+        if getattr(self, '_handle', None) is not None:
+            _lib.lib().empose_rnn_destroy(self._handle)
+            self._handle, self._handle_key = None, None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+    def cell_init(self, inputs_):
+        """Initial (h_0, c_0); with `learn_init_state` from the first frame (reference layers.py:121-131)."""
+        if not self.learn_init_state:
+            return self.init_state
+        first = inputs_[:, 0].contiguous().float()
+        shape = lambda t: t.reshape(-1, self.num_layers, self.hidden_size).transpose(0, 1).contiguous()
+        c0 = shape(linear_hip(first, self.to_init_state_c))
+        h0 = shape(linear_hip(first, self.to_init_state_h))
+        # The reference returns (c0, h0) and nn.LSTM reads the pair as (h_0, c_0): kept as is.
+        return c0, h0
+
+    def forward(self, x, seq_lengths):
+        """(N, F, input) -> (N, F, directions*hidden) through empose_rnn_fwd; ragged sequences, carried state."""
+        if self.training:
+            raise NotImplementedError('RNNLayer.forward is the inference path; training uses forward_torch')
+        if not x.is_cuda:
+            raise _lib.EmposeError('RNNLayer needs GPU tensors; there is no CPU fallback')
+        dev = x.device
+        B, F = x.shape[0], x.shape[1]
+        x = x.contiguous().float()
+        self.init_state = self.cell_init(x)
+        lens = seq_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        U, H = self.num_layers * self.num_directions, self.hidden_size
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            handle = self._ensure_handle(dev)
+            y = torch.empty(B, F, self.num_directions * H, dtype=torch.float32, device=dev)
+            h_n = torch.empty(U, B, H, dtype=torch.float32, device=dev)
+            c_n = torch.empty(U, B, H, dtype=torch.float32, device=dev)
+            h0 = c0 = None
+            if self.init_state is not None:
+                h0, c0 = [t.to(device=dev, dtype=torch.float32).contiguous() for t in self.init_state]
+                assert h0.shape == (U, B, H) and c0.shape == (U, B, H)
+            nbytes = lib.empose_rnn_workspace_bytes(handle, B, F)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_rnn_fwd(handle, B, F, _lib.dptr(x), x.shape[2], _lib.dptr(lens), _lib.dptr(h0),
+                                          _lib.dptr(c0), _lib.dptr(y), _lib.dptr(h_n), _lib.dptr(c_n), _lib.dptr(ws),
+                                          nbytes, _lib.current_stream()))
+        self.final_state = (h_n, c_n)
+        if isinstance(self.to_out, nn.Linear):
+            y = linear_hip(y.reshape(B * F, -1), self.to_out).reshape(B, F, -1)
+        return y
 
     def forward_torch(self, x, seq_lengths):
         """Training path only: nn.LSTM over packed sequences with the carried state (reference layers.py:133-157)."""
@@ -182,12 +297,10 @@ class RNNLayer(nn.Module):
         out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])
         return out
 
-    def forward(self, x, seq_lengths):
-        raise NotImplementedError('RNNLayer runs inside IterativeErrorFeedback.forward on the HIP path')
-
 
 class FeedForwardResidualBlock(nn.Module):
-    """y = relu(W x + b + x)  (reference nn/layers.py:170-182). Plain torch: only used by the CPU plumbing config."""
+    """y = relu(W x + b + x)  (reference nn/layers.py:170-182). GPU tensors: one fp32 MFMA launch with the residual
+    and the ReLU in the epilogue; CPU tensors: plain torch (BASELINE.json configs[0] is a CPU plumbing check)."""
 
     def __init__(self, input_size, output_size):
         super(FeedForwardResidualBlock, self).__init__()
@@ -195,4 +308,8 @@ class FeedForwardResidualBlock(nn.Module):
         self.activate = nn.ReLU()
 
     def forward(self, x):
+        if x.is_cuda and not self.training:
+            lead = x.shape[:-1]
+            x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+            return linear_hip(x2, self.dense, resid=x2, act=2).reshape(lead + (self.dense.out_features,))
         return self.activate(self.dense(x) + x)

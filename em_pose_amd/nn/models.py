@@ -21,7 +21,7 @@ import torch.nn as nn
 from em_pose_amd import _lib
 from em_pose_amd.bodymodels import tables as TB
 from em_pose_amd.helpers.configuration import CONSTANTS as CONST
-from em_pose_amd.nn.layers import MLP, FeedForwardResidualBlock, RNNLayer, fill_dense_desc
+from em_pose_amd.nn.layers import MLP, FeedForwardResidualBlock, RNNLayer, fill_dense_desc, linear_hip
 
 
 def create_model(config, *args):
@@ -31,7 +31,7 @@ def create_model(config, *args):
     elif m_type in ('ief', 'lgd'):
         return IterativeErrorFeedback(config, *args)
     elif m_type == 'rnn':
-        raise NotImplementedError("The BiRNN baseline ('rnn') is outside the LGD path (SURVEY.md 8f-3).")
+        return SimpleRNN(config, *args)
     raise ValueError("Model type '{}' unknown.".format(m_type))
 
 
@@ -46,6 +46,18 @@ def reconstruction_loss(markers_gt, markers_hat, seq_lengths=None, marker_mask=N
     """reference nn/loss.py:23-41 (used for reporting loss values only; the in-loop residual lives in the kernels)."""
     diff = markers_hat - markers_gt
     per = torch.sqrt((diff * diff).sum(dim=-1)).sum(dim=-1)
+    if marker_mask is not None:
+        per = per * marker_mask.logical_not().any(dim=-1).logical_not()
+    if seq_lengths is not None:
+        mask = mask_from_seq_lengths(seq_lengths, per.shape[1]).to(per.dtype)
+        per = (per * mask).sum(-1) / seq_lengths.to(per.dtype)
+    return per.mean()
+
+
+def normal_mse(x_gt, x_hat, seq_lengths=None, marker_mask=None):
+    """reference nn/loss.py:44-62: squared error summed over joints, padded mean over frames, mean over the batch."""
+    diff = x_hat - x_gt
+    per = (diff * diff).sum(dim=-1).sum(dim=-1)
     if marker_mask is not None:
         per = per * marker_mask.logical_not().any(dim=-1).logical_not()
     if seq_lengths is not None:
@@ -180,6 +192,68 @@ class BaseModel(nn.Module):
             batch_inputs['seq_lengths'] = batch.seq_lengths
             yield batch_inputs
 
+    def model_name(self):
+        """Suffix shared by the baselines (reference models.py:86-96)."""
+        base_name = ''
+        if self.estimate_shape is not None:
+            base_name += '-shape{}{}'.format(self.config.m_shape_hidden_size, '-avg' if self.shape_avg else '')
+        if self.do_fk:
+            base_name += '-fk{}'.format(self.fk_loss_weight)
+        base_name += '-n{}'.format(self.n_markers)
+        base_name += '-lr{}'.format(self.config.lr)
+        return base_name
+
+    def maybe_do_fk(self, pose_hat, shape_hat):
+        """Joints of the predicted pose if an FK loss is configured (reference models.py:134-144)."""
+        if not self.do_fk:
+            return None
+        n, f = pose_hat.shape[0], pose_hat.shape[1]
+        joints = self.smpl.fk_joints(pose_hat[:, :, 3:].reshape(n * f, -1), shape_hat.reshape(n * f, -1),
+                                     poses_root=pose_hat[:, :, :3].reshape(n * f, -1))
+        return joints.reshape(n, f, -1)
+
+    def _heads(self, features):
+        """pose head, optional shape MLP (+ per-window mean), optional FK: shared by the two baselines."""
+        n, f = features.shape[0], features.shape[1]
+        flat = features.reshape(n * f, -1).contiguous().float()
+        if flat.is_cuda:
+            pose_hat = linear_hip(flat, self.to_pose).reshape(n, f, -1)
+        else:
+            pose_hat = self.to_pose(features)
+        shape_hat = None
+        if self.to_shape is not None:
+            shape_hat = (self.to_shape(flat) if flat.is_cuda else self.to_shape.forward_torch(flat)).reshape(n, f, -1)
+            if self.shape_avg:
+                shape_hat = torch.mean(shape_hat, dim=1, keepdim=True).repeat((1, f, 1))
+        joints_hat = self.maybe_do_fk(pose_hat, shape_hat)
+        return {'pose_hat': pose_hat[:, :, 3:], 'root_ori_hat': pose_hat[:, :, :3], 'shape_hat': shape_hat,
+                'joints_hat': joints_hat}
+
+    def _baseline_backward(self, batch, model_out, writer=None, global_step=None):
+        """Loss values of the two baselines (reference models.py:223-262, 326-366).  The HIP path is inference only, so
+        the outputs carry no autograd graph: in training mode this raises instead of silently skipping the update."""
+        if self.training:
+            raise NotImplementedError('training of the baselines is not available on the HIP path (SURVEY.md 8f-3)')
+        pose_hat, root_hat, shape_hat = model_out['pose_hat'], model_out['root_ori_hat'], model_out['shape_hat']
+        dev, n, f = pose_hat.device, batch.batch_size, batch.seq_length
+        sl = batch.seq_lengths.to(dev)
+        masks = batch.marker_masks.to(dev) if batch.marker_masks is not None else None
+        pose_loss = normal_mse(batch.poses_body.to(dev).reshape(n, f, -1, 3), pose_hat.reshape(n, f, -1, 3), sl, masks)
+        root_loss = normal_mse(batch.poses_root.to(dev).reshape(n, f, -1, 3), root_hat.reshape(n, f, -1, 3), sl, masks)
+        shape_loss, fk_loss = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        if self.estimate_shape:
+            shape_loss = padded_loss(batch.shapes.to(dev).unsqueeze(1).repeat((1, shape_hat.shape[1], 1)), shape_hat,
+                                     self.shape_loss, sl)
+        if self.do_fk:
+            fk_loss = reconstruction_loss(batch.joints_gt.to(dev).reshape(n, f, -1, 3),
+                                          model_out['joints_hat'].reshape(n, f, -1, 3), sl, masks)
+        total = pose_loss + root_loss + shape_loss + self.fk_loss_weight * fk_loss
+        loss_vals = {'pose': pose_loss.item(), 'root_pose': root_loss.item(), 'shape': shape_loss.item(),
+                     'fk': fk_loss.item(), 'total_loss': total.item()}
+        if writer is not None:
+            self.log_loss_vals(loss_vals, writer, global_step)
+        return total, loss_vals
+
     def log_loss_vals(self, loss_vals, writer, global_step):
         mode_prefix = 'train' if self.training else 'valid'
         for k in loss_vals:
@@ -188,24 +262,68 @@ class BaseModel(nn.Module):
 
 class FeedForwardResNet(BaseModel):
     """
-    Frame-wise residual MLP baseline (reference models.py:166-262), pose only. Restated in plain PyTorch because
-    BASELINE.json's config 0 is "forward on PyTorch CPU ... plumbing, no GPU"; it is not on the accelerated path.
+    Frame-wise residual MLP baseline (reference models.py:166-262). On GPU tensors every layer is one fp32 MFMA
+    launch (residual + ReLU in the epilogue); on CPU tensors it is plain PyTorch, because BASELINE.json configs[0] is
+    "forward on PyTorch CPU ... plumbing, no GPU".
     """
 
     def create_model(self):
-        h = self.config.m_hidden_size
-        self.from_input = nn.Linear(self.input_size, h)
-        self.blocks = nn.Sequential(*[FeedForwardResidualBlock(h, h) for _ in range(self.config.m_num_layers)])
-        self.to_output = nn.Linear(h, self.output_size)
+        cfg = self.config
+        self.hidden_size, self.num_layers = cfg.m_hidden_size, cfg.m_num_layers
+        self.from_input = nn.Linear(self.input_size, self.hidden_size)
+        self.blocks = nn.Sequential(*[FeedForwardResidualBlock(self.hidden_size, self.hidden_size)
+                                      for _ in range(self.num_layers)])
+        self.to_pose = nn.Linear(self.hidden_size, self.output_size)
+        self.to_shape = MLP(self.hidden_size, CONST.N_SHAPE_PARAMS, cfg.m_shape_hidden_size, 2, cfg.m_dropout_hidden,
+                            cfg.m_skip_connections, use_batch_norm=False) if self.estimate_shape else None
+        self.shape_loss = nn.L1Loss(reduction='none')
 
     def model_name(self):
-        return 'ResNet-{}x{}-n{}-lr{}'.format(self.config.m_num_layers, self.config.m_hidden_size, self.n_markers,
-                                              self.config.lr)
+        return 'ResNet-{}x{}'.format(self.num_layers, self.hidden_size) + super(FeedForwardResNet, self).model_name()
 
     def forward(self, batch, window_size=None, is_new_sequence=True):
         inputs_ = self.prepare_inputs(batch.get_inputs())
-        pose = self.to_output(self.blocks(self.from_input(inputs_)))
-        return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3], 'shape_hat': None, 'joints_hat': None}
+        if inputs_.is_cuda and not self.training:
+            n, f = inputs_.shape[0], inputs_.shape[1]
+            x = linear_hip(inputs_.reshape(n * f, -1).contiguous().float(), self.from_input)
+            x = self.blocks(x).reshape(n, f, -1)
+        else:
+            x = self.blocks(self.from_input(inputs_))
+        return self._heads(x)
+
+    def backward(self, batch, model_out, writer=None, global_step=None):
+        return self._baseline_backward(batch, model_out, writer, global_step)
+
+
+class SimpleRNN(BaseModel):
+    """The (Bi)RNN baseline (reference models.py:265-366): (Bi)LSTM -> linear pose head (+ shape MLP, + FK joints)."""
+
+    def create_model(self):
+        cfg = self.config
+        hidden, dirs = cfg.m_hidden_size, (2 if cfg.m_bidirectional else 1)
+        self.rnn = RNNLayer(self.input_size, hidden, cfg.m_num_layers, bidirectional=cfg.m_bidirectional,
+                            dropout=cfg.m_dropout, learn_init_state=cfg.m_learn_init_state)
+        self.to_pose = nn.Linear(hidden * dirs, self.output_size)
+        self.to_shape = MLP(hidden * dirs, CONST.N_SHAPE_PARAMS, cfg.m_shape_hidden_size, 2, cfg.m_dropout_hidden,
+                            cfg.m_skip_connections, use_batch_norm=False) if self.estimate_shape else None
+        self.shape_loss = nn.L1Loss(reduction='none')
+
+    def model_name(self):
+        name = 'RNN-{}'.format('-'.join([str(self.config.m_hidden_size)] * self.config.m_num_layers))
+        if self.config.m_bidirectional:
+            name = 'Bi' + name
+        return name + super(SimpleRNN, self).model_name()
+
+    def forward(self, batch, window_size=None, is_new_sequence=True):
+        if is_new_sequence:
+            self.rnn.final_state = None
+        self.rnn.init_state = self.rnn.final_state
+        inputs_ = self.prepare_inputs(batch.get_inputs())
+        lstm_out = self.rnn(inputs_, batch.seq_lengths)
+        return self._heads(lstm_out)
+
+    def backward(self, batch, model_out, writer=None, global_step=None):
+        return self._baseline_backward(batch, model_out, writer, global_step)
 
 
 class IterativeErrorFeedback(BaseModel):

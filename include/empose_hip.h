@@ -35,6 +35,7 @@ extern "C" {
 typedef void* empose_stream_t;
 typedef struct empose_model empose_model_t;
 typedef struct empose_mesh empose_mesh_t;
+typedef struct empose_rnn empose_rnn_t;
 
 const char* empose_last_error(void);
 /* Library/ABI version and the offload architecture it was compiled for ("gfx950"). */
@@ -211,6 +212,31 @@ int empose_lstm_fwd(const empose_model_t* model, int B, int F, const float* x, i
  * Exposed for tests and for host code that needs a plain fp32 linear layer. */
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream);
+
+/* As empose_linear_f32 with an optional residual operand resid [M][ldr]:
+ *   act 0: y = acc*scale + shift (+ resid);  act 1: PReLU(slope) then + resid (MLP skip connection, layers.py:35-43);
+ *   act 2: + resid, then ReLU (FeedForwardResidualBlock of the ResNet baseline, reference nn/layers.py:170-182). */
+int empose_linear_f32_ex(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                         const float* scale, const float* shift, const float* resid, int ldr, int act, float slope,
+                         empose_stream_t stream);
+
+/* ---- stand-alone (Bi)LSTM: the RNNLayer of the BiRNN baseline --------------------------------- */
+/* reference nn/layers.py:80-157 (nn.LSTM, optionally bidirectional, packed ragged sequences). Parameter index
+ * u = layer * dirs + direction (direction 1 = reverse), as PyTorch orders `*_l{k}` / `*_l{k}_reverse`; layer k > 0 of
+ * a bidirectional stack takes 2*hidden inputs. State tensors are [num_layers*dirs][B][H]; y is [B][F][dirs*H]. */
+typedef struct {
+  int num_layers, input_size, hidden_size, bidirectional;
+  const float* w_ih[8];
+  const float* w_hh[8];
+  const float* b_ih[8];
+  const float* b_hh[8];
+} empose_rnn_desc;
+int empose_rnn_create(const empose_rnn_desc* desc, empose_rnn_t** out);
+void empose_rnn_destroy(empose_rnn_t* rnn);
+size_t empose_rnn_workspace_bytes(const empose_rnn_t* rnn, int B, int F);
+int empose_rnn_fwd(const empose_rnn_t* rnn, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                   const float* h0, const float* c0, float* y, float* h_n, float* c_n, void* workspace,
+                   size_t workspace_bytes, empose_stream_t stream);
 
 /* Virtual sensor positions and local frames from full-mesh vertices [T][V][3]
  * (replaces VirtualMarkerHelper.get_virtual_pos_and_rot, reference data/virtual_sensors.py:85-96, and

@@ -246,35 +246,97 @@ def mlp_forward(sd, prefix, x, num_layers=2, batch_norm=True, skip=False):
     return lin(prefix + 'hidden_to_output.', y)
 
 
-def lstm_forward(sd, prefix, x, seq_lengths, state=None, num_layers=2):
+def lstm_forward(sd, prefix, x, seq_lengths, state=None, num_layers=2, bidirectional=False):
     """
-    Stacked unidirectional LSTM over ragged sequences, written out explicitly (gate order i,f,g,o).
-    Padded steps produce zero output and leave the state untouched (pack/pad semantics, reference layers.py:141-149).
-    :return: y (B,F,H), (h_n, c_n) each (L,B,H)
+    Stacked (bi)directional LSTM over ragged sequences, written out explicitly (gate order i,f,g,o).
+    Padded steps produce zero output and leave the state untouched (pack/pad semantics, reference layers.py:141-149);
+    the reverse direction of row b starts at its last valid frame len_b-1.  States are indexed layer*dirs + direction.
+    :return: y (B,F,dirs*H), (h_n, c_n) each (L*dirs,B,H)
     """
     B, F, _ = x.shape
     H = sd[prefix + 'weight_hh_l0'].shape[1]
+    dirs = 2 if bidirectional else 1
     inp = x
     hs, cs = [], []
     for l in range(num_layers):
-        w_ih, w_hh = sd[prefix + 'weight_ih_l%d' % l], sd[prefix + 'weight_hh_l%d' % l]
-        b = sd[prefix + 'bias_ih_l%d' % l] + sd[prefix + 'bias_hh_l%d' % l]
-        h = torch.zeros(B, H, dtype=x.dtype) if state is None else state[0][l]
-        c = torch.zeros(B, H, dtype=x.dtype) if state is None else state[1][l]
-        outs = []
-        for t in range(F):
-            g = inp[:, t] @ w_ih.t() + h @ w_hh.t() + b
-            i, f, gg, o = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
-            c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
-            h_new = torch.sigmoid(o) * torch.tanh(c_new)
-            live = (t < seq_lengths)[:, None]
-            c = torch.where(live, c_new, c)
-            h = torch.where(live, h_new, h)
-            outs.append(torch.where(live, h_new, torch.zeros_like(h_new)))
-        inp = torch.stack(outs, dim=1)
-        hs.append(h)
-        cs.append(c)
+        per_dir = []
+        for d in range(dirs):
+            sfx = 'l%d' % l + ('_reverse' if d == 1 else '')
+            w_ih, w_hh = sd[prefix + 'weight_ih_' + sfx], sd[prefix + 'weight_hh_' + sfx]
+            b = sd[prefix + 'bias_ih_' + sfx] + sd[prefix + 'bias_hh_' + sfx]
+            u = l * dirs + d
+            h = torch.zeros(B, H, dtype=x.dtype) if state is None else state[0][u]
+            c = torch.zeros(B, H, dtype=x.dtype) if state is None else state[1][u]
+            outs = [None] * F
+            for t in (range(F) if d == 0 else range(F - 1, -1, -1)):
+                g = inp[:, t] @ w_ih.t() + h @ w_hh.t() + b
+                i, f, gg, o = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+                c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+                h_new = torch.sigmoid(o) * torch.tanh(c_new)
+                live = (t < seq_lengths)[:, None]
+                c = torch.where(live, c_new, c)
+                h = torch.where(live, h_new, h)
+                outs[t] = torch.where(live, h_new, torch.zeros_like(h_new))
+            per_dir.append(torch.stack(outs, dim=1))
+            hs.append(h)
+            cs.append(c)
+        inp = torch.cat(per_dir, dim=-1)
     return inp, (torch.stack(hs), torch.stack(cs))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The two baselines (reference models.py:166-221 ResNet, 265-324 (Bi)RNN).
+# ----------------------------------------------------------------------------------------------------------------------
+def _baseline_inputs(inputs, n_markers, dt):
+    pos, ori = inputs['marker_pos'].to(dt), inputs['marker_oris'].to(dt)
+    B, F = pos.shape[0], pos.shape[1]
+    m_pos, m_ori = pos.reshape(B, F, -1, 3), ori.reshape(B, F, -1, 9)
+    if n_markers == 6:
+        m_pos, m_ori = m_pos[:, :, S_CONFIG_6], m_ori[:, :, S_CONFIG_6]
+    return torch.cat([m_pos.reshape(B, F, -1), m_ori.reshape(B, F, -1)], dim=-1)
+
+
+def _baseline_heads(sd, bm, feats, estimate_shape, shape_avg, do_fk, skip):
+    B, F = feats.shape[0], feats.shape[1]
+    flat = feats.reshape(B * F, -1)
+    pose = torch.addmm(sd['to_pose.bias'], flat, sd['to_pose.weight'].t()).reshape(B, F, -1)
+    shape = joints = None
+    if estimate_shape:
+        shape = mlp_forward(sd, 'to_shape.', flat, 2, batch_norm=False, skip=skip).reshape(B, F, -1)
+        if shape_avg:
+            shape = shape.mean(dim=1, keepdim=True).repeat(1, F, 1)
+    if do_fk:
+        _, j = smpl_fk(bm, pose[:, :, 3:].reshape(B * F, -1), shape.reshape(B * F, -1),
+                       poses_root=pose[:, :, :3].reshape(B * F, -1))
+        joints = j[:, :22].reshape(B, F, -1)
+    return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3], 'shape_hat': shape, 'joints_hat': joints}
+
+
+def resnet_forward(sd, bm, inputs, n_markers=12, num_layers=3, estimate_shape=True, shape_avg=True, do_fk=True,
+                   skip=False):
+    """Frame-wise residual MLP: Linear, `num_layers` x relu(W x + b + x), heads (reference models.py:198-221)."""
+    dt = sd['to_pose.weight'].dtype
+    x = _baseline_inputs(inputs, n_markers, dt)
+    B, F = x.shape[0], x.shape[1]
+    y = torch.addmm(sd['from_input.bias'], x.reshape(B * F, -1), sd['from_input.weight'].t())
+    for l in range(num_layers):
+        y = torch.relu(torch.addmm(sd['blocks.%d.dense.bias' % l], y, sd['blocks.%d.dense.weight' % l].t()) + y)
+    return _baseline_heads(sd, bm, y.reshape(B, F, -1), estimate_shape, shape_avg, do_fk, skip)
+
+
+def simple_rnn_forward(sd, bm, inputs, n_markers=12, num_layers=2, bidirectional=True, learn_init_state=False,
+                       state=None, estimate_shape=True, shape_avg=True, do_fk=True, skip=False):
+    """(Bi)LSTM + heads (reference models.py:298-324). :return: (model_out, (h_n, c_n))"""
+    dt = sd['to_pose.weight'].dtype
+    x = _baseline_inputs(inputs, n_markers, dt)
+    if learn_init_state:
+        # reference layers.py:121-131 returns (c0, h0) and nn.LSTM reads the pair as (h_0, c_0): kept.
+        H = sd['rnn.lstm.weight_hh_l0'].shape[1]
+        mk = lambda n: torch.addmm(sd['rnn.to_init_state_%s.bias' % n], x[:, 0],
+                                   sd['rnn.to_init_state_%s.weight' % n].t()).reshape(-1, num_layers, H).transpose(0, 1)
+        state = (mk('c'), mk('h'))
+    y, final = lstm_forward(sd, 'rnn.lstm.', x, inputs['seq_lengths'], state, num_layers, bidirectional)
+    return _baseline_heads(sd, bm, y, estimate_shape, shape_avg, do_fk, skip), final
 
 
 # ----------------------------------------------------------------------------------------------------------------------

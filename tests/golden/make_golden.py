@@ -170,10 +170,76 @@ def save_case(name, net, w, recs, extra=None):
     print('wrote', path, '%.0f KB' % (os.path.getsize(path) / 1024))
 
 
+def baseline_flags(m_type, n_markers, **kw):
+    fl = dict(m_type=m_type, m_hidden_size=32, m_num_layers=2, window_size=32, use_marker_pos=True,
+              use_marker_ori=True, use_real_offsets=True, offset_noise_level=0, m_estimate_shape=True,
+              m_shape_hidden_size=24, m_average_shape=True, m_fk_loss=0.1, n_markers=n_markers, lr=0.001)
+    fl.update(kw)
+    return fl
+
+
+def make_baselines(vids):
+    """Cases F: the ResNet and (Bi)RNN baselines (reference models.py:166-366) in eval mode, with loss values."""
+    from empose.bodymodels.smpl import create_default_smpl_model
+    from empose.nn.models import create_model
+    smpl = create_default_smpl_model(torch.device('cpu'))
+    lgd_net, _ = make_net(lgd_flags(12, True, 1, 32, 32), 5, vids)  # only to synthesise consistent sensor readings
+    cases = (('birnn12_ragged', baseline_flags('rnn', 12, m_bidirectional=True), 41, 'ragged'),
+             ('rnn6_learninit_carry', baseline_flags('rnn', 6, m_learn_init_state=True, m_average_shape=False), 42,
+              'carry'),
+             ('rnn12_carry', baseline_flags('rnn', 12, m_num_layers=3), 43, 'carry'),
+             ('resnet12', baseline_flags('resnet', 12, m_num_layers=3, m_skip_connections=True), 44, 'ragged'))
+    for tag, fl, seed, mode in cases:
+        torch.manual_seed(seed)
+        net = create_model(ref_config(**fl), smpl)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if name.startswith('to_pose') or 'hidden_to_output' in name:
+                    p.mul_(3.0)
+        net.eval()
+        recs = {}
+        if mode == 'ragged':
+            w = synthetic.make_windows(3, 24, seed, sensors_from_reference(lgd_net, smpl))
+            lengths = torch.tensor([24, 17, 6])
+            masks = np.ones((3, 24, 12), dtype=np.float32)
+            masks[0, 3:6, 4] = 0.0
+            for b, n in enumerate(lengths.tolist()):
+                for k in ('marker_pos', 'marker_oris', 'poses'):
+                    w[k][b, n:] = 0.0
+                masks[b, n:] = 0.0
+            chunks = [('run', real_batch(w, lengths, masks=masks), True)]
+            w = dict(w, marker_masks=masks, seq_lengths=lengths.numpy())
+        else:
+            w = synthetic.make_windows(2, 48, seed, sensors_from_reference(lgd_net, smpl))
+            sl = torch.tensor([24, 24])
+            chunks = [('chunk0', real_batch(w, sl, sf=0, ef=24), True), ('chunk1', real_batch(w, sl, sf=24, ef=48), False)]
+        for name, batch, new_seq in chunks:
+            B, F = batch.batch_size, batch.seq_length
+            with torch.no_grad():
+                _, jgt = smpl(poses_body=batch.poses_body.reshape(B * F, -1),
+                              betas=batch.shapes.unsqueeze(1).repeat(1, F, 1).reshape(B * F, -1),
+                              poses_root=batch.poses_root.reshape(B * F, -1))
+                batch.joints_gt = jgt[:, :22].reshape(B, F, 66)
+                out = net(batch, is_new_sequence=new_seq)
+                total, loss_vals = net.backward(batch, out)
+            rec = {'out_' + k: v.numpy() for k, v in out.items() if v is not None}
+            rec['joints_gt'] = batch.joints_gt.numpy()
+            for k, v in loss_vals.items():
+                rec['loss_' + k] = np.asarray(v)
+            if fl['m_type'] == 'rnn':
+                rec['rnn_h'], rec['rnn_c'] = [t.numpy() for t in net.rnn.final_state]
+            recs[name] = rec
+        save_case(tag, net, w, recs, {'n_markers': fl['n_markers'], 'vertex_ids': vids,
+                                      'model_name': net.model_name(), 'flags': json.dumps(fl, sort_keys=True)})
+
+
 def main():
     model = build_small_model()
-    np.savez_compressed(os.path.join(HERE, 'smpl_small.npz'), **{k: v for k, v in model.items()})
     vids = synthetic.small_vertex_ids(160)
+    if '--only-baselines' in sys.argv:
+        sys.argv.remove('--only-baselines')
+        return make_baselines(vids)
+    np.savez_compressed(os.path.join(HERE, 'smpl_small.npz'), **{k: v for k, v in model.items()})
     H = 32
 
     from empose.helpers.configuration import CONSTANTS as C
@@ -311,6 +377,7 @@ def main():
                  'me_n_rows': np.concatenate(me.eucl_dists).shape[0]})
     np.savez_compressed(os.path.join(HERE, 'components.npz'), **comp)
     print('wrote components.npz')
+    make_baselines(vids)
 
 
 if __name__ == '__main__':

@@ -60,3 +60,17 @@ def run_oracle(case, tag, inp, dtype=torch.float32, state=None):
     sd = sd_to_torch(case['sd'], dtype)
     return R.ief_forward(sd, bm, tables, vids, inp, n_markers=int(meta['n_markers']), N=int(meta['N']),
                          rnn_init=bool(meta['rnn']), rnn_state=state)
+
+
+def run_oracle_baseline(case, inp, state=None, dtype=torch.float32):
+    """The ResNet / (Bi)RNN baselines through the oracle, configured from the fixture's recorded reference flags."""
+    import json
+    fl = json.loads(str(case['meta']['flags']))
+    bm = R.BodyModelTensors(small_model(), dtype=dtype)
+    sd = sd_to_torch(case['sd'], dtype)
+    common = dict(n_markers=fl['n_markers'], num_layers=fl['m_num_layers'], estimate_shape=fl['m_estimate_shape'],
+                  shape_avg=fl['m_average_shape'], do_fk=fl['m_fk_loss'] > 0, skip=fl.get('m_skip_connections', False))
+    if fl['m_type'] == 'resnet':
+        return R.resnet_forward(sd, bm, inp, **common), None
+    return R.simple_rnn_forward(sd, bm, inp, bidirectional=fl.get('m_bidirectional', False),
+                                learn_init_state=fl.get('m_learn_init_state', False), state=state, **common)

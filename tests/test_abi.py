@@ -51,7 +51,7 @@ def test_struct_layouts_match_the_header_field_order():
     for cname, cls in (('empose_smpl_desc', _lib.SmplDesc), ('empose_dense_desc', _lib.DenseDesc),
                        ('empose_mlp_desc', _lib.MlpDesc), ('empose_lstm_desc', _lib.LstmDesc),
                        ('empose_model_desc', _lib.ModelDesc), ('empose_lgd_io', _lib.LgdIO),
-                       ('empose_mesh_desc', _lib.MeshDesc)):
+                       ('empose_mesh_desc', _lib.MeshDesc), ('empose_rnn_desc', _lib.RnnDesc)):
         assert fields(cname) == [f[0] for f in cls._fields_], cname
 
 

@@ -1,0 +1,194 @@
+"""
+GPU parity tests of the two baselines next to the LGD path (reference models.py:166-366,
+layers.py:80-182): the stand-alone (Bi)LSTM entry point `empose_rnn_fwd`, the fused residual block of
+`empose_linear_f32_ex`, and the `SimpleRNN` / `FeedForwardResNet` modules against the oracle and the vectors recorded
+from the reference.  Tolerance as everywhere: 1e-4 abs fp32 (BASELINE.json north_star).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from em_pose_amd import _lib, synthetic
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.data.data import RealBatch
+from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.helpers.configuration import Configuration
+from em_pose_amd.nn.layers import FeedForwardResidualBlock, RNNLayer
+from em_pose_amd.nn.models import create_model
+from oracle import torch_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+DEV = 'cuda:0'
+
+
+def _lstm_sd(layer):
+    return {'lstm.' + k: v.detach().cpu() for k, v in layer.lstm.state_dict().items()}
+
+
+@pytest.mark.parametrize('bi,L,In,Hd,B,F', [
+    (False, 1, 8, 4, 1, 1),          # smallest legal shapes
+    (False, 3, 72, 36, 5, 7),        # hidden size not a multiple of the 32-unit tile
+    (True, 1, 12, 32, 3, 5),
+    (True, 2, 144, 64, 7, 24),
+    (True, 2, 144, 512, 33, 32),     # the released BiRNN width, rows not a multiple of the 64-row tile
+    (True, 4, 16, 40, 4, 9),         # 8 units = the most the handle packs
+    (False, 2, 144, 512, 70, 40),
+])
+def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
+    """empose_rnn_fwd: ragged rows, both directions, given initial state, final state (reference layers.py:133-157)."""
+    torch.manual_seed(B * 1000 + F)
+    layer = RNNLayer(In, Hd, L, bidirectional=bi).eval()
+    with torch.no_grad():
+        for p in layer.lstm.parameters():
+            p.mul_(2.0)   # default init is +-1/sqrt(H): make the gates leave their linear range
+    x = torch.randn(B, F, In)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0] = F
+    U = L * (2 if bi else 1)
+    h0, c0 = 0.5 * torch.randn(U, B, Hd), 0.5 * torch.randn(U, B, Hd)
+    for state in (None, (h0, c0)):
+        want, (wh, wc) = R.lstm_forward(_lstm_sd(layer), 'lstm.', x, lens, state, L, bi)
+        # the plain PyTorch op on the same inputs (packed sequences), to pin the oracle's loop here as well
+        from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        with torch.no_grad():
+            packed = pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+            ref, (rh, rc) = layer.lstm(packed, state)
+            ref, _ = pad_packed_sequence(ref, batch_first=True, total_length=F)
+        np.testing.assert_allclose(want.numpy(), ref.numpy(), atol=2e-5)
+        np.testing.assert_allclose(wh.numpy(), rh.numpy(), atol=2e-5)
+
+        g = layer.to(DEV)
+        g.init_state = None if state is None else tuple(t.to(DEV) for t in state)
+        got = g(x.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=ATOL)
+        np.testing.assert_allclose(g.final_state[0].cpu().numpy(), wh.numpy(), atol=ATOL)
+        np.testing.assert_allclose(g.final_state[1].cpu().numpy(), wc.numpy(), atol=ATOL)
+        layer = g.cpu()
+    layer.release()
+
+
+def test_rnn_layer_rejects_what_it_cannot_do():
+    layer = RNNLayer(16, 8, 1, bidirectional=True).eval()
+    with pytest.raises(_lib.EmposeError):
+        layer(torch.zeros(1, 2, 16), torch.tensor([2]))        # CPU tensors: no fallback
+    with pytest.raises(NotImplementedError):
+        RNNLayer(16, 8, 1, dropout=0.1)
+    with pytest.raises(NotImplementedError):
+        RNNLayer(16, 8, 1, bidirectional=True, learn_init_state=True)
+    lib = _lib.lib()
+    desc = _lib.RnnDesc()
+    desc.num_layers, desc.input_size, desc.hidden_size, desc.bidirectional = 5, 16, 8, 1
+    handle = _lib.C.c_void_p()
+    assert lib.empose_rnn_create(_lib.C.byref(desc), _lib.C.byref(handle)) != 0  # 10 units > 8
+    desc.num_layers, desc.hidden_size = 1, 6
+    assert lib.empose_rnn_create(_lib.C.byref(desc), _lib.C.byref(handle)) != 0  # hidden % 4
+
+
+@pytest.mark.parametrize('M,Hd', [(1, 4), (77, 64), (1000, 512)])
+def test_residual_block_vs_torch(M, Hd):
+    """relu(W x + b + x) in one launch (reference layers.py:170-182)."""
+    torch.manual_seed(M)
+    blk = FeedForwardResidualBlock(Hd, Hd).eval()
+    x = torch.randn(M, Hd)
+    with torch.no_grad():
+        want = torch.relu(x @ blk.dense.weight.t() + blk.dense.bias + x)
+    got = blk.to(DEV)(x.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=ATOL)
+    assert (got >= 0).all()
+
+
+def _build(case):
+    fl = json.loads(str(case['meta']['flags']))
+    net = create_model(Configuration.defaults(**fl), SMPLLayer(H.small_model()))
+    missing, unexpected = net.load_state_dict(H.sd_to_torch(case['sd']), strict=False)
+    assert not unexpected and all(k.startswith('smpl.') for k in missing)
+    assert net.model_name() == str(case['meta']['model_name'])
+    return net.to(DEV).eval(), fl
+
+
+def _batch(w, rec, lengths, masks, sf=None, ef=None):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    B = w['poses'].shape[0]
+    F = w['poses'][:, sf:ef].shape[1]
+    masks = np.ones((B, F, 12), dtype=np.float32) if masks is None else masks[:, sf:ef]
+    b = RealBatch(list(range(B)), torch.as_tensor(lengths), t(w['poses'][:, sf:ef]), t(w['shapes']),
+                  torch.zeros(B, F, 3), t(w['marker_pos'][:, sf:ef]), t(w['marker_oris'][:, sf:ef]), t(masks),
+                  t(w['offset_t']), t(w['offset_r'])).to_gpu(torch.device(DEV))
+    b.joints_gt = t(rec['joints_gt']).to(DEV)
+    return b
+
+
+def _check(net, rec, out, loss_vals):
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        assert out[k].shape == rec['out_' + k].shape
+        np.testing.assert_allclose(out[k].cpu().numpy(), rec['out_' + k], atol=ATOL, err_msg=k)
+    for k in ('pose', 'root_pose', 'shape', 'fk', 'total_loss'):
+        np.testing.assert_allclose(loss_vals[k], float(rec['loss_' + k]), rtol=1e-4, atol=1e-5, err_msg=k)
+    if 'rnn_h' in rec:
+        np.testing.assert_allclose(net.rnn.final_state[0].cpu().numpy(), rec['rnn_h'], atol=ATOL)
+        np.testing.assert_allclose(net.rnn.final_state[1].cpu().numpy(), rec['rnn_c'], atol=ATOL)
+
+
+@pytest.mark.parametrize('name', ['birnn12_ragged', 'resnet12'])
+def test_golden_baselines_ragged_masked(name):
+    """forward(batch) + loss values of the reference's baselines on a ragged batch with missing sensors."""
+    case = H.load_case(name)
+    net, _ = _build(case)
+    w = case['in']
+    b = _batch(w, case['run'], w['seq_lengths'], w['marker_masks'])
+    out = net(b)
+    _, loss_vals = net.backward(b, out)
+    _check(net, case['run'], out, loss_vals)
+
+
+@pytest.mark.parametrize('name', ['rnn12_carry', 'rnn6_learninit_carry'])
+def test_golden_rnn_baselines_state_carry(name):
+    """Two consecutive chunks: `is_new_sequence=False` carries (h, c); a learned initial state replaces it."""
+    case = H.load_case(name)
+    net, _ = _build(case)
+    for tag, (sf, ef), new in (('chunk0', (0, 24), True), ('chunk1', (24, 48), False)):
+        b = _batch(case['in'], case[tag], [24, 24], None, sf, ef)
+        out = net(b, is_new_sequence=new)
+        _, loss_vals = net.backward(b, out)
+        _check(net, case[tag], out, loss_vals)
+
+
+@pytest.mark.parametrize('m_type', ['rnn', 'resnet'])
+def test_full_size_baselines_vs_oracle(m_type):
+    """The released widths (BiRNN 2x512, ResNet 512) on the V=6890 body model against the oracle."""
+    model = synthetic.make_model()
+    flags = dict(m_type=m_type, m_hidden_size=512, m_num_layers=2, m_bidirectional=(m_type == 'rnn'), window_size=32,
+                 use_marker_pos=True, use_marker_ori=True, m_estimate_shape=True, m_shape_hidden_size=128,
+                 m_average_shape=True, m_fk_loss=0.1, n_markers=12)
+    torch.manual_seed(3)
+    net = create_model(Configuration.defaults(**flags), SMPLLayer(model)).eval()
+    B, F = 6, 32
+    bm = R.BodyModelTensors(model)
+    tables = R.sensor_tables(model['f'], CONST.VERTEX_IDS)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, CONST.VERTEX_IDS, torch.from_numpy(poses),
+                                          torch.from_numpy(betas), torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    w = synthetic.make_windows(B, F, 11, sensors)
+    lens = torch.tensor([32, 32, 20, 32, 1, 9])
+    inp = H.oracle_inputs(w, sl=lens)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    kw = dict(n_markers=12, num_layers=2, estimate_shape=True, shape_avg=True, do_fk=True)
+    if m_type == 'rnn':
+        want, _ = R.simple_rnn_forward(sd, bm, inp, bidirectional=True, **kw)
+    else:
+        want = R.resnet_forward(sd, bm, inp, **kw)
+    net = net.to(DEV)
+    b = _batch(w, {'joints_gt': np.zeros((B, F, 66), np.float32)}, lens, None)
+    out = net(b)
+    torch.cuda.synchronize()
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        np.testing.assert_allclose(out[k].cpu().numpy(), want[k].numpy(), atol=ATOL, err_msg=k)

@@ -94,3 +94,31 @@ def test_components():
     np.testing.assert_allclose(j.numpy(), z['fk_j'], atol=1e-6)
     v, j = R.smpl_fk(bm, torch.from_numpy(z['fk_pose']), torch.from_numpy(z['fk_betas'][0]))
     np.testing.assert_allclose(v.numpy(), z['fk_v_noroot_bcast'], atol=1e-6)
+
+
+def _check_baseline(rec, out, final, tol=TOL):
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        np.testing.assert_allclose(out[k].numpy(), rec['out_' + k], atol=tol, rtol=0, err_msg=k)
+    if final is not None:
+        np.testing.assert_allclose(final[0].numpy(), rec['rnn_h'], atol=tol, rtol=0)
+        np.testing.assert_allclose(final[1].numpy(), rec['rnn_c'], atol=tol, rtol=0)
+
+
+def test_baselines_ragged():
+    """ResNet and BiRNN baselines (reference models.py:166-366) on a ragged, masked batch."""
+    for name in ('birnn12_ragged', 'resnet12'):
+        case = H.load_case(name)
+        inp = H.oracle_inputs(case['in'], sl=case['in']['seq_lengths'])
+        out, final = H.run_oracle_baseline(case, inp)
+        _check_baseline(case['run'], out, final)
+
+
+def test_baselines_carry():
+    """Uni-directional RNN baselines over two chunks: carried state, and the learned initial state, which replaces
+    the carried one (reference layers.py:121-131, models.py:298-302)."""
+    for name in ('rnn12_carry', 'rnn6_learninit_carry'):
+        case = H.load_case(name)
+        out0, st = H.run_oracle_baseline(case, H.oracle_inputs(case['in'], sf=0, ef=24))
+        _check_baseline(case['chunk0'], out0, st)
+        out1, st1 = H.run_oracle_baseline(case, H.oracle_inputs(case['in'], sf=24, ef=48), state=st)
+        _check_baseline(case['chunk1'], out1, st1)
