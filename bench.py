@@ -112,7 +112,7 @@ def cpu_baseline(net, model, w, seconds_target=20.0):
                       % (nb, F, len(reps), os.cpu_count())}
 
 
-def pmc_traffic(T, hidden):
+def pmc_traffic(T, hidden, kernel_name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes). Only valid for the workload
     the counters were collected on; otherwise null."""
@@ -124,7 +124,8 @@ def pmc_traffic(T, hidden):
         return None
     with open(files[-1]) as f:
         ks = json.load(f)['kernels']
-    hit = [v for k, v in ks.items() if 'gemm_tn_f32_kernel' in k and ', 1>(' in k]
+    norm = lambda k: k.replace('empose::', '').replace('void ', '').replace(' ', '')
+    hit = [v for k, v in ks.items() if norm(k).startswith(kernel_name.replace(' ', ''))]
     return hit[0]['hbm_bytes_per_launch_corrected'] if hit else None
 
 
@@ -284,9 +285,10 @@ def main():
         avg_ms = ms / cnt
         flops = 2 * 2.0 * (B * F) * h * h  # both update nets in one launch
         ach = flops / (avg_ms * 1e-3) / 1e12
+        kname = lib.empose_profile_gemm_kernel_name(B * F, h, h, 2, 1).decode()
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(B * F, h),
-                              'kernel': 'gemm_tn_f32_kernel<Cfg<4,2,2,2,32>,1> (update-net hidden layer, both nets per launch)',
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(B * F, h, kname),
+                              'kernel': kname + ' (update-net hidden layer, both nets per launch)',
                               'avg_launch_ms': avg_ms, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,
                               'hbm_frac_on_algorithmic_bytes': value * 1162.0 / 1e9 / PEAK_HBM_GBS}

@@ -112,6 +112,7 @@ SIGNATURES = {
     'empose_profile_ntags': (C.c_int, []),
     'empose_profile_tag_name': (C.c_char_p, [C.c_int]),
     'empose_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    'empose_profile_gemm_kernel_name': (C.c_char_p, [C.c_int] * 5),
     'empose_mesh_create': (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
     'empose_mesh_destroy': (None, [C.c_void_p]),
     'empose_mesh_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),

@@ -507,6 +507,10 @@ int empose_profile_ntags(void) { return P_NTAGS; }
 
 const char* empose_profile_tag_name(int tag) { return (tag >= 0 && tag < P_NTAGS) ? kProfNames[tag] : ""; }
 
+const char* empose_profile_gemm_kernel_name(int M, int N, int K, int count, int role) {
+  return gemm_kernel_name(M, N, K, count < 1 ? 1 : (count > 2 ? 2 : count), role);
+}
+
 int empose_profile_read(double* total_ms, long long* count) {
   if (!total_ms || !count) return fail(EMPOSE_EINVAL, "null argument");
   for (int i = 0; i < P_NTAGS; ++i) { total_ms[i] = 0.0; count[i] = 0; }

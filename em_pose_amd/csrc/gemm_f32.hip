@@ -13,6 +13,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace empose {
 
@@ -58,6 +59,64 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const float4 (&r
     const int r = slot / C::C4, c4 = (slot % C::C4) * 4;
     *reinterpret_cast<float4*>(lds + r * C::LDT + c4) = regs[i];
   }
+}
+
+// Epilogue of a wave's WM x WN grid of 32x32 accumulator tiles whose top-left element is (mw0, nw0): per-column
+// scale/shift (bias, folded eval-mode BatchNorm), activation, residual.  C/D layout of the 32x32 MFMA:
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// Everything the loops need is copied out of the (kernarg-resident) problem descriptor first and the activation /
+// residual / edge cases are resolved OUTSIDE the loops: the stores through p.C could alias the descriptor as far as
+// the compiler knows, which otherwise costs a scalar reload + wait per stored element.
+template <int WM, int WN, int MODE, bool FULL>   // MODE 0: act 0/1, 1: act 0/1 + residual, 2: residual block (act 2)
+__device__ __forceinline__ void epilogue_mode(float* __restrict__ C, const float* __restrict__ resid, long ldc, long ldr,
+                                              int M, int N, float slope, const float* __restrict__ scale,
+                                              const float* __restrict__ shift, const f32x16 (&acc)[WM][WN], int mw0,
+                                              int nw0, int l31, int lh) {
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = nw0 + j * 32 + l31;
+    if (n >= N) continue;
+    const float sc = scale ? scale[n] : 1.f;
+    const float sh = shift ? shift[n] : 0.f;
+    float* cj = C + (long)(mw0 + 4 * lh) * ldc + n;
+    const float* rj = MODE ? resid + (long)(mw0 + 4 * lh) * ldr + n : nullptr;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (!FULL && mw0 + 4 * lh + dm >= M) continue;
+        float y = acc[i][j][r] * sc + sh;
+        if (MODE == 2) {        // relu(W x + b + x), reference layers.py:170-182
+          if (rj) y += rj[dm * ldr];
+          y = y > 0.f ? y : 0.f;
+        } else {
+          y = y >= 0.f ? y : slope * y;      // slope == 1 when there is no activation (exact identity)
+          if (MODE == 1) y += rj[dm * ldr];  // skip connection around a block (after the activation)
+        }
+        cj[dm * ldc] = y;
+      }
+    }
+  }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void epilogue(const GemmProb& p, const f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31,
+                                         int lh) {
+  float* C = p.C;
+  const float* resid = p.resid;
+  const float* scale = p.scale;
+  const float* shift = p.shift;
+  const long ldc = p.ldc, ldr = p.ldr;
+  const int M = p.M, N = p.N, act = p.act;
+  const float slope = act == 1 ? p.slope : 1.f;
+  const bool full = mw0 + 32 * WM <= M;
+#define EMPOSE_EPI(MODE, FULL) \
+  epilogue_mode<WM, WN, MODE, FULL>(C, resid, ldc, ldr, M, N, slope, scale, shift, acc, mw0, nw0, l31, lh)
+  if (act == 2) { if (full) EMPOSE_EPI(2, true); else EMPOSE_EPI(2, false); }
+  else if (resid) { if (full) EMPOSE_EPI(1, true); else EMPOSE_EPI(1, false); }
+  else { if (full) EMPOSE_EPI(0, true); else EMPOSE_EPI(0, false); }
+#undef EMPOSE_EPI
 }
 
 // ROLE only separates instantiations by name so that profilers report the update-net hidden layers (ROLE 1) apart
@@ -147,31 +206,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
     }
   }
 
-  // Epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int n = n0 + wcol * 32 * WN + j * 32 + l31;
-    if (n >= p.N) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float sh = p.shift ? p.shift[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wrow * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= p.M) continue;
-        float y = acc[i][j][r] * sc + sh;
-        if (p.act == 2) {  // residual block of the ResNet baseline: relu(W x + b + x), reference layers.py:170-182
-          if (p.resid) y += p.resid[(size_t)m * p.ldr + n];
-          y = y > 0.f ? y : 0.f;
-        } else {
-          if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
-          if (p.resid) y += p.resid[(size_t)m * p.ldr + n];  // skip connection around a block (after the activation)
-        }
-        p.C[(size_t)m * p.ldc + n] = y;
-      }
-    }
-  }
+  epilogue<WM, WN>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
 }
 
 template <typename C, int ROLE = 0>
@@ -192,6 +227,211 @@ static hipError_t launch_cfg(const GemmBatch& batch, hipStream_t stream) {
     attr = true;
   }
   hipLaunchKernelGGL((gemm_tn_f32_kernel<C, ROLE>), dim3(blocks, batch.count), dim3(C::NT), lds, stream, batch);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide tile for the large contractions (update-net layers at T >= 32k rows): block 256 x 256, FOUR waves, each wave a
+// 128 x 128 tile = 4 x 4 MFMA tiles (256 accumulator registers, one wave per SIMD).  Compared with the 8-wave
+// 256 x 128 tile above this halves the LDS bytes read per flop and takes a third off the global->LDS bytes, but with a
+// single wave per SIMD nothing hides a stall any more, so the K loop is software-pipelined by hand:
+//   k-group 0 : MFMAs of group 0 | fragment reads of group 1 | 16 global loads of the NEXT K tile -> registers
+//   k-group 1 : MFMAs of group 1 | fragment reads of group 2
+//   k-group 2 : MFMAs of group 2 | fragment reads of group 3 | 16 LDS writes of the next K tile -> other LDS stage
+//   barrier
+//   k-group 3 : MFMAs of group 3 | fragment reads of group 0 of the next K tile
+// (LDS double-buffered: 2 x 73,728 B; one barrier per K tile.)  `sched_group_barrier` pins the interleaving: one memory
+// instruction every two to four MFMAs (an MFMA occupies the matrix pipe for 64 cycles = 16 issue slots).
+// ---------------------------------------------------------------------------------------------------------------
+namespace wide {
+constexpr int BM = 256, BN = 256, BK = 32, LDT = BK + 4, NT = 256;
+constexpr int STAGE = (BM + BN) * LDT;
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
+constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+}  // namespace wide
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define EMPOSE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#ifdef EMPOSE_GEMM_TRACE   // dev lab only: per-phase shader-clock stamps of two blocks
+__device__ long long g_gemm_trace[2][64];
+#define EMPOSE_STAMP(i)                                                                              \
+  if (tid == 0 && blockIdx.x == 0) {                                                                 \
+    g_gemm_trace[blockIdx.y][(i)] = clock64();                                                       \
+    if ((i) == 0) g_gemm_trace[blockIdx.y][62] = wall_clock64();                                     \
+    else g_gemm_trace[blockIdx.y][63] = wall_clock64();                                              \
+  }
+#else
+#define EMPOSE_STAMP(i)
+#endif
+
+template <int ROLE>
+__global__ __launch_bounds__(wide::NT) void gemm_wide_f32_kernel(GemmBatch batch) {
+  using namespace wide;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const GemmProb& p = batch.p[blockIdx.y];
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nt = tiles_n * tiles_m;
+  if ((int)blockIdx.x >= nt) return;
+  int tile = blockIdx.x;
+  if (batch.xcd_swizzle) {  // contiguous run of tiles per XCD, see gemm_tn_f32_kernel
+    const int q = nt / 8, r = nt % 8, xcd = tile % 8, k = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave >> 1, wcol = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // Global side: thread t moves 16 bytes of row (t / 8) + 32 i, columns 4 (t % 8) .. +3 of both operands, i = 0..7.
+  // Rows past the end are clamped (their products land in accumulator rows / columns that are never stored).
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
+  const float* pa[8];
+  const float* pb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ra = m0 + lr + 32 * i, rb = n0 + lr + 32 * i;
+    pa[i] = p.A + (size_t)(ra < p.M ? ra : p.M - 1) * p.lda + lc;
+    pb[i] = p.W + (size_t)(rb < p.N ? rb : p.N - 1) * p.ldw + lc;
+  }
+  const int wofs = lr * LDT + lc;                                  // LDS write offset (floats) of the i = 0 piece
+  const int a_rd = (wrow * 128 + l31) * LDT + lh * 4;              // fragment read offsets (floats), tile i adds 32 rows
+  const int b_rd = BM * LDT + (wcol * 128 + l31) * LDT + lh * 4;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 g[16];         // global -> LDS staging of one K tile (8 pieces of A, 8 of W)
+  f32x4 fa[2][4], fb[2][4];  // MFMA operand fragments, double-buffered over the k-groups
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      g[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+      g[8 + i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
+    }
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *reinterpret_cast<f32x4*>(st + wofs + i * 32 * LDT) = g[i];
+      *reinterpret_cast<f32x4*>(st + BM * LDT + wofs + i * 32 * LDT) = g[8 + i];
+    }
+  };
+  auto fread = [&](const float* st, int kk, f32x4 (&a)[4], f32x4 (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + a_rd + i * 32 * LDT + kk * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + b_rd + j * 32 * LDT + kk * 8);
+  };
+  // 64 MFMAs of one k-group; consecutive instructions go to different accumulators.
+  auto mma = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  // A ragged last K tile: this thread's 4 columns are either all inside K or all outside (K % 4 == 0); outside, they
+  // are fetched from column 0 of the row (always valid) and zeroed before they reach the LDS.
+  const bool col_ok = (nk - 1) * BK + lc < p.K;
+  const bool ragged = (p.K % BK) != 0;
+
+  EMPOSE_STAMP(0)
+  gload(nk == 1 && !col_ok ? -lc : 0);
+  if (nk == 1 && !col_ok) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  lwrite(lds);
+  __syncthreads();
+  fread(lds, 0, fa[0], fb[0]);
+  EMPOSE_STAMP(1)
+  // Every iteration runs the same body (one scheduling pattern): the last one re-fetches K tile 0 into the idle stage,
+  // which nobody reads afterwards.
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* cur = lds + (kt & 1) * STAGE;
+    float* nxt = lds + ((kt + 1) & 1) * STAGE;
+    const bool last_fetch = kt + 2 == nk;   // this iteration fetches the (possibly ragged) last K tile
+    const int k_next = kt + 1 < nk ? (kt + 1) * BK : 0;
+    const bool kill = ragged && last_fetch && !col_ok;
+    // ---- k-group 0
+    fread(cur, 1, fa[1], fb[1]);
+    gload(kill ? -lc : k_next);
+    mma(fa[0], fb[0]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { EMPOSE_SGB(SG_MFMA, 2); EMPOSE_SGB(SG_DS_RD, 1); }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { EMPOSE_SGB(SG_MFMA, 2); EMPOSE_SGB(SG_VMEM_RD, 1); }
+    EMPOSE_SGB(SG_MFMA, 16);
+    // ---- k-group 1
+    fread(cur, 2, fa[0], fb[0]);
+    mma(fa[1], fb[1]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { EMPOSE_SGB(SG_MFMA, 4); EMPOSE_SGB(SG_DS_RD, 1); }
+    EMPOSE_SGB(SG_MFMA, 32);
+    if (ragged && last_fetch) {   // uniform branch, taken once per block at most
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[i][e] = col_ok ? g[i][e] : 0.f;
+    }
+    // ---- k-group 2
+    fread(cur, 3, fa[1], fb[1]);
+    lwrite(nxt);
+    mma(fa[0], fb[0]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { EMPOSE_SGB(SG_MFMA, 2); EMPOSE_SGB(SG_DS_RD, 1); }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { EMPOSE_SGB(SG_MFMA, 2); EMPOSE_SGB(SG_DS_WR, 1); }
+    EMPOSE_SGB(SG_MFMA, 16);
+    __syncthreads();
+    // ---- k-group 3
+    fread(nxt, 0, fa[0], fb[0]);
+    mma(fa[1], fb[1]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { EMPOSE_SGB(SG_MFMA, 4); EMPOSE_SGB(SG_DS_RD, 1); }
+    EMPOSE_SGB(SG_MFMA, 32);
+    EMPOSE_STAMP(2 + kt)
+  }
+
+  epilogue<4, 4>(p, acc, m0 + wrow * 128, n0 + wcol * 128, l31, lh);
+  EMPOSE_STAMP(2 + nk)
+}
+
+template <int ROLE>
+static hipError_t launch_wide(const GemmBatch& batch, hipStream_t stream) {
+  int blocks = 0;
+  for (int i = 0; i < batch.count; ++i) {
+    const GemmProb& p = batch.p[i];
+    const int t = ((p.M + wide::BM - 1) / wide::BM) * ((p.N + wide::BN - 1) / wide::BN);
+    blocks = t > blocks ? t : blocks;
+  }
+  if (blocks == 0) return hipSuccess;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_f32_kernel<ROLE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_wide_f32_kernel<ROLE>), dim3(blocks, batch.count), dim3(wide::NT), wide::LDS_BYTES, stream,
+                     batch);
   return hipGetLastError();
 }
 
@@ -220,16 +460,15 @@ static hipError_t launch_large(const GemmBatch& batch, hipStream_t stream) {
   }
 }
 
-hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
-  GemmBatch batch = batch_in;
-  static const int swz = getenv("EMPOSE_GEMM_SWIZZLE") ? atoi(getenv("EMPOSE_GEMM_SWIZZLE")) : 1;  // dev A/B only
-  batch.xcd_swizzle = swz;
+enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE };
+
+static GemmPick pick_gemm(const GemmBatch& batch) {
   int maxM = 0, maxN = 0;
   for (int i = 0; i < batch.count; ++i) {
     maxM = batch.p[i].M > maxM ? batch.p[i].M : maxM;
     maxN = batch.p[i].N > maxN ? batch.p[i].N : maxN;
   }
-  // Narrow outputs (heads: 66 / 10 columns) and short batches take the smaller tiles; everything else 128x128,
+  // Narrow outputs (heads: 66 / 10 columns) and short batches take the smaller tiles; everything else the large ones,
   // unless that would leave most of the 256 CUs without a block.
   const bool narrow = maxN <= 64;
   const bool shortm = maxM <= 64;
@@ -239,12 +478,50 @@ hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
       t += (long)((batch.p[i].M + bm - 1) / bm) * ((batch.p[i].N + bn - 1) / bn);
     return t;
   };
-  if (shortm && narrow) return launch_cfg<CfgS11>(batch, stream);
-  if (shortm) return launch_cfg<CfgS12>(batch, stream);
-  if (narrow) return launch_cfg<CfgS21>(batch, stream);
-  if (nblocks(128, 128) >= 512) return batch.role == 1 ? launch_large<1>(batch, stream) : launch_large<0>(batch, stream);
-  if (nblocks(64, 128) >= 256) return launch_cfg<CfgS12>(batch, stream);
-  return launch_cfg<CfgS11>(batch, stream);
+  if (shortm && narrow) return PICK_S11;
+  if (shortm) return PICK_S12;
+  if (narrow) return PICK_S21;
+  // The 256 x 256 four-wave tile runs one block per CU, so it only pays when the tiles fill whole rounds of the 256
+  // CUs and the 256-wide column tiles are not mostly padding (measured: 125 vs 114 TFLOP/s at M=2x32768, N=K=512;
+  // 105 vs 96 at K=296; but 48 vs 76 at N=200).
+  static const int wide_on = getenv("EMPOSE_GEMM_WIDE") ? atoi(getenv("EMPOSE_GEMM_WIDE")) : 1;  // dev A/B only
+  bool wide_ok = wide_on != 0;
+  for (int i = 0; i < batch.count; ++i) wide_ok = wide_ok && batch.p[i].N % wide::BN == 0 && batch.p[i].K >= 2 * wide::BK;
+  if (wide_ok) {
+    const long t = nblocks(wide::BM, wide::BN);
+    const long rounds = (t + 255) / 256;
+    if (t >= 256 && t * 10 >= rounds * 256 * 8) return PICK_WIDE;
+  }
+  if (nblocks(128, 128) >= 512) return PICK_LARGE;
+  if (nblocks(64, 128) >= 256) return PICK_S12;
+  return PICK_S11;
+}
+
+// Name (as a profiler prints it) of the kernel `launch_gemm` runs for `count` problems of this shape.
+const char* gemm_kernel_name(int M, int N, int K, int count, int role) {
+  GemmBatch b;
+  b.count = count; b.role = role;
+  for (int i = 0; i < count && i < 2; ++i) { b.p[i] = GemmProb{}; b.p[i].M = M; b.p[i].N = N; b.p[i].K = K; }
+  switch (pick_gemm(b)) {
+    case PICK_S11: return "gemm_tn_f32_kernel<Cfg<2,2,1,1,32,false>,0>";
+    case PICK_S12: return "gemm_tn_f32_kernel<Cfg<2,2,1,2,32,false>,0>";
+    case PICK_S21: return "gemm_tn_f32_kernel<Cfg<2,2,2,1,32,false>,0>";
+    case PICK_WIDE: return role == 1 ? "gemm_wide_f32_kernel<1>" : "gemm_wide_f32_kernel<0>";
+    default: return role == 1 ? "gemm_tn_f32_kernel<Cfg<4,2,2,2,32,false>,1>" : "gemm_tn_f32_kernel<Cfg<4,2,2,2,32,false>,0>";
+  }
+}
+
+hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
+  GemmBatch batch = batch_in;
+  static const int swz = getenv("EMPOSE_GEMM_SWIZZLE") ? atoi(getenv("EMPOSE_GEMM_SWIZZLE")) : 1;  // dev A/B only
+  batch.xcd_swizzle = swz;
+  switch (pick_gemm(batch)) {
+    case PICK_S11: return launch_cfg<CfgS11>(batch, stream);
+    case PICK_S12: return launch_cfg<CfgS12>(batch, stream);
+    case PICK_S21: return launch_cfg<CfgS21>(batch, stream);
+    case PICK_WIDE: return batch.role == 1 ? launch_wide<1>(batch, stream) : launch_wide<0>(batch, stream);
+    default: return batch.role == 1 ? launch_large<1>(batch, stream) : launch_large<0>(batch, stream);
+  }
 }
 
 }  // namespace empose

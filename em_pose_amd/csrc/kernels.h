@@ -24,6 +24,7 @@ struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; 
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
+const char* gemm_kernel_name(int M, int N, int K, int count, int role);
 
 // ---------------------------------------------------------------------------------------------------------------
 // LSTM

@@ -158,11 +158,19 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
   }
 
   // Epilogue. C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + r.
+  // The unit descriptor lives in kernarg memory; everything the loop needs is copied into registers first, because the
+  // stores below could alias it as far as the compiler knows (a scalar reload + wait per element otherwise).
   const int unit = j0 + wcol * 16 + l15;
   if (unit >= H) return;
-  const float bi = L.bias[unit], bf = L.bias[H + unit], bg = L.bias[2 * H + unit], bo = L.bias[3 * H + unit];
-  const float* h_prev = L.h[t & 1];
-  float* h_next = L.h[(t + 1) & 1];
+  const float* __restrict__ bias = L.bias;
+  const float bi = bias[unit], bf = bias[H + unit], bg = bias[2 * H + unit], bo = bias[3 * H + unit];
+  const float* __restrict__ h_prev = L.h[t & 1];
+  float* __restrict__ h_next = L.h[(t + 1) & 1];
+  float* __restrict__ cst = L.c;
+  float* __restrict__ yout = L.y;
+  const int* __restrict__ lens = a.seq_lengths;
+  const int F = a.F;
+  const long y_ld = L.y_ld, y_col = L.y_col;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -170,20 +178,20 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
       const int row = m0 + wrow * 32 + i * 16 + lq * 4 + r;
       if (row >= B) continue;
       const size_t hc = (size_t)row * H + unit;
-      const int len = a.seq_lengths ? a.seq_lengths[row] : a.F;
+      const int len = lens ? lens[row] : F;
       const bool live = t < len;
       const int t_out = (rev && live) ? len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
       float h_new;
       if (live) {
-        const float c_new = sigmoidf_(acc[i][1][r] + bf) * L.c[hc] + sigmoidf_(acc[i][0][r] + bi) * tanhf(acc[i][2][r] + bg);
+        const float c_new = sigmoidf_(acc[i][1][r] + bf) * cst[hc] + sigmoidf_(acc[i][0][r] + bi) * tanhf(acc[i][2][r] + bg);
         h_new = sigmoidf_(acc[i][3][r] + bo) * tanhf(c_new);
-        L.c[hc] = c_new;
+        cst[hc] = c_new;
         h_next[hc] = h_new;
       } else {
         h_next[hc] = h_prev[hc];
         h_new = 0.f;
       }
-      if (L.y) L.y[((size_t)row * a.F + t_out) * L.y_ld + L.y_col + unit] = h_new;
+      if (yout) yout[((size_t)row * F + t_out) * y_ld + y_col + unit] = h_new;
     }
 }
 

@@ -256,6 +256,9 @@ int empose_profile_enable(int on);
 int empose_profile_ntags(void);
 const char* empose_profile_tag_name(int tag);
 int empose_profile_read(double* total_ms, long long* count);
+/* Name, as rocprofv3 prints it, of the kernel a linear layer of `count` (1 or 2) problems of shape M x N x K is
+ * dispatched to (role 1 = update-net hidden layer); lets bench.py label its roofline entry with the kernel that ran. */
+const char* empose_profile_gemm_kernel_name(int M, int N, int K, int count, int role);
 
 /* ---- full-mesh evaluation (final vertices; ground-truth preprocessing) ---------------------------------------- */
 
