@@ -42,12 +42,26 @@ struct LstmUnitArgs {        // one (layer, direction), selected by blockIdx.z
   float* c;            // [B][H] updated in place
   float* y; int y_ld; int y_col;   // output sequence [B][F][y_ld], columns [y_col, y_col + H), or nullptr
 };
+struct LstmSeg {             // one operand segment (input part / recurrent part) of a unit's step; built on the host
+  const float* a;            // A rows: a + row * lda (+ per-row time offset, below)
+  const float* w;            // W rows: w + (gate * H + unit) * ldw
+  int lda, ldw;
+  int K;
+  int tstride;               // != 0: reverse unit on a stored sequence; row b adds max(len_b - 1 - k, 0) * tstride
+  int k;                     // the unit's step index
+  int ntiles;                // ceil(K / 64)
+  int unit;                  // index into LstmWaveArgs::unit
+  int pad;
+};
 struct LstmWaveArgs {
   LstmUnitArgs unit[4];
   int n_units;
   const int* seq_lengths;    // [B] or nullptr (required for reverse units)
   int B, F, H;
   int s;                     // launch index
+  // set by launch_lstm_wave: blockIdx.z walks through the segments [z_beg[z], z_beg[z] + z_cnt[z]) (two per active unit)
+  LstmSeg seg[8];
+  int z_beg[4], z_cnt[4];
 };
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 

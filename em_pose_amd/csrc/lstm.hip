@@ -21,6 +21,8 @@
 // each 16-lane group takes 4 consecutive k of a 16-wide chunk so that one ds_read_b128 feeds four MFMAs.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace empose {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -195,9 +197,327 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(LstmWaveArgs a) {
     }
 }
 
-hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream) {
-  dim3 grid((a.H + LUNITS - 1) / LUNITS, (a.B + LROWS - 1) / LROWS, a.n_units);
-  hipLaunchKernelGGL(lstm_wave_kernel, grid, dim3(256), 0, stream, a);
+// ---------------------------------------------------------------------------------------------------------------
+// Chained, software-pipelined variant (the one that is launched).
+//
+// A block owns one (64 batch rows) x (32 hidden units x 4 gates) tile and walks through a CHAIN of units one after the
+// other -- for the stacked wavefront: layer 0 (K = input + H) then layer 1 (K = 2H) -- so every block does the same
+// amount of work whatever the layers' K, and the 256 blocks of B = 1024, H = 512 are one block per CU.  The K tiles of
+// the whole chain form one flat stream through a double-buffered LDS (2 x 48 KB, 64-wide K tiles, unpadded rows with
+// the 16-byte chunks XOR-swizzled by row so that the ds_read_b128 lane groups of the 16x16x4 operand layout are
+// conflict-free), one barrier per K tile, global loads two tiles ahead, and the instruction interleaving pinned with
+// sched_group_barrier: with a single wave per SIMD nothing else hides a stall.
+//   chunk 0 (k 0..15) : 32 MFMAs | fragment reads of chunk 1 | LDS writes of tile j+1 (fetched during tile j-1)
+//   chunk 1           : 32 MFMAs | fragment reads of chunk 2 | global loads of tile j+2
+//   chunk 2           : 32 MFMAs | fragment reads of chunk 3
+//   barrier
+//   chunk 3           : 32 MFMAs | fragment reads of chunk 0 of tile j+1
+// The cell non-linearities run when the stream leaves a unit.
+// ---------------------------------------------------------------------------------------------------------------
+namespace lc {
+constexpr int BM = 64, BU = 32, BK = 64;
+constexpr int ROWS = BM + 4 * BU;
+constexpr int STAGE = ROWS * BK;
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
+constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+}  // namespace lc
+
+#define LSTM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+#ifdef EMPOSE_LSTM_TRACE   // dev lab only: per-phase shader-clock stamps of block (0,0,0)
+__device__ long long g_lstm_trace[128];
+#define LSTM_STAMP(i) \
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_lstm_trace[(i)] = clock64();
+#else
+#define LSTM_STAMP(i)
+#endif
+
+// Fast cell non-linearities: v_exp_f32 / v_rcp_f32 (about 1 ulp each); absolute error ~1e-7, far inside the 1e-4 parity
+// budget, and the unit finish is no longer a visible fraction of the launch.
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+
+typedef const __attribute__((address_space(1))) f32x4* gvec_t;
+typedef const __attribute__((address_space(1))) char* gbyte_t;
+
+__global__ __launch_bounds__(256) void lstm_chain_kernel(LstmWaveArgs a) {
+  using namespace lc;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  LSTM_STAMP(0)
+  const int H = a.H, B = a.B, F = a.F;
+  const int j0 = blockIdx.x * BU, m0 = blockIdx.y * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave >> 1, wcol = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int seg_beg = a.z_beg[blockIdx.z], n_seg = a.z_cnt[blockIdx.z];
+  if (n_seg == 0) return;
+
+  // ---- per-thread constants
+  const int lr = tid >> 4, c16 = tid & 15;                 // global side: row lr + 16 i, 16-byte chunk c16 of the K tile
+  int a_row[4], a_len[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = m0 + lr + 16 * i;
+    a_row[i] = r < B ? r : B - 1;
+    a_len[i] = a.seq_lengths ? a.seq_lengths[a_row[i]] : F;
+  }
+  int w_row[8];                                            // gate * H + unit of the thread's 8 weight rows
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int wr = lr + 16 * i, un = j0 + (wr & 31);
+    w_row[i] = (wr >> 5) * H + (un < H ? un : H - 1);
+  }
+  const int wr_ofs = lr * BK + ((c16 ^ (lr & 15)) << 2);   // LDS write offset of piece 0 (floats); piece i: + 16 i rows
+  const int a_rd = (wrow * 32 + l15) * BK;                 // fragment rows (floats); row tile i: + 16 rows
+  const int b_rd = (BM + wcol * 16 + l15) * BK;            // gate g: + 32 rows
+  int sw[4];                                               // swizzled chunk offset of k-chunk ch for this lane
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) sw[ch] = ((((ch << 2) ^ (l15 & 12)) | (lq ^ (l15 & 3))) << 2);
+
+  f32x4 g[12];
+  bool g_ok = true;
+  f32x4 fa[2][2], fb[2][4];
+  f32x4 acc[2][4];
+
+  // ---- the load side of the tile stream: current segment (scalar registers), the thread's byte offsets into its two
+  // operands (recomputed when the stream enters a segment) and the k tile within the segment
+  LstmSeg ld = a.seg[seg_beg];
+  int ld_seg = 0, ld_kt = 0;
+  unsigned a_off[4], w_off[8];
+  auto seg_offsets = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tr = a_len[i] - 1 - ld.k;
+      a_off[i] = (unsigned)(((long)a_row[i] * ld.lda + (long)(tr > 0 ? tr : 0) * ld.tstride + c16 * 4) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w_off[i] = (unsigned)(((long)w_row[i] * ld.ldw + c16 * 4) * 4);
+  };
+  seg_offsets();
+  auto gload = [&]() -> bool {   // fetch the tile under the load cursor; returns whether it is ragged
+    g_ok = ld_kt * BK + c16 * 4 < ld.K;
+    const unsigned back = g_ok ? 0u : (unsigned)(c16 * 16);   // lanes past K re-read chunk 0 of the tile; zeroed later
+    gbyte_t pa = (gbyte_t)(ld.a + ld_kt * BK);
+    gbyte_t pw = (gbyte_t)(ld.w + ld_kt * BK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = *(gvec_t)(pa + (a_off[i] - back));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[4 + i] = *(gvec_t)(pw + (w_off[i] - back));
+    return (ld_kt + 1) * BK > ld.K;
+  };
+  auto ld_advance = [&]() {      // uniform; past the end of the stream it parks on a valid tile that is never used
+    if (++ld_kt == ld.ntiles) {
+      ld_kt = 0;
+      if (ld_seg + 1 < n_seg) { ++ld_seg; ld = a.seg[seg_beg + ld_seg]; seg_offsets(); }
+    }
+  };
+  auto gzero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[i][e] = g_ok ? g[i][e] : 0.f;
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(st + wr_ofs + i * 16 * BK) = g[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(st + BM * BK + wr_ofs + i * 16 * BK) = g[4 + i];
+  };
+  auto fread = [&](const float* st, int ch, f32x4 (&fa_)[2], f32x4 (&fb_)[4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa_[i] = *reinterpret_cast<const f32x4*>(st + a_rd + i * 16 * BK + sw[ch]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb_[q] = *reinterpret_cast<const f32x4*>(st + b_rd + q * 32 * BK + sw[ch]);
+  };
+  auto mma = [&](const f32x4 (&fa_)[2], const f32x4 (&fb_)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa_[i][e], fb_[q][e], acc[i][q], 0, 0, 0);
+  };
+  // Cell non-linearities of a finished unit; C/D layout: col = lane & 15, row = 4 * (lane >> 4) + r.  What they read
+  // besides the accumulators (bias, old cell state, lengths, old hidden state of rows past their length) is fetched
+  // when the stream ENTERS the unit, so the finish itself is arithmetic and stores only.  Nobody else touches these
+  // (row, unit) elements during the launch.
+  const int e_unit = j0 + wcol * 16 + l15;
+  const int e_unit_c = e_unit < H ? e_unit : H - 1;
+  float e_bias[4], e_c[8], e_hp[8];
+  int e_len[8];
+  auto enter_unit = [&](int u) {
+    const LstmUnitArgs& L = a.unit[u];
+    const int t = a.s - L.t_offset;
+    const float* __restrict__ bias = L.bias;
+    const float* __restrict__ h_prev = L.h[t & 1];
+    const float* __restrict__ cst = L.c;
+    const int* __restrict__ lens = a.seq_lengths;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_bias[q] = bias[q * H + e_unit_c];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = m0 + wrow * 32 + (e >> 2) * 16 + lq * 4 + (e & 3);
+      const int rc = row < B ? row : B - 1;
+      const size_t hc = (size_t)rc * H + e_unit_c;
+      e_c[e] = cst[hc];
+      e_len[e] = lens ? lens[rc] : F;
+      e_hp[e] = lens ? h_prev[hc] : 0.f;   // only rows past their length carry the old state over
+    }
+  };
+  auto finish_unit = [&](int u) {
+    const LstmUnitArgs& L = a.unit[u];
+    const int t = a.s - L.t_offset;
+    const bool rev = L.reverse != 0;
+    if (e_unit >= H) return;
+    float* __restrict__ h_next = L.h[(t + 1) & 1];
+    float* __restrict__ cst = L.c;
+    float* __restrict__ yout = L.y;
+    const long y_ld = L.y_ld, y_col = L.y_col;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = e >> 2, r = e & 3;
+      const int row = m0 + wrow * 32 + i * 16 + lq * 4 + r;
+      if (row >= B) continue;
+      const size_t hc = (size_t)row * H + e_unit;
+      const bool live = t < e_len[e];
+      const int t_out = (rev && live) ? e_len[e] - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
+      const float c_new = fsigmoid(acc[i][1][r] + e_bias[1]) * e_c[e] +
+                          fsigmoid(acc[i][0][r] + e_bias[0]) * ftanh(acc[i][2][r] + e_bias[2]);
+      const float h_new = fsigmoid(acc[i][3][r] + e_bias[3]) * ftanh(c_new);
+      if (live) cst[hc] = c_new;
+      h_next[hc] = live ? h_new : e_hp[e];
+      if (yout) yout[((size_t)row * F + t_out) * y_ld + y_col + e_unit] = live ? h_new : 0.f;
+    }
+  };
+
+  LSTM_STAMP(1)
+  // ---- prologue: tile 0 -> stage 0, tile 1 in flight
+  bool ragged = gload();
+  if (ragged) gzero();
+  lwrite(lds);
+  ld_advance();
+  ragged = gload();
+  ld_advance();
+  __syncthreads();
+  fread(lds, 0, fa[0], fb[0]);
+  LSTM_STAMP(2)
+  int stamp = 3;
+  (void)stamp;
+
+  int parity = 0;
+  for (int us = 0; us < n_seg; us += 2) {   // one unit = two consecutive segments
+    const int unit_tiles = a.seg[seg_beg + us].ntiles + a.seg[seg_beg + us + 1].ntiles;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    enter_unit(a.seg[seg_beg + us].unit);
+    for (int j = 0; j < unit_tiles; ++j) {
+      const float* cur = lds + parity * STAGE;
+      float* nxt = lds + (parity ^ 1) * STAGE;
+      parity ^= 1;
+      if (ragged) gzero();     // uniform branch; the registers hold the next tile of the stream
+      // ---- chunk 0
+      fread(cur, 1, fa[1], fb[1]);
+#ifndef LSTM_EXP_NOWRITE
+      lwrite(nxt);
+#endif
+      mma(fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 1); LSTM_SGB(SG_DS_RD, 1); }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_WR, 1); }
+      LSTM_SGB(SG_MFMA, 2);
+      // ---- chunk 1
+      fread(cur, 2, fa[0], fb[0]);
+#ifndef LSTM_EXP_NOLOAD
+      ragged = gload();
+#endif
+      mma(fa[1], fb[1]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 1); LSTM_SGB(SG_DS_RD, 1); }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_VMEM_RD, 1); }
+      LSTM_SGB(SG_MFMA, 2);
+      // ---- chunk 2
+      fread(cur, 3, fa[1], fb[1]);
+      mma(fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_RD, 1); }
+      LSTM_SGB(SG_MFMA, 20);
+#ifndef LSTM_EXP_NOBARRIER
+      __syncthreads();
+#endif
+      // ---- chunk 3
+      fread(nxt, 0, fa[0], fb[0]);
+      mma(fa[1], fb[1]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_RD, 1); }
+      LSTM_SGB(SG_MFMA, 20);
+      ld_advance();
+      LSTM_STAMP(stamp++)
+    }
+    finish_unit(a.seg[seg_beg + us].unit);
+    LSTM_STAMP(stamp++)
+  }
+}
+
+// Segment table of one launch: two segments per active unit, grouped by blockIdx.z.
+static void lstm_build_chain(LstmWaveArgs& a, int units_per_block) {
+  int n = 0, z = 0;
+  for (int u0 = 0; u0 < a.n_units; u0 += units_per_block, ++z) {
+    a.z_beg[z] = n;
+    for (int u = u0; u < u0 + units_per_block && u < a.n_units; ++u) {
+      const LstmUnitArgs& L = a.unit[u];
+      const int t = a.s - L.t_offset;
+      if (t < 0 || t >= a.F) continue;   // idle while the wavefront ramps up or down
+      for (int s = 0; s < 2; ++s) {
+        LstmSeg d;
+        d.k = t; d.tstride = 0; d.unit = u; d.pad = 0;
+        if (s == 0) {
+          if (L.in_from < 0) {
+            d.lda = a.F * L.in_ld;
+            if (L.reverse) { d.a = L.in_seq; d.tstride = L.in_ld; }
+            else d.a = L.in_seq + (size_t)t * L.in_ld;
+          } else {
+            d.a = a.unit[L.in_from].h[(t + 1) & 1]; d.lda = a.H;
+          }
+          d.w = L.w_ih; d.ldw = L.in_k; d.K = L.in_k;
+        } else {
+          d.a = L.h[t & 1]; d.lda = a.H; d.w = L.w_hh; d.ldw = a.H; d.K = a.H;
+        }
+        d.ntiles = (d.K + lc::BK - 1) / lc::BK;
+        a.seg[n++] = d;
+      }
+    }
+    a.z_cnt[z] = n - a.z_beg[z];
+  }
+  for (; z < 4; ++z) { a.z_beg[z] = 0; a.z_cnt[z] = 0; }
+}
+
+hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
+  LstmWaveArgs a = a_in;
+  static const int legacy = getenv("EMPOSE_LSTM_LEGACY") ? atoi(getenv("EMPOSE_LSTM_LEGACY")) : 0;  // dev A/B only
+  if (legacy) {
+    dim3 grid((a.H + LUNITS - 1) / LUNITS, (a.B + LROWS - 1) / LROWS, a.n_units);
+    hipLaunchKernelGGL(lstm_wave_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
+  const int tiles = ((a.H + lc::BU - 1) / lc::BU) * ((a.B + lc::BM - 1) / lc::BM);
+  // Chain all units in one block (equal work per block) once the tiles alone fill the CUs; spread them otherwise.
+  const int units_per_block = tiles >= 192 ? a.n_units : 1;
+  lstm_build_chain(a, units_per_block);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_chain_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  dim3 grid((a.H + lc::BU - 1) / lc::BU, (a.B + lc::BM - 1) / lc::BM,
+            (a.n_units + units_per_block - 1) / units_per_block);
+  hipLaunchKernelGGL(lstm_chain_kernel, grid, dim3(256), lc::LDS_BYTES, stream, a);
   return hipGetLastError();
 }
 
