@@ -136,7 +136,7 @@ int upload(std::vector<void*>& allocs, const T* host, size_t count, T** dev) {
   } while (0)
 
 // Packs every index/weight table the chain kernel needs into one array of 32-bit words (staged into LDS per block).
-void build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, ChainTabs& off, int* n_chunks) {
+int build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, ChainTabs& off, int* n_chunks) {
   auto put_i = [&](const std::vector<int>& v) { int o = (int)blob.size(); for (int x : v) blob.push_back((uint32_t)x); return o; };
   auto put_f = [&](const float* p, size_t n) {
     int o = (int)blob.size();
@@ -184,21 +184,35 @@ void build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, Ch
         for (int c = 0; c < 3; ++c) faces[((size_t)m * s.max_deg + k) * 3 + c] = s.s_center[m];
     off.s_faces = put_i(faces);
   }
+  // Incidence lists of P4d as packed words (see the kernel): offsets are relative to the frame's LDS record.
+  const ChainLds lay = chain_layout(s.nv, s.ncp, s.max_deg, *n_chunks);
+  if (lay.total >= (1 << 13)) return fail(EMPOSE_EINVAL, "sensor sub-mesh too large for the packed incidence words");
+  auto pack = [](int a, int b, int use_b, int neg) {
+    return (int)((uint32_t)a | ((uint32_t)b << 13) | ((uint32_t)use_b << 26) | ((uint32_t)neg << 27));
+  };
   std::vector<int> inc_ptr(s.nv + 1, 0), inc_code;
   for (int v = 0; v < s.nv; ++v) {
     inc_ptr[v] = (int)inc_code.size();
     for (int m = 0; m < 12; ++m) {
-      if (s.s_center[m] == v) inc_code.push_back((m << 3) | 3);
-      if (s.s_helper[m] == v) inc_code.push_back((m << 3) | 4);
+      if (s.s_center[m] == v) { const int o = lay.scr + m * 9 + 3; inc_code.push_back(pack(o, o, 0, 0)); }
+      if (s.s_helper[m] == v) { const int o = lay.scr + m * 9 + 6; inc_code.push_back(pack(o, o, 0, 0)); }
       for (int k = 0; k < s.s_deg[m]; ++k)
         for (int c = 0; c < 3; ++c)
-          if (s.s_faces[((size_t)m * s.max_deg + k) * 3 + c] == v) inc_code.push_back(((m * s.max_deg + k) << 3) | c);
+          if (s.s_faces[((size_t)m * s.max_deg + k) * 3 + c] == v) {
+            const int fg = lay.fg + (m * s.max_deg + k) * 6;
+            if (c == 0) inc_code.push_back(pack(fg, fg + 3, 1, 1));       // v0: -(d e1 + d e2)
+            else if (c == 1) inc_code.push_back(pack(fg, fg, 0, 0));      // v1: + d e1
+            else inc_code.push_back(pack(fg + 3, fg + 3, 0, 0));          // v2: + d e2
+          }
     }
+    while ((inc_code.size() - (size_t)inc_ptr[v]) % 4 != 0) inc_code.push_back((int)(1u << 28));   // null
   }
   inc_ptr[s.nv] = (int)inc_code.size();
   off.inc_ptr = put_i(inc_ptr);
   off.inc_code = put_i(inc_code);
+  while (blob.size() % 4 != 0) blob.push_back(0u);   // staged into LDS in 16-byte pieces
   off.total = (int)blob.size();
+  return EMPOSE_OK;
 }
 
 int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
@@ -571,7 +585,7 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
     for (int i = 0; i < 12; ++i)
       if (s.s_deg[i] < 1 || s.s_deg[i] > s.max_deg) return bail(fail(EMPOSE_EINVAL, "sensor degree out of range"));
     std::vector<uint32_t> blob;
-    build_chain_blob(s, blob, t.off, &t.n_chunks);
+    MTRY(build_chain_blob(s, blob, t.off, &t.n_chunks));
     uint32_t* bp;
     MTRY(upload(m->allocs, blob.data(), blob.size(), &bp));
     t.blob = bp;

@@ -69,6 +69,35 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 // SMPL sub-mesh kernels
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CHAIN_CHUNK = 8;  // pairs per partial-sum chunk of the per-bone (vertex, weight) lists
+constexpr int NB = 22;           // body joints
+
+// LDS record of one frame in chain_sensors_kernel (shared with the host, which packs LDS offsets into the tables).
+struct ChainLds {  // per-frame float offsets
+  int rot, out, g, at, v, dv, u, total;
+  // inside u (time-shared): fn | fg | scr   then   part | m | x
+  int fn, fg, scr, part, m, x;
+};
+
+__host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, int n_chunks) {
+  ChainLds l;
+  int o = 0;
+  l.rot = o; o += NB * 9;
+  l.out = o; o += ncp;
+  l.g = o; o += NB * 12;    // per joint: G^R (9, row-major) | G^t (3)
+  l.at = o; o += NB * 3;    // A^t = G^t - G^R J
+  l.v = o; o += nv * 3;
+  l.dv = o; o += nv * 3;
+  l.u = o;
+  const int nf = 12 * max_deg;
+  l.fn = l.u; l.fg = l.fn + nf * 3; l.scr = l.fg + nf * 6;
+  const int sz1 = nf * 9 + 12 * 9;
+  l.part = l.u; l.m = l.part + n_chunks * 12; l.x = l.m + NB * 12;
+  const int sz2 = n_chunks * 12 + 2 * NB * 12;
+  o += sz1 > sz2 ? sz1 : sz2;
+  l.total = (o + 3) & ~3;
+  return l;
+}
+
 
 // Word offsets into the packed table blob that chain_sensors_kernel stages into LDS (all entries are 32-bit).
 struct ChainTabs {

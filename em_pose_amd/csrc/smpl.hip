@@ -19,7 +19,6 @@
 
 namespace empose {
 
-constexpr int NB = 22;
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void pack_inputs_kernel(PackArgs a) {
@@ -225,32 +224,6 @@ constexpr int CH_THREADS = 192;
 constexpr int CH_FRAMES = 2;
 constexpr int CHUNK = CHAIN_CHUNK;  // (vertex, weight) pairs per partial-sum chunk, lists padded with weight 0
 
-struct ChainLds {  // per-frame float offsets
-  int rot, out, g, at, v, dv, u, total;
-  // inside u (time-shared): fn | fg | scr   then   part | m | x
-  int fn, fg, scr, part, m, x;
-};
-
-__host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, int n_chunks) {
-  ChainLds l;
-  int o = 0;
-  l.rot = o; o += NB * 9;
-  l.out = o; o += ncp;
-  l.g = o; o += NB * 12;    // per joint: G^R (9, row-major) | G^t (3)
-  l.at = o; o += NB * 3;    // A^t = G^t - G^R J
-  l.v = o; o += nv * 3;
-  l.dv = o; o += nv * 3;
-  l.u = o;
-  const int nf = 12 * max_deg;
-  l.fn = l.u; l.fg = l.fn + nf * 3; l.scr = l.fg + nf * 6;
-  const int sz1 = nf * 9 + 12 * 9;
-  l.part = l.u; l.m = l.part + n_chunks * 12; l.x = l.m + NB * 12;
-  const int sz2 = n_chunks * 12 + 2 * NB * 12;
-  o += sz1 > sz2 ? sz1 : sz2;
-  l.total = (o + 3) & ~3;
-  return l;
-}
-
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block) {
   const ChainLds l = chain_layout(tab.nv, tab.ncp, tab.max_deg, tab.n_chunks);
   return ((size_t)l.total * frames_per_block + ((tab.off.total + 3) & ~3)) * sizeof(float);
@@ -263,15 +236,24 @@ __device__ __forceinline__ void cross3(const float* a, const float* b, float* o)
 }
 __device__ __forceinline__ float norm3(const float* a) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 // y = x/|x|  ->  dx = (dy - y (y.dy)) / |x|
-__device__ __forceinline__ void unit_bwd(const float* dy, const float* y, float n, float* dx) {
+__device__ __forceinline__ void unit_bwd(const float* dy, const float* y, float inv_n, float* dx) {
   const float d = dy[0] * y[0] + dy[1] * y[1] + dy[2] * y[2];
-  dx[0] = (dy[0] - y[0] * d) / n;
-  dx[1] = (dy[1] - y[1] * d) / n;
-  dx[2] = (dy[2] - y[2] * d) / n;
+  dx[0] = (dy[0] - y[0] * d) * inv_n;
+  dx[1] = (dy[1] - y[1] * d) * inv_n;
+  dx[2] = (dy[2] - y[2] * d) * inv_n;
 }
+
+#ifdef EMPOSE_CHAIN_TRACE   // dev build only (scripts/dev/chain_trace.sh): shader-clock stamps of two blocks per phase
+__device__ long long g_chain_trace[2][32];
+#define CH_STAMP(i) \
+  if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 9000)) g_chain_trace[blockIdx.x != 0][(i)] = clock64();
+#else
+#define CH_STAMP(i)
+#endif
 
 __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  CH_STAMP(0)
   const SmplTables& tb = a.tab;
   const ChainTabs& O = tb.off;
   const ChainLds L = chain_layout(tb.nv, tb.ncp, tb.max_deg, tb.n_chunks);
@@ -289,20 +271,24 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // ---- P0: tables + per-frame rot | out.  Loads are issued in batches of 4 before the first LDS store so that the
   // round trips overlap (a plain strided copy loop serialises one global latency per iteration).
   {
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)L.total * CH_FRAMES);
-    for (int i0 = tid; i0 < O.total; i0 += 4 * CH_THREADS) {
-      uint32_t v[4];
+    // (16-byte pieces of the table blob, eight per thread in flight: the whole table is one or two round trips.)
+    uint4* dst = reinterpret_cast<uint4*>(smem + (size_t)L.total * CH_FRAMES);
+    const uint4* src = reinterpret_cast<const uint4*>(tb.blob);
+    const int n16 = (O.total + 3) >> 2;   // the blob is padded to a multiple of 4 words
+    for (int i0 = tid; i0 < n16; i0 += 8 * CH_THREADS) {
+      uint4 v[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CH_THREADS; v[u] = i < O.total ? tb.blob[i] : 0u; }
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * CH_THREADS; v[u] = i < n16 ? src[i] : uint4{0u, 0u, 0u, 0u}; }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = i0 + u * CH_THREADS; if (i < O.total) dst[i] = v[u]; }
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * CH_THREADS; if (i < n16) dst[i] = v[u]; }
     }
     const int row = NB * 9 + tb.ncp;
     const int n = nf * row;
-    for (int i0 = tid; i0 < n; i0 += 4 * CH_THREADS) {
-      float v[4];
+    constexpr int FB = 6;   // 2 frames x (198 + ncp ~ 320) floats / 192 threads: one batch
+    for (int i0 = tid; i0 < n; i0 += FB * CH_THREADS) {
+      float v[FB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FB; ++u) {
         const int i = i0 + u * CH_THREADS;
         v[u] = 0.f;
         if (i < n) {
@@ -311,13 +297,14 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < FB; ++u) {
         const int i = i0 + u * CH_THREADS;
         if (i < n) frames[(i / row) * L.total + (i % row)] = v[u];
       }
     }
   }
   __syncthreads();
+  CH_STAMP(1)
 
   // ---- P2: forward chain
   for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
@@ -352,6 +339,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     if (a.joints2) a.joints2[go] = tr;
   }
   __syncthreads();
+  CH_STAMP(2)
 
   // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
@@ -370,6 +358,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.v + sr] = T0 * vp[0] + T1 * vp[1] + T2 * vp[2] + T3;
   }
   __syncthreads();
+  CH_STAMP(3)
 
   // ---- P4a: un-normalised face normals
   for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
@@ -385,6 +374,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     cross3(e1, e2, S + L.fn + mk * 3);
   }
   __syncthreads();
+  CH_STAMP(4)
 
   // ---- P4b: per sensor
   for (int i = tid; i < nf * 12; i += CH_THREADS) {
@@ -398,23 +388,25 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
       const float* fn = S + L.fn + (m * md + k) * 3;
       n[0] += fn[0]; n[1] += fn[1]; n[2] += fn[2];
     }
-    const float fdeg = (float)deg;
-    n[0] /= fdeg; n[1] /= fdeg; n[2] /= fdeg;
-    const float nn = norm3(n);
-    const float nh[3] = {n[0] / nn, n[1] / nn, n[2] / nn};
+    // One (IEEE) reciprocal per normalisation, then multiplications: the per-sensor arithmetic runs on 24 of the 192
+    // lanes, so its instruction count is the phase's latency.
+    const float inv_deg = 1.f / (float)deg;
+    n[0] *= inv_deg; n[1] *= inv_deg; n[2] *= inv_deg;
+    const float inv_nn = 1.f / norm3(n);
+    const float nh[3] = {n[0] * inv_nn, n[1] * inv_nn, n[2] * inv_nn};
     const float* vc = V + c * 3;
     const float* vh = V + h * 3;
     const float e[3] = {vh[0] - vc[0], vh[1] - vc[1], vh[2] - vc[2]};
-    const float ne = norm3(e);
-    const float sv[3] = {e[0] / ne, e[1] / ne, e[2] / ne};
+    const float inv_ne = 1.f / norm3(e);
+    const float sv[3] = {e[0] * inv_ne, e[1] * inv_ne, e[2] * inv_ne};
     float bb[3];
     cross3(nh, sv, bb);
-    const float nb = norm3(bb);
-    const float tv[3] = {bb[0] / nb, bb[1] / nb, bb[2] / nb};
+    const float inv_nb = 1.f / norm3(bb);
+    const float tv[3] = {bb[0] * inv_nb, bb[1] * inv_nb, bb[2] * inv_nb};
     float aa[3];
     cross3(tv, nh, aa);
-    const float na = norm3(aa);
-    const float s2[3] = {aa[0] / na, aa[1] / na, aa[2] / na};
+    const float inv_na = 1.f / norm3(aa);
+    const float s2[3] = {aa[0] * inv_na, aa[1] * inv_na, aa[2] * inv_na};
     // R_m columns (s2, tv, nh)
     const float Rm[9] = {s2[0], tv[0], nh[0], s2[1], tv[1], nh[1], s2[2], tv[2], nh[2]};
     const int w = t / a.F;
@@ -462,14 +454,14 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
       const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
       const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
       const float r0 = pos[0] - tp[0], r1 = pos[1] - tp[1], r2 = pos[2] - tp[2];
-      const float rn = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-      dpos[0] = r0 / rn * scale; dpos[1] = r1 / rn * scale; dpos[2] = r2 / rn * scale;
+      const float sp = scale / sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+      dpos[0] = r0 * sp; dpos[1] = r1 * sp; dpos[2] = r2 * sp;
       float q = 0.f;
 #pragma unroll
       for (int k = 0; k < 9; ++k) { dori[k] = ori[k] - tori[k]; q += dori[k] * dori[k]; }
-      q = sqrtf(q);
+      const float so = scale / sqrtf(q);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) dori[k] = dori[k] / q * scale;
+      for (int k = 0; k < 9; ++k) dori[k] *= so;
     }
     // dR_m = dori Ro^T + dpos (x) to
     float dRm[9];
@@ -483,27 +475,28 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     float dt[3] = {dRm[1], dRm[4], dRm[7]};
     float dnh[3] = {dRm[2], dRm[5], dRm[8]};
     float da[3], tmp[3];
-    unit_bwd(ds2, s2, na, da);       // a = t x nh
+    unit_bwd(ds2, s2, inv_na, da);   // a = t x nh
     cross3(nh, da, tmp); dt[0] += tmp[0]; dt[1] += tmp[1]; dt[2] += tmp[2];
     cross3(da, tv, tmp); dnh[0] += tmp[0]; dnh[1] += tmp[1]; dnh[2] += tmp[2];
     float db[3];
-    unit_bwd(dt, tv, nb, db);        // b = nh x s
+    unit_bwd(dt, tv, inv_nb, db);    // b = nh x s
     cross3(sv, db, tmp); dnh[0] += tmp[0]; dnh[1] += tmp[1]; dnh[2] += tmp[2];
     float dsv[3];
     cross3(db, nh, dsv);
     float de[3];
-    unit_bwd(dsv, sv, ne, de);
+    unit_bwd(dsv, sv, inv_ne, de);
     float dn[3];
-    unit_bwd(dnh, nh, nn, dn);
+    unit_bwd(dnh, nh, inv_nn, dn);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      scr[k] = dn[k] / fdeg;
+      scr[k] = dn[k] * inv_deg;
       scr[3 + k] = dpos[k] - de[k];
       scr[6 + k] = de[k];
     }
   }
   if (!bwd) return;
   __syncthreads();
+  CH_STAMP(5)
 
   // ---- P4c: per (sensor, face): cotangents of the two edge vectors
   for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
@@ -522,25 +515,37 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     cross3(dfn, e1, fg + 3);  // d e2
   }
   __syncthreads();
+  CH_STAMP(6)
 
-  // ---- P4d: gather the vertex cotangents (fixed order => deterministic)
+  // ---- P4d: gather the vertex cotangents (fixed order => deterministic).  Every incidence is one packed word
+  // (a:13 | b:13 | use_b:1 | negate:1 | null:1, offsets into the frame's LDS record): contribution = +-(S[a+r] + S[b+r]);
+  // lists are padded to a multiple of 4 with null words, so four independent LDS round trips are in flight.
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
     const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
     float* S = frames + f * L.total;
     float acc = 0.f;
     const int q0 = TI[O.inc_ptr + s], q1 = TI[O.inc_ptr + s + 1];
-    for (int q = q0; q < q1; ++q) {
-      const uint32_t code = TI[O.inc_code + q];
-      const int slot = code >> 3, type = code & 7;
-      if (type == 0) acc -= S[L.fg + slot * 6 + r] + S[L.fg + slot * 6 + 3 + r];
-      else if (type == 1) acc += S[L.fg + slot * 6 + r];
-      else if (type == 2) acc += S[L.fg + slot * 6 + 3 + r];
-      else if (type == 3) acc += S[L.scr + slot * 9 + 3 + r];
-      else acc += S[L.scr + slot * 9 + 6 + r];
+    for (int q = q0; q < q1; q += 4) {
+      uint32_t code[4];
+      float x[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) code[u] = TI[O.inc_code + q + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        x[u] = S[(code[u] & 0x1fffu) + r];
+        y[u] = S[((code[u] >> 13) & 0x1fffu) + r];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = x[u] + ((code[u] >> 26) & 1u ? y[u] : 0.f);
+        const float sg = (code[u] >> 28) & 1u ? 0.f : ((code[u] >> 27) & 1u ? -1.f : 1.f);
+        acc += sg * v;
+      }
     }
     S[L.dv + sr] = acc;
   }
   __syncthreads();
+  CH_STAMP(7)
 
   // ---- P5: d v_posed (to global) and per-chunk force / world-space moment partial sums
   for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     for (int k = 0; k < 12; ++k) S[L.part + ch * 12 + k] = acc[k];
   }
   __syncthreads();
+  CH_STAMP(8)
 
   // ---- P5c: per bone: sum its chunks (chunks of a bone are contiguous)
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -611,34 +617,34 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     S[L.m + be] = acc;
   }
   __syncthreads();
+  CH_STAMP(9)
 
-  // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j
+  // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j   (members taken four at a time: the LDS reads of a
+  // round are independent, the additions keep the ascending-joint order)
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
     const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
     float* S = frames + f * L.total;
     uint32_t sm = TI[O.sub_mask + j];
-    if (e < 9) {
-      const int ar = e / 3, cc = e % 3;
-      float ms = 0.f, fs = 0.f;
-      while (sm) {
-        const int d = __ffs(sm) - 1;
-        sm &= sm - 1;
+    const int ar = e < 9 ? e / 3 : e - 9, cc = e % 3;
+    float ms = 0.f, fs = 0.f;
+    while (sm) {
+      float mv[4], fv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool on = sm != 0;
+        const int d = on ? __ffs(sm) - 1 : 0;
+        sm &= sm - 1;   // 0 stays 0
         const float* Mb = S + L.m + d * 12;
-        ms += Mb[e];
-        fs += Mb[9 + ar];
+        mv[u] = on ? Mb[e] : 0.f;
+        fv[u] = on ? Mb[9 + ar] : 0.f;
       }
-      S[L.x + je] = ms - fs * S[L.g + j * 12 + 9 + cc];
-    } else {
-      float fs = 0.f;
-      while (sm) {
-        const int d = __ffs(sm) - 1;
-        sm &= sm - 1;
-        fs += S[L.m + d * 12 + e];
-      }
-      S[L.x + je] = fs;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ms += mv[u]; fs += fv[u]; }
     }
+    S[L.x + je] = e < 9 ? ms - fs * S[L.g + j * 12 + 9 + cc] : fs;
   }
   __syncthreads();
+  CH_STAMP(10)
 
   // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
       a.d_out[(size_t)(t0 + f) * tb.ncp + tb.j_off + j * 3 + cc] = acc;
     }
   }
+  CH_STAMP(11)
 }
 
 hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
@@ -939,3 +946,9 @@ hipError_t launch_virtual_sensors(const VirtualSensorArgs& a, hipStream_t stream
 }
 
 }  // namespace empose
+
+#ifdef EMPOSE_CHAIN_TRACE
+extern "C" int empose_debug_chain_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(empose::g_chain_trace), sizeof(long long) * 64);
+}
+#endif

@@ -3,6 +3,8 @@ import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 from em_pose_amd import _lib, synthetic
+if os.environ.get('EMPOSE_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['EMPOSE_LIB_PATH']  # dev: a traced build of the library (scripts/dev/chain_trace.sh)
 from em_pose_amd.bodymodels.smpl import SMPLLayer
 from em_pose_amd.helpers.configuration import lgd_config
 from em_pose_amd.nn.models import create_model
@@ -29,3 +31,16 @@ lib.empose_profile_enable(1)
 for _ in range(10): run()
 p = _lib.profile_read(); lib.empose_profile_enable(0)
 print('stop', os.environ.get('EMPOSE_CHAIN_STOP', '0'), {k: round(v[0] / v[1] * 1000, 1) for k, v in p.items()}, 'us/launch')
+
+if os.environ.get('EMPOSE_LIB_PATH'):
+    import ctypes as C
+    tr = (C.c_longlong * 64)()
+    fn = lib.empose_debug_chain_trace
+    fn.argtypes = [C.POINTER(C.c_longlong)]
+    assert fn(tr) == 0
+    names = ['P0 stage', 'P2 chain', 'P3 skin', 'P4a normals', 'P4b sensors', 'P4c edges', 'P4d gather', 'P5 dv+parts',
+             'P5c bones', 'P6 subtree', 'P7 dR/dJ']
+    for b in range(2):
+        t = [tr[b * 32 + i] for i in range(12)]
+        print('block', 0 if b == 0 else 9000, 'total', t[11] - t[0], 'cycles:',
+              ', '.join('%s %d' % (n, t[i + 1] - t[i]) for i, n in enumerate(names)))

@@ -233,9 +233,38 @@ def make_baselines(vids):
                                       'model_name': net.model_name(), 'flags': json.dumps(fl, sort_keys=True)})
 
 
+def train_sensitivity(vids):
+    """How far the REFERENCE's own train-mode forward moves when its sensor inputs are perturbed by one unit in the
+    last place (relative 1e-7, random signs): the residual direction r/|r| and train-mode BatchNorm over 48 frames
+    amplify round-off, so this is the noise floor any other arithmetic order (ours, another BLAS, another GPU) sees.
+    Stored in train_sensitivity.json; the training parity test scales its output tolerance with it."""
+    res = {}
+    for tag, rnn, nm, N, seed in (('train_lgdrnn12_n2', True, 12, 2, 31), ('train_lgd6_n2', False, 6, 2, 32)):
+        outs = []
+        for eps in (0.0, 1e-7, -1e-7):
+            net, smpl = make_net(lgd_flags(nm, rnn, N, 32, 32), seed, vids)
+            w = synthetic.make_windows(3, 16, seed, sensors_from_reference(net, smpl))
+            rng = np.random.RandomState(0)
+            for k in ('marker_pos', 'marker_oris'):
+                w[k] = (w[k] * (1.0 + eps * rng.choice([-1.0, 1.0], size=w[k].shape))).astype(np.float32)
+            batch = _SynthBatch(w, torch.tensor([16, 16, 11]))
+            batch.joints_gt = torch.zeros(3, 16, 66)
+            net.train()
+            out = net(batch)
+            outs.append({k: v.detach().numpy().astype(np.float64) for k, v in out.items()})
+        res[tag] = {k: float(max(np.abs(outs[1][k] - outs[0][k]).max(), np.abs(outs[2][k] - outs[0][k]).max()))
+                    for k in outs[0]}
+    with open(os.path.join(HERE, 'train_sensitivity.json'), 'w') as f:
+        json.dump(res, f, indent=2, sort_keys=True)
+    print(res)
+
+
 def main():
     model = build_small_model()
     vids = synthetic.small_vertex_ids(160)
+    if '--only-train-sensitivity' in sys.argv:
+        sys.argv.remove('--only-train-sensitivity')
+        return train_sensitivity(vids)
     if '--only-baselines' in sys.argv:
         sys.argv.remove('--only-baselines')
         return make_baselines(vids)
@@ -378,6 +407,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'components.npz'), **comp)
     print('wrote components.npz')
     make_baselines(vids)
+    train_sensitivity(vids)
 
 
 if __name__ == '__main__':
