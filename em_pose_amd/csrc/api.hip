@@ -187,6 +187,7 @@ int build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, Cha
   // Incidence lists of P4d as packed words (see the kernel): offsets are relative to the frame's LDS record.
   const ChainLds lay = chain_layout(s.nv, s.ncp, s.max_deg, *n_chunks);
   if (lay.total >= (1 << 13)) return fail(EMPOSE_EINVAL, "sensor sub-mesh too large for the packed incidence words");
+  if (s.max_deg > 64) return fail(EMPOSE_EINVAL, "more than 64 faces around a sensor vertex");
   auto pack = [](int a, int b, int use_b, int neg) {
     return (int)((uint32_t)a | ((uint32_t)b << 13) | ((uint32_t)use_b << 26) | ((uint32_t)neg << 27));
   };

@@ -222,6 +222,14 @@ hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CH_THREADS = 192;
 constexpr int CH_FRAMES = 2;
+static_assert(CH_FRAMES == 2, "frame_split() assumes at most two frames per block");
+
+// (frame, item) of flat index i < 2 * n without an integer division (n is a run-time value in most phases, and a
+// division costs ~25 instructions in a kernel whose limit is instruction issue).
+__device__ __forceinline__ void frame_split(int i, int n, int& f, int& o) {
+  f = i >= n ? 1 : 0;
+  o = i - (f ? n : 0);
+}
 constexpr int CHUNK = CHAIN_CHUNK;  // (vertex, weight) pairs per partial-sum chunk, lists padded with weight 0
 
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block) {
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   const int nf = min(CH_FRAMES, a.T - t0);
   const int nv3 = tb.nv * 3;
   const int md = tb.max_deg;
+  const uint32_t md_magic = 65536u / (uint32_t)md + 1u;   // floor(x * magic / 65536) == x / md for x < 12 * md (md <= 64)
   const bool cot = a.cot_pos != nullptr;          // external cotangents (training) instead of the residual
   const bool bwd = a.tgt != nullptr || cot;
   float* frames = smem;
@@ -292,14 +301,19 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
         const int i = i0 + u * CH_THREADS;
         v[u] = 0.f;
         if (i < n) {
-          const int f = i / row, o = i % row;
+          int f, o;
+          frame_split(i, row, f, o);
           v[u] = o < NB * 9 ? a.rot[(size_t)(t0 + f) * (NB * 9) + o] : a.out[(size_t)(t0 + f) * tb.ncp + (o - NB * 9)];
         }
       }
 #pragma unroll
       for (int u = 0; u < FB; ++u) {
         const int i = i0 + u * CH_THREADS;
-        if (i < n) frames[(i / row) * L.total + (i % row)] = v[u];
+        if (i < n) {
+          int f, o;
+          frame_split(i, row, f, o);
+          frames[f * L.total + o] = v[u];
+        }
       }
     }
   }
@@ -308,7 +322,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P2: forward chain
   for (int i = tid; i < nf * NB * 3; i += CH_THREADS) {
-    const int f = i / (NB * 3), jr = i % (NB * 3), j = jr / 3, r = jr % 3;
+    int f, jr;
+    frame_split(i, NB * 3, f, jr);
+    const int j = jr / 3, r = jr % 3;
     float* S = frames + f * L.total;
     const float* sR = S + L.rot;
     const float* sJ = S + L.out + tb.j_off;
@@ -343,7 +359,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P3: linear blend skinning of the needed vertices, one (vertex, coordinate) per lane
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
-    const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
+    int f, sr;
+    frame_split(i, nv3, f, sr);
+    const int s = sr / 3, r = sr % 3;
     float* S = frames + f * L.total;
     const float* vp = S + L.out + s * 3;
     float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;  // row r of the blended 3x4 transform
@@ -362,7 +380,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P4a: un-normalised face normals
   for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
-    const int f = i / (12 * md), mk = i % (12 * md);
+    int f, mk;
+    frame_split(i, 12 * md, f, mk);
     float* S = frames + f * L.total;
     const float* V = S + L.v;
     const uint32_t* fc = TI + O.s_faces + mk * 3;  // padding faces are (c,c,c): zero normal, zero cotangent
@@ -378,7 +397,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P4b: per sensor
   for (int i = tid; i < nf * 12; i += CH_THREADS) {
-    const int f = i / 12, m = i % 12;
+    int f, m;
+    frame_split(i, 12, f, m);
     const int t = t0 + f;
     float* S = frames + f * L.total;
     const float* V = S + L.v;
@@ -500,7 +520,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P4c: per (sensor, face): cotangents of the two edge vectors
   for (int i = tid; i < nf * 12 * md; i += CH_THREADS) {
-    const int f = i / (12 * md), mk = i % (12 * md), m = mk / md;
+    int f, mk;
+    frame_split(i, 12 * md, f, mk);
+    const int m = (int)(((uint32_t)mk * md_magic) >> 16);   // mk / md for mk < 12 * md <= 4096
     float* S = frames + f * L.total;
     const float* V = S + L.v;
     const uint32_t* fc = TI + O.s_faces + mk * 3;
@@ -521,7 +543,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // (a:13 | b:13 | use_b:1 | negate:1 | null:1, offsets into the frame's LDS record): contribution = +-(S[a+r] + S[b+r]);
   // lists are padded to a multiple of 4 with null words, so four independent LDS round trips are in flight.
   for (int i = tid; i < nf * nv3; i += CH_THREADS) {
-    const int f = i / nv3, sr = i % nv3, s = sr / 3, r = sr % 3;
+    int f, sr;
+    frame_split(i, nv3, f, sr);
+    const int s = sr / 3, r = sr % 3;
     float* S = frames + f * L.total;
     float acc = 0.f;
     const int q0 = TI[O.inc_ptr + s], q1 = TI[O.inc_ptr + s + 1];
@@ -549,7 +573,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P5: d v_posed (to global) and per-chunk force / world-space moment partial sums
   for (int i = tid; i < nf * tb.ncp; i += CH_THREADS) {
-    const int f = i / tb.ncp, col = i % tb.ncp;
+    int f, col;
+    frame_split(i, tb.ncp, f, col);
     if (col >= tb.j_off && col < tb.j_off + NB * 3) continue;  // d J is written in P7
     float acc = 0.f;
     if (col < nv3) {
@@ -566,7 +591,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     a.d_out[(size_t)(t0 + f) * tb.ncp + col] = acc;
   }
   for (int i = tid; i < nf * tb.n_chunks; i += CH_THREADS) {
-    const int f = i / tb.n_chunks, ch = i % tb.n_chunks;
+    int f, ch;
+    frame_split(i, tb.n_chunks, f, ch);
     float* S = frames + f * L.total;
     const int b = TI[O.chunk_bone + ch];
     const int q0 = TI[O.chunk_beg + ch];
@@ -601,7 +627,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P5c: per bone: sum its chunks (chunks of a bone are contiguous)
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
-    const int f = i / (NB * 12), be = i % (NB * 12), b = be / 12, e = be % 12;
+    int f, be;
+    frame_split(i, NB * 12, f, be);
+    const int b = be / 12, e = be % 12;
     float* S = frames + f * L.total;
     float acc = 0.f;
     for (int ch = TI[O.bone_chunk_ptr + b]; ch < (int)TI[O.bone_chunk_ptr + b + 1]; ++ch) acc += S[L.part + ch * 12 + e];
@@ -622,7 +650,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j   (members taken four at a time: the LDS reads of a
   // round are independent, the additions keep the ascending-joint order)
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
-    const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
+    int f, je;
+    frame_split(i, NB * 12, f, je);
+    const int j = je / 12, e = je % 12;
     float* S = frames + f * L.total;
     uint32_t sm = TI[O.sub_mask + j];
     const int ar = e < 9 ? e / 3 : e - 9, cc = e % 3;
@@ -648,7 +678,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 
   // ---- P7: d R_j = G_p^T X_j G_j  and  d J_j = (G_p - G_j)^T Fs_j
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
-    const int f = i / (NB * 12), je = i % (NB * 12), j = je / 12, e = je % 12;
+    int f, je;
+    frame_split(i, NB * 12, f, je);
+    const int j = je / 12, e = je % 12;
     const float* S = frames + f * L.total;
     const float* Gj = S + L.g + j * 12;
     const float* X = S + L.x + j * 12;
