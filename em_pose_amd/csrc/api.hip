@@ -34,11 +34,11 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline numbers ---------
 enum ProfTag { P_PACK = 0, P_LSTM_PROJ, P_LSTM_STEP, P_HEADS, P_UPDATE_FEAT, P_BLEND_GEMM, P_CHAIN, P_BLEND_T_GEMM,
-               P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_INIT_MLP, P_COPY, P_END, P_NTAGS };
+               P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_MLP_FUSED, P_INIT_MLP, P_COPY, P_END, P_NTAGS };
 const char* const kProfNames[P_NTAGS] = {"pack_inputs", "lstm_input_proj_gemm", "lstm_step", "init_heads_gemm",
                                          "update_feat", "blend_gemm", "chain_sensors", "blend_T_gemm",
                                          "rodrigues_bwd", "mlp_in_gemm", "mlp_hidden_gemm", "mlp_out_gemm",
-                                         "init_mlp_gemm", "copies", "end"};
+                                         "mlp_fused", "init_mlp_gemm", "copies", "end"};
 struct Profiler {
   bool on = false;
   std::vector<hipEvent_t> ev;
@@ -335,6 +335,55 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
   const int L = nets[0]->n_layers;
   for (int i = 1; i < n_nets; ++i)
     if (nets[i]->n_layers != L) return fail(EMPOSE_EINVAL, "paired MLPs must have the same depth");
+
+  // Large batches: every layer of both nets in ONE launch (mlp_fused.hip); a workgroup keeps 128 rows through all the
+  // layers. Needs enough row panels to fill the chip and layers no wider than the four 128-column waves.
+  {
+    static const int fused_on = getenv("EMPOSE_MLP_FUSED") ? atoi(getenv("EMPOSE_MLP_FUSED")) : 1;  // dev A/B only
+    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 127) / 128) * n_nets >= 200;
+    for (int i = 0; i < n_nets && ok; ++i)
+      for (int l = 0; l < L; ++l) {
+        const Dense& d = nets[i]->layers[l];
+        if (d.out_dim > FUSED_MAX_WIDTH || d.act > 1) ok = false;
+        if (l < L - 1 && d.out_dim != nets[i]->layers[0].out_dim) ok = false;   // one scratch row length per net
+      }
+    if (ok) {
+      FusedMlpArgs fa;
+      fa.count = n_nets; fa.M = T;
+      for (int i = 0; i < n_nets; ++i) {
+        FusedNet& fn = fa.net[i];
+        fn.x = x; fn.ldx = ldx; fn.out = outs[i]; fn.ld_out = out_ld[i];
+        fn.ld_buf = nets[i]->layers[0].out_dim; fn.n_layers = L;
+        for (int k = 0; k < 3; ++k) fn.buf[k] = ws.buf[k] ? ws.buf[k] + (size_t)i * T * hidden_max : nullptr;
+        int cur = -1, block_in = -1;
+        for (int l = 0; l < L; ++l) {
+          const Dense& d = nets[i]->layers[l];
+          FusedLayer& fl = fn.layer[l];
+          fl.W = d.w; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
+          fl.slope = d.slope; fl.act = d.act;
+          const bool block_first = (l >= 1) && (l % 2 == 1) && (l < L - 1);
+          const bool block_last = (l >= 2) && (l % 2 == 0) && (l < L - 1);
+          if (block_first) block_in = cur;
+          fl.in_buf = cur;
+          fl.resid_buf = (block_last && nets[i]->skip) ? block_in : -1;
+          if (l == L - 1) {
+            fl.out_buf = -1;
+          } else {
+            int k = 0;
+            while (k == cur || (nets[i]->skip && k == block_in)) ++k;
+            if (k > 2 || !ws.buf[k]) return fail(EMPOSE_EINVAL, "internal: MLP scratch buffers exhausted");
+            fl.out_buf = k;
+            cur = k;
+          }
+        }
+      }
+      prof_mark(init_net ? P_INIT_MLP : P_MLP_FUSED, stream);
+      hipError_t e = launch_mlp_fused(fa, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mlp launch: %s", hipGetErrorString(e));
+      return EMPOSE_OK;
+    }
+  }
+
   int cur[2] = {-1, -1}, block_in[2] = {-1, -1};
   for (int l = 0; l < L; ++l) {
     GemmBatch b;

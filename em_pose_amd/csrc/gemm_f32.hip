@@ -11,13 +11,13 @@
 // Tile: 256 threads = 2x2 waves, each wave WM x WN tiles of 32x32 -> block tile (64*WM) x (64*WN), BK = 32.
 // LDS rows are padded to 36 floats: 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots.
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace empose {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Tile configuration: WR x WC waves per block, each wave WM x WN tiles of 32x32, K tile BK, DB = LDS double buffering
 // (one barrier per K tile instead of two).
@@ -59,64 +59,6 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const float4 (&r
     const int r = slot / C::C4, c4 = (slot % C::C4) * 4;
     *reinterpret_cast<float4*>(lds + r * C::LDT + c4) = regs[i];
   }
-}
-
-// Epilogue of a wave's WM x WN grid of 32x32 accumulator tiles whose top-left element is (mw0, nw0): per-column
-// scale/shift (bias, folded eval-mode BatchNorm), activation, residual.  C/D layout of the 32x32 MFMA:
-// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-// Everything the loops need is copied out of the (kernarg-resident) problem descriptor first and the activation /
-// residual / edge cases are resolved OUTSIDE the loops: the stores through p.C could alias the descriptor as far as
-// the compiler knows, which otherwise costs a scalar reload + wait per stored element.
-template <int WM, int WN, int MODE, bool FULL>   // MODE 0: act 0/1, 1: act 0/1 + residual, 2: residual block (act 2)
-__device__ __forceinline__ void epilogue_mode(float* __restrict__ C, const float* __restrict__ resid, long ldc, long ldr,
-                                              int M, int N, float slope, const float* __restrict__ scale,
-                                              const float* __restrict__ shift, const f32x16 (&acc)[WM][WN], int mw0,
-                                              int nw0, int l31, int lh) {
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int n = nw0 + j * 32 + l31;
-    if (n >= N) continue;
-    const float sc = scale ? scale[n] : 1.f;
-    const float sh = shift ? shift[n] : 0.f;
-    float* cj = C + (long)(mw0 + 4 * lh) * ldc + n;
-    const float* rj = MODE ? resid + (long)(mw0 + 4 * lh) * ldr + n : nullptr;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
-        if (!FULL && mw0 + 4 * lh + dm >= M) continue;
-        float y = acc[i][j][r] * sc + sh;
-        if (MODE == 2) {        // relu(W x + b + x), reference layers.py:170-182
-          if (rj) y += rj[dm * ldr];
-          y = y > 0.f ? y : 0.f;
-        } else {
-          y = y >= 0.f ? y : slope * y;      // slope == 1 when there is no activation (exact identity)
-          if (MODE == 1) y += rj[dm * ldr];  // skip connection around a block (after the activation)
-        }
-        cj[dm * ldc] = y;
-      }
-    }
-  }
-}
-
-template <int WM, int WN>
-__device__ __forceinline__ void epilogue(const GemmProb& p, const f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31,
-                                         int lh) {
-  float* C = p.C;
-  const float* resid = p.resid;
-  const float* scale = p.scale;
-  const float* shift = p.shift;
-  const long ldc = p.ldc, ldr = p.ldr;
-  const int M = p.M, N = p.N, act = p.act;
-  const float slope = act == 1 ? p.slope : 1.f;
-  const bool full = mw0 + 32 * WM <= M;
-#define EMPOSE_EPI(MODE, FULL) \
-  epilogue_mode<WM, WN, MODE, FULL>(C, resid, ldc, ldr, M, N, slope, scale, shift, acc, mw0, nw0, l31, lh)
-  if (act == 2) { if (full) EMPOSE_EPI(2, true); else EMPOSE_EPI(2, false); }
-  else if (resid) { if (full) EMPOSE_EPI(1, true); else EMPOSE_EPI(1, false); }
-  else { if (full) EMPOSE_EPI(0, true); else EMPOSE_EPI(0, false); }
-#undef EMPOSE_EPI
 }
 
 // ROLE only separates instantiations by name so that profilers report the update-net hidden layers (ROLE 1) apart
@@ -250,7 +192,6 @@ constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);
 constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
 }  // namespace wide
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define EMPOSE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 

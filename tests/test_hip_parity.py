@@ -209,6 +209,45 @@ def test_update_nets_and_lstm_vs_oracle():
     np.testing.assert_allclose(cn.cpu().numpy(), want_c.numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize('hidden,skip,T', [(32, False, 12800 + 77), (512, False, 12800), (256, True, 13000)])
+def test_update_nets_large_batch_single_launch_path(hidden, skip, T):
+    """Large batches run both update MLPs in ONE launch (csrc/mlp_fused.hip: a workgroup keeps 128 rows through all six
+    layers): same results as the oracle's layer-by-layer MLP, incl. the ragged first layer (K = 296), the narrow output
+    layers (66 / 10 columns), a ragged last row panel, skip connections, and the per-layer path on the first rows."""
+    torch.manual_seed(hidden + T)
+    cfg = lgd_config(12, False, 1, hidden=hidden, m_skip_connections=skip)
+    net = create_model(cfg, SMPLLayer(H.small_model()))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    net.vertex_ids = synthetic.small_vertex_ids(160)
+    net = net.to(DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    x = torch.randn(T, 296, generator=g)
+    with torch.no_grad():
+        want_p = R.mlp_forward(sd, 'pose_net_iter.', x, skip=skip).numpy()
+        want_s = R.mlp_forward(sd, 'shape_net_iter.', x, skip=skip).numpy()
+    xg = x.to(DEV)
+    outs = {}
+    for rows in (T, 200):   # 200 rows: too few row panels for the single launch -> the layer-by-layer kernels
+        dp, ds = torch.full((rows, 66), 7.0, device=DEV), torch.full((rows, 10), 7.0, device=DEV)
+        nbytes = lib.empose_update_workspace_bytes(handle, rows)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.empose_update_nets_fwd(handle, rows, _lib.dptr(xg), 296, _lib.dptr(dp), _lib.dptr(ds),
+                                              _lib.dptr(ws), nbytes, _lib.current_stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(dp.cpu().numpy(), want_p[:rows], atol=ATOL)
+        np.testing.assert_allclose(ds.cpu().numpy(), want_s[:rows], atol=ATOL)
+        outs[rows] = (dp.cpu().numpy(), ds.cpu().numpy())
+    # both paths accumulate every dot product in the same k order: identical bits, not just close
+    assert np.array_equal(outs[T][0][:200], outs[200][0]) and np.array_equal(outs[T][1][:200], outs[200][1])
+
+
 def test_mlp_module_forward_vs_oracle():
     case = H.load_case('lgd12_n4')
     net = build_net(cfg_of(case['meta']), H.small_model(), case['meta']['vertex_ids'], case['sd'])
