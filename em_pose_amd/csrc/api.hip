@@ -62,6 +62,7 @@ void prof_mark(int tag, hipStream_t stream) {
 struct Dense {
   int in_dim = 0, out_dim = 0;
   float* w = nullptr;      // [out][in]
+  float* wp = nullptr;     // the same weights in MFMA fragment order (mlp_fused.hip), only for MLP layers
   float* scale = nullptr;  // nullptr => 1
   float* shift = nullptr;  // bias (and folded BN)
   int act = 0;
@@ -242,6 +243,26 @@ int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* ou
   return EMPOSE_OK;
 }
 
+// Weights in the order the matrix cores consume them (mlp_fused.hip): for every k-group of 8 and every 32-column tile,
+// lane (n = lane & 31, half = lane >> 5) owns W[tile * 32 + n][kg * 8 + half * 4 .. + 3]; columns / k past the matrix
+// are zero, so a wave's fragment is one coalesced 1 KB read and ragged K needs no masking on this operand.
+int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
+  const int K = d.in_dim, N = d.out_dim;
+  const int KG = (K + 7) / 8, NT = (N + 31) / 32;
+  std::vector<float> buf((size_t)KG * NT * 256, 0.f);
+  for (int kg = 0; kg < KG; ++kg)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = nt * 32 + (lane & 31);
+        if (n >= N) continue;
+        for (int e = 0; e < 4; ++e) {
+          const int k = kg * 8 + (lane >> 5) * 4 + e;
+          if (k < K) buf[(((size_t)kg * NT + nt) * 64 + lane) * 4 + e] = d.weight[(size_t)n * K + k];
+        }
+      }
+  return upload(allocs, buf.data(), buf.size(), &out->wp);
+}
+
 int pack_mlp(std::vector<void*>& allocs, const empose_mlp_desc& d, Mlp* out, int* hidden_max, int* any_skip) {
   out->n_layers = d.n_layers;
   out->skip = d.skip;
@@ -251,6 +272,7 @@ int pack_mlp(std::vector<void*>& allocs, const empose_mlp_desc& d, Mlp* out, int
     return fail(EMPOSE_EINVAL, "mlp: n_layers=%d unsupported", d.n_layers);
   for (int i = 0; i < d.n_layers; ++i) {
     TRY(pack_dense(allocs, d.layers[i], &out->layers[i]));
+    TRY(pack_fragments(allocs, d.layers[i], &out->layers[i]));
     if (i > 0 && d.layers[i].in_dim != d.layers[i - 1].out_dim) return fail(EMPOSE_EINVAL, "mlp: layer dims do not chain");
     if (i + 1 < d.n_layers && d.layers[i].out_dim > *hidden_max) *hidden_max = d.layers[i].out_dim;
   }
@@ -340,7 +362,7 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
   // layers. Needs enough row panels to fill the chip and layers no wider than the four 128-column waves.
   {
     static const int fused_on = getenv("EMPOSE_MLP_FUSED") ? atoi(getenv("EMPOSE_MLP_FUSED")) : 1;  // dev A/B only
-    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 127) / 128) * n_nets >= 200;
+    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 63) / 64) * n_nets >= 400;
     for (int i = 0; i < n_nets && ok; ++i)
       for (int l = 0; l < L; ++l) {
         const Dense& d = nets[i]->layers[l];
@@ -359,7 +381,7 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
         for (int l = 0; l < L; ++l) {
           const Dense& d = nets[i]->layers[l];
           FusedLayer& fl = fn.layer[l];
-          fl.W = d.w; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
+          fl.W = d.wp; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
           fl.slope = d.slope; fl.act = d.act;
           const bool block_first = (l >= 1) && (l % 2 == 1) && (l < L - 1);
           const bool block_last = (l >= 2) && (l % 2 == 0) && (l < L - 1);

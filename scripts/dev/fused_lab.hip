@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     for (int l = 0; l < 6; ++l) {
       FusedLayer& L = fn.layer[l];
       L.K = l == 0 ? LDX : Hd; L.N = l == 5 ? nout : Hd;
-      L.W = dev_rand((size_t)L.N * L.K, 100 + 10 * n + l, 0.06f);
+      L.W = dev_rand((size_t)((L.K + 7) / 8) * ((L.N + 31) / 32) * 256, 100 + 10 * n + l, 0.06f);   // fragment order
       L.scale = dev_rand(L.N, 7, 1.f); L.shift = dev_rand(L.N, 8, 0.1f);
       L.slope = 0.25f; L.act = l < 5;
       L.in_buf = cur; L.resid_buf = -1;
@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
   printf("  block (0,0): ");
   for (int l = 0; l < 6; ++l)
     printf("L%d: prologue %lld, k-loop %lld (%.0f/tile), epilogue %lld | ", l, tr[1 + 4 * l] - tr[4 * l], tr[2 + 4 * l] - tr[1 + 4 * l],
-           (double)(tr[2 + 4 * l] - tr[1 + 4 * l]) / ((l == 0 ? LDX + 15 : Hd) / 16), tr[3 + 4 * l] - tr[2 + 4 * l]);
+           (double)(tr[2 + 4 * l] - tr[1 + 4 * l]) / ((l == 0 ? LDX + 31 : Hd) / 32), tr[3 + 4 * l] - tr[2 + 4 * l]);
   printf("total %lld\n", tr[3 + 4 * 5] - tr[0]);
   return 0;
 }
