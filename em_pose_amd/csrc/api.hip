@@ -249,7 +249,8 @@ int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* ou
 int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
   const int K = d.in_dim, N = d.out_dim;
   const int KG = (K + 7) / 8, NT = (N + 31) / 32;
-  std::vector<float> buf((size_t)KG * NT * 256, 0.f);
+  const int KG4 = (KG + 3) & ~3;   // the kernel walks four k-groups per iteration
+  std::vector<float> buf((size_t)KG4 * NT * 256, 0.f);
   for (int kg = 0; kg < KG; ++kg)
     for (int nt = 0; nt < NT; ++nt)
       for (int lane = 0; lane < 64; ++lane) {
@@ -362,46 +363,34 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
   // layers. Needs enough row panels to fill the chip and layers no wider than the four 128-column waves.
   {
     static const int fused_on = getenv("EMPOSE_MLP_FUSED") ? atoi(getenv("EMPOSE_MLP_FUSED")) : 1;  // dev A/B only
-    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 63) / 64) * n_nets >= 400;
-    for (int i = 0; i < n_nets && ok; ++i)
+    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 63) / 64) * n_nets >= 256;
+    for (int i = 0; i < n_nets && ok; ++i) {
+      if (nets[i]->skip || nets[i]->layers[0].in_dim > FUSED_MAX_WIDTH) ok = false;   // no room for a block input
       for (int l = 0; l < L; ++l) {
         const Dense& d = nets[i]->layers[l];
         if (d.out_dim > FUSED_MAX_WIDTH || d.act > 1) ok = false;
-        if (l < L - 1 && d.out_dim != nets[i]->layers[0].out_dim) ok = false;   // one scratch row length per net
       }
+    }
     if (ok) {
       FusedMlpArgs fa;
       fa.count = n_nets; fa.M = T;
       for (int i = 0; i < n_nets; ++i) {
         FusedNet& fn = fa.net[i];
         fn.x = x; fn.ldx = ldx; fn.out = outs[i]; fn.ld_out = out_ld[i];
-        fn.ld_buf = nets[i]->layers[0].out_dim; fn.n_layers = L;
-        for (int k = 0; k < 3; ++k) fn.buf[k] = ws.buf[k] ? ws.buf[k] + (size_t)i * T * hidden_max : nullptr;
-        int cur = -1, block_in = -1;
+        fn.ld_buf = 0; fn.n_layers = L;
+        for (int k = 0; k < 3; ++k) fn.buf[k] = nullptr;   // the activations stay in LDS
         for (int l = 0; l < L; ++l) {
           const Dense& d = nets[i]->layers[l];
           FusedLayer& fl = fn.layer[l];
           fl.W = d.wp; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
           fl.slope = d.slope; fl.act = d.act;
-          const bool block_first = (l >= 1) && (l % 2 == 1) && (l < L - 1);
-          const bool block_last = (l >= 2) && (l % 2 == 0) && (l < L - 1);
-          if (block_first) block_in = cur;
-          fl.in_buf = cur;
-          fl.resid_buf = (block_last && nets[i]->skip) ? block_in : -1;
-          if (l == L - 1) {
-            fl.out_buf = -1;
-          } else {
-            int k = 0;
-            while (k == cur || (nets[i]->skip && k == block_in)) ++k;
-            if (k > 2 || !ws.buf[k]) return fail(EMPOSE_EINVAL, "internal: MLP scratch buffers exhausted");
-            fl.out_buf = k;
-            cur = k;
-          }
+          fl.in_buf = l == 0 ? -1 : 0; fl.resid_buf = -1; fl.out_buf = l == L - 1 ? -1 : 0;
         }
       }
       prof_mark(init_net ? P_INIT_MLP : P_MLP_FUSED, stream);
       hipError_t e = launch_mlp_fused(fa, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mlp launch: %s", hipGetErrorString(e));
+      prof_mark(P_END, stream);   // close the dominant kernel's interval at its completion, not at the next launch
       return EMPOSE_OK;
     }
   }

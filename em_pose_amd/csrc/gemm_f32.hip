@@ -379,26 +379,14 @@ static hipError_t launch_wide(const GemmBatch& batch, hipStream_t stream) {
 using CfgS11 = Cfg<2, 2, 1, 1, 32, false>;   //  64 x  64
 using CfgS12 = Cfg<2, 2, 1, 2, 32, false>;   //  64 x 128
 using CfgS21 = Cfg<2, 2, 2, 1, 32, false>;   // 128 x  64
-using CfgL = Cfg<2, 2, 2, 2, 32, false>;     // 128 x 128, 2 barriers per K tile
-using CfgLdb = Cfg<2, 2, 2, 2, 32, true>;    // 128 x 128, double-buffered LDS
 using CfgX = Cfg<4, 2, 2, 2, 32, false>;     // 256 x 128, 8 waves
-using CfgXdb = Cfg<4, 2, 2, 2, 32, true>;    // 256 x 128, 8 waves, double-buffered
-using CfgL64 = Cfg<2, 2, 2, 2, 64, false>;   // 128 x 128, BK = 64
-using CfgY = Cfg<2, 4, 2, 2, 32, false>;     // 128 x 256, 8 waves
 
+// Measured on MI355X (M = 65536, N = K = 512, before the epilogue fix): 128x128 / 4 waves 94 TF, + LDS double buffer
+// 96, BK = 64 95, 256x128 / 8 waves 105, 128x256 / 8 waves 106 TFLOP/s -> the 8-wave 256x128 tile is the large tile
+// of this template; the hand-pipelined 256x256 tile above takes over when whole rounds of it fill the CUs.
 template <int ROLE>
 static hipError_t launch_large(const GemmBatch& batch, hipStream_t stream) {
-  static const int variant = getenv("EMPOSE_GEMM_VARIANT") ? atoi(getenv("EMPOSE_GEMM_VARIANT")) : 0;  // dev A/B only
-  // Measured on MI355X (M=65536, N=K=512): 128x128/4 waves 94 TF, +LDS double buffer 96, BK=64 95,
-  // 256x128/8 waves 105, 128x256/8 waves 106 TFLOP/s -> the 8-wave 256x128 tile is the default.
-  switch (variant) {
-    case 1: return launch_cfg<CfgLdb, ROLE>(batch, stream);
-    case 2: return launch_cfg<CfgL, ROLE>(batch, stream);
-    case 3: return launch_cfg<CfgXdb, ROLE>(batch, stream);
-    case 4: return launch_cfg<CfgL64, ROLE>(batch, stream);
-    case 5: return launch_cfg<CfgY, ROLE>(batch, stream);
-    default: return launch_cfg<CfgX, ROLE>(batch, stream);
-  }
+  return launch_cfg<CfgX, ROLE>(batch, stream);
 }
 
 enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE };
@@ -454,8 +442,7 @@ const char* gemm_kernel_name(int M, int N, int K, int count, int role) {
 
 hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
   GemmBatch batch = batch_in;
-  static const int swz = getenv("EMPOSE_GEMM_SWIZZLE") ? atoi(getenv("EMPOSE_GEMM_SWIZZLE")) : 1;  // dev A/B only
-  batch.xcd_swizzle = swz;
+  batch.xcd_swizzle = 1;
   switch (pick_gemm(batch)) {
     case PICK_S11: return launch_cfg<CfgS11>(batch, stream);
     case PICK_S12: return launch_cfg<CfgS12>(batch, stream);

@@ -26,19 +26,20 @@ struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; 
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
 const char* gemm_kernel_name(int M, int N, int K, int count, int role);
 
-// One or two whole MLPs (all layers) in one launch: a workgroup keeps 64 rows through every layer (mlp_fused.hip).
+// One or two whole MLPs (all layers) in one launch: a workgroup keeps the activations of 64 rows in LDS from the first
+// layer to the last (mlp_fused.hip).
 constexpr int FUSED_MAX_LAYERS = 8;
 constexpr int FUSED_MAX_WIDTH = 512;     // widest layer output the four 128-column waves cover
 struct FusedLayer {
   const float* W; int K, N;              // weights in fragment order (api.hip pack_fragments), K % 4 == 0, N <= FUSED_MAX_WIDTH
   const float* scale; const float* shift;
   float slope; int act;                  // 0 none, 1 PReLU
-  int in_buf, out_buf, resid_buf;        // scratch buffer index; -1 = the net's input x / its output / no skip connection
+  int in_buf, out_buf, resid_buf;        // out_buf < 0: the last layer (writes the net's output); others unused
 };
 struct FusedNet {
   const float* x; int ldx;
   float* out; int ld_out;
-  float* buf[3]; int ld_buf;             // scratch [M][ld_buf] each
+  float* buf[3]; int ld_buf;             // unused (the activations never leave LDS)
   int n_layers;
   FusedLayer layer[FUSED_MAX_LAYERS];
 };

@@ -1,0 +1,32 @@
+"""Dev: empose_update_nets_fwd alone (both update MLPs, T rows), back-to-back launches, real model weights of the bench."""
+import os, sys
+sys.path.insert(0, '.')
+import torch
+from em_pose_amd import _lib, synthetic
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.helpers.configuration import lgd_config
+from em_pose_amd.nn.models import create_model
+dev = torch.device('cuda:0')
+T = int(os.environ.get('T', 32768))
+torch.manual_seed(0)
+net = create_model(lgd_config(12, True, 4), SMPLLayer(synthetic.make_model())).to(dev).eval()
+h = net._ensure_handle(dev)
+lib = _lib.lib()
+for kind in ('randn', 'zeros'):
+    x = torch.randn(T, 296, device=dev) if kind == 'randn' else torch.zeros(T, 296, device=dev)
+    dp, ds = torch.empty(T, 66, device=dev), torch.empty(T, 10, device=dev)
+    nb = lib.empose_update_workspace_bytes(h, T); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    def run():
+        _lib.check(lib.empose_update_nets_fwd(h, T, _lib.dptr(x), 296, _lib.dptr(dp), _lib.dptr(ds), _lib.dptr(ws), nb, None))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(3):
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 10)
+    flops = 2.0 * T * ((296 * 512 + 4 * 512 * 512 + 512 * 66) + (296 * 512 + 4 * 512 * 512 + 512 * 10))
+    t = min(ts)
+    print('x=%s T=%d: %.1f us/launch  %.1f TFLOP/s' % (kind, T, t * 1e3, flops / t / 1e9))

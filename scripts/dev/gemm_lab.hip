@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
     // reference result: the small-tile configuration (independent code path of the same template)
     GemmBatch br = b;
     for (int i = 0; i < s.nprob; ++i) br.p[i].C = Cr[i];
-    launch_cfg<CfgL, 0>(br, 0);
+    launch_cfg<Cfg<2, 2, 2, 2, 32, false>, 0>(br, 0);
     hipDeviceSynchronize();
     using CfgWdb = Cfg<2, 2, 4, 4, 32, true>;    // 256 x 256, 4 waves, wave tile 128 x 128, double-buffered LDS
     using CfgWsb = Cfg<2, 2, 4, 4, 32, false>;

@@ -40,7 +40,6 @@ int main(int argc, char** argv) {
   }
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int variant = 0; variant < 2; ++variant) {
-    if (variant == 0) setenv("EMPOSE_LSTM_LEGACY", "0", 1);
     a.s = 5;
     for (int i = 0; i < 5; ++i) { a.s = 5 + i; (void)launch_lstm_wave(a, 0); }
     (void)hipDeviceSynchronize();

@@ -11,7 +11,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile > $OUT.log 2>&1 )
   ls $OUT | head
 done
-python - <<'PY'
-import csv, glob, collections, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else os.environ.get('TAG', 'r1')
-PY
+python scripts/dev/make_pmc_json.py $TAG
