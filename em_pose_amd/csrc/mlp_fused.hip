@@ -59,12 +59,25 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
   const int col_tile0 = NARROW ? (wave >> 1) * 2 : wave * 4;
   // Column tiles past the layer's width are clamped to the last one: fetched and multiplied like the others (no
   // branch in the pipelined loop), never stored.
-  unsigned b_tile[WN];
+  // B side: fragment (kg, nt) starts at byte ((kg * NT32 + nt) * 64) * 16 and this lane owns 16 bytes of it: a scalar
+  // base per k-group plus a constant 32-bit lane offset per column tile (no vector address arithmetic in the loop).
+  unsigned b_voff[WN];
 #pragma unroll
-  for (int j = 0; j < WN; ++j) b_tile[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 1024);
-  // B side: this lane's 16 bytes of a fragment; fragment (kg, nt) starts at byte ((kg * NT32 + nt) * 64) * 16
-  fm_gbyte_t wb = (fm_gbyte_t)L.W + (size_t)lane * 16;
+  for (int j = 0; j < WN; ++j)
+    b_voff[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 1024 + lane * 16);
+  fm_gbyte_t wb = (fm_gbyte_t)L.W;
   const float* a_rd = act + (row_tile0 * 32 + l31) * LDA + lh * 4;   // A fragments: row tile i adds 32 rows, group g adds 8
+
+  // epilogue constants of this lane's columns, fetched now so that their latency hides under the K loop
+  float e_sc[WN], e_sh[WN];
+  const float e_slope = L.act == 1 ? L.slope : 1.f;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = (col_tile0 + j) * 32 + l31;
+    const int nc = n < N ? n : N - 1;
+    e_sc[j] = L.scale ? L.scale[nc] : 1.f;
+    e_sh[j] = L.shift ? L.shift[nc] : 0.f;
+  }
 
   f32x16 acc[WM][WN];
   f32x4 fa[2][WM];              // A fragments, double-buffered over the k-groups
@@ -78,7 +91,7 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
     const int kc = kg < KG4 ? kg : KG4 - 1;
     fm_gbyte_t p = wb + (size_t)kc * NT32 * 1024;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) b[j] = *(fm_gvec_t)(p + b_tile[j]);
+    for (int j = 0; j < WN; ++j) b[j] = *(fm_gvec_t)(p + b_voff[j]);
   };
   auto mma = [&](const f32x4 (&a)[WM], const f32x4 (&b)[WN]) {   // consecutive MFMAs go to different accumulator tiles
 #pragma unroll
@@ -145,26 +158,19 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
   } else {
     // hidden layer: scale/shift (bias, folded BatchNorm) and PReLU, in place into the activation buffer.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    const float slope = L.act == 1 ? L.slope : 1.f;
-    const float* __restrict__ scale = L.scale;
-    const float* __restrict__ shift = L.shift;
-    const int KGN = ((N + 7) / 8 + 3) & ~3;          // the next layer reads columns [0, 8 * KGN): zero the padding
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int n = (col_tile0 + j) * 32 + l31;
-      if (col_tile0 + j >= NT32) continue;            // wave-uniform
+      if (col_tile0 + j >= NT32) continue;            // wave-uniform; NT32 * 32 == the next layer's padded K
       const bool real = n < N;
-      const float sc = (real && scale) ? scale[n] : 1.f;
-      const float sh = (real && shift) ? shift[n] : 0.f;
-      if (n >= 8 * KGN) continue;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float y = acc[i][j][r] * sc + sh;
-          y = y >= 0.f ? y : slope * y;               // slope == 1 when there is no activation (exact identity)
-          act[row * LDA + n] = real ? y : 0.f;
+          float y = acc[i][j][r] * e_sc[j] + e_sh[j];
+          y = y >= 0.f ? y : e_slope * y;             // slope == 1 when there is no activation (exact identity)
+          act[row * LDA + n] = real ? y : 0.f;        // columns past N are the next layer's zero padding
         }
     }
   }
