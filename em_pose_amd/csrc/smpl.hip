@@ -277,44 +277,47 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   const uint32_t* TI = reinterpret_cast<const uint32_t*>(smem + (size_t)L.total * CH_FRAMES);  // tables (ints)
   const float* TF = reinterpret_cast<const float*>(TI);                                        // tables (floats)
 
-  // ---- P0: tables + per-frame rot | out.  Loads are issued in batches of 4 before the first LDS store so that the
-  // round trips overlap (a plain strided copy loop serialises one global latency per iteration).
+  // ---- P0: tables + per-frame rot | out.  Every global load of the phase (16-byte pieces of the table blob, the
+  // frames' rot | out rows) is issued before the first LDS store, so the phase costs one round trip instead of one per
+  // copy-loop iteration; tables or frame rows larger than one batch fall through to the batched loops below.
   {
-    // (16-byte pieces of the table blob, eight per thread in flight: the whole table is one or two round trips.)
     uint4* dst = reinterpret_cast<uint4*>(smem + (size_t)L.total * CH_FRAMES);
     const uint4* src = reinterpret_cast<const uint4*>(tb.blob);
     const int n16 = (O.total + 3) >> 2;   // the blob is padded to a multiple of 4 words
-    for (int i0 = tid; i0 < n16; i0 += 8 * CH_THREADS) {
-      uint4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = i0 + u * CH_THREADS; v[u] = i < n16 ? src[i] : uint4{0u, 0u, 0u, 0u}; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int i = i0 + u * CH_THREADS; if (i < n16) dst[i] = v[u]; }
-    }
     const int row = NB * 9 + tb.ncp;
     const int n = nf * row;
-    constexpr int FB = 6;   // 2 frames x (198 + ncp ~ 320) floats / 192 threads: one batch
-    for (int i0 = tid; i0 < n; i0 += FB * CH_THREADS) {
-      float v[FB];
+    constexpr int TB = 8, FB = 6;   // 8 x 192 x 16 B = 24 KB of tables; 2 frames x (198 + ncp ~ 320) floats / 192 threads
+    auto frame_src = [&](int i) -> float {
+      int f, o;
+      frame_split(i, row, f, o);
+      return o < NB * 9 ? a.rot[(size_t)(t0 + f) * (NB * 9) + o] : a.out[(size_t)(t0 + f) * tb.ncp + (o - NB * 9)];
+    };
+    auto frame_dst = [&](int i, float v) {
+      int f, o;
+      frame_split(i, row, f, o);
+      frames[f * L.total + o] = v;
+    };
+    uint4 tv[TB];
+    float fv[FB];
 #pragma unroll
-      for (int u = 0; u < FB; ++u) {
-        const int i = i0 + u * CH_THREADS;
-        v[u] = 0.f;
-        if (i < n) {
-          int f, o;
-          frame_split(i, row, f, o);
-          v[u] = o < NB * 9 ? a.rot[(size_t)(t0 + f) * (NB * 9) + o] : a.out[(size_t)(t0 + f) * tb.ncp + (o - NB * 9)];
-        }
-      }
+    for (int u = 0; u < TB; ++u) { const int i = tid + u * CH_THREADS; tv[u] = i < n16 ? src[i] : uint4{0u, 0u, 0u, 0u}; }
 #pragma unroll
-      for (int u = 0; u < FB; ++u) {
-        const int i = i0 + u * CH_THREADS;
-        if (i < n) {
-          int f, o;
-          frame_split(i, row, f, o);
-          frames[f * L.total + o] = v[u];
-        }
-      }
+    for (int u = 0; u < FB; ++u) { const int i = tid + u * CH_THREADS; fv[u] = i < n ? frame_src(i) : 0.f; }
+#pragma unroll
+    for (int u = 0; u < TB; ++u) { const int i = tid + u * CH_THREADS; if (i < n16) dst[i] = tv[u]; }
+#pragma unroll
+    for (int u = 0; u < FB; ++u) { const int i = tid + u * CH_THREADS; if (i < n) frame_dst(i, fv[u]); }
+    for (int i0 = tid + TB * CH_THREADS; i0 < n16; i0 += TB * CH_THREADS) {
+#pragma unroll
+      for (int u = 0; u < TB; ++u) { const int i = i0 + u * CH_THREADS; tv[u] = i < n16 ? src[i] : uint4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+      for (int u = 0; u < TB; ++u) { const int i = i0 + u * CH_THREADS; if (i < n16) dst[i] = tv[u]; }
+    }
+    for (int i0 = tid + FB * CH_THREADS; i0 < n; i0 += FB * CH_THREADS) {
+#pragma unroll
+      for (int u = 0; u < FB; ++u) { const int i = i0 + u * CH_THREADS; fv[u] = i < n ? frame_src(i) : 0.f; }
+#pragma unroll
+      for (int u = 0; u < FB; ++u) { const int i = i0 + u * CH_THREADS; if (i < n) frame_dst(i, fv[u]); }
     }
   }
   __syncthreads();
@@ -403,6 +406,29 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     float* S = frames + f * L.total;
     const float* V = S + L.v;
     const int c = TI[O.s_center + m], h = TI[O.s_helper + m], deg = TI[O.s_deg + m];
+    // Everything this sensor reads from global memory is requested up front: the stores of pos / ori further down
+    // would otherwise sit between two dependent round trips (offsets, then targets).
+    const int w = t / a.F;
+    float Ro[9], to[3];
+    {
+      const float* pr = a.offset_r + ((size_t)w * 12 + m) * 9;
+      const float* pt = a.offset_t + ((size_t)w * 12 + m) * 3;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Ro[k] = pr[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) to[k] = pt[k];
+    }
+    const int slot_m = a.used_slot[m];
+    float tp[3] = {0.f, 0.f, 0.f}, tori[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, scale = 0.f;
+    if (bwd && !cot && slot_m >= 0) {
+      const float* p3 = a.tgt + (size_t)t * a.ld_tgt + slot_m * 3;
+      const float* p9 = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot_m * 9;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = p3[k];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) tori[k] = p9[k];
+      scale = a.frame_scale[t];
+    }
     float n[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < deg; ++k) {
       const float* fn = S + L.fn + (m * md + k) * 3;
@@ -429,9 +455,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     const float s2[3] = {aa[0] * inv_na, aa[1] * inv_na, aa[2] * inv_na};
     // R_m columns (s2, tv, nh)
     const float Rm[9] = {s2[0], tv[0], nh[0], s2[1], tv[1], nh[1], s2[2], tv[2], nh[2]};
-    const int w = t / a.F;
-    const float* Ro = a.offset_r + ((size_t)w * 12 + m) * 9;
-    const float* to = a.offset_t + ((size_t)w * 12 + m) * 3;
     float ori[9], pos[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -464,15 +487,11 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 #pragma unroll
       for (int k = 0; k < 9; ++k) dori[k] = co[k];
     } else {
-      const int slot = a.used_slot[m];
-      const float scale = a.frame_scale[t];
-      if (slot < 0 || scale == 0.f) {
+      if (slot_m < 0 || scale == 0.f) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) scr[k] = 0.f;
         continue;
       }
-      const float* tp = a.tgt + (size_t)t * a.ld_tgt + slot * 3;
-      const float* tori = a.tgt + (size_t)t * a.ld_tgt + a.n_markers * 3 + slot * 9;
       const float r0 = pos[0] - tp[0], r1 = pos[1] - tp[1], r2 = pos[2] - tp[2];
       const float sp = scale / sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
       dpos[0] = r0 * sp; dpos[1] = r1 * sp; dpos[2] = r2 * sp;
