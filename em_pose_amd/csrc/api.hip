@@ -86,6 +86,8 @@ struct Lstm {   // unit u = layer * dirs + direction
 struct empose_model {
   std::vector<void*> allocs;
   SmplTables tab;
+  float* wc_frag = nullptr;    // tab.wc / tab.wct in MFMA fragment order (row-block GEMM)
+  float* wct_frag = nullptr;
   int n_markers = 12;
   int marker_idx[12];
   int used_slot[12];
@@ -246,10 +248,9 @@ int pack_dense(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* ou
 // Weights in the order the matrix cores consume them (mlp_fused.hip): for every k-group of 8 and every 32-column tile,
 // lane (n = lane & 31, half = lane >> 5) owns W[tile * 32 + n][kg * 8 + half * 4 .. + 3]; columns / k past the matrix
 // are zero, so a wave's fragment is one coalesced 1 KB read and ragged K needs no masking on this operand.
-int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
-  const int K = d.in_dim, N = d.out_dim;
+int pack_fragments_raw(std::vector<void*>& allocs, const float* weight, int N, int K, float** out) {
   const int KG = (K + 7) / 8, NT = (N + 31) / 32;
-  const int KG4 = (KG + 3) & ~3;   // the kernel walks four k-groups per iteration
+  const int KG4 = (KG + 3) & ~3;   // the kernels walk four k-groups per iteration
   std::vector<float> buf((size_t)KG4 * NT * 256, 0.f);
   for (int kg = 0; kg < KG; ++kg)
     for (int nt = 0; nt < NT; ++nt)
@@ -258,10 +259,14 @@ int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense
         if (n >= N) continue;
         for (int e = 0; e < 4; ++e) {
           const int k = kg * 8 + (lane >> 5) * 4 + e;
-          if (k < K) buf[(((size_t)kg * NT + nt) * 64 + lane) * 4 + e] = d.weight[(size_t)n * K + k];
+          if (k < K) buf[(((size_t)kg * NT + nt) * 64 + lane) * 4 + e] = weight[(size_t)n * K + k];
         }
       }
-  return upload(allocs, buf.data(), buf.size(), &out->wp);
+  return upload(allocs, buf.data(), buf.size(), out);
+}
+
+int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
+  return pack_fragments_raw(allocs, d.weight, d.out_dim, d.in_dim, &out->wp);
 }
 
 int pack_mlp(std::vector<void*>& allocs, const empose_mlp_desc& d, Mlp* out, int* hidden_max, int* any_skip) {
@@ -539,7 +544,9 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
   p.M = T; p.N = m->tab.ncp; p.K = 200;
   p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
   prof_mark(P_BLEND_GEMM, stream);
-  hipError_t e = launch_gemm(b, stream);
+  hipError_t e = (m->wc_frag && gemm_rows_applicable(T, m->tab.ncp, 200))
+                     ? launch_gemm_rows(ws.feat, 200, m->wc_frag, ws.out, m->tab.ncp, T, m->tab.ncp, 200, stream)
+                     : launch_gemm(b, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm: %s", hipGetErrorString(e));
   ChainArgs c;
   c.tab = m->tab;
@@ -557,7 +564,9 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
     p.A = ws.d_out; p.lda = m->tab.ncp; p.W = m->tab.wct; p.ldw = m->tab.ncp; p.C = ws.d_feat; p.ldc = 200;
     p.M = T; p.N = 200; p.K = m->tab.ncp;
     prof_mark(P_BLEND_T_GEMM, stream);
-    e = launch_gemm(b, stream);
+    e = (m->wct_frag && gemm_rows_applicable(T, 200, m->tab.ncp))
+            ? launch_gemm_rows(ws.d_out, m->tab.ncp, m->wct_frag, ws.d_feat, 200, T, 200, m->tab.ncp, stream)
+            : launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
@@ -627,6 +636,8 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
   float* fp; int* ip;
   MTRY(upload(m->allocs, s.wc, (size_t)s.ncp * 200, &fp)); t.wc = fp;
   MTRY(upload(m->allocs, s.wct, (size_t)s.ncp * 200, &fp)); t.wct = fp;
+  MTRY(pack_fragments_raw(m->allocs, s.wc, s.ncp, 200, &m->wc_frag));     // the same two matrices in MFMA fragment order
+  MTRY(pack_fragments_raw(m->allocs, s.wct, 200, s.ncp, &m->wct_frag));
   MTRY(upload(m->allocs, s.parents, 22, &ip)); t.parents = ip;
   MTRY(upload(m->allocs, s.skin_idx, (size_t)s.nv * s.kb, &ip)); t.skin_idx = ip;
   MTRY(upload(m->allocs, s.skin_w, (size_t)s.nv * s.kb, &fp)); t.skin_w = fp;

@@ -45,6 +45,10 @@ struct FusedNet {
 };
 struct FusedMlpArgs { FusedNet net[2]; int count; int M; };
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream);
+// One linear layer C = A . W^T with A's row block resident in LDS and W (fragment order) streamed from L2.
+bool gemm_rows_applicable(int M, int N, int K);
+hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, int ldc, int M, int N, int K,
+                            hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // LSTM

@@ -40,23 +40,19 @@ __device__ long long g_fused_trace[64];
 typedef const __attribute__((address_space(1))) f32x4* fm_gvec_t;
 typedef const __attribute__((address_space(1))) char* fm_gbyte_t;
 
-// One layer for the workgroup's 64 rows; the input activations are in `act` (columns [0, 8 * KG4) valid or zero).
-template <bool NARROW>
-__device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act,
-                                            int layer_index) {
+// One layer for the workgroup's rows; the input activations are in `act` (row stride lda, columns [0, 8 * KG4) valid or
+// zero).  The wave computes WM x WN tiles of 32 x 32 starting at (row_tile0, col_tile0).
+template <int WM, int WN>
+__device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act,
+                                              int lda, int row_tile0, int col_tile0, int layer_index) {
   using namespace fm;
   FM_STAMP(4 * layer_index)
-  constexpr int WM = NARROW ? 1 : 2;          // 32-row tiles per wave
-  constexpr int WN = NARROW ? 2 : 4;          // 32-column tiles per wave
   constexpr int NMMA = WM * WN * 4;           // MFMAs per k-group of 8
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = threadIdx.x & 63;
   const int l31 = lane & 31, lh = lane >> 5;
   const int K = L.K, N = L.N;
   const int NT32 = (N + 31) / 32;             // column tiles of the packed weights
   const int KG4 = ((K + 7) / 8 + 3) & ~3;     // k-groups of the packed weights (padded with zeros to a multiple of 4)
-  const int row_tile0 = NARROW ? (wave & 1) : 0;
-  const int col_tile0 = NARROW ? (wave >> 1) * 2 : wave * 4;
   // Column tiles past the layer's width are clamped to the last one: fetched and multiplied like the others (no
   // branch in the pipelined loop), never stored.
   // B side: fragment (kg, nt) starts at byte ((kg * NT32 + nt) * 64) * 16 and this lane owns 16 bytes of it: a scalar
@@ -66,7 +62,7 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
   for (int j = 0; j < WN; ++j)
     b_voff[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 1024 + lane * 16);
   fm_gbyte_t wb = (fm_gbyte_t)L.W;
-  const float* a_rd = act + (row_tile0 * 32 + l31) * LDA + lh * 4;   // A fragments: row tile i adds 32 rows, group g adds 8
+  const float* a_rd = act + (row_tile0 * 32 + l31) * lda + lh * 4;   // A fragments: row tile i adds 32 rows, group g adds 8
 
   // epilogue constants of this lane's columns, fetched now so that their latency hides under the K loop
   float e_sc[WN], e_sh[WN];
@@ -85,7 +81,7 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
 
   auto fread = [&](int g, f32x4 (&a)[WM]) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * LDA + g * 8);
+    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * lda + g * 8);
   };
   auto bload = [&](f32x4 (&b)[WN], int kg) {   // k-group kg of the packed weights (clamped: fetched, never used)
     const int kc = kg < KG4 ? kg : KG4 - 1;
@@ -103,7 +99,7 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
   auto pattern = [&]() {   // one k-group: WM fragment reads and WN weight loads spread over the NMMA MFMAs
-    constexpr int step = NARROW ? 1 : 2;
+    constexpr int step = NMMA >= 2 * (WM + WN) + 2 ? 2 : 1;
 #pragma unroll
     for (int q = 0; q < WM; ++q) { FM_SGB(SG_MFMA, step); FM_SGB(SG_DS_RD, 1); }
 #pragma unroll
@@ -170,7 +166,7 @@ __device__ __forceinline__ void fused_layer(const FusedNet& net, const FusedLaye
           const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           float y = acc[i][j][r] * e_sc[j] + e_sh[j];
           y = y >= 0.f ? y : e_slope * y;             // slope == 1 when there is no activation (exact identity)
-          act[row * LDA + n] = real ? y : 0.f;        // columns past N are the next layer's zero padding
+          act[row * lda + n] = real ? y : 0.f;        // columns past N are the next layer's zero padding
         }
     }
   }
@@ -202,9 +198,89 @@ __global__ __launch_bounds__(fm::NT) void mlp_fused_kernel(FusedMlpArgs args) {
 
   for (int l = 0; l < net.n_layers; ++l) {
     const FusedLayer& L = net.layer[l];
-    if (L.N <= 128) fused_layer<true>(net, L, M, m0, act, l);
-    else fused_layer<false>(net, L, M, m0, act, l);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (L.N <= 128) fused_layer_t<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, l);   // 32 x 64 per wave
+    else fused_layer_t<2, 4>(net, L, M, m0, act, LDA, 0, wave * 4, l);                            // 64 x 128 per wave
   }
+}
+
+// A single linear layer with the same machinery, for contractions whose K fits the LDS with the row block
+// (the SMPL blend-shape GEMMs, K = 200 / 320): the A block [BM][K] is staged once, the weights stream from L2 in
+// fragment order, no barrier in the K loop.  Waves are arranged WROWS x WCOLS, each WM x WN tiles of 32 x 32.
+template <int BM_, int WM, int WN, int WCOLS>
+__global__ __launch_bounds__(fm::NT) void gemm_rows_kernel(FusedMlpArgs args) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, m0 = blockIdx.x * BM_;
+  const int tid = threadIdx.x;
+  const int K0 = L.K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
+  const int lda = kpad + 4;
+  {
+    const int c4n = kpad / 4;
+    for (int i0 = tid; i0 < BM_ * c4n; i0 += 4 * fm::NT) {   // four 16-byte pieces per thread in flight
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < BM_ * c4n) {
+          const int r = i / c4n, c = (i % c4n) * 4;
+          const int row = m0 + r < M ? m0 + r : M - 1;
+          if (c < K0) v[u] = *reinterpret_cast<const f32x4*>(net.x + (size_t)row * net.ldx + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        if (i < BM_ * c4n) *reinterpret_cast<f32x4*>(act + (i / c4n) * lda + (i % c4n) * 4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  fused_layer_t<WM, WN>(net, L, M, m0, act, lda, (wave / WCOLS) * WM, (wave % WCOLS) * WN, 0);
+}
+
+template <int BM_, int WM, int WN, int WCOLS>
+static hipError_t launch_gemm_rows_cfg(const FusedMlpArgs& args, hipStream_t stream) {
+  const int K0 = args.net[0].layer[0].K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
+  const size_t lds = (size_t)BM_ * (kpad + 4) * sizeof(float) + 64;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<BM_, WM, WN, WCOLS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  hipLaunchKernelGGL((gemm_rows_kernel<BM_, WM, WN, WCOLS>), dim3((args.M + BM_ - 1) / BM_), dim3(fm::NT), lds, stream,
+                     args);
+  return hipGetLastError();
+}
+
+// C[M][N] = A[M][K] . Wp^T with Wp in fragment order. Returns false when the row-block kernel does not pay (the caller
+// then uses the generic GEMM).  Measured at M = 32768: N = 320, K = 200 as 2 x 2 waves of 64 x 160 over 128 rows:
+// 57 us against 73 us for the generic tile; N = 200, K = 320 as 2 x 2 waves of 32 x 128 over 64 rows: 65 us against 55,
+// so only the first configuration is dispatched.
+bool gemm_rows_applicable(int M, int N, int K) {
+  if (K % 4 != 0) return false;
+  return N <= 320 && N > 256 && K <= 288 && M >= 128 * 192;
+}
+
+hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, int ldc, int M, int N, int K,
+                            hipStream_t stream) {
+  FusedMlpArgs a;
+  a.count = 1; a.M = M;
+  FusedNet& fn = a.net[0];
+  fn.x = A; fn.ldx = lda; fn.out = C; fn.ld_out = ldc; fn.n_layers = 1; fn.ld_buf = 0;
+  for (int k = 0; k < 3; ++k) fn.buf[k] = nullptr;
+  FusedLayer& L = fn.layer[0];
+  L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
+  L.in_buf = -1; L.out_buf = -1; L.resid_buf = -1;
+  if (N > 256) return launch_gemm_rows_cfg<128, 2, 5, 2>(a, stream);
+  return launch_gemm_rows_cfg<64, 1, 4, 2>(a, stream);
 }
 
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream) {
