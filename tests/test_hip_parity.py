@@ -142,6 +142,42 @@ def test_smpl_sensors_fwd_bwd(which, n_markers, big_model):
     assert (g_th.cpu().numpy()[scale == 0] == 0).all()
 
 
+def test_smpl_sensors_large_batch_blend_gemm_path(big_model):
+    """At bench-size batches the blend-shape contraction runs on the row-block GEMM (csrc/mlp_fused.hip
+    gemm_rows_kernel: A block resident in LDS, weights in fragment order).  Its first 96 frames must carry the bits of a
+    96-frame call, which takes the generic tile and is checked against the float64 blueprint above."""
+    model, vids = big_model, CONST.VERTEX_IDS
+    F, T_small, T_big = 8, 96, 128 * 200
+    theta, beta, off_r, off_t, tgt, scale, ref = _smpl_case(model, vids, T_small, F, 11, 12)
+    rng = np.random.default_rng(5)
+    reps = T_big // T_small + 1
+    tile = lambda a: np.concatenate([a] * reps, axis=0)
+    theta_b = tile(theta)[:T_big] + np.concatenate([np.zeros((T_small, 66)), rng.normal(0, 0.05, size=(T_big - T_small, 66))])
+    beta_b, tgt_b, scale_b = tile(beta)[:T_big], tile(tgt)[:T_big], tile(scale)[:T_big]
+    off_r_b, off_t_b = tile(off_r)[:T_big // F], tile(off_t)[:T_big // F]
+    net = build_net(lgd_config(12, False, 1, hidden=32), model, vids)
+    handle = net._ensure_handle(torch.device(DEV))
+    lib = _lib.lib()
+    outs = {}
+    for T, (th_, be_, or_, ot_, tg_, sc_) in ((T_small, (theta, beta, off_r, off_t, tgt, scale)),
+                                             (T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
+        th, be, o_r, o_t, tg, sc = gpu(th_), gpu(be_), gpu(or_), gpu(ot_), gpu(tg_), gpu(sc_)
+        pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
+        g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
+        nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10, _lib.dptr(o_r),
+                                                   _lib.dptr(o_t), _lib.dptr(tg), tg.shape[1], _lib.dptr(sc),
+                                                   _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), _lib.dptr(g_th), 66,
+                                                   _lib.dptr(g_be), 10, _lib.dptr(ws), nbytes, _lib.current_stream()))
+        torch.cuda.synchronize()
+        outs[T] = [t.cpu().numpy() for t in (pos, ori, joints, g_th, g_be)]
+    np.testing.assert_allclose(outs[T_small][0].reshape(T_small, 12, 3), ref['pos'], atol=1e-5)
+    for a, b in zip(outs[T_small], outs[T_big]):
+        assert np.array_equal(a, b[:T_small])     # same k order in both kernels: identical bits
+        assert np.isfinite(b).all()
+
+
 def test_smpl_forward_only_matches(big_model):
     """tgt=NULL: positions/orientations/joints only (the final evaluation of the loop)."""
     T, F = 64, 32
@@ -209,7 +245,8 @@ def test_update_nets_and_lstm_vs_oracle():
     np.testing.assert_allclose(cn.cpu().numpy(), want_c.numpy(), atol=1e-5)
 
 
-@pytest.mark.parametrize('hidden,skip,T', [(32, False, 12800 + 77), (512, False, 12800), (256, True, 13000)])
+@pytest.mark.parametrize('hidden,skip,T', [(32, False, 12800 + 77), (512, False, 12800), (256, True, 13000),
+                                           (100, False, 8192 + 5), (36, False, 9000)])
 def test_update_nets_large_batch_single_launch_path(hidden, skip, T):
     """Large batches run both update MLPs in ONE launch (csrc/mlp_fused.hip: a workgroup keeps 128 rows through all six
     layers): same results as the oracle's layer-by-layer MLP, incl. the ragged first layer (K = 296), the narrow output
