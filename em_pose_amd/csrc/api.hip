@@ -382,14 +382,12 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
       for (int i = 0; i < n_nets; ++i) {
         FusedNet& fn = fa.net[i];
         fn.x = x; fn.ldx = ldx; fn.out = outs[i]; fn.ld_out = out_ld[i];
-        fn.ld_buf = 0; fn.n_layers = L;
-        for (int k = 0; k < 3; ++k) fn.buf[k] = nullptr;   // the activations stay in LDS
+        fn.n_layers = L;   // the activations stay in LDS: no scratch
         for (int l = 0; l < L; ++l) {
           const Dense& d = nets[i]->layers[l];
           FusedLayer& fl = fn.layer[l];
           fl.W = d.wp; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
           fl.slope = d.slope; fl.act = d.act;
-          fl.in_buf = l == 0 ? -1 : 0; fl.resid_buf = -1; fl.out_buf = l == L - 1 ? -1 : 0;
         }
       }
       prof_mark(init_net ? P_INIT_MLP : P_MLP_FUSED, stream);

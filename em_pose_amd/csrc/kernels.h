@@ -34,13 +34,11 @@ struct FusedLayer {
   const float* W; int K, N;              // weights in fragment order (api.hip pack_fragments), K % 4 == 0, N <= FUSED_MAX_WIDTH
   const float* scale; const float* shift;
   float slope; int act;                  // 0 none, 1 PReLU
-  int in_buf, out_buf, resid_buf;        // out_buf < 0: the last layer (writes the net's output); others unused
 };
 struct FusedNet {
   const float* x; int ldx;
   float* out; int ld_out;
-  float* buf[3]; int ld_buf;             // unused (the activations never leave LDS)
-  int n_layers;
+  int n_layers;                          // the last layer writes `out`, the others stay in LDS
   FusedLayer layer[FUSED_MAX_LAYERS];
 };
 struct FusedMlpArgs { FusedNet net[2]; int count; int M; };

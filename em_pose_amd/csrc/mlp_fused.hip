@@ -44,7 +44,7 @@ typedef const __attribute__((address_space(1))) char* fm_gbyte_t;
 // zero).  The wave computes WM x WN tiles of 32 x 32 starting at (row_tile0, col_tile0).
 template <int WM, int WN>
 __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act,
-                                              int lda, int row_tile0, int col_tile0, int layer_index) {
+                                              int lda, int row_tile0, int col_tile0, int layer_index, bool last) {
   using namespace fm;
   FM_STAMP(4 * layer_index)
   constexpr int NMMA = WM * WN * 4;           // MFMAs per k-group of 8
@@ -142,7 +142,7 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   FM_STAMP(4 * layer_index + 2)
 
   __syncthreads();   // every wave has read its last A fragment: the buffer may be overwritten
-  if (L.out_buf < 0) {
+  if (last) {
     // last layer: to the net's output
     GemmProb p;
     p.C = net.out; p.ldc = net.ld_out;
@@ -199,8 +199,9 @@ __global__ __launch_bounds__(fm::NT) void mlp_fused_kernel(FusedMlpArgs args) {
   for (int l = 0; l < net.n_layers; ++l) {
     const FusedLayer& L = net.layer[l];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (L.N <= 128) fused_layer_t<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, l);   // 32 x 64 per wave
-    else fused_layer_t<2, 4>(net, L, M, m0, act, LDA, 0, wave * 4, l);                            // 64 x 128 per wave
+    const bool last = l == net.n_layers - 1;
+    if (L.N <= 128) fused_layer_t<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, l, last);   // 32 x 64 per wave
+    else fused_layer_t<2, 4>(net, L, M, m0, act, LDA, 0, wave * 4, l, last);                            // 64 x 128 per wave
   }
 }
 
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_kernel(FusedMlpArgs args) {
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  fused_layer_t<WM, WN>(net, L, M, m0, act, lda, (wave / WCOLS) * WM, (wave % WCOLS) * WN, 0);
+  fused_layer_t<WM, WN>(net, L, M, m0, act, lda, (wave / WCOLS) * WM, (wave % WCOLS) * WN, 0, true);
 }
 
 template <int BM_, int WM, int WN, int WCOLS>
@@ -274,11 +275,9 @@ hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, 
   FusedMlpArgs a;
   a.count = 1; a.M = M;
   FusedNet& fn = a.net[0];
-  fn.x = A; fn.ldx = lda; fn.out = C; fn.ld_out = ldc; fn.n_layers = 1; fn.ld_buf = 0;
-  for (int k = 0; k < 3; ++k) fn.buf[k] = nullptr;
+  fn.x = A; fn.ldx = lda; fn.out = C; fn.ld_out = ldc; fn.n_layers = 1;
   FusedLayer& L = fn.layer[0];
   L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
-  L.in_buf = -1; L.out_buf = -1; L.resid_buf = -1;
   if (N > 256) return launch_gemm_rows_cfg<128, 2, 5, 2>(a, stream);
   return launch_gemm_rows_cfg<64, 1, 4, 2>(a, stream);
 }

@@ -17,7 +17,7 @@ int main() {
     fn.x = dev_rand((size_t)T * K, 1, 1.f); fn.ldx = K; fn.out = dev_rand((size_t)T * N, 0, 0.f); fn.ld_out = N; fn.n_layers = 1;
     FusedLayer& L = fn.layer[0];
     L.K = K; L.N = N; L.W = dev_rand((size_t)((((K + 7) / 8) + 3) & ~3) * ((N + 31) / 32) * 256, 3, 0.05f);
-    L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0; L.in_buf = -1; L.out_buf = -1; L.resid_buf = -1;
+    L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) (void)launch_mlp_fused(a, 0);
     (void)hipDeviceSynchronize();

@@ -30,18 +30,13 @@ int main(int argc, char** argv) {
     FusedNet& fn = a.net[n];
     const int nout = n == 0 ? 66 : 10;
     fn.x = x; fn.ldx = LDX; fn.out = dev_rand((size_t)T * nout, 0, 0.f); fn.ld_out = nout;
-    for (int k = 0; k < 3; ++k) fn.buf[k] = k < 2 ? dev_rand((size_t)T * Hd, 0, 0.f) : nullptr;
-    fn.ld_buf = Hd; fn.n_layers = 6;
-    int cur = -1;
+    fn.n_layers = 6;
     for (int l = 0; l < 6; ++l) {
       FusedLayer& L = fn.layer[l];
       L.K = l == 0 ? LDX : Hd; L.N = l == 5 ? nout : Hd;
       L.W = dev_rand((size_t)((((L.K + 7) / 8) + 3) & ~3) * ((L.N + 31) / 32) * 256, 100 + 10 * n + l, 0.06f);   // fragment order
       L.scale = dev_rand(L.N, 7, 1.f); L.shift = dev_rand(L.N, 8, 0.1f);
       L.slope = 0.25f; L.act = l < 5;
-      L.in_buf = cur; L.resid_buf = -1;
-      L.out_buf = l == 5 ? -1 : 0;
-      cur = L.out_buf;
       flops += 2.0 * T * L.N * L.K;
     }
   }
