@@ -451,6 +451,9 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
              const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
   const int H = r.H, L = r.num_layers, D = r.dirs, U = L * D;
   const size_t bh = (size_t)B * H;
+  // the wavefront kernel addresses its operands with 32-bit byte offsets from a per-segment base
+  if ((size_t)B * F * (size_t)(ldx > 2 * H ? ldx : 2 * H) * sizeof(float) >= ((size_t)1 << 32))
+    return fail(EMPOSE_EINVAL, "LSTM batch of %d x %d frames is too large for one call; split the batch", B, F);
   prof_mark(P_COPY, stream);
   for (int u = 0; u < U; ++u) {
     if (h0) HIP_TRY(hipMemcpyAsync(ws.h[u][0], h0 + u * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
