@@ -33,9 +33,9 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // ---- optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline numbers ---------
-enum ProfTag { P_PACK = 0, P_LSTM_PROJ, P_LSTM_STEP, P_HEADS, P_UPDATE_FEAT, P_BLEND_GEMM, P_CHAIN, P_BLEND_T_GEMM,
+enum ProfTag { P_PACK = 0, P_LSTM_STEP, P_HEADS, P_UPDATE_FEAT, P_BLEND_GEMM, P_CHAIN, P_BLEND_T_GEMM,
                P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_MLP_FUSED, P_INIT_MLP, P_COPY, P_END, P_NTAGS };
-const char* const kProfNames[P_NTAGS] = {"pack_inputs", "lstm_input_proj_gemm", "lstm_step", "init_heads_gemm",
+const char* const kProfNames[P_NTAGS] = {"pack_inputs", "lstm_step", "init_heads_gemm",
                                          "update_feat", "blend_gemm", "chain_sensors", "blend_T_gemm",
                                          "rodrigues_bwd", "mlp_in_gemm", "mlp_hidden_gemm", "mlp_out_gemm",
                                          "mlp_fused", "init_mlp_gemm", "copies", "end"};
