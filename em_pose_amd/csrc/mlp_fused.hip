@@ -53,6 +53,11 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   const int K = L.K, N = L.N;
   const int NT32 = (N + 31) / 32;             // column tiles of the packed weights
   const int KG4 = ((K + 7) / 8 + 3) & ~3;     // k-groups of the packed weights (padded with zeros to a multiple of 4)
+  if (col_tile0 >= NT32) {   // wave-uniform: nothing of this layer falls to this wave; keep the two barriers
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   // Column tiles past the layer's width are clamped to the last one: fetched and multiplied like the others (no
   // branch in the pipelined loop), never stored.
   // B side: fragment (kg, nt) starts at byte ((kg * NT32 + nt) * 64) * 16 and this lane owns 16 bytes of it: a scalar
@@ -100,6 +105,7 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   };
   auto pattern = [&]() {   // one k-group: WM fragment reads and WN weight loads spread over the NMMA MFMAs
     constexpr int step = NMMA >= 2 * (WM + WN) + 2 ? 2 : 1;
+    static_assert(NMMA >= step * (WM + WN), "k-group too small for its memory operations");
 #pragma unroll
     for (int q = 0; q < WM; ++q) { FM_SGB(SG_MFMA, step); FM_SGB(SG_DS_RD, 1); }
 #pragma unroll
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(fm::NT) void mlp_fused_kernel(FusedMlpArgs args) {
     const FusedLayer& L = net.layer[l];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool last = l == net.n_layers - 1;
-    if (L.N <= 128) fused_layer_t<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, l, last);   // 32 x 64 per wave
+    if (L.N <= 32) fused_layer_t<1, 1>(net, L, M, m0, act, LDA, wave & 1, wave >> 1, l, last);          // 32 x 32, two waves
+    else if (L.N <= 128) fused_layer_t<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, l, last);   // 32 x 64 per wave
     else fused_layer_t<2, 4>(net, L, M, m0, act, LDA, 0, wave * 4, l, last);                            // 64 x 128 per wave
   }
 }

@@ -12,8 +12,9 @@ torch.manual_seed(0)
 net = create_model(lgd_config(12, True, 4), SMPLLayer(synthetic.make_model())).to(dev).eval()
 h = net._ensure_handle(dev)
 lib = _lib.lib()
-for kind in ('randn', 'zeros'):
-    x = torch.randn(T, 296, device=dev) if kind == 'randn' else torch.zeros(T, 296, device=dev)
+flush = torch.empty(160 * 1024 * 1024, device=dev)  # 640 MB: evicts L2 and the 256 MB Infinity Cache
+for kind in ('randn', 'zeros', 'randn+flush'):
+    x = torch.zeros(T, 296, device=dev) if kind == 'zeros' else torch.randn(T, 296, device=dev)
     dp, ds = torch.empty(T, 66, device=dev), torch.empty(T, 10, device=dev)
     nb = lib.empose_update_workspace_bytes(h, T); ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     def run():
@@ -23,6 +24,14 @@ for kind in ('randn', 'zeros'):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(3):
+        if kind.endswith('flush'):
+            tot = 0.0
+            for _ in range(10):
+                flush.fill_(1.0)
+                e0.record(); run(); e1.record(); torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            ts.append(tot / 10)
+            continue
         e0.record()
         for _ in range(10): run()
         e1.record(); torch.cuda.synchronize()
@@ -30,3 +39,11 @@ for kind in ('randn', 'zeros'):
     flops = 2.0 * T * ((296 * 512 + 4 * 512 * 512 + 512 * 66) + (296 * 512 + 4 * 512 * 512 + 512 * 10))
     t = min(ts)
     print('x=%s T=%d: %.1f us/launch  %.1f TFLOP/s' % (kind, T, t * 1e3, flops / t / 1e9))
+
+# sustained load: does the per-launch time drift once the chip is warm?
+x = torch.randn(T, 296, device=dev)
+for block in range(6):
+    e0.record()
+    for _ in range(100): run()
+    e1.record(); torch.cuda.synchronize()
+    print('sustained block %d: %.1f us/launch' % (block, e0.elapsed_time(e1) / 100 * 1e3))
