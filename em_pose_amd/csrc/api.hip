@@ -154,6 +154,22 @@ int build_chain_blob(const empose_smpl_desc& s, std::vector<uint32_t>& blob, Cha
   off.path_mask = put_i(path_mask);
   off.sub_mask = put_i(sub_mask);
   off.parents = put_i(parents);
+  {
+    // depth-first pre-order: every subtree is a contiguous range, so a subtree sum is a difference of prefix sums
+    std::vector<int> pos(22, 0), size(22, 0), stack, order;
+    stack.push_back(0);
+    while (!stack.empty()) {
+      const int j = stack.back();
+      stack.pop_back();
+      pos[j] = (int)order.size();
+      order.push_back(j);
+      for (int c = 21; c >= 1; --c)
+        if (parents[c] == j) stack.push_back(c);
+    }
+    for (int j = 0; j < 22; ++j) size[j] = __builtin_popcount((unsigned)sub_mask[j]);
+    off.dfs_pos = put_i(pos);
+    off.sub_size = put_i(size);
+  }
   off.skin_idx = put_i(std::vector<int>(s.skin_idx, s.skin_idx + (size_t)s.nv * s.kb));
   off.skin_w = put_f(s.skin_w, (size_t)s.nv * s.kb);
   // per-bone (vertex, weight) lists cut into chunks of CHAIN_CHUNK pairs, each chunk padded with (vertex 0, weight 0)

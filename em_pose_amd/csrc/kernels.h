@@ -96,8 +96,8 @@ constexpr int NB = 22;           // body joints
 // LDS record of one frame in chain_sensors_kernel (shared with the host, which packs LDS offsets into the tables).
 struct ChainLds {  // per-frame float offsets
   int rot, out, g, at, v, dv, u, total;
-  // inside u (time-shared): fn | fg | scr   then   part | m | x
-  int fn, fg, scr, part, m, x;
+  // inside u (time-shared): fn | fg | scr   then   part (later: pd, fp64 prefix sums) | m | x
+  int fn, fg, scr, part, pd, m, x;
 };
 
 __host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, int n_chunks) {
@@ -109,12 +109,15 @@ __host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, i
   l.at = o; o += NB * 3;    // A^t = G^t - G^R J
   l.v = o; o += nv * 3;
   l.dv = o; o += nv * 3;
+  o = (o + 1) & ~1;         // 8-byte alignment for the fp64 prefix sums (below)
   l.u = o;
   const int nf = 12 * max_deg;
   l.fn = l.u; l.fg = l.fn + nf * 3; l.scr = l.fg + nf * 6;
   const int sz1 = nf * 9 + 12 * 9;
-  l.part = l.u; l.m = l.part + n_chunks * 12; l.x = l.m + NB * 12;
-  const int sz2 = n_chunks * 12 + 2 * NB * 12;
+  const int pd_floats = (NB + 1) * 12 * 2;             // [23][12] doubles, aliases the chunk partial sums
+  const int part_size = n_chunks * 12 > pd_floats ? n_chunks * 12 : pd_floats;
+  l.part = l.u; l.pd = l.u; l.m = l.part + part_size; l.x = l.m + NB * 12;
+  const int sz2 = part_size + 2 * NB * 12;
   o += sz1 > sz2 ? sz1 : sz2;
   l.total = (o + 3) & ~3;
   return l;
@@ -124,6 +127,7 @@ __host__ __device__ inline ChainLds chain_layout(int nv, int ncp, int max_deg, i
 // Word offsets into the packed table blob that chain_sensors_kernel stages into LDS (all entries are 32-bit).
 struct ChainTabs {
   int path_mask, sub_mask, parents;       // [22] each: ancestors-or-self mask, subtree mask, parent index
+  int dfs_pos, sub_size;                  // [22] each: position of a joint in depth-first pre-order, size of its subtree
   int skin_idx, skin_w;                   // [nv*kb]
   int chunk_bone, chunk_beg;              // [n_chunks]: CHAIN_CHUNK-pair slices of the per-bone (vertex, weight) lists
   int bone_chunk_ptr;                     // [23]

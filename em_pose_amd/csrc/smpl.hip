@@ -661,36 +661,43 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
         else acc += dj[j * 3 + (e - 9)];
       }
     }
-    S[L.m + be] = acc;
+    S[L.m + (int)TI[O.dfs_pos + b] * 12 + e] = acc;   // stored in depth-first order for the prefix sums below
   }
   __syncthreads();
   CH_STAMP(9)
 
-  // ---- P6: subtree sums:  X_j = sum_sub M_b - Fs_j (x) t_j   (members taken four at a time: the LDS reads of a
-  // round are independent, the additions keep the ascending-joint order)
+  // ---- P6: subtree sums  X_j = sum_sub M_b - Fs_j (x) t_j.  With the bones in depth-first pre-order a subtree is a
+  // contiguous range, so the sum is a difference of two prefix sums; the prefix runs in fp64 (22 additions per lane), so
+  // the difference, rounded once to fp32, is the correctly rounded subtree sum.
+  for (int i = tid; i < nf * 12; i += CH_THREADS) {
+    int f, e;
+    frame_split(i, 12, f, e);
+    float* S = frames + f * L.total;
+    double* P = reinterpret_cast<double*>(S + L.pd);
+    float mv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) mv[k] = S[L.m + k * 12 + e];
+    double run = 0.0;
+    P[e] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { run += (double)mv[k]; P[(k + 1) * 12 + e] = run; }
+  }
+  __syncthreads();
   for (int i = tid; i < nf * NB * 12; i += CH_THREADS) {
     int f, je;
     frame_split(i, NB * 12, f, je);
     const int j = je / 12, e = je % 12;
     float* S = frames + f * L.total;
-    uint32_t sm = TI[O.sub_mask + j];
+    const double* P = reinterpret_cast<const double*>(S + L.pd);
+    const int p0 = TI[O.dfs_pos + j], p1 = p0 + (int)TI[O.sub_size + j];
     const int ar = e < 9 ? e / 3 : e - 9, cc = e % 3;
-    float ms = 0.f, fs = 0.f;
-    while (sm) {
-      float mv[4], fv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool on = sm != 0;
-        const int d = on ? __ffs(sm) - 1 : 0;
-        sm &= sm - 1;   // 0 stays 0
-        const float* Mb = S + L.m + d * 12;
-        mv[u] = on ? Mb[e] : 0.f;
-        fv[u] = on ? Mb[9 + ar] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { ms += mv[u]; fs += fv[u]; }
+    const float fs = (float)(P[p1 * 12 + 9 + ar] - P[p0 * 12 + 9 + ar]);
+    if (e < 9) {
+      const float ms = (float)(P[p1 * 12 + e] - P[p0 * 12 + e]);
+      S[L.x + je] = ms - fs * S[L.g + j * 12 + 9 + cc];
+    } else {
+      S[L.x + je] = fs;
     }
-    S[L.x + je] = e < 9 ? ms - fs * S[L.g + j * 12 + 9 + cc] : fs;
   }
   __syncthreads();
   CH_STAMP(10)
