@@ -323,8 +323,102 @@ static void lstm_build_chain(LstmWaveArgs& a, int units_per_block) {
   for (; z < 4; ++z) { a.z_beg[z] = 0; a.z_cnt[z] = 0; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (the one-recording-at-a-time driver: B = 1, F = 256): a step is a matrix-VECTOR product, bound by
+// streaming the weights (13.8 MB per wavefront step for 2 x 512), not by arithmetic; the matrix-core kernel above would
+// spend a 64-row tile on one row.  Here a wave owns one hidden unit of one layer: its lanes split K, read the four gate
+// rows of the unit as coalesced 16-byte pieces, and reduce with DPP shuffles; 4 units per block, so 2 x 128 blocks
+// keep every CU streaming.  Same operands (host-built segment table), same state handling as lstm_chain_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MB>   // rows handled, B <= MB
+__global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
+  const int n_seg = a.z_cnt[blockIdx.y];
+  if (n_seg == 0) return;
+  const int seg_beg = a.z_beg[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, B = a.B, F = a.F;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= H) return;   // no barrier below: whole waves may leave
+  const LstmUnitArgs& L = a.unit[a.seg[seg_beg].unit];
+  const int t = a.seg[seg_beg].k;
+  const int* __restrict__ lens = a.seq_lengths;
+
+  float acc[4][MB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[g][b] = 0.f;
+
+  for (int s = 0; s < 2; ++s) {
+    const LstmSeg sg = a.seg[seg_beg + s];
+    const float* __restrict__ wbase = sg.w + (size_t)unit * sg.ldw;
+    for (int k4 = lane * 4; k4 < sg.K; k4 += 256) {
+      f32x4 w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * H * sg.ldw + k4);
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        if (b >= B) break;   // uniform
+        const int tr = (lens ? lens[b] : F) - 1 - sg.k;
+        const float* row = sg.a + (size_t)b * sg.lda + (size_t)(tr > 0 ? tr : 0) * sg.tstride;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + k4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g][b] += w[g][0] * v[0] + w[g][1] * v[1] + w[g][2] * v[2] + w[g][3] * v[3];
+      }
+    }
+  }
+  // wave-wide sums (every lane ends up with all of them)
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      if (b >= B) break;
+      float v = acc[g][b];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[g][b] = v;
+    }
+  // lane b finishes row b
+  float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+    if (lane == b) { gi = acc[0][b]; gf = acc[1][b]; gg = acc[2][b]; go = acc[3][b]; }
+  if (lane < B) {
+    const int row = lane;
+    const bool rev = L.reverse != 0;
+    const float* __restrict__ bias = L.bias;
+    const float* __restrict__ h_prev = L.h[t & 1];
+    float* __restrict__ h_next = L.h[(t + 1) & 1];
+    float* __restrict__ cst = L.c;
+    const size_t hc = (size_t)row * H + unit;
+    const int len = lens ? lens[row] : F;
+    const bool live = t < len;
+    const int t_out = (rev && live) ? len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
+    float h_new = 0.f;
+    if (live) {
+      const float c_new = fsigmoid(gf + bias[H + unit]) * cst[hc] + fsigmoid(gi + bias[unit]) * ftanh(gg + bias[2 * H + unit]);
+      h_new = fsigmoid(go + bias[3 * H + unit]) * ftanh(c_new);
+      cst[hc] = c_new;
+      h_next[hc] = h_new;
+    } else {
+      h_next[hc] = h_prev[hc];
+    }
+    if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + unit] = h_new;
+  }
+}
+
+constexpr int LSTM_SMALL_B = 16;
+
 hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   LstmWaveArgs a = a_in;
+  if (a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
+    lstm_build_chain(a, 1);
+    dim3 grid((a.H + 3) / 4, a.n_units);
+    if (a.B <= 4) hipLaunchKernelGGL(lstm_small_kernel<4>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(lstm_small_kernel<LSTM_SMALL_B>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   const int tiles = ((a.H + lc::BU - 1) / lc::BU) * ((a.B + lc::BM - 1) / lc::BM);
   // Chain all units in one block (equal work per block) once the tiles alone fill the CUs; spread them otherwise.
   const int units_per_block = tiles >= 192 ? a.n_units : 1;
