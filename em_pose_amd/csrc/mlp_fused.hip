@@ -127,7 +127,7 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   fread(0, fa[0]);
   FM_STAMP(4 * layer_index + 1)
 
-  for (int g = 0; g < KG4; g += 4) {
+  auto quad = [&](int g) {   // four k-groups: ring slots 0..3 in turn
     fread(g + 1, fa[1]);
     bload(fb[3], g + 3);
     mma(fa[0], fb[0]);
@@ -144,7 +144,13 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
     bload(fb[2], g + 6);
     mma(fa[1], fb[3]);
     pattern();
-  }
+  };
+  // The first iteration is peeled: the loop header then merges two states with the same outstanding loads, and the
+  // compiler's wait-count insertion keeps the ring's prefetch distance (vmcnt(10)) instead of draining every load at
+  // the top of each iteration (vmcnt(0)).  Measured floor of this loop: 8272 cycles per four k-groups with no memory
+  // operations (8192 ideal), 8700 with the sixteen 1 KB weight-fragment loads, i.e. ~23 cycles per load.
+  quad(0);
+  for (int g = 4; g < KG4; g += 4) quad(g);
   FM_STAMP(4 * layer_index + 2)
 
   __syncthreads();   // every wave has read its last A fragment: the buffer may be overwritten
