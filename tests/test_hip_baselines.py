@@ -37,6 +37,8 @@ def _lstm_sd(layer):
     (True, 2, 144, 512, 33, 32),     # the released BiRNN width, rows not a multiple of the 64-row tile
     (True, 4, 16, 40, 4, 9),         # 8 units = the most the handle packs
     (False, 2, 144, 512, 70, 40),
+    (True, 2, 144, 64, 16, 9),       # the largest batch of the weight-streaming small-batch kernel ...
+    (True, 2, 144, 64, 17, 9),       # ... and the smallest of the matrix-core kernel
 ])
 def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
     """empose_rnn_fwd: ragged rows, both directions, given initial state, final state (reference layers.py:133-157)."""
