@@ -96,6 +96,14 @@ class SMPLFK(object):
         return batch
 
 
+def load_offsets_npz(path):
+    """One `*_offsets.npz` file of the reference (transforms.py:145-155): per-sensor offset means (M,3), covariances
+    (M,3,3), local-to-global orientation offsets r (M,3,3) and the sensor vertex ids (M,)."""
+    d = np.load(path)
+    return {'means': d['means'], 'covs': d['covs'] if 'covs' in d.files else None, 'r': d['r'],
+            'vertex_ids': d['vertex_ids']}
+
+
 class SampleMarkersWithOffsets(object):
     """
     Virtual sensors sampled from the ground-truth mesh with per-subject offsets applied
@@ -107,8 +115,10 @@ class SampleMarkersWithOffsets(object):
 
     def __init__(self, smpl_model, offset_sets):
         from em_pose_amd.data.virtual_sensors import VirtualMarkerHelper
-        if isinstance(offset_sets, dict):
+        if isinstance(offset_sets, (dict, str)):
             offset_sets = [offset_sets]
+        # the reference passes `*_offsets.npz` paths (transforms.py:142-155: keys means, covs, r, vertex_ids)
+        offset_sets = [load_offsets_npz(o) if isinstance(o, str) else o for o in offset_sets]
         self.n_offsets = len(offset_sets)
         self.offset_means = np.stack([np.asarray(o['means'], dtype=np.float32) for o in offset_sets])
         self.r = np.stack([np.asarray(o['r'], dtype=np.float32) for o in offset_sets])

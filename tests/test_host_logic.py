@@ -120,3 +120,18 @@ def test_resnet_plumbing_on_cpu():
                   torch.randn(1, 32, 36), torch.randn(1, 32, 108), torch.ones(1, 32, 12))
     out = net(b)
     assert out['pose_hat'].shape == (1, 32, 63) and out['root_ori_hat'].shape == (1, 32, 3)
+
+
+def test_offsets_npz_file_format(tmp_path):
+    """`*_offsets.npz` as the reference stores them (data/transforms.py:145-155) load into the transform's offset sets."""
+    from em_pose_amd.data.transforms import load_offsets_npz
+    rng = np.random.default_rng(0)
+    path = str(tmp_path / 'subject_offsets.npz')
+    means, covs, r = rng.normal(size=(12, 3)), rng.normal(size=(12, 3, 3)), rng.normal(size=(12, 3, 3))
+    vids = np.arange(12) * 7
+    np.savez(path, means=means, covs=covs, r=r, vertex_ids=vids)
+    o = load_offsets_npz(path)
+    np.testing.assert_array_equal(o['means'], means)
+    np.testing.assert_array_equal(o['r'], r)
+    np.testing.assert_array_equal(o['covs'], covs)
+    assert o['vertex_ids'].tolist() == vids.tolist()
