@@ -69,15 +69,20 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   fm_gbyte_t wb = (fm_gbyte_t)L.W;
   const float* a_rd = act + (row_tile0 * 32 + l31) * lda + lh * 4;   // A fragments: row tile i adds 32 rows, group g adds 8
 
-  // epilogue constants of this lane's columns, fetched now so that their latency hides under the K loop
+  // epilogue constants of this lane's columns, fetched now so that their latency hides under the K loop.  Columns past
+  // N (zero padding of the next layer's K) get scale = shift = 0, so the hidden epilogue needs no select for them.
+  // PReLU with a slope in [0, 1] is max(y, slope * y): the same bits as the select of the layer-by-layer epilogue, one
+  // instruction fewer; other slopes take the select.
   float e_sc[WN], e_sh[WN];
   const float e_slope = L.act == 1 ? L.slope : 1.f;
+  const bool slope_unit = e_slope >= 0.f && e_slope <= 1.f;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int n = (col_tile0 + j) * 32 + l31;
-    const int nc = n < N ? n : N - 1;
-    e_sc[j] = L.scale ? L.scale[nc] : 1.f;
-    e_sh[j] = L.shift ? L.shift[nc] : 0.f;
+    const bool real = n < N;
+    const int nc = real ? n : N - 1;
+    e_sc[j] = real ? (L.scale ? L.scale[nc] : 1.f) : 0.f;
+    e_sh[j] = real ? (L.shift ? L.shift[nc] : 0.f) : 0.f;
   }
 
   f32x16 acc[WM][WN];
@@ -170,16 +175,26 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
     for (int j = 0; j < WN; ++j) {
       const int n = (col_tile0 + j) * 32 + l31;
       if (col_tile0 + j >= NT32) continue;            // wave-uniform; NT32 * 32 == the next layer's padded K
-      const bool real = n < N;
+      // columns past N: 0 * acc + 0 = the next layer's zero padding
+      if (slope_unit) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float y = acc[i][j][r] * e_sc[j] + e_sh[j];
-          y = y >= 0.f ? y : e_slope * y;             // slope == 1 when there is no activation (exact identity)
-          act[row * lda + n] = real ? y : 0.f;        // columns past N are the next layer's zero padding
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float y = acc[i][j][r] * e_sc[j] + e_sh[j];
+            act[row * lda + n] = fmaxf(y, y * e_slope);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float y = acc[i][j][r] * e_sc[j] + e_sh[j];
+            act[row * lda + n] = y >= 0.f ? y : y * e_slope;
+          }
+      }
     }
   }
   __syncthreads();   // the next layer's A operand is complete
