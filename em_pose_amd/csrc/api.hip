@@ -112,8 +112,11 @@ struct empose_mesh {
   std::vector<void*> allocs;
   int V = 0, j_off = 0, ncp = 0, kb = 0;
   float* wc = nullptr;
+  float* wc_frag = nullptr;     // vertex rows of wc in matrix-core fragment order, per 32-vertex tile (mesh.hip)
   int* skin_idx = nullptr;
   float* skin_w = nullptr;
+  int* skin_idx4 = nullptr;     // first four bones / weights per vertex, padded to whole tiles
+  float* skin_w4 = nullptr;
   int* parents = nullptr;
 };
 
@@ -1087,6 +1090,36 @@ void empose_mesh_destroy(empose_mesh_t* mesh) {
   delete mesh;
 }
 
+// Tables of mesh_rows_kernel: for every 32-vertex tile, k-group of 8 and coordinate c, lane (v = lane & 31,
+// half = lane >> 5) owns wc[(tile * 32 + v) * 3 + c][kg * 8 + half * 4 .. + 3] -- the three coordinate planes of a tile
+// are separate 32-column operands, so a lane's accumulators hold x, y and z of the same vertex.  Vertices past V are
+// zero.  Skinning tables: the first four (bone, weight) pairs per vertex, zero-padded.
+static int pack_mesh_tiles(empose_mesh* m, const empose_mesh_desc* d) {
+  const int V = d->n_vertices, NT = (V + 31) / 32, KG = 25, K = 200;
+  std::vector<float> buf((size_t)NT * KG * 3 * 256, 0.f);
+  for (int t = 0; t < NT; ++t)
+    for (int kg = 0; kg < KG; ++kg)
+      for (int c = 0; c < 3; ++c)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int v = t * 32 + (lane & 31);
+          if (v >= V) continue;
+          const float* src = d->wc + ((size_t)v * 3 + c) * K + kg * 8 + (lane >> 5) * 4;
+          float* dst = &buf[((((size_t)t * KG + kg) * 3 + c) * 64 + lane) * 4];
+          for (int e = 0; e < 4; ++e) dst[e] = src[e];
+        }
+  TRY(upload(m->allocs, buf.data(), buf.size(), &m->wc_frag));
+  std::vector<int> idx4((size_t)NT * 32 * 4, 0);
+  std::vector<float> w4((size_t)NT * 32 * 4, 0.f);
+  for (int v = 0; v < V; ++v)
+    for (int k = 0; k < 4 && k < d->kb; ++k) {
+      idx4[(size_t)v * 4 + k] = d->skin_idx[(size_t)v * d->kb + k];
+      w4[(size_t)v * 4 + k] = d->skin_w[(size_t)v * d->kb + k];
+    }
+  TRY(upload(m->allocs, idx4.data(), idx4.size(), &m->skin_idx4));
+  TRY(upload(m->allocs, w4.data(), w4.size(), &m->skin_w4));
+  return EMPOSE_OK;
+}
+
 int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
   *out = nullptr;
@@ -1099,7 +1132,7 @@ int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if ((rc = upload(m->allocs, d->wc, (size_t)d->ncp * 200, &m->wc)) ||
       (rc = upload(m->allocs, d->skin_idx, (size_t)d->n_vertices * d->kb, &m->skin_idx)) ||
       (rc = upload(m->allocs, d->skin_w, (size_t)d->n_vertices * d->kb, &m->skin_w)) ||
-      (rc = upload(m->allocs, d->parents, 22, &m->parents))) {
+      (rc = upload(m->allocs, d->parents, 22, &m->parents)) || (rc = pack_mesh_tiles(m, d))) {
     empose_mesh_destroy(m);
     return rc;
   }
@@ -1162,7 +1195,9 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
     MeshSkinArgs sa;
     sa.feat = feat; sa.wc = mesh->wc; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
-    e = launch_mesh_skin(sa, stream);
+    sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
+    static const bool old_kernel = getenv("EMPOSE_MESH_OLD") != nullptr;
+    e = old_kernel ? launch_mesh_skin(sa, stream) : launch_mesh_rows(sa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;

@@ -1,0 +1,230 @@
+// Full-mesh SMPL-H evaluation (reference smpl_torch_batch.py / bodymodels' SMPLLayer forward: v_posed = v_template +
+// shapedirs . beta + posedirs . (R - I), then linear blend skinning of all V vertices), gfx950 only.
+//
+// One workgroup owns 64 frames for the whole launch: their 200 pose/shape features and their 22 relative bone
+// transforms stay in LDS (120 KB), and the workgroup's eight waves walk the 32-vertex tiles of the mesh.  For a tile a
+// wave computes v_posed of 32 vertices x 64 frames on the fp32 matrix cores -- six 32x32 accumulators: two frame
+// tiles x the three coordinate planes, so a lane ends up with x, y and z of the same (frame, vertex) pairs -- and skins
+// them in registers; the (T x 20670) v_posed matrix never exists in memory and the vertices are written once.
+// The coefficient matrix is consumed from L2 in matrix-core fragment order (one coalesced 1 KB read per k-group and
+// coordinate plane, packed by the host when the mesh handle is created) through a five-slot register ring that runs
+// four k-groups ahead and straight across tile boundaries; there is no barrier after the staging.  Two waves per SIMD:
+// one wave's skinning (LDS reads + VALU + stores) overlaps the other's matrix-core work.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace empose {
+
+namespace mr {
+constexpr int BM = 64;              // frames per workgroup
+constexpr int NW = 8;               // waves per workgroup
+constexpr int K = 200, KG = K / 8;  // 25 k-groups of 8
+constexpr int LDA = K + 4;
+constexpr int RING = 5;             // KG % RING == 0: a k-group's ring slot does not depend on the tile
+constexpr int A_FLOATS = BM * LDA;
+constexpr int XF_FLOATS = BM * NB * 12;
+constexpr int TR_FLOATS = BM * 4;
+constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + XF_FLOATS + TR_FLOATS) * sizeof(float) + 64;
+constexpr int TILE_FLOATS = KG * 3 * 256;   // one 32-vertex tile of the packed coefficients
+static_assert(KG % RING == 0, "ring slots must line up across tiles");
+}  // namespace mr
+
+#define MR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define MR_MFMA 0x008
+#define MR_VMEM_RD 0x020
+#define MR_DS_RD 0x100
+
+template <bool EXTRA>   // EXTRA: body models with more than four bones per vertex (not SMPL-H)
+__global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) {
+  using namespace mr;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;
+  float* XFs = lds + A_FLOATS;
+  float* TRs = XFs + XF_FLOATS;
+  const int T = a.T, V = a.V;
+  const int f0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- staging: features, relative transforms and translations of the block's frames (rows past T repeat row T-1;
+  // their results are never stored)
+  {
+    const float* __restrict__ feat = a.feat;
+    for (int i = tid; i < BM * (K / 4); i += NW * 64) {
+      const int r = i / (K / 4), c = (i % (K / 4)) * 4;
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      *reinterpret_cast<f32x4*>(As + r * LDA + c) = *reinterpret_cast<const f32x4*>(feat + (size_t)row * K + c);
+    }
+    if (tid < BM) *reinterpret_cast<f32x4*>(As + tid * LDA + K) = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ xf = a.xf;
+    for (int i = tid; i < BM * NB * 3; i += NW * 64) {
+      const int r = i / (NB * 3), c = i % (NB * 3);
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      *reinterpret_cast<f32x4*>(XFs + i * 4) = *reinterpret_cast<const f32x4*>(xf + ((size_t)row * NB * 3 + c) * 4);
+    }
+    if (tid < BM) {
+      const int row = f0 + tid < T ? f0 + tid : T - 1;
+      f32x4 t{0.f, 0.f, 0.f, 0.f};
+      if (a.trans) { t[0] = a.trans[(size_t)row * 3]; t[1] = a.trans[(size_t)row * 3 + 1]; t[2] = a.trans[(size_t)row * 3 + 2]; }
+      *reinterpret_cast<f32x4*>(TRs + tid * 4) = t;
+    }
+  }
+  __syncthreads();
+
+  // ---- this wave's tiles: vt = first + wave, + NW, ... below `end`
+  const int n_tiles = (V + 31) / 32;
+  const int per_block = (n_tiles + gridDim.y - 1) / gridDim.y;
+  const int first = blockIdx.y * per_block;
+  const int end = min(first + per_block, n_tiles);
+  int vt = first + wave;
+  if (vt >= end) return;
+
+  epi_cgbyte_t wbase = (epi_cgbyte_t)a.wc_frag;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto tile_base = [&](int t) { return wbase + (size_t)t * (TILE_FLOATS * 4); };
+  auto bload = [&](f32x4 (&dst)[3], epi_cgbyte_t base, int g) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dst[c] = *(const __attribute__((address_space(1))) f32x4*)(base + ((unsigned)((g * 3 + c) * 1024) + lane16));
+  };
+
+  f32x4 ring[RING][3];
+  {
+    epi_cgbyte_t b0 = tile_base(vt);
+#pragma unroll
+    for (int g = 0; g < RING - 1; ++g) bload(ring[g], b0, g);
+  }
+
+  const float* a_lane = As + l31 * LDA + lh * 4;
+  // A fragments: read one k-group ahead into three slots (k-groups u = 0..4 of a ring pass use slots 0,1,0,1,2, so the
+  // slot being filled is never the one being consumed although a pass has an odd number of k-groups)
+#define FA_SLOT(u) ((u) == RING - 1 ? 2 : ((u) & 1))
+  f32x4 fa[3][2];
+  fa[0][0] = *reinterpret_cast<const f32x4*>(a_lane);
+  fa[0][1] = *reinterpret_cast<const f32x4*>(a_lane + 32 * LDA);
+  epi_gbyte_t vbase = (epi_gbyte_t)a.vertices;
+  const int kb = a.kb;
+  const size_t vrow_bytes = (size_t)V * 12;
+
+  for (; vt < end; vt += NW) {
+    epi_cgbyte_t bcur = tile_base(vt);
+    // the prefetch runs into the wave's next tile; past the last one it re-reads this tile (never consumed)
+    epi_cgbyte_t bnext = vt + NW < end ? tile_base(vt + NW) : bcur;
+    const int s = vt * 32 + l31;            // this lane's vertex (the packed tables are padded to whole tiles)
+    const int4 bone4 = *reinterpret_cast<const int4*>(a.skin_idx4 + (size_t)s * 4);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.skin_w4 + (size_t)s * 4);
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+#pragma unroll 1
+    for (int g0 = 0; g0 < KG; g0 += RING) {
+#pragma unroll
+      for (int u = 0; u < RING; ++u) {
+        const int g = g0 + u;
+        {
+          // A fragments of the next k-group (k-group 0 again after the last one: the next tile starts there)
+          const int gn = g + 1 < KG ? g + 1 : 0;
+          f32x4 (&fn)[2] = fa[u + 1 == RING ? 0 : FA_SLOT(u + 1)];
+          fn[0] = *reinterpret_cast<const f32x4*>(a_lane + gn * 8);
+          fn[1] = *reinterpret_cast<const f32x4*>(a_lane + 32 * LDA + gn * 8);
+          const int gp = g + RING - 1;   // k-group to prefetch: this tile's, or the first ones of the next tile
+          epi_cgbyte_t src = gp < KG ? bcur : bnext - (size_t)KG * 3 * 1024;
+          bload(ring[(u + RING - 1) % RING], src, gp);
+        }
+        const f32x4 (&fc)[2] = fa[FA_SLOT(u)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc[i][e], ring[u][c][e], acc[i][c], 0, 0, 0);
+        // 24 MFMAs with the two fragment reads and the three weight loads spread between them
+        MR_SGB(MR_MFMA, 2) MR_SGB(MR_DS_RD, 1) MR_SGB(MR_MFMA, 2) MR_SGB(MR_DS_RD, 1)
+        MR_SGB(MR_MFMA, 2) MR_SGB(MR_VMEM_RD, 1) MR_SGB(MR_MFMA, 2) MR_SGB(MR_VMEM_RD, 1)
+        MR_SGB(MR_MFMA, 2) MR_SGB(MR_VMEM_RD, 1) MR_SGB(MR_MFMA, 14)
+      }
+    }
+
+    // ---- skinning of the lane's 32 (frame, vertex) pairs: blended 3x4 transform, then one mat-vec
+    // (reference order: T = sum_k w_k G_k, v = T . [v_posed, 1] + trans).  Addresses are a per-lane part that only
+    // depends on the tile (bones, vertex, lane half) plus a compile-time / wave-uniform part per accumulator element.
+    if (s < V) {
+      const char* xfl = reinterpret_cast<const char*>(XFs) + lh * (4 * NB * 48);
+      const char* xk[4] = {xfl + bone4.x * 48, xfl + bone4.y * 48, xfl + bone4.z * 48, xfl + bone4.w * 48};
+      const float w[4] = {w4[0], w4[1], w4[2], w4[3]};
+      const char* trl = reinterpret_cast<const char*>(TRs) + lh * 64;
+      const unsigned lane_off = ((unsigned)(f0 + 4 * lh) * (unsigned)V + (unsigned)s) * 12u;
+      auto skin = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);   // frame within the block, less 4 * lh
+            const float vx = acc[i][0][r], vy = acc[i][1][r], vz = acc[i][2][r];
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(trl + dm * 16);
+            float out[3];
+#pragma unroll
+            for (int row = 0; row < 3; ++row) {
+              float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const f32x4 gk = *reinterpret_cast<const f32x4*>(xk[k] + dm * (NB * 48) + row * 16);
+                T0 += w[k] * gk[0]; T1 += w[k] * gk[1]; T2 += w[k] * gk[2]; T3 += w[k] * gk[3];
+              }
+              if (EXTRA)
+                for (int k = 4; k < kb; ++k) {
+                  const int b = a.skin_idx[(size_t)s * kb + k];
+                  const float wk = a.skin_w[(size_t)s * kb + k];
+                  const f32x4 gk = *reinterpret_cast<const f32x4*>(xfl + b * 48 + dm * (NB * 48) + row * 16);
+                  T0 += wk * gk[0]; T1 += wk * gk[1]; T2 += wk * gk[2]; T3 += wk * gk[3];
+                }
+              out[row] = T0 * vx + T1 * vy + T2 * vz + T3;
+              out[row] += tr[row];
+            }
+            if (FULL || f0 + 4 * lh + dm < T) {
+              epi_gfloat_t o = (epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + lane_off);
+              o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+            }
+          }
+      };
+      if (f0 + BM <= T) skin(std::true_type{}); else skin(std::false_type{});
+    }
+  }
+}
+
+hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mr::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)mr::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int bx = (a.T + mr::BM - 1) / mr::BM;
+  const int n_tiles = (a.V + 31) / 32;
+  // fewer than one workgroup per CU: split the mesh's tiles over grid.y (at least one tile per wave)
+  int by = bx >= 256 ? 1 : (256 + bx - 1) / bx;
+  const int max_by = (n_tiles + mr::NW - 1) / mr::NW;
+  if (by > max_by) by = max_by;
+  if (a.kb > 4)
+    hipLaunchKernelGGL(mesh_rows_kernel<true>, dim3(bx, by), dim3(mr::NW * 64), mr::LDS_BYTES, stream, a);
+  else
+    hipLaunchKernelGGL(mesh_rows_kernel<false>, dim3(bx, by), dim3(mr::NW * 64), mr::LDS_BYTES, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace empose

@@ -482,6 +482,37 @@ def test_full_mesh_vertices_vs_oracle(big_model):
     np.testing.assert_allclose(v0[1].cpu().numpy(), v0[0].cpu().numpy(), atol=0)
 
 
+def test_full_mesh_ragged_sizes_and_many_bones():
+    """mesh_rows_kernel edge cases: 1 frame, frame counts that are not multiples of the 64-frame block (one and several
+    blocks per CU column), no translation, and a body model whose vertices are skinned by up to
+    six bones (the kernel keeps four in registers and loops over the rest)."""
+    model = dict(H.small_model())
+    V = model['v_template'].shape[0]
+    rng = np.random.default_rng(11)
+    w = np.array(model['weights'], dtype=np.float64, copy=True)
+    for v in range(0, V, 3):                      # every third vertex: six bones
+        bones = rng.choice(22, size=6, replace=False)
+        w[v] = 0
+        w[v, bones] = rng.uniform(0.1, 1.0, size=6)
+        w[v] /= w[v].sum()
+    model['weights'] = w.astype(model['weights'].dtype)
+    from em_pose_amd.bodymodels import tables as TB
+    assert TB.build_full_mesh_tables(model)['kb'] == 6
+    bm = R.BodyModelTensors(model)
+    smpl = SMPLLayer(model).to(DEV)
+    for n, with_trans in ((1, True), (131, False), (700, True)):
+        pose = rng.normal(0, 0.4, size=(n, 63)).astype(np.float32)
+        root = rng.normal(0, 0.5, size=(n, 3)).astype(np.float32)
+        betas = rng.normal(0, 1, size=(n, 10)).astype(np.float32)
+        trans = rng.normal(0, 1, size=(n, 3)).astype(np.float32) if with_trans else None
+        v_ref, j_ref = R.smpl_fk(bm, torch.from_numpy(pose), torch.from_numpy(betas), torch.from_numpy(root),
+                                 torch.from_numpy(trans) if with_trans else None)
+        v, j = smpl(poses_body=gpu(pose), betas=gpu(betas), poses_root=gpu(root),
+                    trans=gpu(trans) if with_trans else None)
+        np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
+        np.testing.assert_allclose(j.cpu().numpy(), j_ref[:, :22].numpy(), atol=2e-5)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def test_streaming_evaluation_driver_matches_oracle_chunk_by_chunk():
     """evaluate_real's loop: one 600-frame recording, 256-frame chunks, LSTM state carried chunk to chunk, missing
