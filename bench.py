@@ -184,7 +184,7 @@ def run_vertices(args, dev):
                      'peak': PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS,
                      'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
                      'frac': tfl / PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else hbm / PEAK_HBM_GBS, 'traffic': None,
-                     'kernel': 'update_feat + rest-joint gemm + mesh_chain + mesh_fused_kernel (device time of the call)',
+                     'kernel': 'update_feat + rest-joint gemm + mesh_chain + mesh_rows_kernel (device time of the call)',
                      'device_ms_per_step': dev_ms, 'hbm_GBs_on_algorithmic_bytes': hbm,
                      'hbm_frac': hbm / PEAK_HBM_GBS, 'fp32_mfma_TFLOPs': tfl, 'mfma_frac': tfl / PEAK_FP32_MFMA_TFLOPS,
                      'algorithmic_bytes_per_frame': bytes_frame, 'flops_per_frame': flops_frame}}))

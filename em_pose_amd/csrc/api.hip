@@ -1196,8 +1196,7 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
     sa.feat = feat; sa.wc = mesh->wc; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
-    static const bool old_kernel = getenv("EMPOSE_MESH_OLD") != nullptr;
-    e = old_kernel ? launch_mesh_skin(sa, stream) : launch_mesh_rows(sa, stream);
+    e = launch_mesh_rows(sa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;

@@ -234,7 +234,6 @@ struct MeshSkinArgs {
   const float* wc_frag;        // [tiles][25][3][64][4]: wc in fragment order per 32-vertex tile (api.hip pack_mesh_tiles)
   const int* skin_idx4; const float* skin_w4;   // [tiles * 32][4]
 };
-hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream);
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream);
 
 struct VirtualSensorArgs {

@@ -8,8 +8,13 @@
 // them in registers; the (T x 20670) v_posed matrix never exists in memory and the vertices are written once.
 // The coefficient matrix is consumed from L2 in matrix-core fragment order (one coalesced 1 KB read per k-group and
 // coordinate plane, packed by the host when the mesh handle is created) through a five-slot register ring that runs
-// four k-groups ahead and straight across tile boundaries; there is no barrier after the staging.  Two waves per SIMD:
-// one wave's skinning (LDS reads + VALU + stores) overlaps the other's matrix-core work.
+// four k-groups ahead and straight across tile boundaries; there is no barrier after the staging.
+// Measured (scripts/dev/mesh_lab.hip, T = 16384): a tile costs a wave 41.1k cycles of K loop (600 MFMAs, 38.4k ideal)
+// plus 11.1k cycles of skinning when it has its SIMD to itself.  The second wave per SIMD hides load and LDS latency
+// but does not overlap the two phases: fp32 vector FMAs and fp32 MFMAs share the SIMD's FMA lanes (the chip's vector
+// and matrix fp32 peaks are the same number), so the cost is the sum of both, and the kernel runs at the power limit
+// (~2.1 GHz).  The skinning is therefore written for the fewest vector instructions: packed FMAs on the halves of
+// each 16-byte transform row.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
@@ -17,6 +22,8 @@
 #include "kernels.h"
 
 namespace empose {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace mr {
 constexpr int BM = 64;              // frames per workgroup
@@ -31,6 +38,14 @@ constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + XF_FLOATS + TR_FLOATS) * sizeof
 constexpr int TILE_FLOATS = KG * 3 * 256;   // one 32-vertex tile of the packed coefficients
 static_assert(KG % RING == 0, "ring slots must line up across tiles");
 }  // namespace mr
+
+#ifdef EMPOSE_MESH_TRACE   // dev lab only (scripts/dev/mesh_lab.hip): shader-clock stamps of the waves of block (0,0)
+__device__ long long g_mesh_trace[8 * 32 * 4];
+#define MR_STAMP(tile, i) \
+  if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_mesh_trace[(wave * 32 + (tile)) * 4 + (i)] = clock64();
+#else
+#define MR_STAMP(tile, i)
+#endif
 
 #define MR_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 #define MR_MFMA 0x008
@@ -109,7 +124,8 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
   const int kb = a.kb;
   const size_t vrow_bytes = (size_t)V * 12;
 
-  for (; vt < end; vt += NW) {
+  for (int seq = 0; vt < end; vt += NW, ++seq) {
+    MR_STAMP(seq, 0)
     epi_cgbyte_t bcur = tile_base(vt);
     // the prefetch runs into the wave's next tile; past the last one it re-reads this tile (never consumed)
     epi_cgbyte_t bnext = vt + NW < end ? tile_base(vt + NW) : bcur;
@@ -155,13 +171,14 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
       }
     }
 
+    MR_STAMP(seq, 1)
     // ---- skinning of the lane's 32 (frame, vertex) pairs: blended 3x4 transform, then one mat-vec
     // (reference order: T = sum_k w_k G_k, v = T . [v_posed, 1] + trans).  Addresses are a per-lane part that only
     // depends on the tile (bones, vertex, lane half) plus a compile-time / wave-uniform part per accumulator element.
     if (s < V) {
       const char* xfl = reinterpret_cast<const char*>(XFs) + lh * (4 * NB * 48);
       const char* xk[4] = {xfl + bone4.x * 48, xfl + bone4.y * 48, xfl + bone4.z * 48, xfl + bone4.w * 48};
-      const float w[4] = {w4[0], w4[1], w4[2], w4[3]};
+      const f32x2 wp[4] = {{w4[0], w4[0]}, {w4[1], w4[1]}, {w4[2], w4[2]}, {w4[3], w4[3]}};
       const char* trl = reinterpret_cast<const char*>(TRs) + lh * 64;
       const unsigned lane_off = ((unsigned)(f0 + 4 * lh) * (unsigned)V + (unsigned)s) * 12u;
       auto skin = [&](auto full_tag) {
@@ -176,21 +193,24 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
             float out[3];
 #pragma unroll
             for (int row = 0; row < 3; ++row) {
-              float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
+              // (T0, T1) and (T2, T3) as register pairs: two packed FMAs per bone on the halves of the 16-byte read
+              f32x4 gk = *reinterpret_cast<const f32x4*>(xk[0] + dm * (NB * 48) + row * 16);
+              f32x2 Ta = wp[0] * f32x2{gk[0], gk[1]}, Tb = wp[0] * f32x2{gk[2], gk[3]};
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const f32x4 gk = *reinterpret_cast<const f32x4*>(xk[k] + dm * (NB * 48) + row * 16);
-                T0 += w[k] * gk[0]; T1 += w[k] * gk[1]; T2 += w[k] * gk[2]; T3 += w[k] * gk[3];
+              for (int k = 1; k < 4; ++k) {
+                gk = *reinterpret_cast<const f32x4*>(xk[k] + dm * (NB * 48) + row * 16);
+                Ta = __builtin_elementwise_fma(wp[k], f32x2{gk[0], gk[1]}, Ta);
+                Tb = __builtin_elementwise_fma(wp[k], f32x2{gk[2], gk[3]}, Tb);
               }
               if (EXTRA)
                 for (int k = 4; k < kb; ++k) {
                   const int b = a.skin_idx[(size_t)s * kb + k];
                   const float wk = a.skin_w[(size_t)s * kb + k];
-                  const f32x4 gk = *reinterpret_cast<const f32x4*>(xfl + b * 48 + dm * (NB * 48) + row * 16);
-                  T0 += wk * gk[0]; T1 += wk * gk[1]; T2 += wk * gk[2]; T3 += wk * gk[3];
+                  gk = *reinterpret_cast<const f32x4*>(xfl + b * 48 + dm * (NB * 48) + row * 16);
+                  Ta = __builtin_elementwise_fma(f32x2{wk, wk}, f32x2{gk[0], gk[1]}, Ta);
+                  Tb = __builtin_elementwise_fma(f32x2{wk, wk}, f32x2{gk[2], gk[3]}, Tb);
                 }
-              out[row] = T0 * vx + T1 * vy + T2 * vz + T3;
-              out[row] += tr[row];
+              out[row] = __builtin_fmaf(Ta[0], vx, __builtin_fmaf(Ta[1], vy, __builtin_fmaf(Tb[0], vz, Tb[1]))) + tr[row];
             }
             if (FULL || f0 + 4 * lh + dm < T) {
               epi_gfloat_t o = (epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + lane_off);
@@ -200,6 +220,7 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
       };
       if (f0 + BM <= T) skin(std::true_type{}); else skin(std::false_type{});
     }
+    MR_STAMP(seq, 2)
   }
 }
 

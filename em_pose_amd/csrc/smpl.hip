@@ -793,159 +793,7 @@ hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Fused full-mesh kernel: v_posed = feat . Wc^T on the fp32 matrix cores and linear blend skinning in the epilogue, so
-// the (T x 20670) v_posed matrix never exists in memory: per frame 800 B of features + 1 KB of relative transforms
-// are read and the 82.7 KB of vertices are written once.
-// Block = 64 frames x 64 vertices, 2x2 waves; a wave keeps three 32x32 accumulators (x, y, z of 32 vertices for 32
-// frames), so a lane holds all three coordinates of one (frame, vertex) pair and skins it without cross-lane traffic.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int MF_BK = 32, MF_LD = MF_BK + 4, MF_FR = 64, MF_VT = 64;
-constexpr int MF_OPER_FLOATS = (MF_FR + 3 * MF_VT) * MF_LD;   // A tile + 3 coordinate planes of W
-constexpr int MF_XF_FLOATS = MF_FR * NB * 12;                 // relative transforms of the block's frames
-constexpr int MF_LDS_FLOATS = MF_OPER_FLOATS > MF_XF_FLOATS ? MF_OPER_FLOATS : MF_XF_FLOATS;
-
-__global__ __launch_bounds__(256) void mesh_fused_kernel(MeshSkinArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;
-  float* Bs = lds + MF_FR * MF_LD;
-  const int f0 = blockIdx.y * MF_FR, s0 = blockIdx.x * MF_VT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wrow = wave >> 1, wcol = wave & 1, l31 = lane & 31, lh = lane >> 5;
-  const int K = 200;
-
-  f32x16 acc[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-
-  // operand staging with a one-tile register prefetch (as in gemm_f32.hip)
-  float4 ra[2], rb[6];
-  auto load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int slot = tid + i * 256, r = slot >> 3, c4 = (slot & 7) * 4;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f0 + r < a.T && k0 + c4 < K) ra[i] = *reinterpret_cast<const float4*>(a.feat + (size_t)(f0 + r) * K + k0 + c4);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int slot = tid + i * 256, r = slot >> 3, c4 = (slot & 7) * 4;  // r = c * 64 + v
-      const int c = r >> 6, sv = s0 + (r & 63);
-      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (sv < a.V && k0 + c4 < K) rb[i] = *reinterpret_cast<const float4*>(a.wc + ((size_t)sv * 3 + c) * K + k0 + c4);
-    }
-  };
-  auto store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int slot = tid + i * 256;
-      *reinterpret_cast<float4*>(As + (slot >> 3) * MF_LD + (slot & 7) * 4) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int slot = tid + i * 256;
-      *reinterpret_cast<float4*>(Bs + (slot >> 3) * MF_LD + (slot & 7) * 4) = rb[i];
-    }
-  };
-  load(0);
-  store();
-  __syncthreads();
-  for (int k0 = 0; k0 < K; k0 += MF_BK) {
-    const bool more = k0 + MF_BK < K;
-    if (more) load(k0 + MF_BK);
-#pragma unroll
-    for (int kk = 0; kk < MF_BK / 8; ++kk) {
-      const float4 av = *reinterpret_cast<const float4*>(As + (wrow * 32 + l31) * MF_LD + kk * 8 + lh * 4);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float4 bv = *reinterpret_cast<const float4*>(Bs + (c * 64 + wcol * 32 + l31) * MF_LD + kk * 8 + lh * 4);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[c], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    if (more) {
-      store();
-      __syncthreads();
-    }
-  }
-
-  // relative transforms of the block's frames -> LDS (operand tiles are dead now)
-  {
-    const int n4 = MF_FR * NB * 3;  // float4 count
-    const int nfr = min(MF_FR, a.T - f0);
-    const float4* src = reinterpret_cast<const float4*>(a.xf + (size_t)f0 * NB * 12);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < n4; i += 256) dst[i] = i < nfr * NB * 3 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-
-  const int s = s0 + wcol * 32 + l31;
-  if (s >= a.V) return;
-  int bone[4];
-  float w[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bone[k] = k < a.kb ? a.skin_idx[(size_t)s * a.kb + k] : 0;
-    w[k] = k < a.kb ? a.skin_w[(size_t)s * a.kb + k] : 0.f;
-  }
-  const float4* XF = reinterpret_cast<const float4*>(lds);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int fl = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    const int t = f0 + fl;
-    if (t >= a.T) continue;
-    const float vx = acc[0][r], vy = acc[1][r], vz = acc[2][r];
-    float out[3];
-#pragma unroll
-    for (int row = 0; row < 3; ++row) {
-      float T0 = 0.f, T1 = 0.f, T2 = 0.f, T3 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 g = XF[(fl * NB + bone[k]) * 3 + row];
-        T0 += w[k] * g.x; T1 += w[k] * g.y; T2 += w[k] * g.z; T3 += w[k] * g.w;
-      }
-      out[row] = T0 * vx + T1 * vy + T2 * vz + T3;
-      if (a.trans) out[row] += a.trans[(size_t)t * 3 + row];
-    }
-    float* o = a.vertices + ((size_t)t * a.V + s) * 3;
-    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
-  }
-  // vertices with more than 4 weights (kb > 4) take the slow generic path
-  if (a.kb > 4) {
-    for (int r = 0; r < 16; ++r) {
-      const int fl = wrow * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int t = f0 + fl;
-      if (t >= a.T) continue;
-      float* o = a.vertices + ((size_t)t * a.V + s) * 3;
-      for (int k = 4; k < a.kb; ++k) {
-        const float wk = a.skin_w[(size_t)s * a.kb + k];
-        const int b = a.skin_idx[(size_t)s * a.kb + k];
-        for (int row = 0; row < 3; ++row) {
-          const float4 g = XF[(fl * NB + b) * 3 + row];
-          o[row] += wk * (g.x * acc[0][r] + g.y * acc[1][r] + g.z * acc[2][r] + g.w);
-        }
-      }
-    }
-  }
-}
-
-hipError_t launch_mesh_skin(const MeshSkinArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)MF_LDS_FLOATS * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  dim3 grid((a.V + MF_VT - 1) / MF_VT, (a.T + MF_FR - 1) / MF_FR);
-  hipLaunchKernelGGL(mesh_fused_kernel, grid, dim3(256), lds, stream, a);
-  return hipGetLastError();
-}
+// The dense skinning of all V vertices is mesh.hip's mesh_rows_kernel.
 
 // ---------------------------------------------------------------------------------------------------------------
 // Virtual sensors from arbitrary full-mesh vertices (reference virtual_sensors.py:16-38,77-96; utils.py:126-146):
