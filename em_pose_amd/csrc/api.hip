@@ -349,6 +349,7 @@ struct LstmWs {
   float* h[8][2];
   float* c[8];
   float* yb[2];   // [B][F][2H] ping-pong between the layers of a bidirectional stack
+  float* xch;     // exchange words of the whole-sequence small-batch kernel (lstm_persist_kernel), or nullptr
 };
 LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
@@ -362,6 +363,7 @@ LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   const bool need_y = r.dirs == 2 && r.num_layers > 1;
   w.yb[0] = need_y ? c.f((size_t)B * F * 2 * H) : nullptr;
   w.yb[1] = (need_y && r.num_layers > 2) ? c.f((size_t)B * F * 2 * H) : nullptr;
+  w.xch = (r.dirs == 1 && B <= LSTM_PERSIST_B) ? c.f(lstm_persist_xch_floats(r.num_layers, B, H)) : nullptr;
   return w;
 }
 LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) { return carve_lstm_of(c, m->rnn, B, F); }
@@ -495,7 +497,16 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
       ua.t_offset = l;
       if (l == L - 1) { ua.y = y; ua.y_ld = H; }
     }
-    for (int s = 0; s < F + L - 1; ++s) {
+    // Small batches: the whole sequence in one cooperative launch (weights in registers, grid barrier per step).
+    bool done = false;
+    const char* sw = getenv("EMPOSE_LSTM_PERSIST");   // dev A/B switch: "0" = step launch by launch
+    if (ws.xch && F >= 4 && !(sw && sw[0] == '0')) {
+      prof_mark(P_LSTM_STEP, stream);
+      a.s = 0;
+      hipError_t e = launch_lstm_persist(a, ws.xch, stream, &done);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel: %s", hipGetErrorString(e));
+    }
+    for (int s = 0; !done && s < F + L - 1; ++s) {
       a.s = s;
       prof_mark(P_LSTM_STEP, stream);
       hipError_t e = launch_lstm_wave(a, stream);

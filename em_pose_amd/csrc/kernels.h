@@ -86,6 +86,10 @@ struct LstmWaveArgs {
   int z_beg[4], z_cnt[4];
 };
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
+// Whole sequence of a stacked uni-directional LSTM in one cooperative launch (B <= 16); *done = false: not covered.
+constexpr int LSTM_PERSIST_B = 16;   // largest batch of the whole-sequence kernel
+size_t lstm_persist_xch_floats(int n_units, int B, int H);   // its exchange buffer (8-byte aligned)
+hipError_t launch_lstm_persist(const LstmWaveArgs& a, float* xch, hipStream_t stream, bool* done);
 
 // ---------------------------------------------------------------------------------------------------------------
 // SMPL sub-mesh kernels

@@ -18,6 +18,9 @@
 // (row half x gate), so i/f/g/o of one (row, unit) sit in the same lane; a block is 2x2 waves = 64 rows x 32 units.
 // Since a dot product does not care about the order of k, each 16-lane group takes 4 consecutive k of a 16-wide chunk
 // so that one ds_read_b128 feeds four MFMAs.
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace empose {
@@ -330,6 +333,11 @@ static void lstm_build_chain(LstmWaveArgs& a, int units_per_block) {
 // rows of the unit as coalesced 16-byte pieces, and reduce with DPP shuffles; 4 units per block, so 2 x 128 blocks
 // keep every CU streaming.  Same operands (host-built segment table), same state handling as lstm_chain_kernel.
 // ---------------------------------------------------------------------------------------------------------------
+// acc + w . v over a lane's four k, in one fixed order (explicit FMAs: both small-batch kernels give the same bits)
+__device__ __forceinline__ float dot4_acc(float acc, const f32x4& w, const f32x4& v) {
+  return __builtin_fmaf(w[3], v[3], __builtin_fmaf(w[2], v[2], __builtin_fmaf(w[1], v[1], __builtin_fmaf(w[0], v[0], acc))));
+}
+
 template <int MB>   // rows handled, B <= MB
 __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
   const int n_seg = a.z_cnt[blockIdx.y];
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
         const float* row = sg.a + (size_t)b * sg.lda + (size_t)(tr > 0 ? tr : 0) * sg.tstride;
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + k4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g][b] += w[g][0] * v[0] + w[g][1] * v[1] + w[g][2] * v[2] + w[g][3] * v[3];
+        for (int g = 0; g < 4; ++g) acc[g][b] = dot4_acc(acc[g][b], w[g], v);
       }
     }
   }
@@ -408,11 +416,306 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches, whole sequence in ONE launch (the streaming driver: B = 1, F = 256 is 257 dependent wavefront steps).
+// The per-step launches above pay a dispatch per step (~6 us back to back) to stream 13.8 MB of weights that never
+// change.  Here a wave owns one hidden unit of one layer for the whole sequence and keeps that unit's four gate rows in
+// REGISTERS (2 x 512: 4 x 1024 floats over 64 lanes = 64 VGPRs), its lanes b < B keep c and h of the unit; a block is
+// four units of one layer and stages the step's input rows ([x_t | h_{t-1}] or [h^{l-1}_t | h^l_{t-1}]) in LDS once.
+// What crosses blocks per step is only the new hidden state (B x H floats per layer).  There is no grid barrier: every
+// exchanged value is an 8-byte word {value, tag = producing step + 1} written with one agent-scope store, and a consumer
+// polls the words it needs until they carry the tag it expects -- the step-to-step critical path is one store reaching
+// the memory side plus one load (a counter barrier costs two more round trips: measured 5.9 us per step against 17 us
+// with cache-wide release/acquire fences).  Two buffers suffice: a block that overwrites the buffer of step s at step
+// s + 2 has consumed every block's step s + 1 output, which those blocks produced after reading step s.
+// The kernel is launched cooperatively (all blocks resident), the polls are bounded: a word that never arrives poisons
+// the outputs with NaN instead of hanging the GPU.  Same arithmetic, in the same order, as lstm_small_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+struct LstmPersistArgs {
+  LstmUnitArgs unit[4];
+  int n_units;
+  const int* seq_lengths;
+  int B, F, H;
+  unsigned long long* xch;   // [2][n_units][B][H] exchange words, zeroed before the launch
+  int spin_limit;
+};
+
+__device__ __forceinline__ unsigned long long xch_pack(float v, unsigned tag) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+template <int P0, int P1>   // 256-wide pieces of the input / recurrent segment (K <= 256 * P)
+__global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];   // [B][K0 + NL * H]: x_t | h^0 | h^1 | ...
+  __shared__ int fail_lds[1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) fail_lds[0] = 0;
+  const int NL = a.n_units, H = a.H, B = a.B, F = a.F;
+  // Every block holds units of ALL layers (wave w: layer w % NL): a block that has staged step s + 1 has then consumed
+  // the step-s outputs of every layer, which is what makes two exchange buffers enough (see above).
+  const int l = wave % NL;
+  const int unit = blockIdx.x * (4 / NL) + wave / NL;
+  const bool have_unit = unit < H;
+  const LstmUnitArgs& U = a.unit[l];
+  const int KX = a.unit[0].in_k;              // stored input of layer 0
+  const int ldr = KX + NL * H;
+  const int K0 = U.in_k, K1 = H;
+  const int in_off = l == 0 ? 0 : KX + (l - 1) * H, rec_off = KX + l * H;
+  const int* __restrict__ lens = a.seq_lengths;
+  const size_t xch_layer = (size_t)B * H, xch_buf = (size_t)NL * xch_layer;
+
+  // this unit's gate rows -> registers
+  f32x4 w0[P0][4], w1[P1][4];
+#pragma unroll
+  for (int p = 0; p < P0; ++p)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k4 = lane * 4 + p * 256;
+      w0[p][g] = (have_unit && k4 < K0) ? *reinterpret_cast<const f32x4*>(U.w_ih + ((size_t)g * H + unit) * K0 + k4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+  for (int p = 0; p < P1; ++p)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k4 = lane * 4 + p * 256;
+      w1[p][g] = (have_unit && k4 < K1) ? *reinterpret_cast<const f32x4*>(U.w_hh + ((size_t)g * H + unit) * K1 + k4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (have_unit)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = U.bias[g * H + unit];
+  // lane b < B: state of (row b, unit)
+  const bool row_lane = have_unit && lane < B;
+  const size_t hc = (size_t)lane * H + unit;
+  float c_reg = row_lane ? U.c[hc] : 0.f;
+  float h_reg = row_lane ? U.h[0][hc] : 0.f;
+  const int len = row_lane ? (lens ? lens[lane] : F) : 0;
+  bool failed = false;
+  __syncthreads();
+
+  const int S = F + NL - 1;
+  for (int s = 0; s < S; ++s) {
+    const int k = s - l;   // this wave's time step (layer l runs one wavefront step behind layer l - 1)
+    // ---- stage the step's rows.  Stored sequence / initial state: plain loads; hidden states produced inside this
+    // launch: exchange words of wavefront step s - 1, which carry tag s.
+    {
+      const unsigned long long* xprev = a.xch + (size_t)((s - 1) & 1) * xch_buf;
+      bool bad = false;
+      if (s < F)
+        for (int i = tid; i < B * KX; i += 256) {
+          const int b = i / KX, c = i - b * KX;
+          rows[b * ldr + c] = a.unit[0].in_seq[((size_t)b * F + s) * a.unit[0].in_ld + c];
+        }
+      // Hidden-state slots, all layers in one sweep: "row" q = hl * B + b is the state of layer hl, batch row b, after
+      // the layer's step kp = s - 1 - hl, produced at wavefront step s - 1 (kp == -1: the layer starts now, initial
+      // state; otherwise unused).  A chunk of polls costs one round trip to the memory side, so a thread keeps RQ rows x
+      // P1 words in flight; rows and layers are uniform loop counters, so no per-word index division.
+      auto sweep = [&](auto rq_tag) {
+        constexpr int RQ = decltype(rq_tag)::value;
+        const int n_rows = NL * B;
+        for (int q0 = 0; q0 < n_rows; q0 += RQ) {
+          unsigned long long wv[RQ][P1];
+          int hl = q0 / B, b = q0 - hl * B;   // uniform
+#pragma unroll
+          for (int u = 0; u < RQ; ++u) {
+            const bool valid = q0 + u < n_rows;
+            const int kp = s - 1 - hl;
+#pragma unroll
+            for (int p = 0; p < P1; ++p) {
+              const int j = tid + p * 256;
+              wv[u][p] = (unsigned long long)(unsigned)s << 32;     // "nothing to wait for"
+              if (valid && j < H) {
+                const size_t m = ((size_t)hl * B + b) * H + j;
+                if (kp >= 0 && kp < F) wv[u][p] = __hip_atomic_load(xprev + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (kp == -1) wv[u][p] |= __float_as_uint(a.unit[hl].h[0][(size_t)b * H + j]);
+              }
+            }
+            if (++b == B) { b = 0; ++hl; }
+          }
+          hl = q0 / B; b = q0 - hl * B;
+#pragma unroll
+          for (int u = 0; u < RQ; ++u) {
+            const bool valid = q0 + u < n_rows;
+#pragma unroll
+            for (int p = 0; p < P1; ++p) {
+              const int j = tid + p * 256;
+              if (valid && j < H) {
+                const size_t m = ((size_t)hl * B + b) * H + j;
+                int spins = 0;
+                while ((unsigned)(wv[u][p] >> 32) != (unsigned)s) {
+                  if (++spins > a.spin_limit) { bad = true; break; }
+                  __builtin_amdgcn_s_sleep(1);
+                  wv[u][p] = __hip_atomic_load(xprev + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                rows[b * ldr + KX + hl * H + j] = __uint_as_float((unsigned)wv[u][p]);
+              }
+            }
+            if (++b == B) { b = 0; ++hl; }
+          }
+        }
+      };
+      if (NL * B <= 4) sweep(std::integral_constant<int, 4>{});
+      else if (NL * B <= 8) sweep(std::integral_constant<int, 8>{});
+      else sweep(std::integral_constant<int, 16>{});
+      if (bad) fail_lds[0] = 1;
+    }
+    __syncthreads();
+    if (fail_lds[0]) failed = true;
+    if (have_unit && k >= 0 && k < F) {
+      for (int b0 = 0; b0 < B; b0 += 4) {
+        float acc[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[g][b] = 0.f;
+#pragma unroll
+        for (int p = 0; p < P0; ++p) {
+          const int k4 = lane * 4 + p * 256;
+          if (k4 < K0)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              if (b0 + b >= B) break;   // uniform
+              const f32x4 v = *reinterpret_cast<const f32x4*>(rows + (b0 + b) * ldr + in_off + k4);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g][b] = dot4_acc(acc[g][b], w0[p][g], v);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P1; ++p) {
+          const int k4 = lane * 4 + p * 256;
+          if (k4 < K1)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              if (b0 + b >= B) break;
+              const f32x4 v = *reinterpret_cast<const f32x4*>(rows + (b0 + b) * ldr + rec_off + k4);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g][b] = dot4_acc(acc[g][b], w1[p][g], v);
+            }
+        }
+        // Wave-wide sums of the 16 (gate, row) partials as a reduce-scatter: at offset 32 a lane keeps 8 of them, at 16
+        // four, ... so 8 + 4 + 2 + 1 + 2 shuffles instead of 16 x 6.  The pairs added at each offset are the ones of the
+        // xor butterfly of lstm_small_kernel, so the sums have the same bits.
+        float r8[8], r4[4], r2[2], r1;
+        {
+          const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0, hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float lo = acc[j >> 2][j & 3], hi = acc[2 + (j >> 2)][j & 3];   // values j and j + 8 (index g * 4 + b)
+            r8[j] = (hi32 ? hi : lo) + __shfl_xor(hi32 ? lo : hi, 32, 64);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r4[j] = (hi16 ? r8[j + 4] : r8[j]) + __shfl_xor(hi16 ? r8[j] : r8[j + 4], 16, 64);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) r2[j] = (hi8 ? r4[j + 2] : r4[j]) + __shfl_xor(hi8 ? r4[j] : r4[j + 2], 8, 64);
+          r1 = (hi4 ? r2[1] : r2[0]) + __shfl_xor(hi4 ? r2[0] : r2[1], 4, 64);
+          r1 += __shfl_xor(r1, 2, 64);
+          r1 += __shfl_xor(r1, 1, 64);
+        }
+        // lane 4 * q (and its quad) now holds value q' with bits (q >> 3, q >> 2 & 1, q >> 1 & 1, q & 1) = (hi32, hi16,
+        // hi8, hi4) of the lane, i.e. value index = lane >> 2 read as g * 4 + b.  Row b's lane collects its four gates.
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int r1i = __float_as_int(r1);
+          const float vi = __int_as_float(__builtin_amdgcn_readlane(r1i, 4 * (0 * 4 + b)));
+          const float vf = __int_as_float(__builtin_amdgcn_readlane(r1i, 4 * (1 * 4 + b)));
+          const float vg = __int_as_float(__builtin_amdgcn_readlane(r1i, 4 * (2 * 4 + b)));
+          const float vo = __int_as_float(__builtin_amdgcn_readlane(r1i, 4 * (3 * 4 + b)));
+          if (lane == b0 + b) { gi = vi; gf = vf; gg = vg; go = vo; }
+        }
+        if (lane >= b0 && lane < b0 + 4 && lane < B) {   // lane b finishes row b
+          const bool live = k < len;
+          float h_new = 0.f;
+          if (live) {
+            const float c_new = fsigmoid(gf + bias[1]) * c_reg + fsigmoid(gi + bias[0]) * ftanh(gg + bias[2]);
+            h_new = fsigmoid(go + bias[3]) * ftanh(c_new);
+            c_reg = c_new;
+            h_reg = h_new;
+          }
+          const float poison = __builtin_nanf("");
+          __hip_atomic_store(a.xch + (size_t)(s & 1) * xch_buf + (size_t)l * xch_layer + hc,
+                             xch_pack(failed ? poison : h_reg, (unsigned)(s + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (U.y) U.y[((size_t)lane * F + k) * U.y_ld + U.y_col + unit] = failed ? poison : h_new;
+        }
+      }
+    }
+    __syncthreads();   // the rows are re-staged next step
+  }
+  if (row_lane) {
+    const float poison = __builtin_nanf("");
+    U.c[hc] = failed ? poison : c_reg;
+    U.h[F & 1][hc] = failed ? poison : h_reg;   // where the step-by-step kernels leave the final state
+  }
+}
+
+template <int P0, int P1>
+static hipError_t launch_lstm_persist_cfg(LstmPersistArgs& a, size_t lds, int grid, hipStream_t stream, bool* fits) {
+  static int capacity = -1;
+  static size_t attr = 0;
+  const void* fn = reinterpret_cast<const void*>(lstm_persist_kernel<P0, P1>);
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+    capacity = -1;
+  }
+  if (capacity < 0) {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, attr);
+    if (e != hipSuccess) return e;
+    capacity = per_cu * prop.multiProcessorCount;
+  }
+  *fits = grid <= capacity;
+  if (!*fits) return hipSuccess;
+  void* params[] = {&a};
+  return hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), params, (unsigned)lds, stream);
+}
+
+size_t lstm_persist_xch_floats(int n_units, int B, int H) { return (size_t)2 * n_units * B * H * 2; }
+
+// Whole-sequence launch for a stacked uni-directional LSTM on a small batch; *done = false when the configuration is
+// outside what the kernel covers (the caller then steps the wavefront launch by launch).
+hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t stream, bool* done) {
+  *done = false;
+  static const int persist_b = getenv("EMPOSE_LSTM_PERSIST_B") ? atoi(getenv("EMPOSE_LSTM_PERSIST_B")) : LSTM_PERSIST_B;  // dev
+  if (w.B > persist_b || w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512) return hipSuccess;
+  if (w.n_units != 1 && w.n_units != 2 && w.n_units != 4) return hipSuccess;   // a block's four waves cover all layers
+  int k0max = 0;
+  for (int u = 0; u < w.n_units; ++u) {
+    const LstmUnitArgs& U = w.unit[u];
+    if (U.reverse || U.in_k % 4 != 0 || U.in_k > 512 || U.t_offset != u) return hipSuccess;
+    if (u == 0 ? U.in_from >= 0 : U.in_from != u - 1) return hipSuccess;
+    k0max = U.in_k > k0max ? U.in_k : k0max;
+  }
+  LstmPersistArgs a;
+  for (int u = 0; u < 4; ++u) a.unit[u] = w.unit[u < w.n_units ? u : 0];
+  a.n_units = w.n_units; a.seq_lengths = w.seq_lengths; a.B = w.B; a.F = w.F; a.H = w.H;
+  a.xch = reinterpret_cast<unsigned long long*>(xch); a.spin_limit = 1 << 20;
+  const size_t lds = (size_t)w.B * (w.unit[0].in_k + w.n_units * w.H) * sizeof(float);
+  const int grid = (w.H * w.n_units + 3) / 4;
+  if (lds > 128 * 1024) return hipSuccess;
+  hipError_t e = hipMemsetAsync(xch, 0, lstm_persist_xch_floats(w.n_units, w.B, w.H) * sizeof(float), stream);
+  if (e != hipSuccess) return e;
+  const bool wide_in = k0max > 256, wide_h = w.H > 256;
+  if (wide_in && wide_h) e = launch_lstm_persist_cfg<2, 2>(a, lds, grid, stream, done);
+  else if (wide_h) e = launch_lstm_persist_cfg<1, 2>(a, lds, grid, stream, done);
+  else if (wide_in) e = launch_lstm_persist_cfg<2, 1>(a, lds, grid, stream, done);
+  else e = launch_lstm_persist_cfg<1, 1>(a, lds, grid, stream, done);
+  return e;
+}
+
 constexpr int LSTM_SMALL_B = 16;
 
 hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   LstmWaveArgs a = a_in;
-  if (a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
+  static const int small_b = getenv("EMPOSE_LSTM_SMALL_B") ? atoi(getenv("EMPOSE_LSTM_SMALL_B")) : LSTM_SMALL_B;  // dev
+  if (a.B <= small_b && a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
     lstm_build_chain(a, 1);
     dim3 grid((a.H + 3) / 4, a.n_units);
     if (a.B <= 4) hipLaunchKernelGGL(lstm_small_kernel<4>, grid, dim3(256), 0, stream, a);

@@ -39,6 +39,10 @@ def _lstm_sd(layer):
     (False, 2, 144, 512, 70, 40),
     (True, 2, 144, 64, 16, 9),       # the largest batch of the weight-streaming small-batch kernel ...
     (True, 2, 144, 64, 17, 9),       # ... and the smallest of the matrix-core kernel
+    (False, 2, 60, 512, 1, 40),      # whole-sequence kernel (uni-directional, B <= 16): the LGD init RNN, streaming
+    (False, 2, 144, 512, 16, 33),    # ... its largest batch
+    (False, 4, 300, 256, 3, 12),     # ... four layers, input wider than 256
+    (False, 1, 16, 8, 2, 4),         # ... one layer, shortest sequence it takes
 ])
 def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
     """empose_rnn_fwd: ragged rows, both directions, given initial state, final state (reference layers.py:133-157)."""
@@ -71,6 +75,32 @@ def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
         np.testing.assert_allclose(g.final_state[0].cpu().numpy(), wh.numpy(), atol=ATOL)
         np.testing.assert_allclose(g.final_state[1].cpu().numpy(), wc.numpy(), atol=ATOL)
         layer = g.cpu()
+    layer.release()
+
+
+def test_whole_sequence_kernel_equals_step_launches(monkeypatch):
+    """B <= 16 uni-directional stacks run the whole sequence in one cooperative launch (lstm_persist_kernel); the same
+    call stepped launch by launch (lstm_small_kernel, dev switch EMPOSE_LSTM_PERSIST=0) gives the same bits: outputs,
+    final state, ragged rows, state carry over two chunks."""
+    torch.manual_seed(5)
+    layer = RNNLayer(60, 512, 2).eval()
+    x = torch.randn(6, 64, 60)
+    lens = torch.tensor([64, 1, 33, 64, 17, 2])
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('EMPOSE_LSTM_PERSIST', mode)
+        g = layer.to(DEV)
+        g.init_state = None
+        outs = []
+        for chunk in range(2):
+            y = g(x[:, chunk * 32:(chunk + 1) * 32].contiguous().to(DEV), (lens - chunk * 32).clamp(0, 32).clamp(min=1).to(DEV))
+            g.init_state = g.final_state
+            outs += [y.cpu(), g.final_state[0].cpu(), g.final_state[1].cpu()]
+        res[mode] = outs
+        layer = g.cpu()
+    for p_, s_ in zip(res['1'], res['0']):
+        assert torch.isfinite(p_).all()
+        assert torch.equal(p_, s_)
     layer.release()
 
 
