@@ -105,6 +105,9 @@ def main():
     p.add_argument('--json', action='store_true', help='Also print one machine-readable JSON line.')
     p.add_argument('--sequential', action='store_true',
                    help='One recording at a time like the reference; default: chunk c of all recordings as one batch.')
+    p.add_argument('--no_warmup', action='store_true',
+                   help='Do not run the first chunk of the first recording once before the timed evaluation '
+                        '(code-object loading, workspace allocation).')
     args = p.parse_args()
 
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
@@ -123,6 +126,9 @@ def main():
     mine = partition_sequences(lengths, world)[rank]
     batches = [load(i) for i in mine]  # data preparation is outside the timed region
     net.keep_history = False
+    if batches and not args.no_warmup:
+        from em_pose_amd.eval.helpers import window_generator
+        evaluate_sequences(net, [next(iter(window_generator(batches[0], 256)))], smpl, device, window_size=256)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
