@@ -18,7 +18,6 @@
 // (row half x gate), so i/f/g/o of one (row, unit) sit in the same lane; a block is 2x2 waves = 64 rows x 32 units.
 // Since a dot product does not care about the order of k, each 16-lane group takes 4 consecutive k of a 16-wide chunk
 // so that one ds_read_b128 feeds four MFMAs.
-#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -674,7 +673,11 @@ static hipError_t launch_lstm_persist_cfg(LstmPersistArgs& a, size_t lds, int gr
   *fits = grid <= capacity;
   if (!*fits) return hipSuccess;
   void* params[] = {&a};
-  return hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), params, (unsigned)lds, stream);
+  if (hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), params, (unsigned)lds, stream) != hipSuccess) {
+    (void)hipGetLastError();   // no cooperative launch in this context: the caller steps launch by launch
+    *fits = false;
+  }
+  return hipSuccess;
 }
 
 size_t lstm_persist_xch_floats(int n_units, int B, int H) { return (size_t)2 * n_units * B * H * 2; }
@@ -683,8 +686,7 @@ size_t lstm_persist_xch_floats(int n_units, int B, int H) { return (size_t)2 * n
 // outside what the kernel covers (the caller then steps the wavefront launch by launch).
 hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t stream, bool* done) {
   *done = false;
-  static const int persist_b = getenv("EMPOSE_LSTM_PERSIST_B") ? atoi(getenv("EMPOSE_LSTM_PERSIST_B")) : LSTM_PERSIST_B;  // dev
-  if (w.B > persist_b || w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512) return hipSuccess;
+  if (w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512) return hipSuccess;
   if (w.n_units != 1 && w.n_units != 2 && w.n_units != 4) return hipSuccess;   // a block's four waves cover all layers
   int k0max = 0;
   for (int u = 0; u < w.n_units; ++u) {
@@ -714,8 +716,7 @@ constexpr int LSTM_SMALL_B = 16;
 
 hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   LstmWaveArgs a = a_in;
-  static const int small_b = getenv("EMPOSE_LSTM_SMALL_B") ? atoi(getenv("EMPOSE_LSTM_SMALL_B")) : LSTM_SMALL_B;  // dev
-  if (a.B <= small_b && a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
+  if (a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
     lstm_build_chain(a, 1);
     dim3 grid((a.H + 3) / 4, a.n_units);
     if (a.B <= 4) hipLaunchKernelGGL(lstm_small_kernel<4>, grid, dim3(256), 0, stream, a);

@@ -18,4 +18,9 @@ rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 5 --warmup 1 --no_cpu_baseline --no_profile > $OUT.log 2>&1 )
 cp $OUT/lgd_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_lgdrnn12_b1024.csv
 rm -rf $OUT
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o v -- python $R/bench.py --workload vertices --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
+cp $OUT/v_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_t16384.csv
+rm -rf $OUT
+python scripts/dev/bench_lstm_small.py > gpurun_out/${TAG}_lstm_small_batch_per_step.txt 2>&1
+python scripts/dev/prof_seq.py > gpurun_out/${TAG}_streaming_forward_b1_f256.txt 2>&1
 ls -la gpurun_out | grep $TAG
