@@ -453,9 +453,10 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
   const int NL = a.n_units, H = a.H, B = a.B, F = a.F;
   // Every block holds units of ALL layers (wave w: layer w % NL): a block that has staged step s + 1 has then consumed
   // the step-s outputs of every layer, which is what makes two exchange buffers enough (see above).
+  const int upb = 4 / NL;                       // units per layer per block (a 3-layer stack leaves one wave idle)
   const int l = wave % NL;
-  const int unit = blockIdx.x * (4 / NL) + wave / NL;
-  const bool have_unit = unit < H;
+  const int unit = blockIdx.x * upb + wave / NL;
+  const bool have_unit = wave < upb * NL && unit < H;
   const LstmUnitArgs& U = a.unit[l];
   const int KX = a.unit[0].in_k;              // stored input of layer 0
   const int ldr = KX + NL * H;
@@ -686,8 +687,8 @@ size_t lstm_persist_xch_floats(int n_units, int B, int H) { return (size_t)2 * n
 // outside what the kernel covers (the caller then steps the wavefront launch by launch).
 hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t stream, bool* done) {
   *done = false;
-  if (w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512) return hipSuccess;
-  if (w.n_units != 1 && w.n_units != 2 && w.n_units != 4) return hipSuccess;   // a block's four waves cover all layers
+  if (w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512 || w.n_units < 1 || w.n_units > 4) return hipSuccess;
+  // (a block's four waves cover all layers: 4, 2 or 1 units of each)
   int k0max = 0;
   for (int u = 0; u < w.n_units; ++u) {
     const LstmUnitArgs& U = w.unit[u];
@@ -700,7 +701,8 @@ hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t st
   a.n_units = w.n_units; a.seq_lengths = w.seq_lengths; a.B = w.B; a.F = w.F; a.H = w.H;
   a.xch = reinterpret_cast<unsigned long long*>(xch); a.spin_limit = 1 << 20;
   const size_t lds = (size_t)w.B * (w.unit[0].in_k + w.n_units * w.H) * sizeof(float);
-  const int grid = (w.H * w.n_units + 3) / 4;
+  const int upb = 4 / w.n_units;
+  const int grid = (w.H + upb - 1) / upb;
   if (lds > 128 * 1024) return hipSuccess;
   hipError_t e = hipMemsetAsync(xch, 0, lstm_persist_xch_floats(w.n_units, w.B, w.H) * sizeof(float), stream);
   if (e != hipSuccess) return e;

@@ -31,7 +31,7 @@ def _lstm_sd(layer):
 
 @pytest.mark.parametrize('bi,L,In,Hd,B,F', [
     (False, 1, 8, 4, 1, 1),          # smallest legal shapes
-    (False, 3, 72, 36, 5, 7),        # hidden size not a multiple of the 32-unit tile
+    (False, 3, 72, 36, 5, 7),        # hidden size not a multiple of the 32-unit tile; three layers, small batch
     (True, 1, 12, 32, 3, 5),
     (True, 2, 144, 64, 7, 24),
     (True, 2, 144, 512, 33, 32),     # the released BiRNN width, rows not a multiple of the 64-row tile
@@ -43,6 +43,7 @@ def _lstm_sd(layer):
     (False, 2, 144, 512, 16, 33),    # ... its largest batch
     (False, 4, 300, 256, 3, 12),     # ... four layers, input wider than 256
     (False, 1, 16, 8, 2, 4),         # ... one layer, shortest sequence it takes
+    (False, 3, 60, 512, 2, 20),      # ... three layers (one idle wave per block)
 ])
 def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
     """empose_rnn_fwd: ragged rows, both directions, given initial state, final state (reference layers.py:133-157)."""
