@@ -326,6 +326,160 @@ static void lstm_build_chain(LstmWaveArgs& a, int units_per_block) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Medium batches (17 .. 256 rows: the batched evaluation driver runs chunk c of all recordings as one ragged batch).
+// With the 64 x 32 tile of lstm_chain_kernel such a batch is 16 .. 64 workgroups whose waves each walk the whole K of
+// their unit (35 us per step however few rows there are).  Here a workgroup owns 32 rows x 16 hidden units of ONE unit
+// and its four waves SPLIT K: wave w takes the 16-wide chunk w of every 64-wide K tile (32 MFMAs per tile instead of
+// 128), and the partial gate sums meet in LDS at the end, added in wave order (deterministic).  Four times as many
+// workgroups, a quarter of the MFMA chain per wave.  Same operands (segment table, two segments per unit), same LDS
+// tile layout (XOR-swizzled 16-byte chunks) and fragment order as lstm_chain_kernel; no instruction-level pipelining:
+// at this size the launch is latency-bound, two workgroups per CU overlap instead.
+// ---------------------------------------------------------------------------------------------------------------
+namespace lm {
+constexpr int BM = 32, BU = 16, BK = 64;
+constexpr int ROWS = BM + 4 * BU;          // 96 staged rows per K tile
+constexpr int STAGE = ROWS * BK;
+constexpr size_t LDS_BYTES = 2 * (size_t)STAGE * sizeof(float);   // 48 KB; the reduction reuses it (4 x 32 x 64 floats)
+}  // namespace lm
+
+__global__ __launch_bounds__(256) void lstm_mid_kernel(LstmWaveArgs a) {
+  using namespace lm;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int H = a.H, B = a.B, F = a.F;
+  const int j0 = blockIdx.x * BU, m0 = blockIdx.y * BM;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int seg_beg = a.z_beg[blockIdx.z], n_seg = a.z_cnt[blockIdx.z];
+  if (n_seg == 0) return;
+  const int u = a.seg[seg_beg].unit;
+  const LstmUnitArgs& L = a.unit[u];
+  const int t = a.seg[seg_beg].k;
+
+  // ---- staging: thread (lr, c16) moves the 16-byte chunk c16 of rows lr + 16 i: i = 0, 1 input rows, 2..5 weight rows
+  const int lr = tid >> 4, c16 = tid & 15;
+  int a_row[2], a_len[2], w_row[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = m0 + lr + 16 * i;
+    a_row[i] = r < B ? r : B - 1;
+    a_len[i] = a.seq_lengths ? a.seq_lengths[a_row[i]] : F;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int un = j0 + lr;
+    w_row[i] = i * H + (un < H ? un : H - 1);     // gate i, unit j0 + lr
+  }
+  const int wr_ofs = lr * BK + ((c16 ^ lr) << 2);
+  const int sw = ((((wave << 2) ^ (l15 & 12)) | (lq ^ (l15 & 3))) << 2);   // this wave's k chunk, swizzled for row l15
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 g[6];
+  auto gload = [&](const LstmSeg& sg, int kt) {
+    const bool ok = kt * BK + c16 * 4 < sg.K;           // lanes past K stage zeros
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int tr = a_len[i] - 1 - sg.k;
+      const float* p = sg.a + (size_t)a_row[i] * sg.lda + (size_t)(tr > 0 ? tr : 0) * sg.tstride + kt * BK + c16 * 4;
+      g[i] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* p = sg.w + (size_t)w_row[i] * sg.ldw + kt * BK + c16 * 4;
+      g[2 + i] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(st + wr_ofs + i * 16 * BK) = g[i];
+  };
+
+  // flat tile stream over the unit's two segments
+  const LstmSeg s0 = a.seg[seg_beg], s1 = a.seg[seg_beg + 1];
+  const int n_tiles = s0.ntiles + s1.ntiles;
+  auto tile_load = [&](int j) { if (j < s0.ntiles) gload(s0, j); else gload(s1, j - s0.ntiles); };
+
+  // what the cell update reads besides the sums: fetched now, used after the K loop.  Wave w finishes the elements
+  // e = 2w, 2w + 1 of the 16x16 C/D layout (row = i * 16 + 4 * (lane >> 4) + r with e = 4 i + r, col = lane & 15).
+  const int e_unit = j0 + l15, e_unit_c = e_unit < H ? e_unit : H - 1;
+  float e_bias[4], e_c[2], e_hp[2];
+  int e_len[2], e_rowi[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) e_bias[q] = L.bias[q * H + e_unit_c];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int e = 2 * wave + x, row = m0 + (e >> 2) * 16 + lq * 4 + (e & 3);
+    const int rc = row < B ? row : B - 1;
+    e_rowi[x] = row;
+    e_c[x] = L.c[(size_t)rc * H + e_unit_c];
+    e_len[x] = a.seq_lengths ? a.seq_lengths[rc] : F;
+    e_hp[x] = L.h[t & 1][(size_t)rc * H + e_unit_c];
+  }
+
+  tile_load(0);
+  lwrite(lds);
+  if (n_tiles > 1) tile_load(1);
+  __syncthreads();
+  for (int j = 0; j < n_tiles; ++j) {
+    const float* cur = lds + (j & 1) * STAGE;
+    float* nxt = lds + ((j + 1) & 1) * STAGE;
+    f32x4 fa[2], fb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(cur + (i * 16 + l15) * BK + sw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x4*>(cur + (BM + q * BU + l15) * BK + sw);
+    if (j + 1 < n_tiles) lwrite(nxt);           // tile j + 1 (in registers since the previous iteration)
+    if (j + 2 < n_tiles) tile_load(j + 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[q][e], acc[i][q], 0, 0, 0);
+    __syncthreads();
+  }
+
+  // ---- partial sums of the four k chunks -> LDS [wave][element e][gate q][lane], summed in wave order
+  float* red = lds;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 8 + i * 4 + r) * 4 + q) * 64 + lane] = acc[i][q][r];
+  __syncthreads();
+  if (e_unit >= H) return;
+  const bool rev = L.reverse != 0;
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int e = 2 * wave + x, row = e_rowi[x];
+    if (row >= B) continue;
+    float gs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = red[((0 * 8 + e) * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int w2 = 1; w2 < 4; ++w2) v += red[((w2 * 8 + e) * 4 + q) * 64 + lane];
+      gs[q] = v;
+    }
+    const size_t hc = (size_t)row * H + e_unit;
+    const bool live = t < e_len[x];
+    const int t_out = (rev && live) ? e_len[x] - 1 - t : t;
+    const float c_new = fsigmoid(gs[1] + e_bias[1]) * e_c[x] + fsigmoid(gs[0] + e_bias[0]) * ftanh(gs[2] + e_bias[2]);
+    const float h_new = fsigmoid(gs[3] + e_bias[3]) * ftanh(c_new);
+    if (live) L.c[hc] = c_new;
+    L.h[(t + 1) & 1][hc] = live ? h_new : e_hp[x];
+    if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + e_unit] = live ? h_new : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Small batches (the one-recording-at-a-time driver: B = 1, F = 256): a step is a matrix-VECTOR product, bound by
 // streaming the weights (13.8 MB per wavefront step for 2 x 512), not by arithmetic; the matrix-core kernel above would
 // spend a 64-row tile on one row.  Here a wave owns one hidden unit of one layer: its lanes split K, read the four gate
@@ -715,6 +869,9 @@ hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t st
 }
 
 constexpr int LSTM_SMALL_B = 16;
+// lstm_mid_kernel against lstm_chain_kernel, us per wavefront step of the 2 x 512 stack (scripts/dev/bench_lstm_mid.py):
+// B = 17..128: 17 vs 36, B = 256: 22 vs 37, B = 512: 44 vs 37.
+constexpr int LSTM_MID_B = 256;
 
 hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   LstmWaveArgs a = a_in;
@@ -723,6 +880,19 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
     dim3 grid((a.H + 3) / 4, a.n_units);
     if (a.B <= 4) hipLaunchKernelGGL(lstm_small_kernel<4>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(lstm_small_kernel<LSTM_SMALL_B>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
+  if (a.B <= LSTM_MID_B) {   // K split over the waves of 32 x 16 tiles, one z slice per unit
+    lstm_build_chain(a, 1);
+    static bool mid_attr = false;
+    if (!mid_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_mid_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm::LDS_BYTES);
+      if (e != hipSuccess) return e;
+      mid_attr = true;
+    }
+    dim3 grid((a.H + lm::BU - 1) / lm::BU, (a.B + lm::BM - 1) / lm::BM, a.n_units);
+    hipLaunchKernelGGL(lstm_mid_kernel, grid, dim3(256), lm::LDS_BYTES, stream, a);
     return hipGetLastError();
   }
   const int tiles = ((a.H + lc::BU - 1) / lc::BU) * ((a.B + lc::BM - 1) / lc::BM);

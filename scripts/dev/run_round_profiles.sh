@@ -10,8 +10,8 @@ python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_
 python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
 python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
-python scripts/evaluate_real.py --synthetic --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
-python scripts/evaluate_real.py --synthetic --sequential --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
+python scripts/evaluate_real.py --synthetic --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
+python scripts/evaluate_real.py --synthetic --sequential --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
@@ -22,5 +22,6 @@ rm -rf $OUT
 cp $OUT/v_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_t16384.csv
 rm -rf $OUT
 python scripts/dev/bench_lstm_small.py > gpurun_out/${TAG}_lstm_small_batch_per_step.txt 2>&1
+python scripts/dev/bench_lstm_mid.py > gpurun_out/${TAG}_lstm_medium_batch_per_step.txt 2>&1
 python scripts/dev/prof_seq.py > gpurun_out/${TAG}_streaming_forward_b1_f256.txt 2>&1
 ls -la gpurun_out | grep $TAG
