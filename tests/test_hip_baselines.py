@@ -37,6 +37,8 @@ def _lstm_sd(layer):
     (True, 2, 144, 512, 33, 32),     # the released BiRNN width, rows not a multiple of the 64-row tile
     (True, 4, 16, 40, 4, 9),         # 8 units = the most the handle packs
     (False, 2, 144, 512, 70, 40),
+    (False, 2, 72, 36, 40, 9),       # K-split kernel (17..256 rows): hidden size not a multiple of its 16-unit tile
+    (True, 1, 20, 24, 257, 5),       # ... and the first batch past it (chain kernel), both directions
     (True, 2, 144, 64, 16, 9),       # the largest batch of the weight-streaming small-batch kernel ...
     (True, 2, 144, 64, 17, 9),       # ... and the smallest of the matrix-core kernel
     (False, 2, 60, 512, 1, 40),      # whole-sequence kernel (uni-directional, B <= 16): the LGD init RNN, streaming
