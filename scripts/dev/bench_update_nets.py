@@ -47,3 +47,15 @@ for block in range(6):
     for _ in range(100): run()
     e1.record(); torch.cuda.synchronize()
     print('sustained block %d: %.1f us/launch' % (block, e0.elapsed_time(e1) / 100 * 1e3))
+
+# what precedes the launch: the same call timed alone after ~1 ms of other work (the in-step situation)
+big = torch.randn(64 * 1024 * 1024, device=dev)
+for name, other in (('idle 2 ms', lambda: torch.cuda._sleep(int(2e-3 * 2.4e9))),
+                    ('elementwise over 256 MB x4', lambda: [big.mul_(1.0001) for _ in range(4)]),
+                    ('nothing', lambda: None)):
+    tot = 0.0
+    for _ in range(20):
+        other()
+        e0.record(); run(); e1.record(); torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    print('after %-28s: %.1f us/launch' % (name, tot / 20 * 1e3))
