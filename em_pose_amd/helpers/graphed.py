@@ -1,0 +1,67 @@
+"""
+One training step (forward + loss + backward) captured in a HIP graph.
+
+The reference's batch of 12 windows is launch-bound on an MI355X: about 2000 small kernels per step, 11 ms of kernel time
+inside a 22 ms step.  Capturing forward + backward once and replaying it removes the per-launch host cost; the gradient
+all-reduce and the optimizer stay outside the graph.  Static shapes only: every batch must have the shape of the batch
+the graph was captured with, and every window must span all F frames (the LSTM then runs without sequence packing,
+which needs a host round trip).
+"""
+import torch
+
+
+class GraphedTrainStep(object):
+    FIELDS = ('poses', 'shapes', 'trans', 'marker_pos_synth', 'marker_ori_synth', 'offset_t_augmented',
+              'offset_r_augmented', 'joints_gt', 'seq_lengths')
+
+    def __init__(self, net, optimizer, example_batch, warmup=3):
+        import copy
+        F = example_batch.seq_length
+        if int(example_batch.seq_lengths.min()) != F:
+            raise ValueError('a captured training step needs full-length windows')
+        self.net, self.optimizer = net, optimizer
+        self.static = copy.copy(example_batch)
+        for k in self.FIELDS:
+            v = getattr(example_batch, k, None)
+            if torch.is_tensor(v):
+                setattr(self.static, k, v.clone())
+        net.full_windows = True
+        # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
+        # workspaces on the first call on a stream, which is not allowed while capturing).
+        # The LSTM runs as PyTorch's native cell-by-cell implementation inside the graph: capturing MIOpen's RNN
+        # crashes in hipStreamEndCapture from 32 time steps on (nn.LSTM(144, 512, 2) on (T, 12, 144): T <= 31 captures,
+        # T >= 32 segfaults; scripts/dev/dbg_lstm_graph.py), and in a replayed graph the per-step launches cost nothing.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.backends.cudnn.flags(enabled=False):
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    optimizer.zero_grad(set_to_none=True)
+                    out = net(self.static)
+                    net.backward(self.static, out, as_tensors=True)
+                side.synchronize()
+                optimizer.zero_grad(set_to_none=True)
+                del out
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                out = net(self.static)
+                self.total, self.loss_vals = net.backward(self.static, out, as_tensors=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    def load(self, batch):
+        for k in self.FIELDS:
+            v = getattr(batch, k, None)
+            if torch.is_tensor(v):
+                dst = getattr(self.static, k)
+                if dst.shape != v.shape:
+                    raise ValueError('batch field {} has shape {}, the graph was captured with {}'.format(
+                        k, tuple(v.shape), tuple(dst.shape)))
+                dst.copy_(v, non_blocking=True)
+
+    def __call__(self, batch):
+        """Replays forward + backward on `batch`; the parameter gradients are then in `.grad` (static tensors).
+        :return: dict of loss values as device tensors (read them after the step, not inside it)"""
+        self.load(batch)
+        self.graph.replay()
+        return self.loss_vals

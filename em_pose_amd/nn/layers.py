@@ -289,9 +289,14 @@ class RNNLayer(nn.Module):
             y = linear_hip(y.reshape(B * F, -1), self.to_out).reshape(B, F, -1)
         return y
 
-    def forward_torch(self, x, seq_lengths):
-        """Training path only: nn.LSTM over packed sequences with the carried state (reference layers.py:133-157)."""
+    def forward_torch(self, x, seq_lengths, full_length=False):
+        """Training path only: nn.LSTM over packed sequences with the carried state (reference layers.py:133-157).
+        `full_length=True` (every row spans all F frames, checked by the caller on the host) skips the packing, which
+        is the same computation without its host round trip -- required inside a captured HIP graph."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        if full_length:   # the module is time-major (batch_first=False, like the reference's); the packing hid that
+            out, self.final_state = self.lstm(x.transpose(0, 1).contiguous(), self.init_state)
+            return out.transpose(0, 1).contiguous()
         packed = pack_padded_sequence(x, seq_lengths.cpu(), batch_first=True, enforce_sorted=False)
         out, self.final_state = self.lstm(packed, self.init_state)
         out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])

@@ -166,7 +166,11 @@ class BaseModel(nn.Module):
         m_ori = batch_inputs['marker_oris'].reshape((n, f, -1, 3, 3))
         assert self.n_markers in [6, 12]
         if self.n_markers == 6:
-            m_pos, m_ori = m_pos[:, :, CONST.S_CONFIG_6], m_ori[:, :, CONST.S_CONFIG_6]
+            idx = getattr(self, '_s6_idx_dev', None)   # device-side index: no host copy per call (graph capture)
+            if idx is None or idx.device != m_pos.device:
+                idx = torch.tensor(list(CONST.S_CONFIG_6), dtype=torch.long, device=m_pos.device)
+                self._s6_idx_dev = idx
+            m_pos, m_ori = m_pos.index_select(2, idx), m_ori.index_select(2, idx)
         model_in = []
         if self.config.use_marker_pos:
             model_in.append(m_pos.reshape((n, f, -1)))
@@ -635,7 +639,7 @@ class IterativeErrorFeedback(BaseModel):
         inputs_flat = inputs_.reshape(T, -1)
         if self.rnn_init:
             self.rnn.init_state = self.rnn.final_state
-            lstm_out = self.rnn.forward_torch(inputs_, seq_lengths)
+            lstm_out = self.rnn.forward_torch(inputs_, seq_lengths, full_length=getattr(self, 'full_windows', False))
             pose = self.pose_net_init(lstm_out).reshape(T, -1)
             shape = self.shape_net_init(lstm_out).reshape(T, -1)
         else:
@@ -741,9 +745,20 @@ class IterativeErrorFeedback(BaseModel):
                 'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
                 'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
 
-    def backward(self, batch, model_out, writer=None, global_step=None):
+    def _select_markers(self, t):
+        """(bs, f, 12, d) -> the model's sensors; the index lives on the device (no host copy per call)."""
+        if len(self.marker_idxs) == t.shape[2]:
+            return t
+        cache = getattr(self, '_marker_idx_dev', None)
+        if cache is None or cache.device != t.device:
+            cache = torch.tensor(self.marker_idxs, dtype=torch.long, device=t.device)
+            self._marker_idx_dev = cache
+        return t.index_select(2, cache)
+
+    def backward(self, batch, model_out, writer=None, global_step=None, as_tensors=False):
         """Losses of reference models.py:634-688 from the recorded histories; in training mode also
-        `total_loss.backward()` (the histories then carry the autograd graph of `_forward_train`)."""
+        `total_loss.backward()` (the histories then carry the autograd graph of `_forward_train`).
+        `as_tensors=True` returns the loss values as device tensors (no host read-back: capturable in a HIP graph)."""
         if self.pose_hat_history is None:
             raise RuntimeError('backward() needs the histories of the preceding forward() (keep_history=True)')
         bs, f = batch.batch_size, batch.seq_length
@@ -764,14 +779,19 @@ class IterativeErrorFeedback(BaseModel):
             if self.do_fk:
                 joints_gt = batch.joints_gt.to(dev).reshape(bs, f, -1, 3)
                 fk += reconstruction_loss(joints_gt, model_out['joints_hat'].reshape(bs, f, -1, 3), sl, masks)
-            m_hat = self.markers_hat_history[i].reshape(bs, f, -1, 3)[:, :, self.marker_idxs]
-            o_hat = self.markers_ori_hat_history[i].reshape(bs, f, -1, 9)[:, :, self.marker_idxs]
+            m_hat = self._select_markers(self.markers_hat_history[i].reshape(bs, f, -1, 3))
+            o_hat = self._select_markers(self.markers_ori_hat_history[i].reshape(bs, f, -1, 9))
             rec += reconstruction_loss(markers_in, m_hat, sl, masks)
             rec += reconstruction_loss(markers_ori_in, o_hat, sl, masks)
         total = (self.pose_weight * pos + self.fk_loss_weight * fk + self.shape_weight * shp + self.r_weight * rec)
         total = total / n_hist
-        loss_vals = {'pose': pos.item() / n_hist, 'shape': shp.item() / n_hist, 'reconstruction': rec.item() / n_hist,
-                     'fk': fk.item() / n_hist, 'total_loss': total.item()}
+        if as_tensors:
+            loss_vals = {'pose': pos / n_hist, 'shape': shp / n_hist, 'reconstruction': rec / n_hist, 'fk': fk / n_hist,
+                         'total_loss': total}
+            loss_vals = {k: v.detach().reshape(()) for k, v in loss_vals.items()}
+        else:
+            loss_vals = {'pose': pos.item() / n_hist, 'shape': shp.item() / n_hist,
+                         'reconstruction': rec.item() / n_hist, 'fk': fk.item() / n_hist, 'total_loss': total.item()}
         if writer is not None:
             self.log_loss_vals(loss_vals, writer, global_step)
         if self.training:

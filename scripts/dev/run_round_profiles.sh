@@ -13,6 +13,7 @@ python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 
 python scripts/evaluate_real.py --synthetic --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
 python scripts/evaluate_real.py --synthetic --sequential --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
+python scripts/train.py --steps 20 --graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph.json
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 5 --warmup 1 --no_cpu_baseline --no_profile > $OUT.log 2>&1 )

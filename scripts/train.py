@@ -45,6 +45,8 @@ def main():
     p.add_argument('--no_rnn', action='store_true')
     p.add_argument('--lr', type=float, default=0.0005)
     p.add_argument('--seed', type=int, default=1615200973)
+    p.add_argument('--graph', action='store_true',
+                   help='capture forward + backward in a HIP graph and replay it (static shapes, full-length windows)')
     p.add_argument('--json', action='store_true')
     args = p.parse_args()
     if not torch.cuda.is_available():
@@ -84,17 +86,28 @@ def main():
         return b
     batches = [make_batch(s) for s in range(4)]  # data preparation is not part of the measured step
     net.train()
+    graphed = None
+    if args.graph:
+        from em_pose_amd.helpers.graphed import GraphedTrainStep
+        graphed = GraphedTrainStep(net, opt, batches[0])
     times = []
     for step in range(args.warmup + args.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         batch = batches[step % len(batches)]
-        opt.zero_grad()
-        out = net(batch)
-        loss, vals = net.backward(batch, out)
-        allreduce_gradients(params)
-        opt.step()
-        torch.cuda.synchronize()
+        if graphed is not None:
+            vals = graphed(batch)            # forward + backward replayed; gradients in the static .grad tensors
+            allreduce_gradients(params)
+            opt.step()
+            torch.cuda.synchronize()
+            vals = {k: float(v) for k, v in vals.items()}
+        else:
+            opt.zero_grad()
+            out = net(batch)
+            loss, vals = net.backward(batch, out)
+            allreduce_gradients(params)
+            opt.step()
+            torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if step >= args.warmup:
             times.append(dt)
@@ -110,7 +123,7 @@ def main():
         med = float(np.median(times))
     if rank == 0:
         res = {'steps_per_sec': 1.0 / med, 'frames_per_sec': world * B * F / med, 'n_gpus': world,
-               'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3}
+               'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3, 'hip_graph': bool(args.graph)}
         print(json.dumps(res) if args.json else res)
     if world > 1:
         import torch.distributed as dist

@@ -682,6 +682,55 @@ def test_training_step_matches_reference_gradients(name):
     assert net._smpl_handle.value == h1
 
 
+@pytest.mark.parametrize('rnn,n_markers', [(True, 12), (False, 6)])
+def test_graphed_training_step_equals_eager(rnn, n_markers):
+    """helpers/graphed.py: forward + backward captured in a HIP graph and replayed on new batches gives the losses and,
+    after three Adam steps, the parameters of the eager loop (same seed, same batches, full-length windows)."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.helpers.graphed import GraphedTrainStep
+    model = H.small_model()
+    vids = H.load_case('train_lgdrnn12_n2')['meta']['vertex_ids']   # twelve sensor vertices of the small test mesh
+    B, F = 4, 8
+
+    def make(seed):
+        torch.manual_seed(seed)
+        net = build_net(lgd_config(n_markers, rnn, 2, hidden=32, rnn_hidden=32), model, vids).train()
+        params = [q for n, q in net.named_parameters() if not n.startswith('smpl.')]
+        return net, params, torch.optim.Adam(params, lr=1e-3)
+
+    def batch_of(seed, nb=B):
+        w = synthetic.make_windows(nb, F, seed)
+        g = torch.Generator().manual_seed(seed)
+        w['marker_pos'] = torch.randn(nb, F, 36, generator=g).numpy()
+        w['marker_oris'] = torch.randn(nb, F, 108, generator=g).numpy()
+        b = SyntheticBatch(w, device=DEV)
+        b.joints_gt = torch.randn(nb, F, 66, generator=g).to(DEV)
+        return b
+    batches = [batch_of(s) for s in (1, 2, 3)]
+
+    net_e, params_e, opt_e = make(7)
+    eager = []
+    with torch.backends.cudnn.flags(enabled=False):   # the captured step runs PyTorch's native LSTM, not MIOpen's
+        for b in batches:
+            opt_e.zero_grad()
+            _, vals = net_e.backward(b, net_e(b))
+            opt_e.step()
+            eager.append(vals)
+
+    net_g, params_g, opt_g = make(7)
+    step = GraphedTrainStep(net_g, opt_g, batches[0])
+    for b, want in zip(batches, eager):
+        vals = step(b)
+        opt_g.step()
+        torch.cuda.synchronize()
+        for k, v in want.items():
+            assert float(vals[k]) == pytest.approx(v, rel=1e-5, abs=1e-7), k
+    for (k, p), q in zip(net_e.named_parameters(), net_g.parameters()):
+        np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().cpu().numpy(), atol=2e-6, err_msg=k)
+    with pytest.raises(ValueError):   # static shapes only
+        step(batch_of(4, nb=B + 1))
+
+
 def test_batched_streaming_equals_sequential():
     """Chunk c of all recordings as one ragged batch (state carried per row) gives the per-recording results of the
     one-recording-at-a-time driver."""
