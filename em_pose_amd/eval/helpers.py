@@ -97,18 +97,17 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
         first_shape_hat = None
         me_ind.reset()
         for c, chunk in enumerate(window_generator(batch, ws)):
+            n_frames = int(chunk.seq_lengths.sum())   # read while the lengths are still on the host
             chunk = chunk.to_gpu(device)
             out = net(chunk, is_new_sequence=(c == 0))
             if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
                 first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
-            # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once, merge twice
-            me_tmp = MetricsEngine(smpl_model)
-            me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
+            # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once per chunk into
+            # the recording's engine (its rows stay on the device until the recording is done), merge once per recording
+            me_ind.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
                            chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
-            st = me_tmp.state()
-            me_all.merge(st)
-            me_ind.merge(st)
-            frames += int(chunk.seq_lengths.sum())
+            frames += n_frames
+        me_all.merge(me_ind.state())
         per_sequence.append((batch.ids[0], me_ind.get_metrics()))
     return me_all, per_sequence, frames
 

@@ -88,7 +88,24 @@ class MetricsEngine(object):
         self.reset()
 
     def reset(self):
-        self.eucl_dists, self.eucl_dists_pa, self.angle_diffs = [], [], []
+        self._eucl, self._eucl_pa, self._angle = [], [], []
+        self._pending = []
+
+    # the accumulators of the reference (lists of per-frame rows); reading them brings pending device rows to the host
+    @property
+    def eucl_dists(self):
+        self._flush()
+        return self._eucl
+
+    @property
+    def eucl_dists_pa(self):
+        self._flush()
+        return self._eucl_pa
+
+    @property
+    def angle_diffs(self):
+        self._flush()
+        return self._angle
 
     # ---- accumulation -------------------------------------------------------------------------------------------
     @staticmethod
@@ -118,11 +135,18 @@ class MetricsEngine(object):
             _lib.check(_lib.lib().empose_metrics_rows(n, _lib.dptr(kp3d), _lib.dptr(kp3d_hat), _lib.dptr(pose),
                                                       _lib.dptr(pose_hat), parents, _lib.dptr(rows),
                                                       _lib.current_stream()))
-        rows = rows.cpu().numpy()
-        self.eucl_dists.append(rows[:, :22])
-        self.eucl_dists_pa.append(rows[:, 22:44])
-        if pose is not None:
-            self.angle_diffs.append(rows[:, 44:])
+        # kept on the device until somebody reads the accumulators: no host round trip per chunk
+        self._pending.append((rows, pose is not None))
+
+    def _flush(self):
+        """Device rows of earlier `compute` calls -> the host accumulators (one copy each, in call order)."""
+        pending, self._pending = self._pending, []
+        for rows, has_angle in pending:
+            rows = rows.cpu().numpy()
+            self._eucl.append(rows[:, :22])
+            self._eucl_pa.append(rows[:, 22:44])
+            if has_angle:
+                self._angle.append(rows[:, 44:])
 
     def _add_eucl(self, kp3d, kp3d_hat):
         gt = kp3d.detach().cpu().numpy().astype(np.float64)
