@@ -96,6 +96,8 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
             log('Evaluate {} ({} frames)'.format(batch.ids[0], int(batch.seq_lengths[0])))
         first_shape_hat = None
         me_ind.reset()
+        # (Staging the whole recording on the device once and slicing views was measured slower: recordings have 36
+        # different lengths, and every new size costs the caching allocator a ~50 ms hipMalloc/hipFree round.)
         for c, chunk in enumerate(window_generator(batch, ws)):
             n_frames = int(chunk.seq_lengths.sum())   # read while the lengths are still on the host
             chunk = chunk.to_gpu(device)

@@ -122,8 +122,9 @@ class MetricsEngine(object):
             mask = torch.logical_and(mask, fm)
         return mask
 
-    def _add_device_rows(self, kp3d, kp3d_hat, pose=None, pose_hat=None):
-        """Euclidean / Procrustes / angle rows from the HIP kernel (empose_metrics_rows); one device->host copy."""
+    def _add_device_rows(self, kp3d, kp3d_hat, pose=None, pose_hat=None, valid=None):
+        """Euclidean / Procrustes / angle rows from the HIP kernel (empose_metrics_rows); `valid` (bool per row, on the
+        device) selects the rows that count when they are brought to the host."""
         import ctypes
         from em_pose_amd import _lib
         n, dev = kp3d.shape[0], kp3d.device
@@ -136,13 +137,17 @@ class MetricsEngine(object):
                                                       _lib.dptr(pose_hat), parents, _lib.dptr(rows),
                                                       _lib.current_stream()))
         # kept on the device until somebody reads the accumulators: no host round trip per chunk
-        self._pending.append((rows, pose is not None))
+        self._pending.append((rows, pose is not None, valid))
 
     def _flush(self):
         """Device rows of earlier `compute` calls -> the host accumulators (one copy each, in call order)."""
         pending, self._pending = self._pending, []
-        for rows, has_angle in pending:
+        for rows, has_angle, valid in pending:
             rows = rows.cpu().numpy()
+            if valid is not None:
+                rows = rows[valid.cpu().numpy()]
+            if rows.shape[0] == 0:
+                continue
             self._eucl.append(rows[:, :22])
             self._eucl_pa.append(rows[:, 22:44])
             if has_angle:
@@ -172,6 +177,19 @@ class MetricsEngine(object):
         n, f = pose.shape[0], pose.shape[1]
         shape_hat = shape if shape_hat is None else shape_hat
         mask = self._mask(seq_lengths, n, f, frame_mask, pose.device)
+        if pose.is_cuda and self.angle_glob and hasattr(self.smpl_model, 'fk_joints'):
+            # device path: joints-only forward kinematics + one metrics kernel over ALL n * f frames;
+            # the valid rows are picked when the accumulators are read (`_flush`), so nothing here waits for the
+            # device -- no compaction by a boolean mask, no emptiness test
+            flat = lambda t: t.reshape(n * f, -1)
+            per_frame = lambda s_: flat(s_) if s_.dim() == 3 else flat(s_.unsqueeze(1).expand(n, f, s_.shape[-1]))
+            zeros = torch.zeros(n * f, 3, dtype=pose.dtype, device=pose.device)
+            root_f = zeros if pose_root is None else flat(pose_root)
+            root_hat_f = zeros if pose_root is None else flat(pose_root_hat)
+            kp3d = self.smpl_model.fk_joints(flat(pose), per_frame(shape), poses_root=root_f)
+            kp3d_hat = self.smpl_model.fk_joints(flat(pose_hat), per_frame(shape_hat), poses_root=root_hat_f)
+            self._add_device_rows(kp3d, kp3d_hat, flat(pose), flat(pose_hat), valid=mask.reshape(n * f))
+            return
         if mask.sum() == 0:
             return
 
@@ -184,12 +202,6 @@ class MetricsEngine(object):
             root_hat_f = torch.zeros_like(root_f)
         else:
             root_f, root_hat_f = pose_root[mask], pose_root_hat[mask]
-        if pose_f.is_cuda and self.angle_glob and hasattr(self.smpl_model, 'fk_joints'):
-            # device path: joints-only forward kinematics + one metrics kernel
-            kp3d = self.smpl_model.fk_joints(pose_f, shape_f, poses_root=root_f)
-            kp3d_hat = self.smpl_model.fk_joints(pose_hat_f, shape_hat_f, poses_root=root_hat_f)
-            self._add_device_rows(kp3d, kp3d_hat, pose_f, pose_hat_f)
-            return
         _, kp3d = self.smpl_model.fk(pose_f.contiguous(), shape_f.contiguous(), poses_root=root_f.contiguous(),
                                      window_size=1000)
         _, kp3d_hat = self.smpl_model.fk(pose_hat_f.contiguous(), shape_hat_f.contiguous(),
