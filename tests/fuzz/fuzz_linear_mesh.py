@@ -1,0 +1,48 @@
+"""Dev: random shapes through empose_linear_f32_ex (bias, PReLU, residual) against fp64 NumPy, and random frame counts
+through the full-mesh kernel against the oracle on the small test mesh."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import helpers as H
+from em_pose_amd import _lib
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from oracle import torch_ref as R
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 40.0
+lib = _lib.lib(); dev = 'cuda:0'
+t_end, n, worst = time.time() + budget, 0, 0.0
+while time.time() < t_end:
+    M = int(rng.choice([1, 2, 31, 64, 65, 127, 128, 200, 513, 1000, 4096, 24576 + int(rng.integers(0, 300))]))
+    N = int(rng.choice([1, 3, 10, 32, 66, 100, 128, 200, 256, 300, 320, 512, 520])); K = int(rng.integers(1, 150)) * 4
+    x = torch.randn(M, K); w = torch.randn(N, K) / np.sqrt(K); b = torch.randn(N)
+    act = int(rng.integers(0, 2)); slope = float(rng.uniform(-0.5, 1.5)); use_res = bool(rng.integers(0, 2))
+    res = torch.randn(M, N) if use_res else None
+    want = x.double() @ w.double().t() + b.double()
+    if act: want = torch.where(want >= 0, want, slope * want)
+    if use_res: want = want + res.double()
+    xg, wg, bg = x.to(dev), w.to(dev), b.to(dev); rg = res.to(dev) if use_res else None
+    out = torch.empty(M, N, device=dev)
+    _lib.check(lib.empose_linear_f32_ex(_lib.dptr(xg), K, _lib.dptr(wg), K, _lib.dptr(out), N, M, N, K, None, _lib.dptr(bg),
+                                        _lib.dptr(rg), N if use_res else 0, act, slope, None))
+    torch.cuda.synchronize()
+    err = float((out.cpu().double() - want).abs().max())
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    worst = max(worst, err); n += 1
+    if not err < tol:
+        print('LINEAR MISMATCH', dict(M=M, N=N, K=K, act=act, slope=slope, res=use_res), err, tol); sys.exit(1)
+print('linear: %d random cases, worst abs error %.2e' % (n, worst))
+
+model = H.small_model(); bm = R.BodyModelTensors(model); smpl = SMPLLayer(model).to(dev)
+t_end, n, worst = time.time() + budget / 2, 0, 0.0
+while time.time() < t_end:
+    T = int(rng.choice([1, 2, 63, 64, 65, 128, 200, 1000, 5000])); g = torch.Generator().manual_seed(n)
+    pose, root = 0.4 * torch.randn(T, 63, generator=g), 0.5 * torch.randn(T, 3, generator=g)
+    betas, trans = torch.randn(T, 10, generator=g), torch.randn(T, 3, generator=g)
+    use_tr = bool(rng.integers(0, 2))
+    v_ref, j_ref = R.smpl_fk(bm, pose, betas, root, trans if use_tr else None)
+    v, j = smpl(poses_body=pose.to(dev), betas=betas.to(dev), poses_root=root.to(dev), trans=trans.to(dev) if use_tr else None)
+    err = max(float((v.cpu() - v_ref).abs().max()), float((j.cpu() - j_ref[:, :22]).abs().max()))
+    worst = max(worst, err); n += 1
+    if not err < 3e-5:
+        print('MESH MISMATCH', T, use_tr, err); sys.exit(1)
+print('mesh: %d random cases, worst abs error %.2e' % (n, worst))
