@@ -1,0 +1,59 @@
+"""Randomized LGD / LGD-RNN forwards (small test mesh, golden weights) against the oracle: batch sizes across the three
+LSTM regimes, ragged lengths, missing sensors, carried LSTM state."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import helpers as H
+from em_pose_amd import synthetic
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.helpers.configuration import lgd_config
+from em_pose_amd.nn.models import create_model
+from oracle import torch_ref as R
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+DEV = 'cuda:0'
+model = H.small_model(); bm = R.BodyModelTensors(model)
+nets = {}
+for name in ('lgdrnn12_n4_carry', 'lgdrnn6_n2', 'lgd12_n4'):
+    case = H.load_case(name); meta = case['meta']
+    vids = [int(v) for v in meta['vertex_ids']]
+    cfg = lgd_config(int(meta['n_markers']), bool(meta['rnn']), int(meta['N']), hidden=32, rnn_hidden=32)
+    net = create_model(cfg, SMPLLayer(model))
+    net.load_state_dict(H.sd_to_torch(case['sd']), strict=False); net.vertex_ids = vids
+    nets[name] = (net.to(DEV).eval(), H.sd_to_torch(case['sd']), meta, vids, R.sensor_tables(model['f'], vids))
+t_end, n, worst = time.time() + budget, 0, 0.0
+while time.time() < t_end:
+    name = list(nets)[int(rng.integers(0, len(nets)))]
+    net, sd, meta, vids, tables = nets[name]
+    B = int(rng.choice([1, 2, 4, 7, 16, 17, 33, 64, 130, 257])); F = int(rng.integers(1, 20))
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    w = synthetic.make_windows(B, F, 1000 + n, sensors)
+    lens = rng.integers(1, F + 1, size=B); lens[0] = F
+    if rng.integers(0, 2):
+        w['marker_masks'] = (rng.uniform(size=(B, F, 12)) > 0.05).astype(np.float32)
+    inp = H.oracle_inputs(w, sl=lens)
+    rnn = bool(meta['rnn']); state = None
+    if rnn and rng.integers(0, 2):
+        state = (0.3 * torch.randn(2, B, 32), 0.3 * torch.randn(2, B, 32))
+    want, tr = R.ief_forward(sd, bm, tables, vids, inp, n_markers=int(meta['n_markers']), N=int(meta['N']), rnn_init=rnn,
+                             rnn_state=state)
+    g = lambda t: None if t is None else t.to(DEV)
+    res = net.forward_tensors(g(inp['marker_pos']), g(inp['marker_oris']), g(inp['offset_t']), g(inp['offset_r']),
+                              marker_masks=g(inp['marker_masks']), seq_lengths=g(inp['seq_lengths']),
+                              state=None if state is None else tuple(g(t) for t in state))
+    valid = (torch.arange(F)[None, :] < torch.as_tensor(lens)[:, None]).numpy()
+    err = 0.0
+    for got, ref in ((res['pose'].cpu().numpy()[:, :, 3:], want['pose_hat'].numpy()),
+                     (res['shape'].cpu().numpy(), want['shape_hat'].numpy()),
+                     (res['joints'].cpu().numpy(), want['joints_hat'].numpy())):
+        err = max(err, float(np.abs(got - ref)[valid].max()))
+    if rnn:
+        err = max(err, float((res['state'][0].cpu() - tr['rnn_state'][0]).abs().max()))
+    worst = max(worst, err); n += 1
+    if not err < 1e-4:
+        print('MISMATCH', name, dict(B=B, F=F, masks='marker_masks' in w, state=state is not None), err); sys.exit(1)
+print('lgd: %d random cases, worst abs error %.2e' % (n, worst))
