@@ -82,66 +82,93 @@ __device__ __forceinline__ void rodrigues(float rx, float ry, float rz, Rod& q, 
   R[8] = 1.f + oc * (-q.dy * q.dy - q.dx * q.dx);
 }
 
-// One thread per (frame, slot): slots 0..21 are joints, 22..31 the ten shape coefficients.
-__global__ void update_feat_kernel(FeatArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = idx >> 5, slot = idx & 31;
-  if (t >= a.T) return;
-  if (slot < NB) {
-    float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
-    float r0 = th[0], r1 = th[1], r2 = th[2];
-    if (a.d_theta) {
-      const float* d = a.d_theta + (size_t)t * 66 + slot * 3;
-      r0 = r0 + d[0] * a.theta_step;
-      r1 = r1 + d[1] * a.theta_step;
-      r2 = r2 + d[2] * a.theta_step;
-      th[0] = r0; th[1] = r1; th[2] = r2;
-    }
-    if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
-    if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
-    Rod q; float R[9];
-    rodrigues(r0, r1, r2, q, R);
-    float* ro = a.rot + ((size_t)t * NB + slot) * 9;
+// One thread per (frame, slot): slots 0..21 are joints, 22..31 the ten shape coefficients.  The two wide outputs (rot:
+// 198 floats per frame, feat: 200) are assembled in LDS and written out by the whole block as contiguous 8 / 16-byte
+// pieces; a lane writing its nine floats at a 36-byte stride reached 2.9 TB/s.
+constexpr int UF_FRAMES = 8;   // frames per 256-thread block
+__global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_rot[UF_FRAMES * NB * 9];
+  __shared__ __attribute__((aligned(16))) float s_feat[UF_FRAMES * 200];
+  const int t0 = blockIdx.x * UF_FRAMES;
+  const int fl = threadIdx.x >> 5, slot = threadIdx.x & 31;
+  const int t = t0 + fl;
+  // Window mean of the shape update (shape_avg): the 32 lanes of a frame each fetch the frames slot, slot + 32, ... of
+  // the frame's window and the sums meet by shuffles -- independent loads instead of a serial walk over the window by
+  // the ten shape lanes.
+  //   shape_avg == 1: mean over ALL frames of the window incl. padded ones (reference models.py:529-532);
+  //   shape_avg == 2: mean over the valid frames only (what an unpadded window of that length would give; used by the
+  //   batched streaming driver so that ragged batches reproduce one-recording-at-a-time results)
+  float d_mean = 0.f;   // for lane slot >= NB: the mean of coefficient slot - NB
+  if (a.d_beta && a.shape_avg) {
+    const int tc = t < a.T ? t : a.T - 1;
+    const int w0 = (tc / a.F) * a.F;
+    const int n = (a.shape_avg == 2 && a.seq_lengths) ? max(1, min(a.F, a.seq_lengths[tc / a.F])) : a.F;
 #pragma unroll
-    for (int e = 0; e < 9; ++e) ro[e] = R[e];
-    if (slot >= 1) {
-      float* f = a.feat + (size_t)t * 200 + (slot - 1) * 9;
-      f[0] = R[0] - 1.f; f[1] = R[1]; f[2] = R[2];
-      f[3] = R[3]; f[4] = R[4] - 1.f; f[5] = R[5];
-      f[6] = R[6]; f[7] = R[7]; f[8] = R[8] - 1.f;
+    for (int k = 0; k < 10; ++k) {
+      float part = 0.f;
+      for (int f = slot; f < n; f += 32) part += a.d_beta[(size_t)(w0 + f) * 10 + k];
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 32);
+      if (slot == NB + k) d_mean = part / (float)n;
     }
-  } else {
-    const int k = slot - NB;
-    float* be = a.beta + (size_t)t * a.ld_beta + k;
-    float v = a.beta_keep != 0.f ? *be * a.beta_keep : 0.f;
-    if (a.d_beta) {
-      float d;
-      if (a.shape_avg) {
-        // shape_avg == 1: mean over ALL frames of the window incl. padded ones (reference models.py:529-532);
-        // shape_avg == 2: mean over the valid frames only (what an unpadded window of that length would give; used
-        // by the batched streaming driver so that ragged batches reproduce one-recording-at-a-time results)
-        const int w0 = (t / a.F) * a.F;
-        const int n = (a.shape_avg == 2 && a.seq_lengths) ? max(1, min(a.F, a.seq_lengths[t / a.F])) : a.F;
-        float s = 0.f;
-        for (int f = 0; f < n; ++f) s += a.d_beta[(size_t)(w0 + f) * 10 + k];
-        d = s / (float)n;
-      } else {
-        d = a.d_beta[(size_t)t * 10 + k];
+  }
+  if (t < a.T) {
+    if (slot < NB) {
+      float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
+      float r0 = th[0], r1 = th[1], r2 = th[2];
+      if (a.d_theta) {
+        const float* d = a.d_theta + (size_t)t * 66 + slot * 3;
+        r0 = r0 + d[0] * a.theta_step;
+        r1 = r1 + d[1] * a.theta_step;
+        r2 = r2 + d[2] * a.theta_step;
+        th[0] = r0; th[1] = r1; th[2] = r2;
       }
-      v = v + d * a.beta_step;
+      if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
+      if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
+      Rod q; float R[9];
+      rodrigues(r0, r1, r2, q, R);
+      float* ro = s_rot + (fl * NB + slot) * 9;
+#pragma unroll
+      for (int e = 0; e < 9; ++e) ro[e] = R[e];
+      if (slot >= 1) {
+        float* f = s_feat + fl * 200 + (slot - 1) * 9;
+        f[0] = R[0] - 1.f; f[1] = R[1]; f[2] = R[2];
+        f[3] = R[3]; f[4] = R[4] - 1.f; f[5] = R[5];
+        f[6] = R[6]; f[7] = R[7]; f[8] = R[8] - 1.f;
+      }
+    } else {
+      const int k = slot - NB;
+      float* be = a.beta + (size_t)t * a.ld_beta + k;
+      float v = a.beta_keep != 0.f ? *be * a.beta_keep : 0.f;
+      if (a.d_beta) {
+        const float d = a.shape_avg ? d_mean : a.d_beta[(size_t)t * 10 + k];
+        v = v + d * a.beta_step;
+      }
+      // The lanes of a window read d_beta of all its frames but write only beta[t][k]: no hazard.
+      *be = v;
+      if (a.out_beta) a.out_beta[(size_t)t * 10 + k] = v;
+      if (a.out_beta2) a.out_beta2[(size_t)t * 10 + k] = v;
+      s_feat[fl * 200 + 189 + k] = v;
+      if (k == 0) s_feat[fl * 200 + 199] = 1.f;
     }
-    // Every (t,k) thread of a window reads d_beta of all its frames but writes only beta[t][k]: no hazard.
-    *be = v;
-    if (a.out_beta) a.out_beta[(size_t)t * 10 + k] = v;
-    if (a.out_beta2) a.out_beta2[(size_t)t * 10 + k] = v;
-    a.feat[(size_t)t * 200 + 189 + k] = v;
-    if (k == 0) a.feat[(size_t)t * 200 + 199] = 1.f;
+  }
+  __syncthreads();
+  // the block's frames are contiguous in both outputs
+  const int nf = min(UF_FRAMES, a.T - t0);
+  {
+    const float2* src = reinterpret_cast<const float2*>(s_rot);
+    float2* dst = reinterpret_cast<float2*>(a.rot + (size_t)t0 * NB * 9);   // 198 floats per frame: 8-byte pieces
+    for (int i = threadIdx.x; i < nf * (NB * 9 / 2); i += 256) dst[i] = src[i];
+  }
+  {
+    const float4* src = reinterpret_cast<const float4*>(s_feat);
+    float4* dst = reinterpret_cast<float4*>(a.feat + (size_t)t0 * 200);
+    for (int i = threadIdx.x; i < nf * 50; i += 256) dst[i] = src[i];
   }
 }
 
 hipError_t launch_update_feat(const FeatArgs& a, hipStream_t stream) {
-  const long n = (long)a.T * 32;
-  hipLaunchKernelGGL(update_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(update_feat_kernel, dim3((unsigned)((a.T + UF_FRAMES - 1) / UF_FRAMES)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
