@@ -12,11 +12,14 @@ Windows are independent, so ranks shard them with no data-path collective (weak 
 all-gather of per-rank result checksums / counts at the end.
 
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
-  roofline      the dominant kernel (the 2x(T x 512 x 512) hidden-layer GEMM launch of the update nets) against the
-                fp32 matrix-core peak, from HIP events recorded around every launch on the launch stream
-                (empose_profile_*), in a profiling pass of the same workload right after the timed region;
+  roofline      the dominant kernel (mlp_fused_kernel: both update MLPs, all layers, one launch per LGD iteration; the
+                hidden-layer GEMM launch when the batch is too small for it) against the fp32 matrix-core peak, from
+                HIP events recorded around every launch on the launch stream (empose_profile_*), in a profiling pass
+                of the same workload right after the timed region;
   cpu_baseline  the oracle (oracle/torch_ref.py: dense full-mesh SMPL-H + autograd, the reference's algorithm) timed on
-                the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                the host cores on a bounded sample of the same workload (rank 0, N=1 only); the sample's outputs are
+                also compared with the HIP outputs for the same windows: `mpjpe_hip_vs_oracle_mm` (the "MPJPE vs ref"
+                half of the metric) and `max_abs_diff_pose_shape_joints` (north-star tolerance: 1e-4).
 """
 import argparse
 import json
@@ -82,8 +85,10 @@ def flops_per_frame(net):
     return fl
 
 
-def cpu_baseline(net, model, w, seconds_target=20.0):
-    """Oracle (reference algorithm: dense full mesh + autograd) on the host cores, bounded sample."""
+def cpu_baseline(net, model, w, hip_out=None, seconds_target=20.0):
+    """Oracle (reference algorithm: dense full mesh + autograd) on the host cores, bounded sample.  The sample's outputs
+    are also compared with what the HIP path produced for the same windows (`hip_out`): the "MPJPE vs ref" half of the
+    metric, in mm, and the largest absolute difference over pose / shape / joints."""
     from em_pose_amd.helpers.configuration import CONSTANTS as C
     from oracle import torch_ref as R
     bm = R.BodyModelTensors(model)
@@ -96,8 +101,10 @@ def cpu_baseline(net, model, w, seconds_target=20.0):
         inp['marker_masks'] = None
         inp['seq_lengths'] = torch.full((nb,), F, dtype=torch.int64)
         t0 = time.perf_counter()
-        R.ief_forward(sd, bm, tables, C.VERTEX_IDS, inp, n_markers=net.n_markers, N=net.N, rnn_init=net.rnn_init)
+        last['out'], _ = R.ief_forward(sd, bm, tables, C.VERTEX_IDS, inp, n_markers=net.n_markers, N=net.N,
+                                       rnn_init=net.rnn_init)
         return time.perf_counter() - t0
+    last = {}
 
     run(2)  # warm-up (thread pools, allocator)
     # The oracle is thousands of small torch ops: more threads are not faster (128 threads measured slower than one).
@@ -119,7 +126,18 @@ def cpu_baseline(net, model, w, seconds_target=20.0):
     finally:
         torch.set_num_threads(all_threads)
     best = float(np.median(reps))
-    return {'value': nb * F / best, 'unit': 'frames/sec', 'cores': best_n, 'kind': 'port',
+    parity = {}
+    if hip_out is not None:
+        want = last['out']
+        j_ref = want['joints_hat'].reshape(nb, F, 22, 3).double()
+        j_hip = hip_out['joints'][:nb].detach().cpu().reshape(nb, F, 22, 3).double()
+        pose_hip = hip_out['pose'][:nb].detach().cpu()
+        diffs = [(j_hip - j_ref).abs().max(), (pose_hip[..., 3:] - want['pose_hat']).abs().max(),
+                 (pose_hip[..., :3] - want['root_ori_hat']).abs().max(),
+                 (hip_out['shape'][:nb].detach().cpu() - want['shape_hat']).abs().max()]
+        parity = {'mpjpe_hip_vs_oracle_mm': float((j_hip - j_ref).norm(dim=-1).mean() * 1000.0),
+                  'max_abs_diff_pose_shape_joints': float(max(diffs))}
+    return {'value': nb * F / best, 'unit': 'frames/sec', 'cores': best_n, 'kind': 'port', **parity,
             'sample': '%d windows x %d frames, median of %d runs of oracle/torch_ref.ief_forward (dense V=6890 '
                       'SMPL-H + autograd, fp32, torch CPU) at the best of the swept thread counts; host has %d logical '
                       'cores' % (nb, F, len(reps), os.cpu_count()),
@@ -319,7 +337,7 @@ def main():
         result['breakdown_ms_per_step'] = {k: v[0] / psteps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         result['breakdown_ms_per_step']['sum_of_kernels'] = total / psteps
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(net, model, w)
+        result['cpu_baseline'] = cpu_baseline(net, model, w, hip_out=out)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
