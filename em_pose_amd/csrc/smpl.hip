@@ -103,13 +103,20 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
     const int tc = t < a.T ? t : a.T - 1;
     const int w0 = (tc / a.F) * a.F;
     const int n = (a.shape_avg == 2 && a.seq_lengths) ? max(1, min(a.F, a.seq_lengths[tc / a.F])) : a.F;
+    float part[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[k] = 0.f;
+    for (int f = slot; f < n; f += 32) {   // ten independent loads per trip (long windows: F = 256 is eight trips)
+      const float* row = a.d_beta + (size_t)(w0 + f) * 10;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) part[k] += row[k];
+    }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      float part = 0.f;
-      for (int f = slot; f < n; f += 32) part += a.d_beta[(size_t)(w0 + f) * 10 + k];
+      float v = part[k];
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 32);
-      if (slot == NB + k) d_mean = part / (float)n;
+      for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
+      if (slot == NB + k) d_mean = v / (float)n;
     }
   }
   if (t < a.T) {
