@@ -389,7 +389,88 @@ static hipError_t launch_large(const GemmBatch& batch, hipStream_t stream) {
   return launch_cfg<CfgX, ROLE>(batch, stream);
 }
 
-enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE };
+// ---------------------------------------------------------------------------------------------------------------
+// Small problems (a few hundred rows: the streaming driver's 256-frame chunks, single windows): with the tiles above a
+// layer is a few dozen workgroups that each walk the whole K behind LDS staging and barriers -- 19 us for
+// 256 x 512 x 512.  Here a workgroup owns ONE 32 x 32 output tile and its four waves split K: every wave fetches its
+// operand fragments straight from global memory (one 16-byte piece per lane and 8 k: the k-permutation of the fused
+// MLP kernel, no LDS, no barrier), the four partial tiles meet in LDS and are added in wave order, each wave finishes a
+// quarter of the tile.  Four times as many workgroups, a quarter of the MFMA chain per wave.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_splitk_f32_kernel(GemmBatch batch) {
+  __shared__ float red[4 * 16 * 64];
+  const GemmProb& p = batch.p[blockIdx.y];
+  const int M = p.M, N = p.N, K = p.K;
+  const int nt_n = (N + 31) / 32, nt_m = (M + 31) / 32;
+  if ((int)blockIdx.x >= nt_n * nt_m) return;
+  const int m0 = ((int)blockIdx.x / nt_n) * 32, n0 = ((int)blockIdx.x % nt_n) * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KG = (K + 7) / 8, gq = (KG + 3) / 4;
+  const int g_beg = wave * gq, g_end = min(g_beg + gq, KG);
+  const float* __restrict__ arow = p.A + (size_t)min(m0 + l31, M - 1) * p.lda + lh * 4;
+  const float* __restrict__ wrow = p.W + (size_t)min(n0 + l31, N - 1) * p.ldw + lh * 4;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int CH = 8;   // k-groups per batch of loads
+  for (int g0 = g_beg; g0 < g_end; g0 += CH) {
+    f32x4 fa[CH], fb[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int k = (g0 + u) * 8 + lh * 4;
+      const bool ok = g0 + u < g_end && k < K;       // K % 4 == 0: a piece is entirely inside or outside
+      fa[u] = ok ? *reinterpret_cast<const f32x4*>(arow + (g0 + u) * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+      fb[u] = ok ? *reinterpret_cast<const f32x4*>(wrow + (g0 + u) * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[u][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+
+  const int n = n0 + l31;
+  if (n >= N) return;
+  const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+  const float slope = p.act == 1 ? p.slope : 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 4 + i;
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // C/D layout of the 32x32 MFMA
+    if (row >= M) continue;
+    float v = red[(0 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+    float y = v * sc + sh;
+    if (p.act == 2) {          // relu(W x + b + x), reference layers.py:170-182
+      if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
+      y = y > 0.f ? y : 0.f;
+    } else {
+      y = y >= 0.f ? y : slope * y;
+      if (p.resid) y += p.resid[(size_t)row * p.ldr + n];   // skip connection (after the activation)
+    }
+    p.C[(size_t)row * p.ldc + n] = y;
+  }
+}
+
+static hipError_t launch_splitk(const GemmBatch& batch, hipStream_t stream) {
+  int blocks = 0;
+  for (int i = 0; i < batch.count; ++i) {
+    const int t = ((batch.p[i].M + 31) / 32) * ((batch.p[i].N + 31) / 32);
+    blocks = t > blocks ? t : blocks;
+  }
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(gemm_splitk_f32_kernel, dim3(blocks, batch.count), dim3(256), 0, stream, batch);
+  return hipGetLastError();
+}
+
+enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK };
+
+constexpr long SPLITK_MAX_TILES = 512;   // 256 x 512 x 512: 8 us against 15; 2048 rows (1024 tiles): 25 against 15
 
 static GemmPick pick_gemm(const GemmBatch& batch) {
   int maxM = 0, maxN = 0;
@@ -407,6 +488,12 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
       t += (long)((batch.p[i].M + bm - 1) / bm) * ((batch.p[i].N + bn - 1) / bn);
     return t;
   };
+  // few 32 x 32 tiles in total and a K worth splitting: one tile per workgroup, K over its four waves
+  const char* sk = getenv("EMPOSE_GEMM_SPLITK");   // dev A/B switch, read per call: "0" = the generic tiles
+  const bool splitk_on = !(sk && sk[0] == '0');
+  int minK = 1 << 30;
+  for (int i = 0; i < batch.count; ++i) minK = batch.p[i].K < minK ? batch.p[i].K : minK;
+  if (splitk_on && minK >= 64 && nblocks(32, 32) <= SPLITK_MAX_TILES) return PICK_SPLITK;
   if (shortm && narrow) return PICK_S11;
   if (shortm) return PICK_S12;
   if (narrow) return PICK_S21;
@@ -432,6 +519,7 @@ const char* gemm_kernel_name(int M, int N, int K, int count, int role) {
   b.count = count; b.role = role;
   for (int i = 0; i < count && i < 2; ++i) { b.p[i] = GemmProb{}; b.p[i].M = M; b.p[i].N = N; b.p[i].K = K; }
   switch (pick_gemm(b)) {
+    case PICK_SPLITK: return "gemm_splitk_f32_kernel";
     case PICK_S11: return "gemm_tn_f32_kernel<Cfg<2,2,1,1,32,false>,0>";
     case PICK_S12: return "gemm_tn_f32_kernel<Cfg<2,2,1,2,32,false>,0>";
     case PICK_S21: return "gemm_tn_f32_kernel<Cfg<2,2,2,1,32,false>,0>";
@@ -444,6 +532,7 @@ hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
   GemmBatch batch = batch_in;
   batch.xcd_swizzle = 1;
   switch (pick_gemm(batch)) {
+    case PICK_SPLITK: return launch_splitk(batch, stream);
     case PICK_S11: return launch_cfg<CfgS11>(batch, stream);
     case PICK_S12: return launch_cfg<CfgS12>(batch, stream);
     case PICK_S21: return launch_cfg<CfgS21>(batch, stream);

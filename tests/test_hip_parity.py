@@ -142,10 +142,11 @@ def test_smpl_sensors_fwd_bwd(which, n_markers, big_model):
     assert (g_th.cpu().numpy()[scale == 0] == 0).all()
 
 
-def test_smpl_sensors_large_batch_blend_gemm_path(big_model):
+def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
     """At bench-size batches the blend-shape contraction runs on the row-block GEMM (csrc/mlp_fused.hip
     gemm_rows_kernel: A block resident in LDS, weights in fragment order).  Its first 96 frames must carry the bits of a
-    96-frame call, which takes the generic tile and is checked against the float64 blueprint above."""
+    96-frame call on the generic tile (same k order; the small call's own default, the split-K kernel, sums in another
+    order and is compared at 1e-6), which is checked against the float64 blueprint above."""
     model, vids = big_model, CONST.VERTEX_IDS
     F, T_small, T_big = 8, 96, 128 * 200
     theta, beta, off_r, off_t, tgt, scale, ref = _smpl_case(model, vids, T_small, F, 11, 12)
@@ -159,8 +160,10 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model):
     handle = net._ensure_handle(torch.device(DEV))
     lib = _lib.lib()
     outs = {}
-    for T, (th_, be_, or_, ot_, tg_, sc_) in ((T_small, (theta, beta, off_r, off_t, tgt, scale)),
-                                             (T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
+    small = (theta, beta, off_r, off_t, tgt, scale)
+    for key, T, (th_, be_, or_, ot_, tg_, sc_) in (('splitk', T_small, small), (T_small, T_small, small),
+                                                  (T_big, T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
+        monkeypatch.setenv('EMPOSE_GEMM_SPLITK', '1' if key == 'splitk' else '0')   # dev switch, read per call
         th, be, o_r, o_t, tg, sc = gpu(th_), gpu(be_), gpu(or_), gpu(ot_), gpu(tg_), gpu(sc_)
         pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
         g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
@@ -171,11 +174,13 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model):
                                                    _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints), _lib.dptr(g_th), 66,
                                                    _lib.dptr(g_be), 10, _lib.dptr(ws), nbytes, _lib.current_stream()))
         torch.cuda.synchronize()
-        outs[T] = [t.cpu().numpy() for t in (pos, ori, joints, g_th, g_be)]
+        outs[key] = [t.cpu().numpy() for t in (pos, ori, joints, g_th, g_be)]
     np.testing.assert_allclose(outs[T_small][0].reshape(T_small, 12, 3), ref['pos'], atol=1e-5)
-    for a, b in zip(outs[T_small], outs[T_big]):
+    for a, b, c in zip(outs[T_small], outs[T_big], outs['splitk']):
         assert np.array_equal(a, b[:T_small])     # same k order in both kernels: identical bits
         assert np.isfinite(b).all()
+        # orientations and gradients amplify last-bit differences of the vertices (tolerances of the fwd/bwd test above)
+        np.testing.assert_allclose(c, a, atol=2e-4 * max(1.0, float(np.abs(a).max())), rtol=1e-3)
 
 
 def test_smpl_forward_only_matches(big_model):
@@ -247,7 +252,7 @@ def test_update_nets_and_lstm_vs_oracle():
 
 @pytest.mark.parametrize('hidden,skip,T', [(32, False, 12800 + 77), (512, False, 12800), (256, True, 13000),
                                            (100, False, 8192 + 5), (36, False, 9000)])
-def test_update_nets_large_batch_single_launch_path(hidden, skip, T):
+def test_update_nets_large_batch_single_launch_path(hidden, skip, T, monkeypatch):
     """Large batches run both update MLPs in ONE launch (csrc/mlp_fused.hip: a workgroup keeps 128 rows through all six
     layers): same results as the oracle's layer-by-layer MLP, incl. the ragged first layer (K = 296), the narrow output
     layers (66 / 10 columns), a ragged last row panel, skip connections, and the per-layer path on the first rows."""
@@ -271,7 +276,10 @@ def test_update_nets_large_batch_single_launch_path(hidden, skip, T):
         want_s = R.mlp_forward(sd, 'shape_net_iter.', x, skip=skip).numpy()
     xg = x.to(DEV)
     outs = {}
-    for rows in (T, 200):   # 200 rows: too few row panels for the single launch -> the layer-by-layer kernels
+    # 200 rows: too few row panels for the single launch -> the layer-by-layer kernels: on the generic tiles (same k order
+    # as the fused kernel) and on their default, the split-K kernel
+    for key, rows in ((T, T), (200, 200), ('splitk', 200)):
+        monkeypatch.setenv('EMPOSE_GEMM_SPLITK', '1' if key == 'splitk' else '0')   # dev switch, read per call
         dp, ds = torch.full((rows, 66), 7.0, device=DEV), torch.full((rows, 10), 7.0, device=DEV)
         nbytes = lib.empose_update_workspace_bytes(handle, rows)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
@@ -280,7 +288,7 @@ def test_update_nets_large_batch_single_launch_path(hidden, skip, T):
         torch.cuda.synchronize()
         np.testing.assert_allclose(dp.cpu().numpy(), want_p[:rows], atol=ATOL)
         np.testing.assert_allclose(ds.cpu().numpy(), want_s[:rows], atol=ATOL)
-        outs[rows] = (dp.cpu().numpy(), ds.cpu().numpy())
+        outs[key] = (dp.cpu().numpy(), ds.cpu().numpy())
     # both paths accumulate every dot product in the same k order: identical bits, not just close
     assert np.array_equal(outs[T][0][:200], outs[200][0]) and np.array_equal(outs[T][1][:200], outs[200][1])
 
