@@ -106,25 +106,40 @@ def load_offsets_npz(path):
 
 class SampleMarkersWithOffsets(object):
     """
-    Virtual sensors sampled from the ground-truth mesh with per-subject offsets applied
-    (reference transforms.py:132-226, the deterministic branch used at evaluation time: `noise_level=-1`, offsets =
-    the stored means).  `offset_sets` is a list of dicts with `means` (M,3), `r` (M,3,3) and `vertex_ids` (M,) -- the
-    content of the reference's `*_offsets.npz` files; one set is drawn per batch entry with the reference's seeded
-    RandomState(6273).
+    Virtual sensors sampled from the ground-truth mesh with per-subject offsets applied (reference
+    transforms.py:132-226).  `offset_sets` is a list of dicts with `means` (M,3), `covs` (M,3,3), `r` (M,3,3) and
+    `vertex_ids` (M,) -- the content of the reference's `*_offsets.npz` files, or the paths of such files; one set is
+    drawn per batch entry with the reference's seeded RandomState(6273).
+
+    `noise_level` as in the reference: -1 deterministic (offsets = the stored means; evaluation), 0 one offset draw per
+    window from N(means, covs), 1 one draw per frame, 2 no positional offset, 3 no positional and no rotational offset.
+    The draws come from torch's global generator (`MultivariateNormal.sample`), like the reference's.
+    `offset_t_augmented` always carries the means: that is what is known at test time.
     """
 
-    def __init__(self, smpl_model, offset_sets):
+    def __init__(self, smpl_model, offset_sets, noise_level=-1):
         from em_pose_amd.data.virtual_sensors import VirtualMarkerHelper
         if isinstance(offset_sets, (dict, str)):
             offset_sets = [offset_sets]
         # the reference passes `*_offsets.npz` paths (transforms.py:142-155: keys means, covs, r, vertex_ids)
         offset_sets = [load_offsets_npz(o) if isinstance(o, str) else o for o in offset_sets]
+        if noise_level not in (-1, 0, 1, 2, 3):
+            raise ValueError('Unknown noise level {}'.format(noise_level))
+        self.noise_level = noise_level
+        self.randomize = noise_level >= 0
         self.n_offsets = len(offset_sets)
         self.offset_means = np.stack([np.asarray(o['means'], dtype=np.float32) for o in offset_sets])
         self.r = np.stack([np.asarray(o['r'], dtype=np.float32) for o in offset_sets])
         self.vertex_ids = [int(v) for v in np.asarray(offset_sets[-1]['vertex_ids']).tolist()]
         self.virtual_helper = VirtualMarkerHelper(smpl_model)
         self.offset_rng = np.random.RandomState(6273)
+        self.normal_dists = None
+        if noise_level in (0, 1):
+            if any(o.get('covs') is None for o in offset_sets):
+                raise ValueError('noise levels 0 and 1 need the offset covariances (`covs`)')
+            covs = np.stack([np.asarray(o['covs'], dtype=np.float32) for o in offset_sets])
+            self.normal_dists = torch.distributions.MultivariateNormal(
+                loc=torch.from_numpy(self.offset_means), covariance_matrix=torch.from_numpy(covs))
 
     def __call__(self, batch):
         n, f = batch.batch_size, batch.seq_length
@@ -134,11 +149,23 @@ class SampleMarkersWithOffsets(object):
         batch.marker_pos_vertex = markers.reshape(n, f, -1)
         batch.marker_ori_vertex = oris.reshape(n, f, -1)
         batch.marker_normal_vertex = normals.reshape(n, f, -1)
-        s_idxs = self.offset_rng.randint(0, self.n_offsets, n)
-        means = torch.from_numpy(self.offset_means[s_idxs]).to(dev)  # (n, M, 3)
-        r = torch.from_numpy(self.r[s_idxs]).to(dev)  # (n, M, 3, 3)
+        s_np = self.offset_rng.randint(0, self.n_offsets, n)
+        s_idxs = torch.from_numpy(s_np).long()
+        means = torch.from_numpy(self.offset_means[s_np]).to(dev)  # (n, M, 3)
+        r = torch.from_numpy(self.r[s_np]).to(dev)  # (n, M, 3, 3)
+        local = means[:, None].expand(n, f, means.shape[1], 3)
+        if self.noise_level == 0:      # one draw per window
+            draw = self.normal_dists.sample((n,))[torch.arange(n), s_idxs]  # (n, M, 3)
+            local = draw.to(dev)[:, None].expand(n, f, draw.shape[1], 3)
+        elif self.noise_level == 1:    # one draw per frame
+            draw = self.normal_dists.sample((n, f))  # (n, f, n_offsets, M, 3)
+            local = draw[torch.arange(n), :, s_idxs].to(dev)  # (n, f, M, 3)
+        elif self.noise_level in (2, 3):
+            local = torch.zeros(n, f, means.shape[1], 3, device=dev)
+        if self.noise_level == 3:
+            r = torch.eye(3, device=dev).expand(n, r.shape[1], 3, 3).contiguous()
         ori = oris.reshape(n, f, -1, 3, 3)
-        pos = markers.reshape(n, f, -1, 3) + torch.matmul(ori, means[:, None, :, :, None]).squeeze(-1)
+        pos = markers.reshape(n, f, -1, 3) + torch.matmul(ori, local.to(ori.dtype).unsqueeze(-1)).squeeze(-1)
         ori = torch.matmul(ori, r[:, None])
         batch.marker_pos_synth = pos.reshape(n, f, -1)
         batch.marker_ori_synth = ori.reshape(n, f, -1)

@@ -997,3 +997,25 @@ def test_ground_truth_preprocessing_round_trip(big_model):
     np.testing.assert_allclose(batch.marker_pos_synth.cpu().numpy().reshape(15, 12, 3), pos.cpu().numpy(), atol=2e-5)
     np.testing.assert_allclose(batch.marker_ori_synth.cpu().numpy().reshape(15, 12, 3, 3), ori.cpu().numpy(), atol=5e-5)
     np.testing.assert_allclose(batch.joints_gt.cpu().numpy().reshape(15, 22, 3), joints.cpu().numpy(), atol=2e-5)
+    # the training-time noise levels of the reference (transforms.py:176-211)
+    for s_ in sets:
+        s_['covs'] = np.tile(np.eye(3, dtype=np.float32) * 1e-4, (12, 1, 1))
+    det_pos, det_ori = batch.marker_pos_synth.clone(), batch.marker_ori_synth.clone()
+    torch.manual_seed(0)
+    b0 = SampleMarkersWithOffsets(smpl, sets, noise_level=0)(batch)
+    d0 = (b0.marker_pos_synth - b0.marker_pos_vertex).reshape(3, 5, 12, 3)
+    local0 = torch.matmul(b0.marker_ori_vertex.reshape(3, 5, 12, 3, 3).transpose(-1, -2), d0.unsqueeze(-1)).squeeze(-1)
+    np.testing.assert_allclose(local0[:, 1:].cpu().numpy(), local0[:, :1].expand(3, 4, 12, 3).cpu().numpy(), atol=1e-5)
+    assert float((local0[:, 0] - b0.offset_t_augmented).abs().max()) < 0.1 and float((local0[:, 0] - b0.offset_t_augmented).abs().max()) > 1e-4
+    b1 = SampleMarkersWithOffsets(smpl, sets, noise_level=1)(batch)
+    d1 = (b1.marker_pos_synth - b1.marker_pos_vertex).reshape(3, 5, 12, 3)
+    local1 = torch.matmul(b1.marker_ori_vertex.reshape(3, 5, 12, 3, 3).transpose(-1, -2), d1.unsqueeze(-1)).squeeze(-1)
+    assert float((local1[:, 1] - local1[:, 0]).abs().max()) > 1e-4        # a new draw every frame
+    b2 = SampleMarkersWithOffsets(smpl, sets, noise_level=2)(batch)
+    np.testing.assert_allclose(b2.marker_pos_synth.cpu().numpy(), b2.marker_pos_vertex.cpu().numpy(), atol=0)
+    b3 = SampleMarkersWithOffsets(smpl, sets, noise_level=3)(batch)
+    np.testing.assert_allclose(b3.marker_ori_synth.cpu().numpy(), b3.marker_ori_vertex.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(b3.offset_r_augmented.cpu().numpy(), np.broadcast_to(np.eye(3), (3, 12, 3, 3)), atol=0)
+    with pytest.raises(ValueError):
+        SampleMarkersWithOffsets(smpl, sets, noise_level=4)
+    assert det_pos.shape == b3.marker_pos_synth.shape and det_ori.shape == b3.marker_ori_synth.shape
