@@ -77,6 +77,13 @@ class RealSample(object):
     def n_frames(self):
         return self.marker_pos_real.shape[0]
 
+    def extract_window(self, start_frame, end_frame):
+        """Frames [start_frame, end_frame) as a new sample; shape and offsets are shared (reference data.py:153-159)."""
+        sf, ef = start_frame, end_frame
+        return RealSample(self.id, self.marker_pos_real[sf:ef], self.marker_ori_real[sf:ef], self.marker_masks[sf:ef],
+                          self.smpl_poses[sf:ef], self.smpl_shape, self.smpl_trans[sf:ef],
+                          {'means': self.offset_means, 'covs': self.offset_covs, 'r': self.offset_r})
+
     def to_tensor(self):
         for name in ('marker_pos_real', 'marker_ori_real', 'marker_masks', 'smpl_poses', 'smpl_shape', 'smpl_trans',
                      'offset_means', 'offset_covs', 'offset_r'):

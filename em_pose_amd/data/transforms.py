@@ -55,6 +55,35 @@ class ToTensor(object):
         return sample
 
 
+class IdentityTransform(object):
+    def __call__(self, sample):
+        return sample
+
+
+class ExtractWindow(object):
+    """A window of `window_size` frames from a sample (reference transforms.py:66-96): at the beginning, around the
+    middle, or at a position drawn from `rng` (a numpy RandomState); shorter samples are returned whole, unpadded."""
+
+    def __init__(self, window_size, rng=None, mode='random'):
+        if mode not in ('random', 'beginning', 'middle'):
+            raise ValueError("Mode '{}' for window extraction unknown.".format(mode))
+        if mode == 'random' and rng is None:
+            raise ValueError('random window extraction needs an rng')
+        self.window_size, self.rng, self.mode = window_size, rng, mode
+
+    def __call__(self, sample):
+        n, ws = sample.n_frames, self.window_size
+        if n <= ws:
+            return sample
+        if self.mode == 'beginning':
+            sf = 0
+        elif self.mode == 'middle':
+            sf = n // 2 - ws // 2
+        else:
+            sf = self.rng.randint(0, n - ws + 1)
+        return sample.extract_window(sf, sf + ws)
+
+
 class NormalizeRoot(object):
     def __init__(self, normalize_root_ori=True, remove_root_trans=True):
         self.normalize_root_ori = normalize_root_ori
@@ -173,3 +202,27 @@ class SampleMarkersWithOffsets(object):
         batch.offset_t_augmented = means
         batch.offset_r_augmented = r
         return batch
+
+
+def get_end_to_end_preprocess_fn(config, smpl_model, offset_files, randomize_if_configured=False):
+    """
+    The reference's preprocessing factory (transforms.py:23-48): NormalizeRoot -> SMPLFK -> SampleMarkersWithOffsets,
+    with the configured offset noise level when `randomize_if_configured`.  `offset_files`: the `*_offsets.npz` files
+    (the reference takes them from its data directory).  The reference's additional sensor-noise function
+    (`get_noise_fn`) is not part of this build.
+    """
+    if not getattr(config, 'use_real_offsets', True):
+        raise ValueError('We expect to use the real offsets.')
+    normalize_root, fk = NormalizeRoot(), SMPLFK(smpl_model)
+    noise_level = getattr(config, 'offset_noise_level', -1) if randomize_if_configured else -1
+    sample_markers = SampleMarkersWithOffsets(smpl_model, list(offset_files), noise_level=noise_level)
+
+    def _preprocess_fn(sample, mode='all', **_):
+        if mode == 'all':
+            return sample_markers(fk(normalize_root(sample)))
+        if mode == 'normalize_only':
+            return normalize_root(sample)
+        if mode == 'after_normalize':
+            return sample_markers(fk(sample))
+        raise ValueError("Mode '{}' unknown.".format(mode))
+    return _preprocess_fn

@@ -997,6 +997,11 @@ def test_ground_truth_preprocessing_round_trip(big_model):
     np.testing.assert_allclose(batch.marker_pos_synth.cpu().numpy().reshape(15, 12, 3), pos.cpu().numpy(), atol=2e-5)
     np.testing.assert_allclose(batch.marker_ori_synth.cpu().numpy().reshape(15, 12, 3, 3), ori.cpu().numpy(), atol=5e-5)
     np.testing.assert_allclose(batch.joints_gt.cpu().numpy().reshape(15, 22, 3), joints.cpu().numpy(), atol=2e-5)
+    # the reference's factory composes the same three transforms (transforms.py:23-48)
+    from em_pose_amd.data.transforms import get_end_to_end_preprocess_fn
+    fn = get_end_to_end_preprocess_fn(lgd_config(12, False, 1, hidden=32), smpl, sets)
+    again = fn(SyntheticBatch(w, device=DEV), mode='after_normalize')
+    np.testing.assert_allclose(again.marker_pos_synth.cpu().numpy(), batch.marker_pos_synth.cpu().numpy(), atol=1e-6)
     # the training-time noise levels of the reference (transforms.py:176-211)
     for s_ in sets:
         s_['covs'] = np.tile(np.eye(3, dtype=np.float32) * 1e-4, (12, 1, 1))

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from em_pose_amd import synthetic
@@ -135,3 +136,26 @@ def test_offsets_npz_file_format(tmp_path):
     np.testing.assert_array_equal(o['r'], r)
     np.testing.assert_array_equal(o['covs'], covs)
     assert o['vertex_ids'].tolist() == vids.tolist()
+
+
+def test_extract_window_modes():
+    """reference transforms.py:66-96: beginning / middle / random windows, short samples returned whole."""
+    from em_pose_amd.data.data import RealSample
+    from em_pose_amd.data.transforms import ExtractWindow
+    f = 50
+    s = RealSample('rec', np.arange(f * 36, dtype=np.float32).reshape(f, 12, 3), np.zeros((f, 12, 3, 3), np.float32),
+                   np.ones((f, 12), np.float32), np.zeros((f, 66), np.float32), np.zeros(10, np.float32),
+                   np.zeros((f, 3), np.float32), {'means': np.zeros((12, 3)), 'covs': np.zeros((12, 3, 3)),
+                                                  'r': np.zeros((12, 3, 3))})
+    first = lambda x: int(x.marker_pos_real[0, 0]) // 36
+    assert first(ExtractWindow(16, mode='beginning')(s)) == 0
+    mid = ExtractWindow(16, mode='middle')(s)
+    assert first(mid) == 25 - 8 and mid.n_frames == 16 and mid.smpl_poses.shape == (16, 66)
+    rng = np.random.RandomState(3)
+    want = np.random.RandomState(3).randint(0, f - 16 + 1)
+    assert first(ExtractWindow(16, rng=rng, mode='random')(s)) == want
+    assert ExtractWindow(64, mode='beginning')(s) is s
+    with pytest.raises(ValueError):
+        ExtractWindow(16, mode='end')
+    with pytest.raises(ValueError):
+        ExtractWindow(16, mode='random')
