@@ -159,3 +159,25 @@ def test_extract_window_modes():
         ExtractWindow(16, mode='end')
     with pytest.raises(ValueError):
         ExtractWindow(16, mode='random')
+
+
+def test_reference_named_helper_modules():
+    """`empose.nn.loss` / `empose.helpers.utils` names resolve; local_to_global round-trips through both formats."""
+    from em_pose_amd.eval.metrics import local_to_global_rotations
+    from em_pose_amd.helpers.configuration import CONSTANTS as C
+    from em_pose_amd.helpers.utils import count_parameters, global_oris_from_pose, local_to_global, mask_from_seq_lengths
+    from em_pose_amd.nn.loss import normal_mse, padded_loss, reconstruction_loss  # noqa: F401
+    rng = np.random.default_rng(0)
+    poses = torch.from_numpy(rng.normal(0, 0.6, size=(7, 66)).astype(np.float32))
+    rot = local_to_global(poses, C.SMPL_PARENTS, output_format='rotmat')
+    want = local_to_global_rotations(poses.numpy().astype(np.float64), C.SMPL_PARENTS)
+    np.testing.assert_allclose(rot.numpy().reshape(7, 22, 3, 3), want, atol=1e-6)
+    aa = local_to_global(poses, C.SMPL_PARENTS)                       # global rotations as axis-angle ...
+    back = local_to_global(aa, [-1] * 22, output_format='rotmat')     # ... exponentiated again without a chain
+    np.testing.assert_allclose(back.numpy(), rot.numpy(), atol=1e-5)
+    same = local_to_global(rot, [-1] * 22, output_format='rotmat', input_format='rotmat')
+    np.testing.assert_allclose(same.numpy(), rot.numpy(), atol=0)
+    oris = global_oris_from_pose(poses[:, :3].reshape(1, 7, 3), poses[:, 3:].reshape(1, 7, 63), C.SMPL_PARENTS, [0, 5])
+    np.testing.assert_allclose(oris.numpy().reshape(7, 2, 9), rot.numpy().reshape(7, 22, 9)[:, [0, 5]], atol=0)
+    assert mask_from_seq_lengths(torch.tensor([2, 3])).tolist() == [[True, True, False], [True, True, True]]
+    assert count_parameters(torch.nn.Linear(3, 2)) == 8
