@@ -181,3 +181,21 @@ def test_reference_named_helper_modules():
     np.testing.assert_allclose(oris.numpy().reshape(7, 2, 9), rot.numpy().reshape(7, 22, 9)[:, [0, 5]], atol=0)
     assert mask_from_seq_lengths(torch.tensor([2, 3])).tolist() == [[True, True, False], [True, True, True]]
     assert count_parameters(torch.nn.Linear(3, 2)) == 8
+
+
+def test_so3_maps_match_scipy_and_the_reference_clamp():
+    from scipy.spatial.transform import Rotation
+    from em_pose_amd.helpers.so3 import so3_exponential_map, so3_log_map, so3_relative_angle
+    rng = np.random.default_rng(1)
+    v = rng.normal(0, 1.0, size=(50, 3))
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * rng.uniform(0.05, 3.0, size=(50, 1))
+    R = so3_exponential_map(torch.from_numpy(v))
+    np.testing.assert_allclose(R.numpy(), Rotation.from_rotvec(v).as_matrix(), atol=1e-12)
+    np.testing.assert_allclose(so3_log_map(R).numpy(), v, atol=1e-9)
+    np.testing.assert_allclose(so3_relative_angle(R, R).numpy(), 0.0, atol=1e-6)
+    # below sqrt(eps) = 0.01 rad the squared angle is clamped (reference so3.py:115-116): the map is I + K + K^2/2 scaled
+    tiny = torch.tensor([[1e-3, 0.0, 0.0]], dtype=torch.float64)
+    Rt = so3_exponential_map(tiny)[0]
+    assert float(Rt[2, 1]) == pytest.approx(1e-3 * np.sin(0.01) / 0.01, rel=1e-12)
+    with pytest.raises(ValueError):
+        so3_exponential_map(torch.zeros(3))
