@@ -1,9 +1,9 @@
 """
 Batch containers: the input contract of the models (reference empose/data/data.py:17-104,193-309).
 
-Only what the LGD path touches is restated: the attribute set of `ABatch`, `RealBatch` with its missing-sensor
-suppression, and `get_inputs(sf, ef)` yielding the dict the model reads.  Sample classes, LMDB / npz
-IO and collation from files are out of scope (host-side IO).
+What the LGD path touches is restated: the attribute set of `ABatch`, `RealBatch` with its missing-sensor suppression,
+`AMASSSample` / `AMASSBatch` (the training-side containers: npz samples, padded collation), and `get_inputs(sf, ef)`
+yielding the dict the model reads.  LMDB datasets are out of scope (host-side IO, data absent).
 """
 import numpy as np
 import torch
@@ -173,3 +173,72 @@ class SyntheticBatch(ABatch):
         return {'marker_pos': self.marker_pos_synth[:, sf:ef], 'marker_oris': self.marker_ori_synth[:, sf:ef],
                 'marker_normals': None, 'joints': None, 'offset_t': self.offset_t_augmented,
                 'offset_r': self.offset_r_augmented, 'marker_masks': None}
+
+
+class AMASSSample(object):
+    """One AMASS / 3DPW sequence of ground-truth SMPL parameters (reference data.py:311-366)."""
+
+    def __init__(self, id, poses, shape, trans, fps, joints=None, gender='unknown'):
+        assert poses.shape[1] >= C.MAX_INDEX_ROOT_AND_BODY   # root orientation first, then the body joints
+        self.id, self.poses, self.shape, self.trans, self.fps, self.gender = id, poses, shape, trans, fps, gender
+        self.joints = None if joints is None else joints[:, :(C.N_JOINTS + 1) * 3]
+
+    @staticmethod
+    def from_disk(sample_path, id):
+        """The npz layout of the AMASS release: poses, betas, trans, mocap_framerate."""
+        raw = np.load(sample_path)
+        return AMASSSample(id, raw['poses'][:, :C.MAX_INDEX_ROOT_AND_BODY], raw['betas'][:C.N_SHAPE_PARAMS], raw['trans'],
+                           raw['mocap_framerate'].tolist())
+
+    @property
+    def n_frames(self):
+        return self.poses.shape[0]
+
+    def to_tensor(self):
+        t = lambda a: torch.from_numpy(np.asarray(a)).to(dtype=C.DTYPE)
+        self.poses, self.shape, self.trans = t(self.poses), t(self.shape), t(self.trans)
+        self.fps = torch.scalar_tensor(self.fps).to(dtype=C.DTYPE)
+        self.joints = None if self.joints is None else t(self.joints)
+
+    def extract_window(self, start_frame, end_frame):
+        sf, ef = start_frame, end_frame
+        return AMASSSample(self.id, self.poses[sf:ef], self.shape, self.trans[sf:ef], self.fps,
+                           None if self.joints is None else self.joints[sf:ef], self.gender)
+
+
+class AMASSBatch(ABatch):
+    """A mini-batch of AMASS sequences, zero-padded to the longest (reference data.py:369-459).  The sensor readings
+    (`marker_*_synth`, `offset_*_augmented`) are filled in by `SMPLFK` + `SampleMarkersWithOffsets`."""
+
+    def __init__(self, seq_ids, seq_lengths, poses, shapes, trans, joints_gt, genders=None):
+        super(AMASSBatch, self).__init__(seq_ids, seq_lengths, poses, shapes, trans, joints_gt)
+        self.genders = ['unknown'] * self.batch_size if genders is None else genders
+
+    @staticmethod
+    def from_sample_list(samples):
+        pad = lambda xs: pad_sequence(xs, batch_first=True)
+        joints = None if any(s.joints is None for s in samples) else pad([s.joints for s in samples])
+        return AMASSBatch([s.id for s in samples], torch.tensor([s.n_frames for s in samples]),
+                          pad([s.poses for s in samples]), torch.stack([s.shape for s in samples]),
+                          pad([s.trans for s in samples]), joints, [s.gender for s in samples])
+
+    def to_gpu(self, device=None):
+        device = C.DEVICE if device is None else device
+        for name in ('seq_lengths', 'poses', 'shapes', 'trans', 'joints_gt'):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, v.to(device=device))
+        return self
+
+    @property
+    def n_markers(self):
+        return self.marker_pos_synth.shape[-1] // 3
+
+    def get_inputs(self, sf=None, ef=None, **kwargs):
+        pick = lambda noisy, synth: None if (noisy is None and synth is None) else \
+            (noisy if noisy is not None else synth).detach()[:, sf:ef]
+        return {'marker_pos': pick(self.marker_pos_noisy, self.marker_pos_synth),
+                'marker_oris': pick(self.marker_ori_noisy, self.marker_ori_synth),
+                'marker_normals': pick(self.marker_normal_noisy, self.marker_normal_synth),
+                'joints': None if self.joints_gt is None else self.joints_gt[:, sf:ef],
+                'offset_t': self.offset_t_augmented, 'offset_r': self.offset_r_augmented, 'marker_masks': None}

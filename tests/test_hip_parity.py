@@ -974,6 +974,33 @@ def test_device_metrics_vs_reference_vectors_and_numpy(big_model):
     np.testing.assert_allclose(rows['eucl_pa'], np.linalg.norm(j - procrustes_align(j, jh), axis=-1), atol=5e-6)
 
 
+def test_amass_batch_through_preprocessing_and_a_training_step():
+    """The training-side containers end to end: AMASSSample -> AMASSBatch -> NormalizeRoot/SMPLFK/SampleMarkersWithOffsets
+    (reference transforms.py:23-48) -> one forward + backward of LGD-RNN in training mode."""
+    from em_pose_amd.data.data import AMASSBatch, AMASSSample
+    from em_pose_amd.data.transforms import ToTensor, get_end_to_end_preprocess_fn
+    case = H.load_case('train_lgdrnn12_n2')
+    model, vids = H.small_model(), [int(v) for v in case['meta']['vertex_ids']]
+    smpl = SMPLLayer(model).to(DEV)
+    rng = np.random.default_rng(8)
+    samples = []
+    for i, n in enumerate((6, 4)):
+        smp = AMASSSample('s%d' % i, rng.normal(0, 0.2, size=(n, 66)).astype(np.float32),
+                          rng.normal(0, 1, size=10).astype(np.float32), rng.normal(0, 1, size=(n, 3)).astype(np.float32), 60.0)
+        samples.append(ToTensor()(smp))
+    batch = AMASSBatch.from_sample_list(samples).to_gpu(torch.device(DEV))
+    offsets = {'means': rng.normal(0, 0.02, size=(12, 3)).astype(np.float32), 'covs': None,
+               'r': np.tile(np.eye(3, dtype=np.float32), (12, 1, 1)), 'vertex_ids': np.asarray(vids)}
+    batch = get_end_to_end_preprocess_fn(cfg_of(case['meta']), smpl, [offsets])(batch)
+    assert batch.marker_pos_synth.shape == (2, 6, 36) and batch.joints_gt.shape == (2, 6, 66)
+    net = build_net(cfg_of(case['meta']), model, vids, case['sd']).train()
+    net.zero_grad()
+    total, vals = net.backward(batch, net(batch))
+    assert np.isfinite(vals['total_loss']) and vals['total_loss'] > 0
+    grads = [p.grad for n_, p in net.named_parameters() if not n_.startswith('smpl.') and p.grad is not None]
+    assert len(grads) >= 14 and all(bool(torch.isfinite(g).all()) for g in grads)
+
+
 def test_ground_truth_preprocessing_round_trip(big_model):
     """SMPLFK + SampleMarkersWithOffsets: sensors sampled from the full ground-truth mesh with offsets
     equal what the LGD sub-mesh path predicts for the same pose/shape/offsets (two independent HIP routes)."""

@@ -199,3 +199,26 @@ def test_so3_maps_match_scipy_and_the_reference_clamp():
     assert float(Rt[2, 1]) == pytest.approx(1e-3 * np.sin(0.01) / 0.01, rel=1e-12)
     with pytest.raises(ValueError):
         so3_exponential_map(torch.zeros(3))
+
+
+def test_amass_sample_and_batch(tmp_path):
+    """reference data.py:311-459: npz sample, window extraction, padded collation, the input dict."""
+    from em_pose_amd.data.data import AMASSBatch, AMASSSample
+    from em_pose_amd.data.transforms import ExtractWindow, ToTensor
+    rng = np.random.default_rng(2)
+    path = str(tmp_path / 'seq.npz')
+    np.savez(path, poses=rng.normal(size=(40, 156)), betas=rng.normal(size=16), trans=rng.normal(size=(40, 3)),
+             mocap_framerate=np.array(120.0))
+    a = AMASSSample.from_disk(path, 'a')
+    assert a.poses.shape == (40, 66) and a.shape.shape == (10,) and a.fps == 120.0 and a.n_frames == 40
+    b = ExtractWindow(16, mode='middle')(a)
+    assert b.n_frames == 16 and np.array_equal(b.poses, a.poses[12:28])
+    samples = [ToTensor()(a), ToTensor()(b)]
+    batch = AMASSBatch.from_sample_list(samples)
+    assert batch.poses.shape == (2, 40, 66) and batch.seq_lengths.tolist() == [40, 16] and batch.joints_gt is None
+    assert float(batch.poses[1, 16:].abs().max()) == 0.0 and batch.genders == ['unknown', 'unknown']
+    batch.marker_pos_synth, batch.marker_ori_synth = torch.zeros(2, 40, 36), torch.ones(2, 40, 108)
+    batch.marker_pos_noisy = torch.full((2, 40, 36), 2.0)
+    inp = batch.get_inputs(sf=4, ef=10)
+    assert inp['marker_pos'].shape == (2, 6, 36) and float(inp['marker_pos'].min()) == 2.0   # noisy wins over synth
+    assert float(inp['marker_oris'].min()) == 1.0 and inp['marker_masks'] is None and inp['joints'] is None
