@@ -66,6 +66,64 @@ def load_model(model_id, device=None):
     return net.to(device).eval(), config, model_dir
 
 
+def get_model_config(model_id):
+    """(Configuration, model directory) of a released model (reference eval/helpers.py:140-145)."""
+    model_dir = get_model_dir(C.EXPERIMENT_DIR, model_id)
+    return Configuration.from_json(os.path.join(model_dir, 'config.json')), model_dir
+
+
+def evaluate(data_loader, net, preprocess_fn, metrics_engine, window_size=None, device=None):
+    """
+    Losses and metrics over a hold-out set (reference eval/helpers.py:51-111): every batch is normalised as a whole,
+    cut into temporal chunks (`window_size`, single-recording `RealBatch`es only, as in the reference), preprocessed,
+    run through the model with the LSTM state carried over the chunks, and fed to the metrics engine with the shape of
+    the first chunk.
+    :return: dict of loss values averaged over the samples of the set.
+    """
+    device = C.DEVICE if device is None else device
+    net.eval()
+    keep = getattr(net, 'keep_history', True)
+    net.keep_history = True            # the loss values are computed from the iteration histories
+    agg, n_samples = defaultdict(float), 0
+    metrics_engine.reset()
+    try:
+        with torch.no_grad():
+            for b, abatch in enumerate(data_loader):
+                abatch = preprocess_fn(abatch, mode='normalize_only')
+                first_shape_hat, seq_vals, n_chunks, bs = None, defaultdict(float), 0, 0
+                for i, achunk in enumerate(window_generator(abatch, window_size)):
+                    chunk = preprocess_fn(achunk.to_gpu(device), mode='after_normalize', reset_rng=(i + b == 0))
+                    out = net(chunk, is_new_sequence=(i == 0))
+                    _, vals = net.backward(chunk, out)
+                    for k, v in vals.items():
+                        seq_vals[k] += v
+                    pose_hat = out['pose_hat'] if out['pose_hat'] is not None else chunk.poses_body
+                    if i == 0:
+                        first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
+                    metrics_engine.compute(chunk.poses_body, chunk.shapes, pose_hat, first_shape_hat, chunk.seq_lengths,
+                                           chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
+                    n_chunks, bs = i + 1, chunk.batch_size
+                for k, v in seq_vals.items():
+                    agg[k] += v / n_chunks * bs
+                n_samples += bs
+    finally:
+        net.keep_history = keep
+    return {k: v / n_samples for k, v in agg.items()}
+
+
+def compute_loss_and_metrics(data_loader, net, preprocess_fn, model_id, smpl_model=None, device=None):
+    """reference eval/helpers.py:114-128"""
+    if smpl_model is None:
+        from em_pose_amd.bodymodels.smpl import create_default_smpl_model
+        smpl_model = create_default_smpl_model(device)
+    me = MetricsEngine(smpl_model)
+    losses = evaluate(data_loader, net, preprocess_fn, me, device=device)
+    print('[LOSS] loss: {:.6f}'.format(losses['total_loss']))
+    metrics = me.get_metrics()
+    print(me.to_pretty_string(metrics, model_id))
+    return losses, metrics
+
+
 def partition_sequences(lengths, world_size):
     """
     Longest-processing-time-first assignment of recordings to ranks.

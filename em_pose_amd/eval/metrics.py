@@ -218,6 +218,30 @@ class MetricsEngine(object):
             gh = rotvec_to_matrix(ph.reshape(ph.shape[0], -1, 3))
         self.angle_diffs.append(geodesic_degrees(g, gh))
 
+    def compute_angle_dist(self, pose, pose_hat, seq_lengths=None, frame_mask=None, rep='aa'):
+        """Joint-angle metric only, on the angles as given (no kinematic chain; reference metrics.py:267-287):
+        pose / pose_hat (N, F, J*3) axis-angle or (N, F, J*9) rotation matrices."""
+        if rep not in ('aa', 'rotmat'):
+            raise ValueError("rep is 'aa' or 'rotmat'")
+        n, f = pose.shape[0], pose.shape[1]
+        mask = self._mask(seq_lengths, n, f, frame_mask, pose.device)
+        if mask.sum() == 0:
+            return
+        p = pose[mask].detach().cpu().numpy().astype(np.float64)
+        ph = pose_hat[mask].detach().cpu().numpy().astype(np.float64)
+        if rep == 'aa':
+            g, gh = rotvec_to_matrix(p.reshape(p.shape[0], -1, 3)), rotvec_to_matrix(ph.reshape(ph.shape[0], -1, 3))
+        else:
+            g, gh = p.reshape(p.shape[0], -1, 3, 3), ph.reshape(ph.shape[0], -1, 3, 3)
+        self.angle_diffs.append(geodesic_degrees(g, gh))
+
+    @staticmethod
+    def to_tensorboard_log(metrics, writer, global_step, prefix=''):
+        """reference metrics.py:342-346"""
+        writer.add_scalar('metrics/{}/mje mean'.format(prefix), metrics['MPJPE [mm]'], global_step)
+        writer.add_scalar('metrics/{}/mje pa mean'.format(prefix), metrics['PA-MPJPE [mm]'], global_step)
+        writer.add_scalar('metrics/{}/mae mean'.format(prefix), metrics['MPJAE [deg]'], global_step)
+
     # ---- mergeable state ------------------------------------------------------------------------------------------
     def state(self):
         cat = lambda xs, w: np.concatenate(xs, axis=0) if xs else np.zeros((0, w))

@@ -1001,6 +1001,51 @@ def test_amass_batch_through_preprocessing_and_a_training_step():
     assert len(grads) >= 14 and all(bool(torch.isfinite(g).all()) for g in grads)
 
 
+def test_validation_loop_evaluate():
+    """eval/helpers.py::evaluate (reference eval/helpers.py:51-111): losses averaged over the samples of a loader, metrics
+    accumulated for every valid frame; plus MetricsEngine.compute_angle_dist on raw joint angles."""
+    from em_pose_amd.data.data import AMASSBatch, AMASSSample
+    from em_pose_amd.data.transforms import ToTensor, get_end_to_end_preprocess_fn
+    from em_pose_amd.eval.helpers import evaluate
+    from em_pose_amd.eval.metrics import MetricsEngine, geodesic_degrees, rotvec_to_matrix
+    case = H.load_case('train_lgdrnn12_n2')
+    model, vids = H.small_model(), [int(v) for v in case['meta']['vertex_ids']]
+    smpl = SMPLLayer(model).to(DEV)
+    net = build_net(cfg_of(case['meta']), model, vids, case['sd'])
+    rng = np.random.default_rng(9)
+    offsets = {'means': rng.normal(0, 0.02, size=(12, 3)).astype(np.float32), 'covs': None,
+               'r': np.tile(np.eye(3, dtype=np.float32), (12, 1, 1)), 'vertex_ids': np.asarray(vids)}
+    fn = get_end_to_end_preprocess_fn(cfg_of(case['meta']), smpl, [offsets])
+
+    def loader():
+        r = np.random.default_rng(10)
+        for lens in ((6, 4), (5,)):
+            yield AMASSBatch.from_sample_list([ToTensor()(AMASSSample(
+                's', r.normal(0, 0.2, size=(n, 66)).astype(np.float32), r.normal(0, 1, size=10).astype(np.float32),
+                np.zeros((n, 3), np.float32), 60.0)) for n in lens])
+    me = MetricsEngine(smpl)
+    losses = evaluate(loader(), net, fn, me, device=torch.device(DEV))
+    assert set(losses) >= {'pose', 'shape', 'reconstruction', 'fk', 'total_loss'} and np.isfinite(losses['total_loss'])
+    assert np.concatenate(me.eucl_dists).shape == (15, 22) and net.keep_history in (True, False)
+    # the same number by hand: per-batch loss weighted by its batch size
+    net.keep_history = True
+    want, n = 0.0, 0
+    with torch.no_grad():
+        for ab in loader():
+            b = fn(ab.to_gpu(torch.device(DEV)), mode='all')
+            want += net.backward(b, net(b))[1]['total_loss'] * b.batch_size
+            n += b.batch_size
+    assert losses['total_loss'] == pytest.approx(want / n, rel=1e-5)
+    # joint-angle metric on the angles as given
+    p, ph = rng.normal(0, 0.5, size=(2, 3, 63)), rng.normal(0, 0.5, size=(2, 3, 63))
+    me2 = MetricsEngine(None)
+    me2.compute_angle_dist(torch.from_numpy(p), torch.from_numpy(ph), seq_lengths=torch.tensor([3, 2]))
+    rows = np.concatenate(me2.angle_diffs)
+    valid = np.array([[1, 1, 1], [1, 1, 0]], bool)
+    np.testing.assert_allclose(rows, geodesic_degrees(rotvec_to_matrix(p[valid].reshape(5, 21, 3)),
+                                                      rotvec_to_matrix(ph[valid].reshape(5, 21, 3))), atol=1e-9)
+
+
 def test_ground_truth_preprocessing_round_trip(big_model):
     """SMPLFK + SampleMarkersWithOffsets: sensors sampled from the full ground-truth mesh with offsets
     equal what the LGD sub-mesh path predicts for the same pose/shape/offsets (two independent HIP routes)."""
