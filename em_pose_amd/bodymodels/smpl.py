@@ -84,6 +84,15 @@ class SMPLLayer(nn.Module):
             self._vertex_faces = torch.from_numpy(vf).to(dtype=torch.long, device=self.bm.f.device)
         return self._vertex_faces
 
+    def vertex_normals(self, vertices, output_vertex_ids=None):
+        """Un-normalised vertex normals of posed meshes (N, V, 3) -> (N, V, 3), or (N, len(ids), 3) for the given vertex
+        ids (reference smpl.py:69-79)."""
+        from em_pose_amd.data.virtual_sensors import VirtualMarkerHelper
+        if getattr(self, '_normal_helper', None) is None:
+            self._normal_helper = VirtualMarkerHelper(self)
+        ids = list(range(vertices.shape[1])) if output_vertex_ids is None else [int(i) for i in output_vertex_ids]
+        return self._normal_helper.get_vertex_normals(vertices, ids)
+
     # -- HIP full-mesh evaluation -----------------------------------------------------------------------------
     def _mesh_handle(self, device):
         if self._mesh is not None and self._mesh[1] == device.index:

@@ -60,3 +60,8 @@ class VirtualMarkerHelper(object):
                                                              _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(nor),
                                                              _lib.current_stream()))
         return pos, ori, nor
+
+    def get_vertex_normals(self, vertices, vertex_ids):
+        """Un-normalised vertex normals (mean of the incident faces' (v1-v0)x(v2-v0)) at `vertex_ids`, (N, M, 3)
+        (reference virtual_sensors.py:77-83)."""
+        return self.get_virtual_pos_and_rot(vertices, vertex_ids)[2]

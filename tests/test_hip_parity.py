@@ -1046,6 +1046,32 @@ def test_validation_loop_evaluate():
                                                       rotvec_to_matrix(ph[valid].reshape(5, 21, 3))), atol=1e-9)
 
 
+def test_vertex_normals_api():
+    """SMPLLayer.vertex_normals / VirtualMarkerHelper.get_vertex_normals (reference smpl.py:69-79,
+    virtual_sensors.py:77-83): mean of the incident faces' un-normalised normals."""
+    model = H.small_model()
+    smpl = SMPLLayer(model).to(DEV)
+    rng = np.random.default_rng(12)
+    v = rng.normal(size=(3, model['v_template'].shape[0], 3)).astype(np.float32)
+    f = np.asarray(model['f'], dtype=np.int64)
+    fn = np.cross(v[:, f[:, 1]] - v[:, f[:, 0]], v[:, f[:, 2]] - v[:, f[:, 0]])        # (3, n_faces, 3)
+    want = np.zeros_like(v)
+    deg = np.zeros(v.shape[1])
+    for k, tri in enumerate(f):
+        for vid in tri:
+            want[:, vid] += fn[:, k]
+            deg[vid] += 1
+    want /= np.maximum(deg, 1)[None, :, None]
+    got = smpl.vertex_normals(gpu(v)).cpu().numpy()
+    used = deg > 0
+    np.testing.assert_allclose(got[:, used], want[:, used], atol=2e-5)
+    ids = [5, 17, 100]
+    np.testing.assert_allclose(smpl.vertex_normals(gpu(v), ids).cpu().numpy(), want[:, ids], atol=2e-5)
+    from em_pose_amd.data.virtual_sensors import VirtualMarkerHelper
+    helper = VirtualMarkerHelper(smpl)
+    np.testing.assert_allclose(helper.get_vertex_normals(gpu(v), ids).cpu().numpy(), want[:, ids], atol=2e-5)
+
+
 def test_ground_truth_preprocessing_round_trip(big_model):
     """SMPLFK + SampleMarkersWithOffsets: sensors sampled from the full ground-truth mesh with offsets
     equal what the LGD sub-mesh path predicts for the same pose/shape/offsets (two independent HIP routes)."""
