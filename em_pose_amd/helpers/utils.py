@@ -9,6 +9,19 @@ from em_pose_amd.eval.helpers import get_model_dir  # noqa: F401  (reference uti
 from em_pose_amd.nn.models import mask_from_seq_lengths  # noqa: F401  (reference utils.py:105-123)
 
 
+def create_model_dir(experiment_dir, experiment_id, model_summary, other_summary=None):
+    """`<experiment_dir>/<id>-<summary>[-<other>]`, must not exist yet (reference utils.py:42-51)."""
+    import os
+    name = '{}-{}'.format(experiment_id, model_summary)
+    if other_summary:
+        name = '{}-{}'.format(name, other_summary)
+    model_dir = os.path.join(experiment_dir, name)
+    if os.path.exists(model_dir):
+        raise ValueError('Model directory already exists {}'.format(model_dir))
+    os.makedirs(model_dir)
+    return model_dir
+
+
 def count_parameters(model):
     """Trainable parameters of a module (reference utils.py:54-56)."""
     return sum(p.numel() for p in model.parameters() if p.requires_grad)

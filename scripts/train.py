@@ -34,6 +34,98 @@ from em_pose_amd.helpers.distributed import allreduce_gradients, init_from_env  
 from em_pose_amd.nn.models import create_model  # noqa: E402
 
 
+def train_on_amass(args, dev, rank, world):
+    """Data-parallel training on AMASS npz sequences: random windows, offsets with the configured noise level, periodic
+    validation on held-out sequences, best checkpoint + config.json in the reference's experiment layout (so that
+    `scripts/evaluate_real.py --model_id <id>` / `eval.helpers.load_model` find them)."""
+    import glob
+    from torch.utils.data import DataLoader
+    from em_pose_amd.data.data import AMASSBatch
+    from em_pose_amd.data.datasets import AMASSNpzDataset
+    from em_pose_amd.data.transforms import ExtractWindow, ToTensor, get_end_to_end_preprocess_fn
+    from em_pose_amd.eval.helpers import evaluate
+    from em_pose_amd.eval.metrics import MetricsEngine
+    from em_pose_amd.helpers.configuration import CONSTANTS as C
+    from em_pose_amd.helpers.utils import count_parameters, create_model_dir
+
+    smpl = SMPLLayer(args.smpl_model if args.smpl_model else synthetic.make_model()).to(dev)
+    torch.manual_seed(args.seed)
+    cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, window_size=args.window_size, lr=args.lr,
+                     offset_noise_level=args.offset_noise_level)
+    net = create_model(cfg, smpl).to(dev)
+    params = [q for n, q in net.named_parameters() if not n.startswith('smpl.')]
+    opt = torch.optim.Adam(params, lr=args.lr)
+    offsets = args.offset_files or sorted(glob.glob(os.path.join(C.DATA_DIR_TEST or '.', '*_offsets.npz')))
+    if not offsets:
+        raise SystemExit('no *_offsets.npz files: pass --offset_files or set EM_DATA_REAL')
+    fn_train = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=True)
+    fn_valid = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=False)
+
+    files = sorted(glob.glob(os.path.join(args.amass_dir, '**', '*.npz'), recursive=True))
+    if len(files) < 2:
+        raise SystemExit('need at least two AMASS sequences under ' + args.amass_dir)
+    n_valid = max(1, int(round(len(files) * args.valid_fraction)))
+    valid_files, train_files = files[::max(1, len(files) // n_valid)][:n_valid], None
+    train_files = [f for f in files if f not in valid_files][rank::world]     # sequences sharded over the ranks
+    win = lambda mode, rng=None: (lambda smp: ToTensor()(ExtractWindow(args.window_size, rng=rng, mode=mode)(smp)))
+    train_data = AMASSNpzDataset(None, win('random', np.random.RandomState(args.seed + rank)), files=train_files)
+    valid_data = AMASSNpzDataset(None, win('middle'), files=valid_files)
+    loader = lambda data, bs, shuffle: DataLoader(data, batch_size=bs, shuffle=shuffle, num_workers=args.data_workers,
+                                                 collate_fn=AMASSBatch.from_sample_list, drop_last=shuffle)
+    train_loader, valid_loader = loader(train_data, args.bs_train, True), loader(valid_data, args.bs_train, False)
+
+    model_dir = checkpoint = None
+    if rank == 0:
+        exp_dir = args.experiment_dir or C.EXPERIMENT_DIR
+        if not exp_dir:
+            raise SystemExit('pass --experiment_dir or set EM_EXPERIMENTS')
+        exp_id = args.experiment_id if args.experiment_id is not None else int(time.time())
+        model_dir = create_model_dir(exp_dir, exp_id, net.model_name())
+        cfg.to_json(os.path.join(model_dir, 'config.json'))
+        checkpoint = os.path.join(model_dir, 'model.pth')
+        print('Model created with {} trainable parameters'.format(count_parameters(net)))
+        print('Saving checkpoints to {}'.format(checkpoint))
+    me = MetricsEngine(smpl)
+    step, best, done = 0, float('inf'), False
+    for epoch in range(args.n_epochs):
+        for i, abatch in enumerate(train_loader):
+            t0 = time.perf_counter()
+            net.train()
+            opt.zero_grad()
+            batch = fn_train(abatch.to_gpu(dev))
+            loss, vals = net.backward(batch, net(batch))
+            allreduce_gradients(params)
+            opt.step()
+            if rank == 0:
+                print('[TRAIN {:0>5d} | {:0>3d}] '.format(i + 1, epoch + 1) +
+                      ' '.join('{}: {:.6f}'.format(k, v) for k, v in vals.items()) +
+                      ' elapsed: {:.3f} secs'.format(time.perf_counter() - t0))
+            step += 1
+            if step % args.eval_every == 0 or step == args.steps:
+                losses = evaluate(valid_loader, net, fn_valid, me, device=dev)     # every rank: same held-out set
+                if rank == 0:
+                    better = losses['total_loss'] < best
+                    print('[VALID {:0>5d} | {:0>3d}] '.format(i + 1, epoch + 1) +
+                          ' '.join('{}: {:.6f}'.format(k, v) for k, v in losses.items()) + (' ***' if better else ''))
+                    print(me.to_pretty_string(me.get_metrics(), 'VALID'))
+                    if better:
+                        best = losses['total_loss']
+                        torch.save({'iteration': i, 'epoch': epoch, 'global_step': step,
+                                    'model_state_dict': net.state_dict(), 'optimizer_state_dict': opt.state_dict(),
+                                    'valid_loss': best}, checkpoint)
+            if args.steps and step >= args.steps:
+                done = True
+                break
+        if done:
+            break
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and args.json:
+        print(json.dumps({'steps': step, 'best_valid_loss': best, 'model_dir': model_dir}))
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument('--steps', type=int, default=20)
@@ -48,6 +140,18 @@ def main():
     p.add_argument('--graph', action='store_true',
                    help='capture forward + backward in a HIP graph and replay it (static shapes, full-length windows)')
     p.add_argument('--json', action='store_true')
+    # training on AMASS sequences (the loop of reference scripts/train.py:125-230 with checkpoints and validation)
+    p.add_argument('--amass_dir', default=None, help='directory tree of AMASS *.npz sequences; switches from the '
+                                                     'synthetic step benchmark to real training')
+    p.add_argument('--offset_files', nargs='*', default=None, help='*_offsets.npz files (default: $EM_DATA_REAL/*_offsets.npz)')
+    p.add_argument('--smpl_model', default=None, help='SMPL-H model.npz (default: the synthetic stand-in body model)')
+    p.add_argument('--experiment_dir', default=None, help='where <id>-<name>/model.pth, config.json go ($EM_EXPERIMENTS)')
+    p.add_argument('--experiment_id', type=int, default=None)
+    p.add_argument('--n_epochs', type=int, default=1)
+    p.add_argument('--eval_every', type=int, default=200)
+    p.add_argument('--valid_fraction', type=float, default=0.1)
+    p.add_argument('--offset_noise_level', type=int, default=0)
+    p.add_argument('--data_workers', type=int, default=0)
     args = p.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('train.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
@@ -56,6 +160,8 @@ def main():
     torch.cuda.set_device(dev)
     rank, world = init_from_env(dev)
 
+    if args.amass_dir:
+        return train_on_amass(args, dev, rank, world)
     model = synthetic.make_model()
     torch.manual_seed(args.seed)  # identical initial replicas on every rank
     cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, window_size=args.window_size, lr=args.lr)

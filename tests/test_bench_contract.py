@@ -57,3 +57,44 @@ def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+def test_train_script_on_amass_npz_writes_a_loadable_checkpoint(tmp_path):
+    """scripts/train.py --amass_dir: AMASS npz sequences -> random windows -> preprocessing -> training steps ->
+    validation -> `<id>-<name>/model.pth` + `config.json` in the reference's experiment layout, loadable again."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    data = tmp_path / 'amass' / 'subject'
+    data.mkdir(parents=True)
+    for i in range(6):
+        n = 30 + 3 * i
+        np.savez(str(data / ('seq%d.npz' % i)), poses=rng.normal(0, 0.2, size=(n, 156)), betas=rng.normal(size=16),
+                 trans=rng.normal(size=(n, 3)), mocap_framerate=np.array(60.0))
+    sys.path.insert(0, ROOT)
+    from em_pose_amd.helpers.configuration import CONSTANTS as C
+    off = str(tmp_path / '0000_offsets.npz')
+    np.savez(off, means=rng.normal(0, 0.02, size=(12, 3)), covs=np.tile(np.eye(3) * 1e-4, (12, 1, 1)),
+             r=np.tile(np.eye(3), (12, 1, 1)), vertex_ids=np.asarray(C.VERTEX_IDS))
+    exp = tmp_path / 'experiments'
+    exp.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train.py'), '--amass_dir', str(tmp_path / 'amass'),
+                        '--offset_files', off, '--experiment_dir', str(exp), '--experiment_id', '42', '--steps', '3',
+                        '--eval_every', '2', '--bs_train', '2', '--window_size', '8', '--iterations', '1', '--n_epochs', '3', '--json'],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['steps'] == 3 and np.isfinite(out['best_valid_loss'])
+    assert '[VALID' in r.stdout and '***' in r.stdout
+    model_dir = out['model_dir']
+    assert os.path.basename(model_dir).startswith('42-') and os.path.exists(os.path.join(model_dir, 'config.json'))
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.eval.helpers import get_model_dir, load_model_weights
+    from em_pose_amd.helpers.configuration import Configuration
+    from em_pose_amd.nn.models import create_model
+    assert get_model_dir(str(exp), 42) == model_dir
+    cfg = Configuration.from_json(os.path.join(model_dir, 'config.json'))
+    net = create_model(cfg, SMPLLayer(synthetic.make_model()))
+    load_model_weights(os.path.join(model_dir, 'model.pth'), net)
+    assert cfg.window_size == 8 and net.N == 1
