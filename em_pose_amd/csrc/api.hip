@@ -1050,6 +1050,22 @@ int empose_linear_f32_ex(const float* A, int lda, const float* W, int ldw, float
   return EMPOSE_OK;
 }
 
+int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long a_ks, const float* W, long w_rs,
+                            long w_ks, float* C, int ldc, const float* bias, empose_stream_t stream_) {
+  if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");
+  if (M <= 0 || N <= 0 || K <= 0 || ldc < N) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (!strided_gemm_applicable(M, N))
+    return fail(EMPOSE_EINVAL, "problem too large for the small-problem GEMM (%d x %d outputs)", M, N);
+  StridedGemm p;
+  p.A = A; p.a_rs = a_rs; p.a_ks = a_ks; p.W = W; p.w_rs = w_rs; p.w_ks = w_ks; p.C = C; p.ldc = ldc; p.bias = bias;
+  p.M = M; p.N = N; p.K = K;
+  hipError_t e = launch_strided_gemm(p, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "strided gemm launch: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_gemm_strided_applicable(int M, int N) { return strided_gemm_applicable(M, N) ? 1 : 0; }
+
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream_) {
   if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");

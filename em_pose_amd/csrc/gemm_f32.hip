@@ -11,6 +11,8 @@
 // Tile: 256 threads = 2x2 waves, each wave WM x WN tiles of 32x32 -> block tile (64*WM) x (64*WN), BK = 32.
 // LDS rows are padded to 36 floats: 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte slots.
 #include "kernels.h"
+#include <cstdint>
+
 #include "gemm_epilogue.h"
 
 #include <cstdlib>
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_f32_kernel(GemmBatch batch) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int CH = 8;   // k-groups per batch of loads
+  constexpr int CH = 16;  // k-groups per batch of loads: a wave's whole share of K = 512 in one round trip
   for (int g0 = g_beg; g0 < g_end; g0 += CH) {
     f32x4 fa[CH], fb[CH];
 #pragma unroll
@@ -468,9 +470,90 @@ static hipError_t launch_splitk(const GemmBatch& batch, hipStream_t stream) {
   return hipGetLastError();
 }
 
-enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK };
-
 constexpr long SPLITK_MAX_TILES = 512;   // 256 x 512 x 512: 8 us against 15; 2048 rows (1024 tiles): 25 against 15
+
+// The same split-K tile for operands of any layout: element (row, k) of an operand lives at base[row * rs + k * ks].
+// ks == 1 is the K-contiguous case above (16-byte pieces); otherwise a lane gathers its four k with the row index
+// running across lanes, so the loads of a wave are still contiguous (ks is then the leading dimension of a transposed
+// matrix).  This is what the backward pass of a small linear layer needs: dX = dY . W (W transposed) and
+// dW = dY^T . X (both transposed) without materialising a transpose.
+template <bool A_KC, bool W_KC>
+__global__ __launch_bounds__(256) void gemm_strided_splitk_kernel(StridedGemm p) {
+  __shared__ float red[4 * 16 * 64];
+  const int M = p.M, N = p.N, K = p.K;
+  const int nt_n = (N + 31) / 32;
+  const int m0 = ((int)blockIdx.x / nt_n) * 32, n0 = ((int)blockIdx.x % nt_n) * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KG = (K + 7) / 8, gq = (KG + 3) / 4;
+  const int g_beg = wave * gq, g_end = min(g_beg + gq, KG);
+  const float* __restrict__ arow = p.A + (size_t)min(m0 + l31, M - 1) * p.a_rs;
+  const float* __restrict__ wrow = p.W + (size_t)min(n0 + l31, N - 1) * p.w_rs;
+  auto fetch = [&](const float* row, long ks, bool kc, int k) {
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    if (kc) {
+      if (k + 3 < K) return *reinterpret_cast<const f32x4*>(row + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = row[k + e];
+      return v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = row[(size_t)(k + e) * ks];
+    return v;
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int CH = 16;  // as above: the loads of a wave's share of K are all in flight together
+  for (int g0 = g_beg; g0 < g_end; g0 += CH) {
+    f32x4 fa[CH], fb[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int k = (g0 + u) * 8 + lh * 4;
+      const bool ok = g0 + u < g_end;
+      fa[u] = ok ? fetch(arow, p.a_ks, A_KC, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      fb[u] = ok ? fetch(wrow, p.w_ks, W_KC, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][e], fb[u][e], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int n = n0 + l31;
+  if (n >= N) return;
+  const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 4 + i;
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (row >= M) continue;
+    float v = red[(0 * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+    p.C[(size_t)row * p.ldc + n] = v + b;
+  }
+}
+
+bool strided_gemm_applicable(int M, int N) {
+  return (long)((M + 31) / 32) * ((N + 31) / 32) <= SPLITK_MAX_TILES;
+}
+
+hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream) {
+  const int blocks = ((p.M + 31) / 32) * ((p.N + 31) / 32);
+  // K-contiguous pieces need 16-byte aligned rows; anything else takes the gathering path
+  auto kc = [](const float* base, long rs, long ks) { return ks == 1 && rs % 4 == 0 && ((uintptr_t)base & 15) == 0; };
+  const bool a_kc = kc(p.A, p.a_rs, p.a_ks), w_kc = kc(p.W, p.w_rs, p.w_ks);
+  if (a_kc && w_kc) hipLaunchKernelGGL((gemm_strided_splitk_kernel<true, true>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (a_kc) hipLaunchKernelGGL((gemm_strided_splitk_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (w_kc) hipLaunchKernelGGL((gemm_strided_splitk_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_strided_splitk_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK };
 
 static GemmPick pick_gemm(const GemmBatch& batch) {
   int maxM = 0, maxN = 0;

@@ -22,6 +22,18 @@ struct GemmProb {
 };
 struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
 
+// C[M][N] = A . W^T (+ bias) with strided operands: A(m, k) = A[m * a_rs + k * a_ks], W(n, k) = W[n * w_rs + k * w_ks]
+// (small problems only, split-K tile; `strided_gemm_applicable`).
+struct StridedGemm {
+  const float* A; long a_rs, a_ks;
+  const float* W; long w_rs, w_ks;
+  float* C; int ldc;
+  const float* bias;
+  int M, N, K;
+};
+bool strided_gemm_applicable(int M, int N);
+hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream);
+
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
 const char* gemm_kernel_name(int M, int N, int K, int count, int role);

@@ -25,6 +25,55 @@ def _np32(t):
     return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
 
 
+def _gemm_strided(M, N, K, a, a_rs, a_ks, w, w_rs, w_ks, out, bias=None):
+    _lib.check(_lib.lib().empose_gemm_strided_f32(M, N, K, _lib.dptr(a), a_rs, a_ks, _lib.dptr(w), w_rs, w_ks,
+                                                  _lib.dptr(out), out.shape[1], _lib.dptr(bias), _lib.current_stream()))
+
+
+class _HipLinearFn(torch.autograd.Function):
+    """y = x W^T + b with forward and backward on the split-K GEMM (`empose_gemm_strided_f32`): the training path's
+    linear layers at the reference's batch size (12 windows x 32 frames = 384 rows) are small problems for which a
+    library GEMM call costs 10-13 us each; dX = dY W and dW = dY^T X read their operands transposed in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
+        M, K, N = x.shape[0], x.shape[1], w.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _gemm_strided(M, N, K, x, K, 1, w, K, 1, y, b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K, N = x.shape[0], x.shape[1], w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:      # dX[m][k] = sum_n dY[m][n] W[n][k]
+            dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+            _gemm_strided(M, K, N, dy, N, 1, w, 1, K, dx)
+        if ctx.needs_input_grad[1]:      # dW[n][k] = sum_m dY[m][n] X[m][k]
+            dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
+            _gemm_strided(N, K, M, dy, 1, N, x, 1, K, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=0)
+        return dx, dw, db
+
+
+def linear_train(x, lin):
+    """`lin(x)` with autograd for the training path: own kernels when the three GEMMs of the layer are small problems
+    (the reference's training batch), `torch.nn.functional.linear` (library GEMMs) otherwise."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    M, K, N = x2.shape[0], lin.in_features, lin.out_features
+    ok = _lib.lib().empose_gemm_strided_applicable
+    if x2.is_cuda and x2.dtype == torch.float32 and ok(M, N) and ok(M, K) and ok(N, K):
+        return _HipLinearFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))
+    return lin(x)
+
+
 class LinearLayers(nn.Module):
     """`num_layers` x (Linear, BatchNorm1d, PReLU, Dropout) with an optional skip from input to output."""
 
@@ -85,11 +134,13 @@ class MLP(nn.Module):
     def forward_torch(self, x):
         """The same network as PyTorch-ROCm ops with autograd (training path only: train-mode BatchNorm statistics,
         parameter gradients). Layer order as reference nn/layers.py:69-77."""
-        y = self.dropout(self.activation_fn(self.batch_norm(self.input_to_hidden(x))))
+        y = self.dropout(self.activation_fn(self.batch_norm(linear_train(x, self.input_to_hidden))))
         for block in self.hidden_layers:
-            z = block.layers(y)
+            z = y
+            for m in block.layers:
+                z = linear_train(z, m) if isinstance(m, nn.Linear) else m(z)
             y = y + z if block.use_skip else z
-        return self.hidden_to_output(y)
+        return linear_train(y, self.hidden_to_output)
 
     def fill_desc(self, desc, keep):
         """Fill an `_lib.MlpDesc` from the current parameters; host arrays are appended to `keep`."""

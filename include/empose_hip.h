@@ -220,6 +220,15 @@ int empose_linear_f32_ex(const float* A, int lda, const float* W, int ldw, float
                          const float* scale, const float* shift, const float* resid, int ldr, int act, float slope,
                          empose_stream_t stream);
 
+/* Small GEMM with strided operands: C[M][ldc] = A . W^T (+ bias[n]) where A(m, k) = A[m * a_rs + k * a_ks] and
+ * W(n, k) = W[n * w_rs + k * w_ks] -- any of the four transposition cases without a transposed copy.  This is what the
+ * backward pass of the training path's linear layers needs (torch.nn.functional.linear's autograd, reference
+ * nn/layers.py:46-77 in train mode): dX = dY . W and dW = dY^T . X.  Only problems of at most 512 output tiles of
+ * 32 x 32 (empose_gemm_strided_applicable); larger ones belong to a library GEMM. */
+int empose_gemm_strided_applicable(int M, int N);
+int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long a_ks, const float* W, long w_rs,
+                            long w_ks, float* C, int ldc, const float* bias, empose_stream_t stream);
+
 /* ---- stand-alone (Bi)LSTM: the RNNLayer of the BiRNN baseline --------------------------------- */
 /* reference nn/layers.py:80-157 (nn.LSTM, optionally bidirectional, packed ragged sequences). Parameter index
  * u = layer * dirs + direction (direction 1 = reverse), as PyTorch orders `*_l{k}` / `*_l{k}_reverse`; layer k > 0 of

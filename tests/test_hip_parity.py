@@ -635,6 +635,32 @@ def test_smpl_sensors_vjp_vs_autograd(big_model):
     np.testing.assert_allclose(s.grad.cpu().numpy(), want_be.numpy(), atol=2e-4 * want_be.abs().max().item(), rtol=1e-3)
 
 
+@pytest.mark.parametrize('M,K,N', [(384, 512, 512), (384, 296, 512), (384, 512, 66), (5, 8, 3), (100, 20, 10)])
+def test_linear_train_function_vs_torch_autograd(M, K, N):
+    """nn/layers.py::linear_train (forward + dX + dW + db on the strided split-K GEMM) against torch.nn.functional.linear
+    and its autograd; strided operands of every transposition case through the C entry point."""
+    from em_pose_amd.nn.layers import linear_train
+    torch.manual_seed(M + K + N)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    dy = torch.randn(M, N, device=DEV)
+    y = linear_train(x, lin)
+    y.backward(dy)
+    got = [y.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = None
+    lin.zero_grad()
+    y2 = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    y2.backward(dy.double())
+    want = [y2.detach(), x.grad, lin.weight.grad, lin.bias.grad]
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.cpu().numpy(), w.cpu().double().numpy(), atol=3e-5 * max(1.0, float(w.abs().max())))
+    lib = _lib.lib()
+    assert lib.empose_gemm_strided_applicable(384, 512) == 1 and lib.empose_gemm_strided_applicable(4096, 512) == 0
+    out = torch.empty(M, N, device=DEV)
+    assert lib.empose_gemm_strided_f32(0, N, K, _lib.dptr(x), K, 1, _lib.dptr(lin.weight), K, 1, _lib.dptr(out), N, None,
+                                       None) != 0
+
+
 @pytest.mark.parametrize('name', ['train_lgdrnn12_n2', 'train_lgd6_n2'])
 def test_training_step_matches_reference_gradients(name):
     """forward (train mode) + backward: losses and EVERY parameter gradient against the reference's own training
