@@ -5,7 +5,7 @@ The reference's batch of 12 windows is launch-bound on an MI355X: about 2000 sma
 inside a 22 ms step.  Capturing forward + backward once and replaying it removes the per-launch host cost; the gradient
 all-reduce and the optimizer stay outside the graph.  Static shapes only: every batch must have the shape of the batch
 the graph was captured with, and every window must span all F frames (the LSTM then runs without sequence packing,
-which needs a host round trip).
+which needs a host round trip, and in pieces short enough for MIOpen's RNN to be captured).
 """
 import torch
 
@@ -28,24 +28,23 @@ class GraphedTrainStep(object):
         net.full_windows = True
         # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
         # workspaces on the first call on a stream, which is not allowed while capturing).
-        # The LSTM runs as PyTorch's native cell-by-cell implementation inside the graph: capturing MIOpen's RNN
-        # crashes in hipStreamEndCapture from 32 time steps on (nn.LSTM(144, 512, 2) on (T, 12, 144): T <= 31 captures,
-        # T >= 32 segfaults; scripts/dev/dbg_lstm_graph.py), and in a replayed graph the per-step launches cost nothing.
+        # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
+        # workspaces on the first call on a stream, which is not allowed while capturing).  The LSTM goes through MIOpen in
+        # pieces of 16 time steps (RNNLayer.forward_torch): its RNN captures up to 31 steps and crashes from 32 on.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.backends.cudnn.flags(enabled=False):
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    optimizer.zero_grad(set_to_none=True)
-                    out = net(self.static)
-                    net.backward(self.static, out, as_tensors=True)
-                side.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
                 optimizer.zero_grad(set_to_none=True)
-                del out
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side):
                 out = net(self.static)
-                self.total, self.loss_vals = net.backward(self.static, out, as_tensors=True)
+                net.backward(self.static, out, as_tensors=True)
+            side.synchronize()
+            optimizer.zero_grad(set_to_none=True)
+            del out
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            out = net(self.static)
+            self.total, self.loss_vals = net.backward(self.static, out, as_tensors=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 

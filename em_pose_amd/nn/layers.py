@@ -247,6 +247,7 @@ class RNNLayer(nn.Module):
             self.to_init_state_h = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
             self.to_init_state_c = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers, bidirectional=bidirectional)
+        self.graph_chunk = 16   # time steps per nn.LSTM call on the capturable training path (forward_torch)
         self.to_out = nn.Linear(hidden_size * self.num_directions, output_size) if output_size is not None \
             else nn.Identity()
         self._handle, self._handle_key = None, None
@@ -346,8 +347,15 @@ class RNNLayer(nn.Module):
         is the same computation without its host round trip -- required inside a captured HIP graph."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         if full_length:   # the module is time-major (batch_first=False, like the reference's); the packing hid that
-            out, self.final_state = self.lstm(x.transpose(0, 1).contiguous(), self.init_state)
-            return out.transpose(0, 1).contiguous()
+            xt = x.transpose(0, 1).contiguous()
+            # Pieces of at most 16 time steps with the state carried: MIOpen's RNN captures into a HIP graph up to 31
+            # steps and crashes the capture from 32 on (scripts/dev/dbg_lstm_graph.py); the arithmetic is unchanged.
+            outs, state = [], self.init_state
+            for t0 in range(0, xt.shape[0], self.graph_chunk):
+                o, state = self.lstm(xt[t0:t0 + self.graph_chunk], state)
+                outs.append(o)
+            self.final_state = state
+            return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)).transpose(0, 1).contiguous()
         packed = pack_padded_sequence(x, seq_lengths.cpu(), batch_first=True, enforce_sorted=False)
         out, self.final_state = self.lstm(packed, self.init_state)
         out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])

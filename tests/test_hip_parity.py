@@ -744,12 +744,12 @@ def test_graphed_training_step_equals_eager(rnn, n_markers):
 
     net_e, params_e, opt_e = make(7)
     eager = []
-    with torch.backends.cudnn.flags(enabled=False):   # the captured step runs PyTorch's native LSTM, not MIOpen's
-        for b in batches:
-            opt_e.zero_grad()
-            _, vals = net_e.backward(b, net_e(b))
-            opt_e.step()
-            eager.append(vals)
+    net_e.full_windows = True   # the captured step runs the LSTM unpacked, in pieces of 16 steps: same kernels here
+    for b in batches:
+        opt_e.zero_grad()
+        _, vals = net_e.backward(b, net_e(b))
+        opt_e.step()
+        eager.append(vals)
 
     net_g, params_g, opt_g = make(7)
     step = GraphedTrainStep(net_g, opt_g, batches[0])
