@@ -104,6 +104,12 @@ SIGNATURES = {
     'empose_gemm_strided_applicable': (C.c_int, [C.c_int, C.c_int]),
     'empose_gemm_strided_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,
                                            C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'empose_bn_prelu_train_fwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    'empose_bn_prelu_train_bwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_rnn_create': (C.c_int, [C.POINTER(RnnDesc), C.POINTER(C.c_void_p)]),
     'empose_rnn_destroy': (None, [C.c_void_p]),
     'empose_rnn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

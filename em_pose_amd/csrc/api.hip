@@ -1066,6 +1066,38 @@ int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long
 
 int empose_gemm_strided_applicable(int M, int N) { return strided_gemm_applicable(M, N) ? 1 : 0; }
 
+int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float* gamma, const float* beta,
+                              const float* slope, float eps, float momentum, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* z, int ldz, float* save_mean, float* save_rstd,
+                              empose_stream_t stream_) {
+  if (!x || !gamma || !beta || !slope || !z || !save_mean || !save_rstd) return fail(EMPOSE_EINVAL, "null argument");
+  if (M <= 0 || C <= 0 || ldx < C || ldz < C) return fail(EMPOSE_EINVAL, "bad sizes");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return fail(EMPOSE_EINVAL, "running_mean and running_var go together");
+  BnPreluArgs a{};
+  a.M = M; a.C = C; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.slope = slope; a.eps = eps;
+  a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var;
+  a.num_batches_tracked = num_batches_tracked; a.z = z; a.ldz = ldz; a.save_mean = save_mean; a.save_rstd = save_rstd;
+  hipError_t e = launch_bn_prelu(a, false, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu forward: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
+                              const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope_partial,
+                              empose_stream_t stream_) {
+  if (!x || !dz || !gamma || !beta || !slope || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !dslope_partial)
+    return fail(EMPOSE_EINVAL, "null argument");
+  if (M <= 0 || C <= 0 || ldx < C || lddz < C || lddx < C) return fail(EMPOSE_EINVAL, "bad sizes");
+  BnPreluArgs a{};
+  a.M = M; a.C = C; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.slope = slope;
+  a.save_mean = const_cast<float*>(save_mean); a.save_rstd = const_cast<float*>(save_rstd);
+  a.dz = dz; a.lddz = lddz; a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dslope_partial = dslope_partial;
+  hipError_t e = launch_bn_prelu(a, true, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu backward: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream_) {
   if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");

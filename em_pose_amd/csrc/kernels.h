@@ -34,6 +34,20 @@ struct StridedGemm {
 bool strided_gemm_applicable(int M, int N);
 hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream);
 
+// Train-mode BatchNorm1d + PReLU, forward or backward (bn_prelu.hip).
+struct BnPreluArgs {
+  int M, C;
+  const float* x; int ldx;
+  const float* gamma; const float* beta; const float* slope;   // slope: one device float
+  float eps, momentum;
+  float* running_mean; float* running_var; long long* num_batches_tracked;   // forward only, may be null
+  float* z; int ldz;                                                         // forward output
+  float* save_mean; float* save_rstd;                                        // written by forward, read by backward
+  const float* dz; int lddz; float* dx; int lddx;                            // backward
+  float* dgamma; float* dbeta; float* dslope_partial;                        // [C], [C], [ceil(C / 32)]
+};
+hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream);
+
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
 const char* gemm_kernel_name(int M, int N, int K, int count, int role);

@@ -62,6 +62,51 @@ class _HipLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _BnPreluFn(torch.autograd.Function):
+    """Train-mode BatchNorm1d followed by PReLU (one shared slope), forward and backward as one HIP kernel each
+    (`empose_bn_prelu_train_fwd/bwd`); the running statistics are updated in place like torch.nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, bn):
+        x = x.contiguous()
+        M, Cn = x.shape
+        dev = x.device
+        z = torch.empty(M, Cn, dtype=torch.float32, device=dev)
+        mean, rstd = torch.empty(Cn, dtype=torch.float32, device=dev), torch.empty(Cn, dtype=torch.float32, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        _lib.check(_lib.lib().empose_bn_prelu_train_fwd(
+            M, Cn, _lib.dptr(x), Cn, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(slope), float(bn.eps),
+            float(bn.momentum), _lib.dptr(bn.running_mean) if track else None,
+            _lib.dptr(bn.running_var) if track else None, _lib.dptr(bn.num_batches_tracked) if track else None,
+            _lib.dptr(z), Cn, _lib.dptr(mean), _lib.dptr(rstd), _lib.current_stream()))
+        ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
+        dz = dz.contiguous()
+        M, Cn = x.shape
+        dev = x.device
+        dx = torch.empty(M, Cn, dtype=torch.float32, device=dev)
+        dgamma, dbeta = torch.empty(Cn, dtype=torch.float32, device=dev), torch.empty(Cn, dtype=torch.float32, device=dev)
+        partial = torch.empty((Cn + 31) // 32, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().empose_bn_prelu_train_bwd(
+            M, Cn, _lib.dptr(x), Cn, _lib.dptr(dz), Cn, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(slope),
+            _lib.dptr(mean), _lib.dptr(rstd), _lib.dptr(dx), Cn, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(partial),
+            _lib.current_stream()))
+        return dx, dgamma, dbeta, partial.sum().reshape(slope.shape), None
+
+
+def bn_prelu_train(x, bn, act):
+    """`act(bn(x))` for the training path: the fused kernels for a train-mode BatchNorm1d with a momentum and a PReLU
+    with one slope on GPU tensors, the torch modules otherwise."""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and isinstance(bn, nn.BatchNorm1d) and bn.training
+            and bn.affine and bn.momentum is not None and isinstance(act, nn.PReLU) and act.weight.numel() == 1):
+        return _BnPreluFn.apply(x, bn.weight, bn.bias, act.weight, bn)
+    return act(bn(x))
+
+
 def linear_train(x, lin):
     """`lin(x)` with autograd for the training path: own kernels when the three GEMMs of the layer are small problems
     (the reference's training batch), `torch.nn.functional.linear` (library GEMMs) otherwise."""
@@ -134,11 +179,16 @@ class MLP(nn.Module):
     def forward_torch(self, x):
         """The same network as PyTorch-ROCm ops with autograd (training path only: train-mode BatchNorm statistics,
         parameter gradients). Layer order as reference nn/layers.py:69-77."""
-        y = self.dropout(self.activation_fn(self.batch_norm(linear_train(x, self.input_to_hidden))))
+        y = self.dropout(bn_prelu_train(linear_train(x, self.input_to_hidden), self.batch_norm, self.activation_fn))
         for block in self.hidden_layers:
             z = y
+            for lin, bn, act in block.dense_specs():
+                z = linear_train(z, lin)
+                z = bn_prelu_train(z, bn, act) if bn is not None else act(z)
+                # (the block's Dropout has p = 0 in every released configuration; applied below when it does not)
             for m in block.layers:
-                z = linear_train(z, m) if isinstance(m, nn.Linear) else m(z)
+                if isinstance(m, nn.Dropout) and m.p > 0:
+                    raise NotImplementedError('dropout inside the hidden blocks is not part of the training path')
             y = y + z if block.use_skip else z
         return linear_train(y, self.hidden_to_output)
 

@@ -229,6 +229,20 @@ int empose_gemm_strided_applicable(int M, int N);
 int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long a_ks, const float* W, long w_rs,
                             long w_ks, float* C, int ldc, const float* bias, empose_stream_t stream);
 
+/* Train-mode BatchNorm1d + PReLU (one shared slope) of an MLP hidden layer, forward and backward as one kernel each
+ * (reference nn/layers.py:13-77 in training mode; torch.nn.BatchNorm1d semantics: batch statistics, biased variance for
+ * the normalisation, running statistics updated with `momentum` and the unbiased variance, num_batches_tracked + 1).
+ * x, z, dz, dx are [M][ld] row-major; gamma, beta, save_mean, save_rstd, dgamma, dbeta are [C]; slope is one device float;
+ * dslope_partial has ceil(C / 32) entries whose sum is the slope gradient. running_* / num_batches_tracked may be NULL. */
+int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float* gamma, const float* beta,
+                              const float* slope, float eps, float momentum, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* z, int ldz, float* save_mean, float* save_rstd,
+                              empose_stream_t stream);
+int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
+                              const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope_partial,
+                              empose_stream_t stream);
+
 /* ---- stand-alone (Bi)LSTM: the RNNLayer of the BiRNN baseline --------------------------------- */
 /* reference nn/layers.py:80-157 (nn.LSTM, optionally bidirectional, packed ragged sequences). Parameter index
  * u = layer * dirs + direction (direction 1 = reverse), as PyTorch orders `*_l{k}` / `*_l{k}_reverse`; layer k > 0 of

@@ -635,6 +635,34 @@ def test_smpl_sensors_vjp_vs_autograd(big_model):
     np.testing.assert_allclose(s.grad.cpu().numpy(), want_be.numpy(), atol=2e-4 * want_be.abs().max().item(), rtol=1e-3)
 
 
+@pytest.mark.parametrize('M,Cn', [(384, 512), (48, 32), (7, 100), (2, 5)])
+def test_bn_prelu_train_function_vs_torch_autograd(M, Cn):
+    """nn/layers.py::bn_prelu_train (train-mode BatchNorm1d + PReLU, one kernel forward, one backward) against the torch
+    modules and their autograd in float64: output, dx, dgamma, dbeta, dslope, running statistics, batch counter."""
+    from em_pose_amd.nn.layers import bn_prelu_train
+    torch.manual_seed(M * 7 + Cn)
+    bn, act = torch.nn.BatchNorm1d(Cn).to(DEV).train(), torch.nn.PReLU().to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.2, 1.5); bn.bias.normal_(0, 0.3); act.weight.fill_(0.17)
+        bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+    bn64, act64 = torch.nn.BatchNorm1d(Cn).double().to(DEV).train(), torch.nn.PReLU().double().to(DEV)
+    bn64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    act64.load_state_dict({k: v.double() for k, v in act.state_dict().items()})
+    x = (torch.randn(M, Cn, device=DEV) * 2 + 0.5).requires_grad_(True)
+    dz = torch.randn(M, Cn, device=DEV)
+    z = bn_prelu_train(x, bn, act)
+    z.backward(dz)
+    x64 = x.detach().double().requires_grad_(True)
+    z64 = act64(bn64(x64))
+    z64.backward(dz.double())
+    tol = lambda w: 5e-5 * max(1.0, float(w.abs().max()))
+    for g, w in ((z, z64), (x.grad, x64.grad), (bn.weight.grad, bn64.weight.grad), (bn.bias.grad, bn64.bias.grad),
+                 (act.weight.grad, act64.weight.grad), (bn.running_mean, bn64.running_mean),
+                 (bn.running_var, bn64.running_var)):
+        np.testing.assert_allclose(g.detach().cpu().numpy(), w.detach().cpu().numpy(), atol=tol(w))
+    assert int(bn.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize('M,K,N', [(384, 512, 512), (384, 296, 512), (384, 512, 66), (5, 8, 3), (100, 20, 10)])
 def test_linear_train_function_vs_torch_autograd(M, K, N):
     """nn/layers.py::linear_train (forward + dX + dW + db on the strided split-K GEMM) against torch.nn.functional.linear
