@@ -109,7 +109,7 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_bn_prelu_train_bwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_rnn_create': (C.c_int, [C.POINTER(RnnDesc), C.POINTER(C.c_void_p)]),
     'empose_rnn_destroy': (None, [C.c_void_p]),
     'empose_rnn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -1084,15 +1084,16 @@ int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float
 
 int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
                               const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
-                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope_partial,
-                              empose_stream_t stream_) {
-  if (!x || !dz || !gamma || !beta || !slope || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !dslope_partial)
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope, float* dslope_partial,
+                              int* counter, empose_stream_t stream_) {
+  if (!x || !dz || !gamma || !beta || !slope || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !dslope ||
+      !dslope_partial || !counter)
     return fail(EMPOSE_EINVAL, "null argument");
   if (M <= 0 || C <= 0 || ldx < C || lddz < C || lddx < C) return fail(EMPOSE_EINVAL, "bad sizes");
   BnPreluArgs a{};
   a.M = M; a.C = C; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.save_mean = const_cast<float*>(save_mean); a.save_rstd = const_cast<float*>(save_rstd);
-  a.dz = dz; a.lddz = lddz; a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dslope_partial = dslope_partial;
+  a.dz = dz; a.lddz = lddz; a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dslope_partial = dslope_partial; a.dslope = dslope; a.counter = counter;
   hipError_t e = launch_bn_prelu(a, true, static_cast<hipStream_t>(stream_));
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu backward: %s", hipGetErrorString(e));
   return EMPOSE_OK;

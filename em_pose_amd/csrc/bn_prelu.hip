@@ -10,7 +10,7 @@
 //             running_mean/var updated with momentum (unbiased variance, as torch.nn.BatchNorm1d does)
 //   backward: dy = y > 0 ? dz : a * dz;  da += sum_{y <= 0} dz * y;  dbeta = sum dy;  dgamma = sum dy * xhat;
 //             dx = gamma * rstd / M * (M * dy - dbeta - xhat * dgamma)
-// The slope gradient is one partial sum per workgroup (summed by the caller: deterministic).
+// The slope gradient is one partial sum per workgroup; the workgroup that finishes last adds them in index order.
 #include "kernels.h"
 
 namespace empose {
@@ -98,6 +98,15 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
     float t = 0.f;
     for (int i = 0; i < COLS; ++i) t += red[i];
     a.dslope_partial[blockIdx.x] = t;
+    // the workgroup that arrives last adds the partial sums in index order (deterministic) and re-arms the counter
+    __threadfence();
+    if (atomicAdd(a.counter, 1) == (int)gridDim.x - 1) {
+      __threadfence();
+      float total = 0.f;
+      for (unsigned i = 0; i < gridDim.x; ++i) total += __hip_atomic_load(a.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.dslope[0] = total;
+      a.counter[0] = 0;
+    }
   }
   if (!ok) return;
   const float k = g * rstd / (float)a.M;

@@ -44,7 +44,8 @@ struct BnPreluArgs {
   float* z; int ldz;                                                         // forward output
   float* save_mean; float* save_rstd;                                        // written by forward, read by backward
   const float* dz; int lddz; float* dx; int lddx;                            // backward
-  float* dgamma; float* dbeta; float* dslope_partial;                        // [C], [C], [ceil(C / 32)]
+  float* dgamma; float* dbeta; float* dslope_partial;                        // [C], [C], [ceil(C / 32)] scratch
+  float* dslope; int* counter;   // slope gradient (one float); arrival counter, zero before the first launch, self re-arming
 };
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream);
 

@@ -65,6 +65,7 @@ class _HipLinearFn(torch.autograd.Function):
 class _BnPreluFn(torch.autograd.Function):
     """Train-mode BatchNorm1d followed by PReLU (one shared slope), forward and backward as one HIP kernel each
     (`empose_bn_prelu_train_fwd/bwd`); the running statistics are updated in place like torch.nn.BatchNorm1d does."""
+    _counters = {}
 
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, bn):
@@ -90,12 +91,16 @@ class _BnPreluFn(torch.autograd.Function):
         dev = x.device
         dx = torch.empty(M, Cn, dtype=torch.float32, device=dev)
         dgamma, dbeta = torch.empty(Cn, dtype=torch.float32, device=dev), torch.empty(Cn, dtype=torch.float32, device=dev)
+        dslope = torch.empty(slope.shape, dtype=torch.float32, device=dev)
         partial = torch.empty((Cn + 31) // 32, dtype=torch.float32, device=dev)
+        counter = _BnPreluFn._counters.get(dev)
+        if counter is None:   # arrival counter of the kernel's last-workgroup reduction: zero once, self re-arming
+            counter = _BnPreluFn._counters[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
         _lib.check(_lib.lib().empose_bn_prelu_train_bwd(
             M, Cn, _lib.dptr(x), Cn, _lib.dptr(dz), Cn, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(slope),
-            _lib.dptr(mean), _lib.dptr(rstd), _lib.dptr(dx), Cn, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(partial),
-            _lib.current_stream()))
-        return dx, dgamma, dbeta, partial.sum().reshape(slope.shape), None
+            _lib.dptr(mean), _lib.dptr(rstd), _lib.dptr(dx), Cn, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(dslope),
+            _lib.dptr(partial), _lib.dptr(counter), _lib.current_stream()))
+        return dx, dgamma, dbeta, dslope, None
 
 
 def bn_prelu_train(x, bn, act):

@@ -233,15 +233,16 @@ int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long
  * (reference nn/layers.py:13-77 in training mode; torch.nn.BatchNorm1d semantics: batch statistics, biased variance for
  * the normalisation, running statistics updated with `momentum` and the unbiased variance, num_batches_tracked + 1).
  * x, z, dz, dx are [M][ld] row-major; gamma, beta, save_mean, save_rstd, dgamma, dbeta are [C]; slope is one device float;
- * dslope_partial has ceil(C / 32) entries whose sum is the slope gradient. running_* / num_batches_tracked may be NULL. */
+ * dslope receives the slope gradient; dslope_partial (ceil(C / 32) floats) and counter (one int, zero before the first
+ * call, left at zero by every call) are scratch. running_mean / running_var / num_batches_tracked may be NULL. */
 int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float* gamma, const float* beta,
                               const float* slope, float eps, float momentum, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float* z, int ldz, float* save_mean, float* save_rstd,
                               empose_stream_t stream);
 int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
                               const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
-                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope_partial,
-                              empose_stream_t stream);
+                              float* dx, int lddx, float* dgamma, float* dbeta, float* dslope, float* dslope_partial,
+                              int* counter, empose_stream_t stream);
 
 /* ---- stand-alone (Bi)LSTM: the RNNLayer of the BiRNN baseline --------------------------------- */
 /* reference nn/layers.py:80-157 (nn.LSTM, optionally bidirectional, packed ragged sequences). Parameter index
