@@ -25,7 +25,8 @@ class GraphedTrainStep(object):
             v = getattr(example_batch, k, None)
             if torch.is_tensor(v):
                 setattr(self.static, k, v.clone())
-        net.full_windows = True
+        was_full = getattr(net, 'full_windows', False)
+        net.full_windows = True   # only while the step is traced: the replayed graph does not go through Python again
         # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
         # workspaces on the first call on a stream, which is not allowed while capturing).
         # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
@@ -47,6 +48,7 @@ class GraphedTrainStep(object):
             self.total, self.loss_vals = net.backward(self.static, out, as_tensors=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        net.full_windows = was_full
 
     def load(self, batch):
         for k in self.FIELDS:
