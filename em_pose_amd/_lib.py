@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libempose_hip.so')
 
 MAX_DENSE = 8
+RODRIGUES = {'smplx': 0, 'so3': 1}   # EMPOSE_RODRIGUES_* (include/empose_hip.h)
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
 
@@ -24,7 +25,8 @@ class SmplDesc(C.Structure):
                 ('skin_idx', c_int_p), ('skin_w', c_float_p),
                 ('bone_ptr', c_int_p), ('bone_vert', c_int_p), ('bone_w', c_float_p),
                 ('s_center', c_int_p), ('s_helper', c_int_p), ('s_deg', c_int_p), ('s_faces', c_int_p),
-                ('path_ptr', c_int_p), ('path', c_int_p), ('sub_ptr', c_int_p), ('sub', c_int_p)]
+                ('path_ptr', c_int_p), ('path', c_int_p), ('sub_ptr', c_int_p), ('sub', c_int_p),
+                ('rodrigues', C.c_int)]
 
 
 class DenseDesc(C.Structure):
@@ -68,7 +70,8 @@ class LgdIO(C.Structure):
 
 class MeshDesc(C.Structure):
     _fields_ = [('n_vertices', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
-                ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p)]
+                ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p),
+                ('n_joints', C.c_int), ('rodrigues', C.c_int)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests check against the header.
@@ -76,6 +79,8 @@ SIGNATURES = {
     'empose_last_error': (C.c_char_p, []),
     'empose_version': (C.c_int, []),
     'empose_arch': (C.c_char_p, []),
+    'empose_set_option': (C.c_int, [C.c_char_p, C.c_int]),
+    'empose_get_option': (C.c_int, [C.c_char_p]),
     'empose_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     'empose_model_destroy': (None, [C.c_void_p]),
     'empose_lgd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
@@ -125,6 +130,7 @@ SIGNATURES = {
     'empose_mesh_create': (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
     'empose_mesh_destroy': (None, [C.c_void_p]),
     'empose_mesh_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
+    'empose_mesh_n_joints': (C.c_int, [C.c_void_p]),
     'empose_mesh_joints_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_size_t, C.c_void_p]),
     'empose_metrics_rows': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int),
@@ -190,6 +196,23 @@ def current_stream():
     the same stream, i.e. to work that is ordered after the kernels still reading it."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class option(object):
+    """Context manager: `with _lib.option('gemm_splitk', 0): ...` selects a kernel variant (empose_set_option) and
+    restores the previous value."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        self.prev = lib().empose_get_option(self.name)
+        check(lib().empose_set_option(self.name, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().empose_set_option(self.name, self.prev))
+        return False
 
 
 def profile_read():

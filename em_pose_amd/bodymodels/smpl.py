@@ -2,11 +2,12 @@
 SMPL-H layer (mirror of reference empose/bodymodels/smpl.py:24-165) backed by the HIP full-mesh kernels.
 
 `SMPLLayer(...)(poses_body, betas, poses_root=None, trans=None, normalize_root=False, window_size=None)` returns
-`(vertices (N,V,3), joints (N,22,3))`.  Differences to the reference, on purpose:
-  * joints holds the 22 body joints; the reference returns 52 (`body.Jtr`) but every caller on this path slices
-    `[:, :22]` (reference models.py:143,481; transforms.py:276).
+`(vertices (N,V,3), joints (N,52,3))` exactly as the reference (`body.v`, `body.Jtr`, smpl.py:121-122): the 30 hand
+joints have zero pose (smpl.py:99) and ride rigidly on the wrists.  Differences to the reference, on purpose:
   * `normalize_root=True` is not implemented (never used on this path, reference smpl.py:112-119).
   * the LGD loop itself never calls this layer: `IterativeErrorFeedback` evaluates only the sensor sub-mesh.
+  * `rodrigues_convention` ('smplx' | 'so3') selects how the axis-angle map guards the angle at zero; the fork that
+    holds the reference's arithmetic is not available, so the choice is explicit (include/empose_hip.h).
 
 Buffers live under `self.bm` with the names of the third-party `BodyModel` (`f, v_template, shapedirs, posedirs,
 J_regressor, weights`) so that `state_dict` keys of released checkpoints (`smpl.bm.*`) match.
@@ -56,10 +57,13 @@ class _BodyModelBuffers(nn.Module):
 
 
 class SMPLLayer(nn.Module):
-    def __init__(self, smpl_path, device=None, vposer_path=None):
+    def __init__(self, smpl_path, device=None, vposer_path=None, rodrigues_convention='smplx'):
         super(SMPLLayer, self).__init__()
         if vposer_path is not None:
             raise NotImplementedError('VPoser is not part of the LGD path')
+        if rodrigues_convention not in _lib.RODRIGUES:
+            raise ValueError('rodrigues_convention must be one of {}'.format(sorted(_lib.RODRIGUES)))
+        self.rodrigues_convention = rodrigues_convention
         self.num_betas = C.N_SHAPE_PARAMS
         self.model = load_model_npz(smpl_path)
         self.bm = _BodyModelBuffers(self.model, self.num_betas)
@@ -94,8 +98,13 @@ class SMPLLayer(nn.Module):
         return self._normal_helper.get_vertex_normals(vertices, ids)
 
     # -- HIP full-mesh evaluation -----------------------------------------------------------------------------
+    @property
+    def n_joints(self):
+        return int(np.asarray(self.model['J_regressor']).shape[0])
+
     def _mesh_handle(self, device):
-        if self._mesh is not None and self._mesh[1] == device.index:
+        key = (device.index, self.rodrigues_convention)
+        if self._mesh is not None and self._mesh[1] == key:
             return self._mesh[0]
         self._release()
         tab = TB.build_full_mesh_tables(self.model, self.num_betas)
@@ -103,10 +112,11 @@ class SMPLLayer(nn.Module):
         desc.n_vertices, desc.j_off, desc.ncp, desc.kb = tab['n_vertices'], tab['j_off'], tab['ncp'], tab['kb']
         desc.wc, desc.skin_idx = _lib.fptr(tab['wc']), _lib.iptr(tab['skin_idx'])
         desc.skin_w, desc.parents = _lib.fptr(tab['skin_w']), _lib.iptr(tab['parents'])
+        desc.n_joints, desc.rodrigues = tab['n_joints'], _lib.RODRIGUES[self.rodrigues_convention]
         handle = _lib.C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().empose_mesh_create(_lib.C.byref(desc), _lib.C.byref(handle)))
-        self._mesh = (handle, device.index)
+        self._mesh = (handle, key)
         return handle
 
     def _release(self):
@@ -138,7 +148,7 @@ class SMPLLayer(nn.Module):
         with torch.cuda.device(dev):
             handle = self._mesh_handle(dev)
             vertices = torch.empty(n, self.n_vertices, 3, dtype=torch.float32, device=dev)
-            joints = torch.empty(n, 22, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(n, self.n_joints, 3, dtype=torch.float32, device=dev)
             ws_bytes = lib.empose_mesh_workspace_bytes(handle, n)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.empose_mesh_vertices_fwd(handle, n, _lib.dptr(poses), _lib.dptr(betas), _lib.dptr(trans),
@@ -147,7 +157,8 @@ class SMPLLayer(nn.Module):
         return vertices, joints
 
     def fk_joints(self, poses_body, betas, poses_root=None, trans=None):
-        """The 22 posed body joints only (no vertices): forward kinematics for the metrics, (N,22,3)."""
+        """The 22 posed body joints only (no vertices): forward kinematics for the metrics, (N,22,3) contiguous
+        (= `fk(...)[1][:, :22]`, what reference eval/metrics.py:223-228 keeps)."""
         if not poses_body.is_cuda:
             raise _lib.EmposeError('SMPLLayer needs GPU tensors; there is no CPU fallback')
         n, dev = poses_body.shape[0], poses_body.device
@@ -161,12 +172,12 @@ class SMPLLayer(nn.Module):
         lib = _lib.lib()
         with torch.cuda.device(dev):
             handle = self._mesh_handle(dev)
-            joints = torch.empty(n, 22, 3, dtype=torch.float32, device=dev)
+            joints = torch.empty(n, self.n_joints, 3, dtype=torch.float32, device=dev)
             ws_bytes = lib.empose_mesh_workspace_bytes(handle, n)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.empose_mesh_joints_fwd(handle, n, _lib.dptr(poses), _lib.dptr(betas), _lib.dptr(trans),
                                                   _lib.dptr(joints), _lib.dptr(ws), ws_bytes, _lib.current_stream()))
-        return joints
+        return joints[:, :C.N_JOINTS + 1].contiguous()
 
     def fk(self, poses_body, betas, poses_root=None, trans=None, normalize_root=False, window_size=None):
         # The reference slices long inputs into windows to bound memory (smpl.py:124-144); the HIP entry point already

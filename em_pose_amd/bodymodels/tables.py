@@ -27,15 +27,23 @@ K_FEAT = 200  # 189 pose-feature columns + 10 betas + 1
 
 
 def vertex_faces_table(faces, n_vertices):
-    """(V, max_degree) table of incident face ids per vertex in ascending order, -1 padded."""
+    """
+    (V, max_degree) table of incident face ids per vertex, -1 padded, in the order of trimesh==3.9.32's
+    `Trimesh.vertex_faces` (reference smpl.py:58-67, virtual_sensors.py:47-75): DESCENDING face id.  trimesh fills the
+    rows from `faces_sparse.dot(identity).nonzero()[1]` (`geometry.vertex_face_indices`); scipy's CSR product emits the
+    columns of a row in reverse insertion order, and trimesh's own slow-loop fallback reverses explicitly to match.  The
+    order matters: `vertex_faces[v, 0]` picks the helper vertex of a sensor frame (reference virtual_sensors.py:55),
+    i.e. the in-plane axes every learned offset lives in.  tests/test_host_logic.py pins this table to the scipy
+    expression.
+    """
     faces = np.asarray(faces, dtype=np.int64)
     flat = faces.reshape(-1)
     counts = np.bincount(flat, minlength=n_vertices)
-    order = np.argsort(flat, kind='stable') // 3
+    order = np.argsort(flat, kind='stable') // 3   # ascending face ids per vertex
     starts = np.concatenate([[0], np.cumsum(counts)])
     table = np.full((n_vertices, max(int(counts.max()), 1)), -1, dtype=np.int64)
     for v in range(n_vertices):
-        table[v, :counts[v]] = order[starts[v]:starts[v + 1]]
+        table[v, :counts[v]] = order[starts[v]:starts[v + 1]][::-1]
     return table
 
 
@@ -139,15 +147,16 @@ def pose_rows(model, num_betas=10):
     return np.concatenate([pd, sd, vt], axis=1)  # (V*3, 200)
 
 
-def joint_rows(model, num_betas=10):
-    """Rows for the 22 rest joints: J = J_reg @ (v_template + shapedirs beta)  ->  [0 (189) | J_S (10) | J_t (1)]."""
-    Jr = np.asarray(model['J_regressor'], dtype=np.float64)[:N_BODY]
+def joint_rows(model, num_betas=10, n_joints=N_BODY):
+    """Rows for the first `n_joints` rest joints: J = J_reg @ (v_template + shapedirs beta)  ->
+    [0 (189) | J_S (10) | J_t (1)]."""
+    Jr = np.asarray(model['J_regressor'], dtype=np.float64)[:n_joints]
     sd = np.asarray(model['shapedirs'], dtype=np.float64)[:, :, :num_betas]
     vt = np.asarray(model['v_template'], dtype=np.float64)
     J_t = Jr @ vt  # (22,3)
     J_S = np.einsum('jv,vkl->jkl', Jr, sd)  # (22,3,10)
-    rows = np.zeros((N_BODY * 3, K_FEAT))
-    rows[:, 189:199] = J_S.reshape(N_BODY * 3, num_betas)
+    rows = np.zeros((n_joints * 3, K_FEAT))
+    rows[:, 189:199] = J_S.reshape(n_joints * 3, num_betas)
     rows[:, 199] = J_t.reshape(-1)
     return rows
 
@@ -223,18 +232,24 @@ def build_lgd_tables(model, vertex_ids, helper_ids=None, num_betas=10, dtype=np.
     }
 
 
-def build_full_mesh_tables(model, num_betas=10, dtype=np.float32):
-    """Constants for the full-mesh vertex kernel (final vertices / ground-truth preprocessing)."""
+def build_full_mesh_tables(model, num_betas=10, dtype=np.float32, n_joints=None):
+    """Constants for the full-mesh vertex kernel (final vertices / ground-truth preprocessing).  `n_joints`: how many
+    posed joints the kernel returns -- all of the model's (52 for SMPL-H, what the reference's `body.Jtr` holds,
+    smpl.py:121-122) by default; the joints past the 22 body joints have zero pose and only need their rest position
+    and parent."""
     parents52 = model_parents(model)
+    n_joints = len(parents52) if n_joints is None else int(n_joints)
+    assert N_BODY <= n_joints <= len(parents52)
+    assert all(p < j for j, p in enumerate(parents52[:n_joints])), 'joints must be topologically ordered'
     V = model['v_template'].shape[0]
     w22 = fold_weights(model['weights'], parents52)
     skin_idx, skin_w, kb = _sparsify(w22)
-    rows = np.concatenate([pose_rows(model, num_betas), joint_rows(model, num_betas)], axis=0)
+    rows = np.concatenate([pose_rows(model, num_betas), joint_rows(model, num_betas, n_joints)], axis=0)
     n_rows = _round_up(rows.shape[0], 4)
     w = np.zeros((n_rows, K_FEAT))
     w[:rows.shape[0]] = rows
-    return {'n_vertices': V, 'j_off': V * 3, 'ncp': n_rows, 'kb': kb,
+    return {'n_vertices': V, 'j_off': V * 3, 'ncp': n_rows, 'kb': kb, 'n_joints': n_joints,
             'wc': np.ascontiguousarray(w, dtype=dtype),
             'skin_idx': np.ascontiguousarray(skin_idx, dtype=np.int32),
             'skin_w': np.ascontiguousarray(skin_w, dtype=dtype),
-            'parents': np.ascontiguousarray(parents52[:N_BODY], dtype=np.int32)}
+            'parents': np.ascontiguousarray(parents52[:n_joints], dtype=np.int32)}

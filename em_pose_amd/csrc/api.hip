@@ -101,6 +101,7 @@ struct empose_model {
   int hidden_max = 0;
   int any_skip = 0;
   int smpl_only = 0;
+  int rod_conv = 0;            // EMPOSE_RODRIGUES_*
 };
 
 struct empose_rnn {
@@ -111,6 +112,8 @@ struct empose_rnn {
 struct empose_mesh {
   std::vector<void*> allocs;
   int V = 0, j_off = 0, ncp = 0, kb = 0;
+  int n_joints = 22;            // posed joints returned (22 body, or all 52 of SMPL-H)
+  int rod_conv = 0;             // EMPOSE_RODRIGUES_*
   float* wc = nullptr;
   float* wc_frag = nullptr;     // vertex rows of wc in matrix-core fragment order, per 32-vertex tile (mesh.hip)
   int* skin_idx = nullptr;
@@ -388,8 +391,7 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
   // Large batches: every layer of both nets in ONE launch (mlp_fused.hip); a workgroup keeps 128 rows through all the
   // layers. Needs enough row panels to fill the chip and layers no wider than the four 128-column waves.
   {
-    static const int fused_on = getenv("EMPOSE_MLP_FUSED") ? atoi(getenv("EMPOSE_MLP_FUSED")) : 1;  // dev A/B only
-    bool ok = fused_on != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 63) / 64) * n_nets >= 256;
+    bool ok = options().mlp_fused != 0 && L <= FUSED_MAX_LAYERS && (long)((T + 63) / 64) * n_nets >= 256;
     for (int i = 0; i < n_nets && ok; ++i) {
       if (nets[i]->skip || nets[i]->layers[0].in_dim > FUSED_MAX_WIDTH) ok = false;   // no room for a block input
       for (int l = 0; l < L; ++l) {
@@ -499,8 +501,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
     }
     // Small batches: the whole sequence in one cooperative launch (weights in registers, grid barrier per step).
     bool done = false;
-    const char* sw = getenv("EMPOSE_LSTM_PERSIST");   // dev A/B switch: "0" = step launch by launch
-    if (ws.xch && F >= 4 && !(sw && sw[0] == '0')) {
+    if (ws.xch && F >= 4 && options().lstm_persist != 0) {
       prof_mark(P_LSTM_STEP, stream);
       a.s = 0;
       hipError_t e = launch_lstm_persist(a, ws.xch, stream, &done);
@@ -605,9 +606,38 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
 
 }  // namespace
 
+namespace empose {
+Options& options() {
+  static Options o;
+  return o;
+}
+}  // namespace empose
+
 extern "C" {
 
 const char* empose_last_error(void) { return g_err.c_str(); }
+
+int empose_set_option(const char* name, int value) {
+  if (!name) return fail(EMPOSE_EINVAL, "null option name");
+  Options& o = options();
+  const struct { const char* n; int* v; } tab[] = {
+      {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
+      {"gemm_wide", &o.gemm_wide}, {"smpl_fused", &o.smpl_fused}, {"lstm_seq", &o.lstm_seq}};
+  for (const auto& e : tab)
+    if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
+  return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
+}
+
+int empose_get_option(const char* name) {
+  if (!name) return -1;
+  const Options& o = options();
+  const struct { const char* n; int v; } tab[] = {
+      {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
+      {"gemm_wide", o.gemm_wide}, {"smpl_fused", o.smpl_fused}, {"lstm_seq", o.lstm_seq}};
+  for (const auto& e : tab)
+    if (std::strcmp(name, e.n) == 0) return e.v;
+  return -1;
+}
 int empose_version(void) { return 1; }
 const char* empose_arch(void) { return "gfx950"; }
 
@@ -659,7 +689,10 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
     return fail(EMPOSE_EINVAL, "inconsistent SMPL table sizes");
   if (d->n_markers != 6 && d->n_markers != 12) return fail(EMPOSE_EINVAL, "n_markers must be 6 or 12");
   if (d->n_iterations < 0) return fail(EMPOSE_EINVAL, "n_iterations < 0");
+  if (s.rodrigues != EMPOSE_RODRIGUES_SMPLX && s.rodrigues != EMPOSE_RODRIGUES_SO3)
+    return fail(EMPOSE_EINVAL, "unknown Rodrigues convention %d", s.rodrigues);
   empose_model* m = new empose_model();
+  m->rod_conv = s.rodrigues;
   auto bail = [&](int rc) { empose_model_destroy(m); return rc; };
 #define MTRY(expr) do { int rc_ = (expr); if (rc_ != EMPOSE_OK) return bail(rc_); } while (0)
   SmplTables& t = m->tab;
@@ -856,7 +889,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     fa.out_theta = hist(io->hist_pose, i, 66); fa.out_beta = hist(io->hist_shape, i, 10);
     fa.out_theta2 = (i == N) ? io->pose_hat : nullptr;
     fa.out_beta2 = (i == N) ? io->shape_hat : nullptr;
-    fa.T = T; fa.F = F;
+    fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
     prof_mark(P_UPDATE_FEAT, stream);
     e = launch_update_feat(fa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
@@ -875,7 +908,7 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
       ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot = w.smpl.d_rot; ra.d_feat = w.smpl.d_feat;
       ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
       ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
-      ra.T = T;
+      ra.T = T; ra.rod_conv = m->rod_conv;
       prof_mark(P_ROD_BWD, stream);
       e = launch_rodrigues_bwd(ra, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
@@ -911,7 +944,7 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-  fa.T = T; fa.F = F;
+  fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
   hipError_t e = launch_update_feat(fa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
   TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, tgt, ld_tgt, frame_scale, pos, ori, joints, nullptr, nullptr,
@@ -920,7 +953,7 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
     RodBwdArgs ra;
     ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
     ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
-    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T;
+    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
     e = launch_rodrigues_bwd(ra, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
   }
@@ -951,7 +984,7 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-  fa.T = T; fa.F = F;
+  fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
   hipError_t e = launch_update_feat(fa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
   TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, pos, ori, joints, nullptr, nullptr, nullptr,
@@ -959,7 +992,7 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   RodBwdArgs ra;
   ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
   ra.g_theta = g_theta; ra.ld_g = 66; ra.g_beta = g_beta; ra.ld_gb = 10;
-  ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T;
+  ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
   e = launch_rodrigues_bwd(ra, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
   return EMPOSE_OK;
@@ -1183,16 +1216,24 @@ static int pack_mesh_tiles(empose_mesh* m, const empose_mesh_desc* d) {
 int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
   *out = nullptr;
-  if (d->n_vertices <= 0 || d->ncp % 4 != 0 || d->j_off != d->n_vertices * 3 || d->j_off + 66 > d->ncp ||
-      d->ncp - d->j_off > 68 || d->kb <= 0)
+  const int nj = d->n_joints == 0 ? 22 : d->n_joints;
+  if (nj < 22 || nj > MESH_MAX_JOINTS) return fail(EMPOSE_EINVAL, "n_joints must be in [22, %d]", MESH_MAX_JOINTS);
+  if (d->rodrigues != EMPOSE_RODRIGUES_SMPLX && d->rodrigues != EMPOSE_RODRIGUES_SO3)
+    return fail(EMPOSE_EINVAL, "unknown Rodrigues convention %d", d->rodrigues);
+  if (d->n_vertices <= 0 || d->ncp % 4 != 0 || d->j_off != d->n_vertices * 3 || d->j_off + nj * 3 > d->ncp ||
+      d->ncp - d->j_off > nj * 3 + 3 || d->kb <= 0 || !d->parents)
     return fail(EMPOSE_EINVAL, "inconsistent mesh table sizes");
+  for (int j = 0; j < nj; ++j)
+    if (d->parents[j] >= j || (j > 0 && d->parents[j] < 0))
+      return fail(EMPOSE_EINVAL, "parents must be topologically ordered with a single root");
   empose_mesh* m = new empose_mesh();
   m->V = d->n_vertices; m->j_off = d->j_off; m->ncp = d->ncp; m->kb = d->kb;
+  m->n_joints = nj; m->rod_conv = d->rodrigues;
   int rc;
   if ((rc = upload(m->allocs, d->wc, (size_t)d->ncp * 200, &m->wc)) ||
       (rc = upload(m->allocs, d->skin_idx, (size_t)d->n_vertices * d->kb, &m->skin_idx)) ||
       (rc = upload(m->allocs, d->skin_w, (size_t)d->n_vertices * d->kb, &m->skin_w)) ||
-      (rc = upload(m->allocs, d->parents, 22, &m->parents)) || (rc = pack_mesh_tiles(m, d))) {
+      (rc = upload(m->allocs, d->parents, (size_t)nj, &m->parents)) || (rc = pack_mesh_tiles(m, d))) {
     empose_mesh_destroy(m);
     return rc;
   }
@@ -1200,60 +1241,62 @@ int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   return EMPOSE_OK;
 }
 
+int empose_mesh_n_joints(const empose_mesh_t* mesh) { return mesh ? mesh->n_joints : 0; }
+
 static const int MESH_SLAB = 16384;  // frames per pass: bounds the scratch (rot, feat, rest joints, transforms)
+
+struct MeshWs { float *rot, *feat, *jrest, *xf, *th, *be; };
+static MeshWs carve_mesh(Carver& c, const empose_mesh* mesh, size_t S) {
+  MeshWs w;
+  w.rot = c.f(S * 198); w.feat = c.f(S * 200); w.jrest = c.f(S * (size_t)(mesh->ncp - mesh->j_off));
+  w.xf = c.f(S * 264); w.th = c.f(S * 66); w.be = c.f(S * 10);
+  return w;
+}
 
 size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T) {
   if (!mesh || T <= 0) return 0;
-  const size_t S = T < MESH_SLAB ? T : MESH_SLAB;
   Carver c(nullptr);
-  c.f(S * 198); c.f(S * 200); c.f(S * 68); c.f(S * 264); c.f(S * 66); c.f(S * 10);
+  carve_mesh(c, mesh, T < MESH_SLAB ? T : MESH_SLAB);
   return c.off;
 }
 
-int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
-                             const float* trans, float* vertices, float* joints, void* workspace,
-                             size_t workspace_bytes, empose_stream_t stream_) {
-  if (!mesh || !poses || !betas || !vertices || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
-  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
-  if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+// Slab by slab: Rodrigues + feature row, rest joints (the joint rows of wc), kinematic chain (all n_joints posed
+// joints + the 22 skinning transforms) and, when `vertices` is given, the full-mesh kernel.
+static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const float* betas, const float* trans,
+                    float* vertices, float* joints, void* workspace, hipStream_t stream) {
   const int S = T < MESH_SLAB ? T : MESH_SLAB;
+  const int jw = mesh->ncp - mesh->j_off, nj = mesh->n_joints;
   Carver c(workspace);
-  float* rot = c.f((size_t)S * 198);
-  float* feat = c.f((size_t)S * 200);
-  float* jrest = c.f((size_t)S * 68);
-  float* xf = c.f((size_t)S * 264);
-  float* th = c.f((size_t)S * 66);
-  float* be = c.f((size_t)S * 10);
+  const MeshWs w = carve_mesh(c, mesh, (size_t)S);
   for (int t0 = 0; t0 < T; t0 += S) {
     const int n = (T - t0) < S ? (T - t0) : S;
-    HIP_TRY(hipMemcpyAsync(th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     FeatArgs fa;
-    fa.theta = th; fa.ld_theta = 66; fa.beta = be; fa.ld_beta = 10;
+    fa.theta = w.th; fa.ld_theta = 66; fa.beta = w.be; fa.ld_beta = 10;
     fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
-    fa.shape_avg = 0; fa.rot = rot; fa.feat = feat;
+    fa.shape_avg = 0; fa.rot = w.rot; fa.feat = w.feat;
     fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-    fa.T = n; fa.F = 1;
+    fa.T = n; fa.F = 1; fa.rod_conv = mesh->rod_conv;
     hipError_t e = launch_update_feat(fa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
-    // rest joints: the last 66 (+2 padding) rows of wc
     GemmBatch b;
     b.count = 1;
     GemmProb& p = b.p[0];
-    p.A = feat; p.lda = 200; p.W = mesh->wc + (size_t)mesh->j_off * 200; p.ldw = 200; p.C = jrest; p.ldc = 68;
-    p.M = n; p.N = mesh->ncp - mesh->j_off; p.K = 200;
+    p.A = w.feat; p.lda = 200; p.W = mesh->wc + (size_t)mesh->j_off * 200; p.ldw = 200; p.C = w.jrest; p.ldc = jw;
+    p.M = n; p.N = jw; p.K = 200;
     p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
     e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "rest-joint gemm: %s", hipGetErrorString(e));
     const float* tr = trans ? trans + (size_t)t0 * 3 : nullptr;
     MeshChainArgs ca;
-    ca.rot = rot; ca.out = jrest; ca.ncp = 68; ca.j_off = 0; ca.parents = mesh->parents;
-    ca.trans = tr; ca.xf = xf; ca.joints = joints + (size_t)t0 * 66; ca.T = n;
+    ca.rot = w.rot; ca.out = w.jrest; ca.ncp = jw; ca.j_off = 0; ca.parents = mesh->parents;
+    ca.trans = tr; ca.xf = w.xf; ca.joints = joints + (size_t)t0 * nj * 3; ca.T = n; ca.n_joints = nj;
     e = launch_mesh_chain(ca, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh chain: %s", hipGetErrorString(e));
+    if (!vertices) continue;
     MeshSkinArgs sa;
-    sa.feat = feat; sa.wc = mesh->wc; sa.xf = xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
+    sa.feat = w.feat; sa.wc = mesh->wc; sa.xf = w.xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
     e = launch_mesh_rows(sa, stream);
@@ -1262,48 +1305,22 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
   return EMPOSE_OK;
 }
 
+int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                             const float* trans, float* vertices, float* joints, void* workspace,
+                             size_t workspace_bytes, empose_stream_t stream_) {
+  if (!mesh || !poses || !betas || !vertices || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
+  if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  return run_mesh(mesh, T, poses, betas, trans, vertices, joints, workspace, static_cast<hipStream_t>(stream_));
+}
+
 int empose_mesh_joints_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
                            const float* trans, float* joints, void* workspace, size_t workspace_bytes,
                            empose_stream_t stream_) {
   if (!mesh || !poses || !betas || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
   if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int S = T < MESH_SLAB ? T : MESH_SLAB;
-  Carver c(workspace);
-  float* rot = c.f((size_t)S * 198);
-  float* feat = c.f((size_t)S * 200);
-  float* jrest = c.f((size_t)S * 68);
-  float* xf = c.f((size_t)S * 264);
-  float* th = c.f((size_t)S * 66);
-  float* be = c.f((size_t)S * 10);
-  for (int t0 = 0; t0 < T; t0 += S) {
-    const int n = (T - t0) < S ? (T - t0) : S;
-    HIP_TRY(hipMemcpyAsync(th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    FeatArgs fa;
-    fa.theta = th; fa.ld_theta = 66; fa.beta = be; fa.ld_beta = 10;
-    fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
-    fa.shape_avg = 0; fa.rot = rot; fa.feat = feat;
-    fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-    fa.T = n; fa.F = 1;
-    hipError_t e = launch_update_feat(fa, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
-    GemmBatch b;
-    b.count = 1;
-    GemmProb& p = b.p[0];
-    p.A = feat; p.lda = 200; p.W = mesh->wc + (size_t)mesh->j_off * 200; p.ldw = 200; p.C = jrest; p.ldc = 68;
-    p.M = n; p.N = mesh->ncp - mesh->j_off; p.K = 200;
-    p.scale = nullptr; p.shift = nullptr; p.resid = nullptr; p.ldr = 0; p.act = 0; p.slope = 0.f;
-    e = launch_gemm(b, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rest-joint gemm: %s", hipGetErrorString(e));
-    MeshChainArgs ca;
-    ca.rot = rot; ca.out = jrest; ca.ncp = 68; ca.j_off = 0; ca.parents = mesh->parents;
-    ca.trans = trans ? trans + (size_t)t0 * 3 : nullptr; ca.xf = xf; ca.joints = joints + (size_t)t0 * 66; ca.T = n;
-    e = launch_mesh_chain(ca, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mesh chain: %s", hipGetErrorString(e));
-  }
-  return EMPOSE_OK;
+  return run_mesh(mesh, T, poses, betas, trans, nullptr, joints, workspace, static_cast<hipStream_t>(stream_));
 }
 
 }  // extern "C"

@@ -572,8 +572,7 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
     return t;
   };
   // few 32 x 32 tiles in total and a K worth splitting: one tile per workgroup, K over its four waves
-  const char* sk = getenv("EMPOSE_GEMM_SPLITK");   // dev A/B switch, read per call: "0" = the generic tiles
-  const bool splitk_on = !(sk && sk[0] == '0');
+  const bool splitk_on = options().gemm_splitk != 0;
   int minK = 1 << 30;
   for (int i = 0; i < batch.count; ++i) minK = batch.p[i].K < minK ? batch.p[i].K : minK;
   if (splitk_on && minK >= 64 && nblocks(32, 32) <= SPLITK_MAX_TILES) return PICK_SPLITK;
@@ -583,8 +582,7 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
   // The 256 x 256 four-wave tile runs one block per CU, so it only pays when the tiles fill whole rounds of the 256
   // CUs and the 256-wide column tiles are not mostly padding (measured: 125 vs 114 TFLOP/s at M=2x32768, N=K=512;
   // 105 vs 96 at K=296; but 48 vs 76 at N=200).
-  static const int wide_on = getenv("EMPOSE_GEMM_WIDE") ? atoi(getenv("EMPOSE_GEMM_WIDE")) : 1;  // dev A/B only
-  bool wide_ok = wide_on != 0;
+  bool wide_ok = options().gemm_wide != 0;
   for (int i = 0; i < batch.count; ++i) wide_ok = wide_ok && batch.p[i].N % wide::BN == 0 && batch.p[i].K >= 2 * wide::BK;
   if (wide_ok) {
     const long t = nblocks(wide::BM, wide::BN);

@@ -6,6 +6,18 @@
 
 namespace empose {
 
+// Kernel-variant selection for A/B and bit-identity tests (empose_set_option in the C ABI).  Plain process-wide ints set
+// by an explicit call -- the library never reads the environment.  All default to 1 (variant enabled).
+struct Options {
+  int mlp_fused = 1;      // one-launch LDS-resident update MLPs (0: layer by layer)
+  int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
+  int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
+  int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
+  int smpl_fused = 1;     // one kernel per SMPL evaluation of the LGD loop (0: feat / GEMM / chain / GEMM^T / rodrigues)
+  int lstm_seq = 1;       // whole-sequence large-batch LSTM kernel (0: one launch per wavefront step)
+};
+Options& options();
+
 // ---------------------------------------------------------------------------------------------------------------
 // fp32 matrix-core linear layer:  C[m][n] = act( (sum_k A[m][k] * W[n][k]) * scale[n] + shift[n] ) (+ resid[m][n])
 // ---------------------------------------------------------------------------------------------------------------
@@ -209,6 +221,7 @@ struct FeatArgs {
   float* out_theta; float* out_beta;   // optional dense copies [T][66], [T][10]
   float* out_theta2; float* out_beta2; // optional second copy (history)
   int T, F;
+  int rod_conv = 0;                    // EMPOSE_RODRIGUES_SMPLX (0) or EMPOSE_RODRIGUES_SO3 (1)
 };
 hipError_t launch_update_feat(const FeatArgs& a, hipStream_t stream);
 
@@ -241,17 +254,20 @@ struct RodBwdArgs {
   float* g_beta; int ld_gb;
   float* trace_g_theta; float* trace_g_beta;  // optional dense copies
   int T;
+  int rod_conv = 0;
 };
 hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream);
 
 // Full-mesh: chain only (joints + relative transforms) and dense skinning.
+constexpr int MESH_MAX_JOINTS = 52;   // SMPL-H: 22 body + 2 x 15 hand joints
 struct MeshChainArgs {
-  const float* rot; const float* out; int ncp; int j_off;
-  const int* parents;
+  const float* rot; const float* out; int ncp; int j_off;   // out: rest joints [T][ncp], n_joints * 3 used from j_off
+  const int* parents;      // [n_joints], topologically ordered
   const float* trans;      // [T][3] or nullptr
-  float* xf;               // [T][22][3][4]: per bone and row (G^R[r][0..2], A^t[r])
-  float* joints;           // [T][66]
+  float* xf;               // [T][22][3][4]: per body bone and row (G^R[r][0..2], A^t[r])
+  float* joints;           // [T][n_joints][3]
   int T;
+  int n_joints = NB;       // 22 (body) or up to MESH_MAX_JOINTS (hand joints ride on their parents, zero hand pose)
 };
 hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream);
 struct MeshSkinArgs {

@@ -1,7 +1,7 @@
 // SMPL-H on the sensor sub-mesh: everything of one body-model evaluation that is not a matrix product.
 //
 //   update_feat    theta/beta update of the LGD step (reference models.py:588-592), Rodrigues per joint
-//                  (smplx convention: angle = ||r + 1e-8||), GEMM feature row [vec(R_j - I) | beta | 1]
+//                  (angle guard switchable: smplx ||r + 1e-8|| or the so3 clamp), GEMM feature row [vec(R_j - I) | beta | 1]
 //   chain_sensors  22-joint kinematic chain, linear blend skinning of the ~84 needed vertices, vertex normals and
 //                  sensor frames (reference virtual_sensors.py:16-38, utils.py:126-146), sensor offsets
 //                  (reference models.py:478-479), the reconstruction residual (reference loss.py:23-41) and its
@@ -61,12 +61,23 @@ hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream) {
 
 // ---------------------------------------------------------------------------------------------------------------
 struct Rod {
-  float ux, uy, uz, ang, dx, dy, dz, s, c;
+  float ux, uy, uz, ang, dx, dy, dz, s, c;   // (ux, uy, uz) = ang * d(ang)/d(r)
 };
 
-__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, Rod& q, float (&R)[9]) {
-  q.ux = rx + 1e-8f; q.uy = ry + 1e-8f; q.uz = rz + 1e-8f;
-  q.ang = sqrtf(q.ux * q.ux + q.uy * q.uy + q.uz * q.uz);
+// Axis-angle -> rotation, R = I + sin(a) K + (1 - cos a) K^2 with K = hat(r / a).  The un-vendored BodyModel's guard of
+// the angle at r = 0 is not pinned, so both published conventions are kept (EMPOSE_RODRIGUES_*):
+//   smplx  a = ||r + 1e-8||                 (smplx lbs.batch_rodrigues)
+//   so3    a = sqrt(max(||r||^2, 1e-4))     (reference helpers/so3.py:116-121; below the clamp a is constant)
+__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, int conv, Rod& q, float (&R)[9]) {
+  if (conv == 0) {
+    q.ux = rx + 1e-8f; q.uy = ry + 1e-8f; q.uz = rz + 1e-8f;
+    q.ang = sqrtf(q.ux * q.ux + q.uy * q.uy + q.uz * q.uz);
+  } else {
+    const float n2 = rx * rx + ry * ry + rz * rz;
+    const bool clamped = n2 < 1e-4f;
+    q.ux = clamped ? 0.f : rx; q.uy = clamped ? 0.f : ry; q.uz = clamped ? 0.f : rz;
+    q.ang = sqrtf(fmaxf(n2, 1e-4f));
+  }
   q.dx = rx / q.ang; q.dy = ry / q.ang; q.dz = rz / q.ang;
   sincosf(q.ang, &q.s, &q.c);
   const float oc = 1.f - q.c;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
       if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
       if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
       Rod q; float R[9];
-      rodrigues(r0, r1, r2, q, R);
+      rodrigues(r0, r1, r2, a.rod_conv, q, R);
       float* ro = s_rot + (fl * NB + slot) * 9;
 #pragma unroll
       for (int e = 0; e < 9; ++e) ro[e] = R[e];
@@ -187,7 +198,7 @@ __global__ void rodrigues_bwd_kernel(RodBwdArgs a) {
   if (slot < NB) {
     const float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
     Rod q; float R[9];
-    rodrigues(th[0], th[1], th[2], q, R);
+    rodrigues(th[0], th[1], th[2], a.rod_conv, q, R);
     float dR[9];
     const float* dr = a.d_rot + ((size_t)t * NB + slot) * 9;
 #pragma unroll
@@ -790,13 +801,16 @@ hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
 // Full mesh (final vertices): chain to relative transforms, then dense skinning of all V vertices.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void mesh_chain_kernel(MeshChainArgs a) {
-  // one thread per (frame, joint, row): walks parents up to the root
+  // one thread per (frame, joint, row): walks parents up to the root.  Joints >= NB (the 30 hand joints of SMPL-H) have
+  // zero pose on this path (reference smpl.py:99), i.e. identity rotation under either Rodrigues convention: they only
+  // translate along their parent's frame and get no skinning transform of their own (weights folded into the wrists).
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.T * NB * 3) return;
-  const int t = idx / (NB * 3), jr = idx % (NB * 3), j = jr / 3, r = jr % 3;
+  const int nj = a.n_joints;
+  if (idx >= a.T * nj * 3) return;
+  const int t = idx / (nj * 3), jr = idx % (nj * 3), j = jr / 3, r = jr % 3;
   const float* R = a.rot + (size_t)t * NB * 9;
   const float* J = a.out + (size_t)t * a.ncp + a.j_off;
-  int path[NB];
+  int path[MESH_MAX_JOINTS];
   int n = 0;
   for (int q = j; q >= 0; q = a.parents[q]) path[n++] = q;
   float row0 = R[r * 3 + 0], row1 = R[r * 3 + 1], row2 = R[r * 3 + 2];
@@ -807,22 +821,26 @@ __global__ void mesh_chain_kernel(MeshChainArgs a) {
     const float* Jq = J + q * 3;
     const float* Jp = J + prev * 3;
     tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;
-    const float* Rq = R + q * 9;
-    const float n0 = row0 * Rq[0] + row1 * Rq[3] + row2 * Rq[6];
-    const float n1 = row0 * Rq[1] + row1 * Rq[4] + row2 * Rq[7];
-    const float n2 = row0 * Rq[2] + row1 * Rq[5] + row2 * Rq[8];
-    row0 = n0; row1 = n1; row2 = n2;
+    if (q < NB) {
+      const float* Rq = R + q * 9;
+      const float n0 = row0 * Rq[0] + row1 * Rq[3] + row2 * Rq[6];
+      const float n1 = row0 * Rq[1] + row1 * Rq[4] + row2 * Rq[7];
+      const float n2 = row0 * Rq[2] + row1 * Rq[5] + row2 * Rq[8];
+      row0 = n0; row1 = n1; row2 = n2;
+    }
     prev = q;
   }
-  const float* Jj = J + j * 3;
-  // relative transform, row r: (G^R[r][0..2], A^t[r]) -- one 16-byte read per (bone, row) in the skinning epilogue
-  *reinterpret_cast<float4*>(a.xf + (((size_t)t * NB + j) * 3 + r) * 4) =
-      make_float4(row0, row1, row2, tr - (row0 * Jj[0] + row1 * Jj[1] + row2 * Jj[2]));
-  a.joints[(size_t)t * 66 + j * 3 + r] = tr + (a.trans ? a.trans[(size_t)t * 3 + r] : 0.f);
+  if (j < NB) {
+    const float* Jj = J + j * 3;
+    // relative transform, row r: (G^R[r][0..2], A^t[r]) -- one 16-byte read per (bone, row) in the skinning epilogue
+    *reinterpret_cast<float4*>(a.xf + (((size_t)t * NB + j) * 3 + r) * 4) =
+        make_float4(row0, row1, row2, tr - (row0 * Jj[0] + row1 * Jj[1] + row2 * Jj[2]));
+  }
+  a.joints[(size_t)t * nj * 3 + j * 3 + r] = tr + (a.trans ? a.trans[(size_t)t * 3 + r] : 0.f);
 }
 
 hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream) {
-  const long n = (long)a.T * NB * 3;
+  const long n = (long)a.T * a.n_joints * 3;
   hipLaunchKernelGGL(mesh_chain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

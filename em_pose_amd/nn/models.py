@@ -414,9 +414,13 @@ class IterativeErrorFeedback(BaseModel):
         return [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
                [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
 
+    def _rodrigues(self):
+        return getattr(self.smpl, 'rodrigues_convention', 'smplx')
+
     def _state_key(self, device):
         ps = self._own_parameters()
         return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N, self.shape_avg_valid_only,
+                self._rodrigues(),
                 tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def release(self):
@@ -451,7 +455,7 @@ class IterativeErrorFeedback(BaseModel):
     def _ensure_smpl_handle(self, device):
         """Body-model-only handle for the training path: its key ignores the network parameters, which change with
         every optimiser step."""
-        key = (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()))
+        key = (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self._rodrigues())
         if self._smpl_handle is not None and key == self._smpl_handle_key:
             return self._smpl_handle
         if self._smpl_handle is not None:
@@ -471,6 +475,7 @@ class IterativeErrorFeedback(BaseModel):
         for k in ('parents', 'skin_idx', 'bone_ptr', 'bone_vert', 's_center', 's_helper', 's_deg', 's_faces',
                   'path_ptr', 'path', 'sub_ptr', 'sub'):
             setattr(s, k, _lib.iptr(tab[k]))
+        s.rodrigues = _lib.RODRIGUES[self._rodrigues()]
         keep.append(tab)
         desc.n_markers = self.n_markers
         for i, v in enumerate(self.marker_idxs):

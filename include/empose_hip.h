@@ -31,6 +31,15 @@ extern "C" {
 #define EMPOSE_N_SENSORS 12   /* virtual sensors always evaluated, reference models.py:383,538 */
 #define EMPOSE_K_FEAT 200     /* 189 pose-feature + 10 shape + 1 */
 #define EMPOSE_MAX_DENSE 8
+#define EMPOSE_N_JOINTS_SMPLH 52  /* joints of `body.Jtr`, reference bodymodels/smpl.py:121-122 */
+
+/* How the axis-angle -> rotation map guards the angle at r = 0.  The body-model arithmetic lives in an un-vendored
+ * dependency (human_body_prior fork, reference requirements.txt:9), so the convention is a property of the model
+ * handle instead of being baked into the kernels:
+ *   SMPLX  angle = ||r + 1e-8||                (smplx lbs.batch_rodrigues; default)
+ *   SO3    angle = sqrt(clamp(||r||^2, 1e-4))  (reference helpers/so3.py:116-121, so3_exponential_map) */
+#define EMPOSE_RODRIGUES_SMPLX 0
+#define EMPOSE_RODRIGUES_SO3 1
 
 typedef void* empose_stream_t;
 typedef struct empose_model empose_model_t;
@@ -41,6 +50,14 @@ const char* empose_last_error(void);
 /* Library/ABI version and the offload architecture it was compiled for ("gfx950"). */
 int empose_version(void);
 const char* empose_arch(void);
+
+/* Kernel-variant selection for A/B measurements and bit-identity tests: several paths have two implementations (the
+ * one-launch fused update MLPs vs layer-by-layer GEMMs, whole-sequence LSTM kernels vs step launches, ...) that must
+ * give the same results.  Options are process-wide ints, default 1 = the faster variant; the library never reads the
+ * environment.  Names: "mlp_fused", "lstm_persist", "lstm_seq", "gemm_splitk", "gemm_wide", "smpl_fused".
+ * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
+int empose_set_option(const char* name, int value);
+int empose_get_option(const char* name);
 
 /* ---- model description (host pointers) ------------------------------------------------------------------------ */
 
@@ -70,6 +87,7 @@ typedef struct {
   const int* path;
   const int* sub_ptr;     /* [23] subtree member lists */
   const int* sub;
+  int rodrigues;          /* EMPOSE_RODRIGUES_*: honoured by the forward, the residual gradient and the training VJP */
 } empose_smpl_desc;
 
 /* One Linear (+ BatchNorm1d in eval mode) (+ PReLU): reference nn/layers.py:13-43,46-77. weight is [out][in]. */
@@ -288,23 +306,28 @@ const char* empose_profile_gemm_kernel_name(int M, int N, int K, int count, int 
 
 typedef struct {
   int n_vertices, j_off, ncp, kb;
-  const float* wc;        /* [ncp][200] rows: V*3 vertex coordinates then 66 joint coordinates */
-  const int* skin_idx;    /* [V][kb] */
+  const float* wc;        /* [ncp][200] rows: V*3 vertex coordinates then n_joints*3 rest-joint coordinates */
+  const int* skin_idx;    /* [V][kb], bone ids < 22 (hand weights folded into the wrists) */
   const float* skin_w;    /* [V][kb] */
-  const int* parents;     /* [22] */
+  const int* parents;     /* [n_joints], topologically ordered, parents[0] < 0 */
+  int n_joints;           /* posed joints returned: 22 (body) ... 52 (all of SMPL-H, as `body.Jtr`); 0 means 22 */
+  int rodrigues;          /* EMPOSE_RODRIGUES_* */
 } empose_mesh_desc;
 
 int empose_mesh_create(const empose_mesh_desc* desc, empose_mesh_t** out);
 void empose_mesh_destroy(empose_mesh_t* mesh);
 size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T);
+int empose_mesh_n_joints(const empose_mesh_t* mesh);
 /* Replaces SMPLLayer.forward/fk (reference bodymodels/smpl.py:81-147): poses [T][66] (root first), betas [T][10],
- * trans [T][3] or NULL -> vertices [T][V][3], joints [T][22][3]. */
+ * trans [T][3] or NULL -> vertices [T][V][3], joints [T][n_joints][3] (n_joints = 52 reproduces `body.Jtr`; the 30 hand
+ * joints have zero pose, reference smpl.py:99, so they ride rigidly on the wrists' frames). */
 int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
                              const float* trans, float* vertices, float* joints,
                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
 
 /* Joints only (forward kinematics without the mesh): what MetricsEngine needs from `smpl_model.fk`
- * (reference eval/metrics.py:223-228 keeps `kp3d[:, :22]` and discards the vertices). Same workspace as above. */
+ * (reference eval/metrics.py:223-228 keeps `kp3d[:, :22]` and discards the vertices). joints [T][n_joints][3]; same
+ * workspace as above. */
 int empose_mesh_joints_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
                            const float* trans, float* joints, void* workspace, size_t workspace_bytes,
                            empose_stream_t stream);

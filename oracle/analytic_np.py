@@ -23,10 +23,19 @@ subtree sums Fs_j, Ms_j:   dR_j = G_p^RT (Ms_j - Fs_j (x) t_j) G_j^R ,   dJ_j = 
 import numpy as np
 
 
-def rodrigues_fwd(theta, eps=1e-8):
-    """theta (...,3) -> R (...,3,3) and the saved quantities for the reverse pass (smplx convention)."""
-    u = theta + eps
-    a = np.sqrt((u * u).sum(-1, keepdims=True))
+def rodrigues_fwd(theta, eps=1e-8, convention='smplx'):
+    """theta (...,3) -> R (...,3,3) and the saved quantities for the reverse pass.  `convention`: 'smplx' guards the
+    angle as ||theta + eps||, 'so3' as sqrt(clamp(||theta||^2, 1e-4)) (reference helpers/so3.py:116-121); `u` is
+    a * d(a)/d(theta) in either case."""
+    if convention == 'smplx':
+        u = theta + eps
+        a = np.sqrt((u * u).sum(-1, keepdims=True))
+    elif convention == 'so3':
+        n2 = (theta * theta).sum(-1, keepdims=True)
+        a = np.sqrt(np.maximum(n2, 1e-4))
+        u = np.where(n2 < 1e-4, 0.0, theta)
+    else:
+        raise ValueError(convention)
     d = theta / a
     s, c = np.sin(a)[..., None], np.cos(a)[..., None]
     K = np.zeros(theta.shape[:-1] + (3, 3), dtype=theta.dtype)
@@ -61,9 +70,9 @@ def _unit_bwd(dy, y, n):
     return (dy - y * (dy * y).sum(-1, keepdims=True)) / n
 
 
-def features(theta, beta):
+def features(theta, beta, convention='smplx'):
     T = theta.shape[0]
-    R, saved = rodrigues_fwd(theta.reshape(T, 22, 3))
+    R, saved = rodrigues_fwd(theta.reshape(T, 22, 3), convention=convention)
     feat = np.zeros((T, 200), dtype=theta.dtype)
     feat[:, :189] = (R[:, 1:] - np.eye(3, dtype=theta.dtype)).reshape(T, 189)
     feat[:, 189:199] = beta
@@ -151,7 +160,8 @@ def frame_scale(seq_lengths, marker_masks, B, F, dtype=np.float64):
     return scale.reshape(B * F)
 
 
-def smpl_sensors(tab, theta, beta, off_r, off_t, tgt_pos=None, tgt_ori=None, idx=None, scale=None):
+def smpl_sensors(tab, theta, beta, off_r, off_t, tgt_pos=None, tgt_ori=None, idx=None, scale=None,
+                 convention='smplx'):
     """
     One evaluation (+ optionally the residual gradient).
     :param theta (T,66) beta (T,10) off_r (T,12,3,3) off_t (T,12,3)
@@ -163,7 +173,7 @@ def smpl_sensors(tab, theta, beta, off_r, off_t, tgt_pos=None, tgt_ori=None, idx
     T = theta.shape[0]
     wc = tab['wc'].astype(dt)
     nv, j_off = tab['nv'], tab['j_off']
-    R, rsaved, feat = features(theta, beta)
+    R, rsaved, feat = features(theta, beta, convention)
     out = feat @ wc.T
     vp = out[:, :nv * 3].reshape(T, nv, 3)
     J = out[:, j_off:j_off + 66].reshape(T, 22, 3)

@@ -26,8 +26,10 @@ N_BODY = 22  # root + 21 body joints; reference configuration.py:104
 
 # ----------------------------------------------------------------------------------------------------------------------
 # Mesh topology helpers (restating what the reference gets from trimesh==3.9.32, reference smpl.py:58-67,
-# virtual_sensors.py:47-75).  [upstream-knowledge]: trimesh lists, for every vertex, the ids of its incident faces in
-# ascending order, right-padded with -1.
+# virtual_sensors.py:47-75).  [upstream-knowledge]: `Trimesh.vertex_faces` = `geometry.vertex_face_indices`, whose rows
+# are filled from `faces_sparse.dot(identity).nonzero()[1]`: scipy's CSR product lists the columns of a row in reverse
+# insertion order, i.e. DESCENDING face id (trimesh's slow-loop fallback reverses explicitly to match).  The stand-in
+# oracle/refstubs/trimesh evaluates that scipy expression itself; this function states the resulting order directly.
 # ----------------------------------------------------------------------------------------------------------------------
 def vertex_faces_table(faces, n_vertices):
     faces = np.asarray(faces, dtype=np.int64)
@@ -40,7 +42,7 @@ def vertex_faces_table(faces, n_vertices):
     for v in range(n_vertices):
         c = counts[v]
         if c:
-            table[v, :c] = face_of[starts[v]:starts[v] + c]
+            table[v, :c] = face_of[starts[v]:starts[v] + c][::-1]
     return table
 
 
@@ -70,9 +72,19 @@ def sensor_tables(faces, vertex_ids):
 # ----------------------------------------------------------------------------------------------------------------------
 # SMPL-H body model (third-party `BodyModel`; PARITY UNPINNED, see module docstring).
 # ----------------------------------------------------------------------------------------------------------------------
-def rodrigues(rot_vecs):
-    """smplx-style axis-angle -> matrix: angle = ||r + 1e-8||, R = I + sin K + (1-cos) K^2.  (N,3) -> (N,3,3)."""
-    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+def rodrigues(rot_vecs, convention='smplx'):
+    """
+    Axis-angle -> matrix, R = I + sin(a) K + (1 - cos a) K^2 with K = hat(r / a).  (N,3) -> (N,3,3).  The two published
+    conventions differ in how the angle a is guarded at r = 0 (SURVEY.md 8c "keep switchable"):
+      'smplx'  a = ||r + 1e-8||                (smplx lbs.batch_rodrigues; what `BodyModel` is believed to use)
+      'so3'    a = sqrt(clamp(||r||^2, 1e-4))  (pytorch3d so3_exponential_map, reference helpers/so3.py:116-121)
+    """
+    if convention == 'smplx':
+        angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    elif convention == 'so3':
+        angle = torch.clamp((rot_vecs * rot_vecs).sum(1, keepdim=True), 1e-4).sqrt()
+    else:
+        raise ValueError('unknown Rodrigues convention {!r}'.format(convention))
     d = rot_vecs / angle
     cos = torch.cos(angle)[:, None]
     sin = torch.sin(angle)[:, None]
@@ -86,9 +98,10 @@ def rodrigues(rot_vecs):
 class BodyModelTensors(object):
     """The buffers `BodyModel` keeps, in its layouts: posedirs (459, V*3), J_regressor (52,V), weights (V,52)."""
 
-    def __init__(self, model, num_betas=10, dtype=torch.float32):
+    def __init__(self, model, num_betas=10, dtype=torch.float32, rodrigues_convention='smplx'):
         t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).to(dtype)
         self.dtype = dtype
+        self.rodrigues_convention = rodrigues_convention
         self.v_template = t(model['v_template'])[None]  # (1,V,3)
         self.shapedirs = t(model['shapedirs'][:, :, :num_betas])  # (V,3,10)
         pd = np.asarray(model['posedirs'], dtype=np.float64)
@@ -114,7 +127,7 @@ def body_model_forward(bm, root_orient, pose_body, betas, pose_hand=None, trans=
     v_shaped = bm.v_template + torch.einsum('bl,mkl->bmk', betas, bm.shapedirs)
     J = torch.einsum('bik,ji->bjk', v_shaped, bm.J_regressor)
     n_j = J.shape[1]
-    R = rodrigues(full_pose.reshape(-1, 3)).view(n, n_j, 3, 3)
+    R = rodrigues(full_pose.reshape(-1, 3), getattr(bm, 'rodrigues_convention', 'smplx')).view(n, n_j, 3, 3)
     ident = torch.eye(3, dtype=dt, device=dev)
     pose_feature = (R[:, 1:] - ident).reshape(n, -1)
     v_posed = v_shaped + torch.matmul(pose_feature, bm.posedirs).view(n, -1, 3)

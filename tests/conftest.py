@@ -18,3 +18,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_kernel_variant_options():
+    """Tests that select a kernel variant (empose_set_option) must not leak their choice into the next test."""
+    yield
+    from em_pose_amd import _lib
+    if _lib._lib is not None:
+        for name in (b'mlp_fused', b'lstm_persist', b'lstm_seq', b'gemm_splitk', b'gemm_wide', b'smpl_fused'):
+            _lib._lib.empose_set_option(name, 1)

@@ -233,6 +233,61 @@ def make_baselines(vids):
                                       'model_name': net.model_name(), 'flags': json.dumps(fl, sort_keys=True)})
 
 
+def make_preprocess(model, vids):
+    """Case G: the reference's ground-truth preprocessing -- NormalizeRoot, SMPLFK and
+    SampleMarkersWithOffsets (reference data/transforms.py:229-282,132-226) -- on the small mesh with three synthetic
+    `*_offsets.npz` files, at every offset-noise level, for a (3, 5) batch and a single-entry batch (the reference's
+    `.squeeze()` at transforms.py:194), two consecutive calls each (the RandomState(6273) offset-set draws advance)."""
+    from empose.bodymodels.smpl import create_default_smpl_model
+    from empose.data.data import ABatch
+    from empose.data.transforms import NormalizeRoot, SMPLFK, SampleMarkersWithOffsets
+    smpl = create_default_smpl_model(torch.device('cpu'))
+    rng = np.random.RandomState(7)
+    files, data = [], {}
+    for i in range(3):
+        A = rng.normal(0, 0.01, size=(12, 3, 3))
+        off = {'means': rng.normal(0, 0.02, size=(12, 3)), 'covs': A @ np.swapaxes(A, -1, -2) + 1e-5 * np.eye(3),
+               'r': synthetic._exp_so3(rng.normal(0, 0.2, size=(12, 3))), 'vertex_ids': np.asarray(vids)}
+        path = os.path.join(_tmp, 'S%d_offsets.npz' % i)
+        np.savez(path, **off)
+        files.append(path)
+        for k, v in off.items():
+            data['offsets/%d/%s' % (i, k)] = v
+
+    def batch_of(n, f, seed):
+        r = np.random.RandomState(seed)
+        poses = r.normal(0, 0.3, size=(n, f, 66)).astype(np.float32)
+        shapes = r.normal(0, 1.0, size=(n, 10)).astype(np.float32)
+        trans = r.normal(0, 0.5, size=(n, f, 3)).astype(np.float32)
+        mk = lambda: ABatch(list(range(n)), torch.full((n,), f, dtype=torch.long), torch.from_numpy(poses.copy()),
+                            torch.from_numpy(shapes.copy()), torch.from_numpy(trans.copy()), None)
+        return mk, {'poses': poses, 'shapes': shapes, 'trans': trans}
+
+    for tag, (n, f, seed) in (('b35', (3, 5, 11)), ('b14', (1, 4, 12))):
+        mk, inp = batch_of(n, f, seed)
+        for k, v in inp.items():
+            data['%s/in/%s' % (tag, k)] = v
+        with torch.no_grad():
+            b = NormalizeRoot()(mk())
+            data[tag + '/normalize_root/poses'] = b.poses.numpy()
+            data[tag + '/normalize_root/trans'] = b.trans.numpy()
+            g = SMPLFK(smpl)(mk())
+            data[tag + '/fk/joints_gt'] = g.joints_gt.numpy()
+            data[tag + '/fk/vertices'] = g.vertices.numpy()
+            for level in (-1, 0, 1, 2, 3):
+                tr = SampleMarkersWithOffsets(smpl, files, noise_level=level)
+                torch.manual_seed(1000 + level)
+                for call in range(2):
+                    o = tr(SMPLFK(smpl)(mk()))
+                    for k in ('marker_pos_synth', 'marker_ori_synth', 'marker_normal_synth', 'marker_pos_vertex',
+                              'marker_ori_vertex', 'marker_normal_vertex', 'offset_t_augmented', 'offset_r_augmented'):
+                        data['%s/level%d/call%d/%s' % (tag, level, call, k)] = getattr(o, k).numpy()
+    data['meta/vertex_ids'] = np.asarray(vids)
+    path = os.path.join(HERE, 'preprocess.npz')
+    np.savez_compressed(path, **data)
+    print('wrote', path, '%.0f KB' % (os.path.getsize(path) / 1024))
+
+
 def train_sensitivity(vids):
     """How far the REFERENCE's own train-mode forward moves when its sensor inputs are perturbed by one unit in the
     last place (relative 1e-7, random signs): the residual direction r/|r| and train-mode BatchNorm over 48 frames
@@ -268,6 +323,9 @@ def main():
     if '--only-baselines' in sys.argv:
         sys.argv.remove('--only-baselines')
         return make_baselines(vids)
+    if '--only-preprocess' in sys.argv:
+        sys.argv.remove('--only-preprocess')
+        return make_preprocess(model, vids)
     np.savez_compressed(os.path.join(HERE, 'smpl_small.npz'), **{k: v for k, v in model.items()})
     H = 32
 
@@ -404,8 +462,29 @@ def main():
                  'me_mask': mmask.numpy(), 'me_MPJPE': mm_['MPJPE [mm]'], 'me_MPJPE_STD': mm_['MPJPE STD'],
                  'me_PA-MPJPE': mm_['PA-MPJPE [mm]'], 'me_PA-MPJPE_STD': mm_['PA-MPJPE STD'],
                  'me_n_rows': np.concatenate(me.eucl_dists).shape[0]})
+    # MetricsEngine.compute (reference eval/metrics.py:183-241): FK of both poses, Euclidean / Procrustes distances and
+    # the global joint-angle error (local_to_global + the quaternion geodesic of the stand-in, see oracle/refstubs).
+    me = MetricsEngine(smpl)
+    cp = 0.4 * torch.randn(3, 6, 63, generator=g)
+    cph = cp + 0.1 * torch.randn(3, 6, 63, generator=g)
+    cr = 0.3 * torch.randn(3, 6, 3, generator=g)
+    crh = cr + 0.05 * torch.randn(3, 6, 3, generator=g)
+    cs = torch.randn(3, 10, generator=g)
+    csh = cs[:, None].repeat(1, 6, 1) + 0.1 * torch.randn(3, 6, 10, generator=g)
+    clen = torch.tensor([6, 4, 1])
+    cmask = (torch.rand(3, 6, 12, generator=g) > 0.05).float()
+    with torch.no_grad():
+        me.compute(cp, cs, cph, csh, clen, cr, crh, cmask)
+    cm = me.get_metrics()
+    comp.update({'mc_pose': cp.numpy(), 'mc_pose_hat': cph.numpy(), 'mc_root': cr.numpy(), 'mc_root_hat': crh.numpy(),
+                 'mc_shape': cs.numpy(), 'mc_shape_hat': csh.numpy(), 'mc_len': clen.numpy(), 'mc_mask': cmask.numpy(),
+                 'mc_eucl_rows': np.concatenate(me.eucl_dists), 'mc_eucl_pa_rows': np.concatenate(me.eucl_dists_pa),
+                 'mc_angle_rows': np.concatenate(me.angle_diffs)})
+    for k_, v_ in cm.items():
+        comp['mc_metric/' + k_] = np.asarray(v_)
     np.savez_compressed(os.path.join(HERE, 'components.npz'), **comp)
     print('wrote components.npz')
+    make_preprocess(model, vids)
     make_baselines(vids)
     train_sensitivity(vids)
 

@@ -23,17 +23,23 @@ def _setup(model, vids, T, seed):
     return theta, beta, off_r, off_t
 
 
-@pytest.mark.parametrize('idx', [None, R.S_CONFIG_6])
-def test_small_model_matches_autograd(idx):
+@pytest.mark.parametrize('idx,conv', [(None, 'smplx'), (R.S_CONFIG_6, 'smplx'), (None, 'so3'), (R.S_CONFIG_6, 'so3')])
+def test_small_model_matches_autograd(idx, conv):
+    """Both Rodrigues conventions (angle guard ||r + 1e-8|| vs the clamp of reference helpers/so3.py:116-121), with
+    joints at exactly zero, below and above the clamp."""
     model = H.small_model()
     vids = synthetic.small_vertex_ids(160)
     tab = TB.build_lgd_tables(model, vids, dtype=np.float64)
     T = 6
     theta, beta, off_r, off_t = _setup(model, vids, T, 3)
+    theta[0, 9:30] = 0.0
+    theta[1, 3:] *= 1e-2
+    theta[2, 6:9] = 0.0099 / np.sqrt(3)
+    theta[2, 9:12] = 0.0101 / np.sqrt(3)
     rng = np.random.default_rng(9)
     ids = list(range(12)) if idx is None else idx
 
-    bm = R.BodyModelTensors(model, dtype=torch.float64)
+    bm = R.BodyModelTensors(model, dtype=torch.float64, rodrigues_convention=conv)
     tables = R.sensor_tables(model['f'], vids)
     th = torch.from_numpy(theta).requires_grad_(True)
     be = torch.from_numpy(beta).requires_grad_(True)
@@ -46,7 +52,7 @@ def test_small_model_matches_autograd(idx):
         torch.sqrt(((ori[:, ids] - torch.from_numpy(tgt_ori)) ** 2).sum((-1, -2))).sum(-1))).sum()
     g_th, g_be = torch.autograd.grad(e, [th, be])
 
-    res = A.smpl_sensors(tab, theta, beta, off_r, off_t, tgt_pos, tgt_ori, ids, scale)
+    res = A.smpl_sensors(tab, theta, beta, off_r, off_t, tgt_pos, tgt_ori, ids, scale, convention=conv)
     np.testing.assert_allclose(res['pos'], pos.detach().numpy(), atol=1e-12)
     np.testing.assert_allclose(res['ori'], ori.detach().numpy(), atol=1e-11)
     np.testing.assert_allclose(res['joints'], joints.detach().numpy(), atol=1e-12)

@@ -83,7 +83,7 @@ def test_rnn_layer_vs_oracle_and_nn_lstm(bi, L, In, Hd, B, F):
 
 def test_whole_sequence_kernel_equals_step_launches(monkeypatch):
     """B <= 16 uni-directional stacks run the whole sequence in one cooperative launch (lstm_persist_kernel); the same
-    call stepped launch by launch (lstm_small_kernel, dev switch EMPOSE_LSTM_PERSIST=0) gives the same bits: outputs,
+    call stepped launch by launch (lstm_small_kernel, empose_set_option("lstm_persist", 0)) gives the same bits: outputs,
     final state, ragged rows, state carry over two chunks."""
     torch.manual_seed(5)
     layer = RNNLayer(60, 512, 2).eval()
@@ -91,7 +91,7 @@ def test_whole_sequence_kernel_equals_step_launches(monkeypatch):
     lens = torch.tensor([64, 1, 33, 64, 17, 2])
     res = {}
     for mode in ('1', '0'):
-        monkeypatch.setenv('EMPOSE_LSTM_PERSIST', mode)
+        _lib.check(_lib.lib().empose_set_option(b'lstm_persist', int(mode)))
         g = layer.to(DEV)
         g.init_state = None
         outs = []

@@ -163,7 +163,7 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
     small = (theta, beta, off_r, off_t, tgt, scale)
     for key, T, (th_, be_, or_, ot_, tg_, sc_) in (('splitk', T_small, small), (T_small, T_small, small),
                                                   (T_big, T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
-        monkeypatch.setenv('EMPOSE_GEMM_SPLITK', '1' if key == 'splitk' else '0')   # dev switch, read per call
+        _lib.check(lib.empose_set_option(b'gemm_splitk', 1 if key == 'splitk' else 0))   # kernel-variant switch
         th, be, o_r, o_t, tg, sc = gpu(th_), gpu(be_), gpu(or_), gpu(ot_), gpu(tg_), gpu(sc_)
         pos, ori, joints = (torch.empty(T, n, device=DEV) for n in (36, 108, 66))
         g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
@@ -279,7 +279,7 @@ def test_update_nets_large_batch_single_launch_path(hidden, skip, T, monkeypatch
     # 200 rows: too few row panels for the single launch -> the layer-by-layer kernels: on the generic tiles (same k order
     # as the fused kernel) and on their default, the split-K kernel
     for key, rows in ((T, T), (200, 200), ('splitk', 200)):
-        monkeypatch.setenv('EMPOSE_GEMM_SPLITK', '1' if key == 'splitk' else '0')   # dev switch, read per call
+        _lib.check(lib.empose_set_option(b'gemm_splitk', 1 if key == 'splitk' else 0))   # kernel-variant switch
         dp, ds = torch.full((rows, 66), 7.0, device=DEV), torch.full((rows, 10), 7.0, device=DEV)
         nbytes = lib.empose_update_workspace_bytes(handle, rows)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)

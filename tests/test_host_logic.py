@@ -89,6 +89,31 @@ def test_tables_match_reference_topology_vectors():
     assert tab['sub_ptr'][1] == 22  # the root's subtree is everything
 
 
+def test_vertex_faces_order_is_trimesh_sparse_product_order():
+    """`Trimesh.vertex_faces` (trimesh==3.9.32) fills its rows from `faces_sparse.dot(identity).nonzero()[1]`; the
+    stand-in oracle/refstubs/trimesh evaluates that scipy expression, the product and the oracle state the resulting
+    order (descending face id) directly.  The helper vertex of every sensor frame hangs on row[0] of this table
+    (reference virtual_sensors.py:55)."""
+    import importlib.util
+    from oracle import torch_ref as R
+    spec = importlib.util.spec_from_file_location(
+        'trimesh_standin', os.path.join(os.path.dirname(H.GOLDEN), '..', 'oracle', 'refstubs', 'trimesh', '__init__.py'))
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    for model in (H.small_model(), synthetic.make_model()):
+        faces = np.asarray(model['f'], dtype=np.int64)
+        n = int(faces.max()) + 1
+        want = tm.Trimesh(np.zeros((n, 3)), faces, process=False).vertex_faces
+        assert (TB.vertex_faces_table(faces, n) == want).all()
+        assert (R.vertex_faces_table(faces, n) == want).all()
+        live = want[:, 0] >= 0
+        assert (want[live, 0] == np.where(want[live] >= 0, want[live], -1).max(axis=1)).all()   # row[0] = largest face id
+    # a ragged mesh (vertex degrees 1..4) keeps the -1 padding on the right
+    faces = np.array([[0, 1, 2], [0, 2, 3], [0, 3, 4], [0, 4, 5], [5, 6, 7]])
+    want = tm.Trimesh(np.zeros((8, 3)), faces, process=False).vertex_faces
+    assert (TB.vertex_faces_table(faces, 8) == want).all() and want[0].tolist() == [3, 2, 1, 0]
+
+
 def test_loss_helpers_match_reference_vectors():
     z = np.load(os.path.join(H.GOLDEN, 'components.npz'))
     gt, hat = torch.from_numpy(z['rl_gt']), torch.from_numpy(z['rl_hat'])
