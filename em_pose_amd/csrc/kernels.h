@@ -185,6 +185,7 @@ struct SmplTables {  // device pointers
   int n_chunks;
   const uint32_t* blob;
   ChainTabs off;
+
   const float* wc; const float* wct;
   const int* parents;
   const int* skin_idx; const float* skin_w;
@@ -245,6 +246,7 @@ struct ChainArgs {
 };
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block);
 hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream);
+
 
 struct RodBwdArgs {
   const float* theta; int ld_theta;

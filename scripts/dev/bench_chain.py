@@ -32,7 +32,7 @@ for _ in range(10): run()
 p = _lib.profile_read(); lib.empose_profile_enable(0)
 print('stop', os.environ.get('EMPOSE_CHAIN_STOP', '0'), {k: round(v[0] / v[1] * 1000, 1) for k, v in p.items()}, 'us/launch')
 
-if os.environ.get('EMPOSE_LIB_PATH'):
+if os.environ.get('EMPOSE_LIB_PATH') and hasattr(lib, 'empose_debug_chain_trace'):
     import ctypes as C
     tr = (C.c_longlong * 64)()
     fn = lib.empose_debug_chain_trace
@@ -44,3 +44,15 @@ if os.environ.get('EMPOSE_LIB_PATH'):
         t = [tr[b * 32 + i] for i in range(12)]
         print('block', 0 if b == 0 else 9000, 'total', t[11] - t[0], 'cycles:',
               ', '.join('%s %d' % (n, t[i + 1] - t[i]) for i, n in enumerate(names)))
+
+if hasattr(lib, 'empose_debug_pair_trace'):
+    import ctypes as C
+    tr = (C.c_longlong * 64)()
+    fn = lib.empose_debug_pair_trace
+    fn.argtypes = [C.POINTER(C.c_longlong)]
+    assert fn(tr) == 0
+    names = ['P0 stage', 'P2 chain', 'P3 skin', 'P4a normals', 'P4b sensors', 'P4c edges', 'P4d gather', 'P5 dvp+chunks',
+             'P5c bones', 'P6 subtree', 'P7 dR/dJ']
+    for b in range(2):
+        t = [tr[b * 32 + i] for i in range(12)]
+        print('block', b, 'total', t[11] - t[0], 'cycles:', ', '.join('%s %d' % (n, t[i + 1] - t[i]) for i, n in enumerate(names)))
