@@ -340,7 +340,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     auto frame_dst = [&](int i, float v) {
       int f, o;
       frame_split(i, row, f, o);
-      frames[f * L.total + o] = v;
+      frames[f * L.total + (o < NB * 9 ? L.rot + o : L.out + (o - NB * 9))] = v;
     };
     uint4 tv[TB];
     float fv[FB];

@@ -289,29 +289,40 @@ def make_preprocess(model, vids):
 
 
 def train_sensitivity(vids):
-    """How far the REFERENCE's own train-mode forward moves when its sensor inputs are perturbed by one unit in the
-    last place (relative 1e-7, random signs): the residual direction r/|r| and train-mode BatchNorm over 48 frames
-    amplify round-off, so this is the noise floor any other arithmetic order (ours, another BLAS, another GPU) sees.
-    Stored in train_sensitivity.json; the training parity test scales its output tolerance with it."""
+    """How far the REFERENCE's own train-mode step moves when its sensor inputs are perturbed by one unit in the last
+    place (relative 1e-7, random signs): the residual direction r/|r| and train-mode BatchNorm over 48 frames amplify
+    round-off, so this is the noise floor any other arithmetic order (ours, another BLAS, another GPU) sees.  Recorded
+    for the outputs and for every parameter gradient of the step of case E; stored in train_sensitivity.json; the
+    training parity test scales its tolerances with it."""
     res = {}
     for tag, rnn, nm, N, seed in (('train_lgdrnn12_n2', True, 12, 2, 31), ('train_lgd6_n2', False, 6, 2, 32)):
-        outs = []
+        outs, grads = [], []
         for eps in (0.0, 1e-7, -1e-7):
             net, smpl = make_net(lgd_flags(nm, rnn, N, 32, 32), seed, vids)
             w = synthetic.make_windows(3, 16, seed, sensors_from_reference(net, smpl))
+            with torch.no_grad():
+                _, jgt = smpl(poses_body=torch.from_numpy(w['poses'].reshape(48, 66)[:, 3:]),
+                              betas=torch.from_numpy(np.repeat(w['shapes'], 16, axis=0)),
+                              poses_root=torch.from_numpy(w['poses'].reshape(48, 66)[:, :3]))
             rng = np.random.RandomState(0)
             for k in ('marker_pos', 'marker_oris'):
                 w[k] = (w[k] * (1.0 + eps * rng.choice([-1.0, 1.0], size=w[k].shape))).astype(np.float32)
             batch = _SynthBatch(w, torch.tensor([16, 16, 11]))
-            batch.joints_gt = torch.zeros(3, 16, 66)
+            batch.joints_gt = jgt[:, :22].reshape(3, 16, 66)
             net.train()
+            net.zero_grad()
             out = net(batch)
+            net.backward(batch, out)
             outs.append({k: v.detach().numpy().astype(np.float64) for k, v in out.items()})
+            grads.append({k: p_.grad.detach().numpy().astype(np.float64) for k, p_ in net.named_parameters()
+                          if not k.startswith('smpl.') and p_.grad is not None})
         res[tag] = {k: float(max(np.abs(outs[1][k] - outs[0][k]).max(), np.abs(outs[2][k] - outs[0][k]).max()))
                     for k in outs[0]}
+        res[tag]['grad'] = {k: float(max(np.abs(grads[1][k] - grads[0][k]).max(), np.abs(grads[2][k] - grads[0][k]).max()))
+                            for k in grads[0]}
     with open(os.path.join(HERE, 'train_sensitivity.json'), 'w') as f:
         json.dump(res, f, indent=2, sort_keys=True)
-    print(res)
+    print({k: {kk: vv for kk, vv in v.items() if kk != 'grad'} for k, v in res.items()})
 
 
 def main():

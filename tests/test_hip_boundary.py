@@ -173,10 +173,13 @@ def test_rodrigues_convention_sensors_and_residual_gradient(conv, big_model):
                                                _lib.dptr(ws), nbytes, _lib.current_stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(pos.cpu().numpy().reshape(T, 12, 3), ref['pos'], atol=5e-6)
-    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=2e-5)
+    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=5e-5)
     np.testing.assert_allclose(joints.cpu().numpy().reshape(T, 22, 3), ref['joints'], atol=5e-6)
-    np.testing.assert_allclose(g_t.cpu().numpy(), ref['g_theta'], atol=2e-4, rtol=2e-4)
-    np.testing.assert_allclose(g_b.cpu().numpy(), ref['g_beta'], atol=2e-4, rtol=2e-4)
+    # fp32 against float64; gradient features are O(10): the residual direction r / |r| and 1 - cos(a) at tiny angles
+    # amplify round-off (same bar as tests/test_hip_parity.py::test_smpl_sensors_fwd_bwd)
+    gmax = max(np.abs(ref['g_theta']).max(), 1.0)
+    np.testing.assert_allclose(g_t.cpu().numpy(), ref['g_theta'], atol=5e-4 * gmax, rtol=1e-3)
+    np.testing.assert_allclose(g_b.cpu().numpy(), ref['g_beta'], atol=5e-4 * max(np.abs(ref['g_beta']).max(), 1.0), rtol=1e-3)
 
 
 @pytest.mark.parametrize('conv', ['smplx', 'so3'])

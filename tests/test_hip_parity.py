@@ -132,11 +132,15 @@ def test_smpl_sensors_fwd_bwd(which, n_markers, big_model):
                                                _lib.dptr(ws), nbytes, _lib.current_stream()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(pos.cpu().numpy().reshape(T, 12, 3), ref['pos'], atol=1e-5)
-    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=2e-5)
+    # frames are unit vectors built from differences of metre-scale fp32 positions over centimetre-scale edges: one ulp
+    # of a position (1.2e-7) is 1e-5 of a frame entry
+    np.testing.assert_allclose(ori.cpu().numpy().reshape(T, 12, 3, 3), ref['ori'], atol=5e-5)
     np.testing.assert_allclose(joints.cpu().numpy().reshape(T, 22, 3), ref['joints'], atol=1e-5)
     gmax = np.abs(ref['g_theta']).max()
-    np.testing.assert_allclose(g_th.cpu().numpy(), ref['g_theta'], atol=2e-4 * max(gmax, 1.0), rtol=1e-3)
-    np.testing.assert_allclose(g_be.cpu().numpy(), ref['g_beta'], atol=2e-4 * max(np.abs(ref['g_beta']).max(), 1.0),
+    # fp32 against the float64 analytic oracle; measured worst case 3e-4 of the gradient scale (the residual direction
+    # r / |r| amplifies the round-off of centimetre-scale differences of metre-scale positions)
+    np.testing.assert_allclose(g_th.cpu().numpy(), ref['g_theta'], atol=5e-4 * max(gmax, 1.0), rtol=1e-3)
+    np.testing.assert_allclose(g_be.cpu().numpy(), ref['g_beta'], atol=5e-4 * max(np.abs(ref['g_beta']).max(), 1.0),
                                rtol=1e-3)
     # frames with zero weight contribute an exactly-zero gradient
     assert (g_th.cpu().numpy()[scale == 0] == 0).all()
@@ -483,7 +487,8 @@ def test_full_mesh_vertices_vs_oracle(big_model):
                              torch.from_numpy(trans))
     v, j = smpl(poses_body=gpu(pose), betas=gpu(betas), poses_root=gpu(root), trans=gpu(trans))
     np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
-    np.testing.assert_allclose(j.cpu().numpy(), j_ref[:, :22].numpy(), atol=2e-5)
+    assert tuple(j.shape) == (n, 52, 3)   # all 52 posed joints, as the reference's `body.Jtr` (smpl.py:121-122)
+    np.testing.assert_allclose(j.cpu().numpy(), j_ref.numpy(), atol=2e-5)
     # zero pose / zero shape reproduces the template; broadcast of a single beta row
     v0, j0 = smpl(poses_body=torch.zeros(2, 63, device=DEV), betas=torch.zeros(10, device=DEV))
     np.testing.assert_allclose(v0[0].cpu().numpy(), big_model['v_template'], atol=1e-6)
@@ -518,7 +523,7 @@ def test_full_mesh_ragged_sizes_and_many_bones():
         v, j = smpl(poses_body=gpu(pose), betas=gpu(betas), poses_root=gpu(root),
                     trans=gpu(trans) if with_trans else None)
         np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
-        np.testing.assert_allclose(j.cpu().numpy(), j_ref[:, :22].numpy(), atol=2e-5)
+        np.testing.assert_allclose(j.cpu().numpy(), j_ref.numpy(), atol=2e-5)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -729,7 +734,9 @@ def test_training_step_matches_reference_gradients(name):
         if pre_bn_bias:  # mathematically zero in both implementations: only check that it is round-off
             assert np.abs(got).max() < 1e-4 * gmax and np.abs(want).max() < 1e-4 * gmax, k
             continue
-        tol = 2e-3 * max(np.abs(want).max(), 1e-4 * gmax)
+        # 2e-3 of the tensor's scale, or four times what the reference's own gradient moves under a one-ulp change of
+        # its inputs (recorded in train_sensitivity.json), whichever is larger
+        tol = max(2e-3 * max(np.abs(want).max(), 1e-4 * gmax), 4.0 * sens['grad'].get(k, 0.0))
         np.testing.assert_allclose(got, want, atol=tol, rtol=2e-3, err_msg=k)
         checked += 1
     assert checked >= 14
