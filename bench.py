@@ -145,20 +145,24 @@ def cpu_baseline(net, model, w, hip_out=None, seconds_target=20.0):
 
 
 def pmc_traffic(T, hidden, kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes). Only valid for the workload
-    the counters were collected on; otherwise null."""
+    """HBM bytes per launch of the dominant kernel, NOT measured in this run: hardware counters need rocprofv3 around the
+    process (`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, scripts/dev/run_pmc.sh,
+    corrected as MI355X_MICROARCH.md prescribes), so the number is read from the newest committed
+    profiles/*pmc_hbm_traffic.json and reported together with that file's name. Only valid for the workload the counters
+    were collected on; otherwise (None, None)."""
     import glob
     if (T, hidden) != (32768, 512):
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_hbm_traffic.json')))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         ks = json.load(f)['kernels']
     norm = lambda k: k.replace('empose::', '').replace('void ', '').replace(' ', '')
     hit = [v for k, v in ks.items() if norm(k).startswith(kernel_name.replace(' ', ''))]
-    return hit[0]['hbm_bytes_per_launch_corrected'] if hit else None
+    if not hit:
+        return None, None
+    return hit[0]['hbm_bytes_per_launch_corrected'], 'profiles/' + os.path.basename(files[-1])
 
 
 def run_vertices(args, dev):
@@ -300,6 +304,9 @@ def main():
                                    '2x512 update MLPs, 2x512 LSTM init, synthetic SMPL-H-shaped body model (V=6890), '
                                    'random-init weights' % ('-RNN' if net.rnn_init else '', args.n_markers, net.N, F, B),
                        'windows_per_gpu': B, 'frames_per_window': F, 'parallelism': 'window-sharded x%d' % world,
+                       'keep_history': False,   # forward_tensors(); the five history tensors (N+1 entries each, 190 MB
+                                                # per step at this batch) are written only when a caller asks for them
+
                        'dense_mflop_per_frame': fpf / 1e6,
                        'whole_path_tflops': value * fpf / 1e12},
         }
@@ -327,11 +334,28 @@ def main():
             kname = lib.empose_profile_gemm_kernel_name(B * F, h, h, 2, 1).decode()
             what = ' (update-net hidden layer, both nets per launch)'
         avg_ms = ms / cnt
+        timing = {'avg_launch_ms_all_launches_bracketed': avg_ms}
+        if 'mlp_fused' in prof:
+            # The pass above puts an event between ALL launches of the step (for the breakdown), which inflates every
+            # interval by the cost of the event packets.  The dominant kernel is therefore timed again inside the step
+            # with events around its launches only, minus the cost of an empty event pair measured in the same pass.
+            _lib.check(lib.empose_profile_enable_only(b'mlp_fused'))
+            for _ in range(psteps):
+                net.forward_tensors(*inputs)
+            solo = _lib.profile_read()
+            lib.empose_profile_enable(0)
+            raw = solo['mlp_fused'][0] / solo['mlp_fused'][1]
+            pair = solo['event_pair'][0] / solo['event_pair'][1] if 'event_pair' in solo else 0.0
+            avg_ms = raw - pair
+            timing.update({'avg_launch_ms_bracketed_alone': raw, 'empty_event_pair_ms': pair})
         ach = flops / (avg_ms * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(B * F, h, kname)
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(B * F, h, kname),
+                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                              'traffic_source': (traffic_src + ' (rocprofv3 --pmc passes of this command in a separate '
+                                                 'run; not measured by this process)') if traffic_src else None,
                               'kernel': kname + what,
-                              'avg_launch_ms': avg_ms, 'launches_per_step': cnt / psteps,
+                              'avg_launch_ms': avg_ms, 'timing': timing, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,
                               'hbm_frac_on_algorithmic_bytes': value * 1162.0 / 1e9 / PEAK_HBM_GBS}
         result['breakdown_ms_per_step'] = {k: v[0] / psteps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}

@@ -123,6 +123,7 @@ SIGNATURES = {
     'empose_virtual_sensors_fwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_profile_enable': (C.c_int, [C.c_int]),
+    'empose_profile_enable_only': (C.c_int, [C.c_char_p]),
     'empose_profile_ntags': (C.c_int, []),
     'empose_profile_tag_name': (C.c_char_p, [C.c_int]),
     'empose_profile_read': (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

@@ -34,13 +34,14 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- optional per-launch timing (HIP events on the launch stream), used by bench.py for the roofline numbers ---------
 enum ProfTag { P_PACK = 0, P_LSTM_STEP, P_HEADS, P_UPDATE_FEAT, P_BLEND_GEMM, P_CHAIN, P_BLEND_T_GEMM,
-               P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_MLP_FUSED, P_INIT_MLP, P_COPY, P_END, P_NTAGS };
+               P_ROD_BWD, P_MLP_IN, P_MLP_HIDDEN, P_MLP_OUT, P_MLP_FUSED, P_INIT_MLP, P_COPY, P_EVENT_PAIR, P_END, P_NTAGS };
 const char* const kProfNames[P_NTAGS] = {"pack_inputs", "lstm_step", "init_heads_gemm",
                                          "update_feat", "blend_gemm", "chain_sensors", "blend_T_gemm",
                                          "rodrigues_bwd", "mlp_in_gemm", "mlp_hidden_gemm", "mlp_out_gemm",
-                                         "mlp_fused", "init_mlp_gemm", "copies", "end"};
+                                         "mlp_fused", "init_mlp_gemm", "copies", "event_pair", "end"};
 struct Profiler {
   bool on = false;
+  int only = -1;            // >= 0: bracket launches of this tag only (and one empty event pair per forward: P_EVENT_PAIR)
   std::vector<hipEvent_t> ev;
   std::vector<int> tags;
   size_t used = 0;
@@ -49,6 +50,12 @@ Profiler g_prof;
 
 void prof_mark(int tag, hipStream_t stream) {
   if (!g_prof.on) return;
+  // Single-kernel mode: events go around the launches of ONE tag (start, then P_END right after the launch), so the
+  // rest of the step runs unperturbed; P_EVENT_PAIR / P_END pairs with nothing in between measure what the two event
+  // packets themselves cost (the caller subtracts it).
+  if (g_prof.only >= 0 && tag != g_prof.only && tag != P_EVENT_PAIR &&
+      !(tag == P_END && !g_prof.tags.empty() && (g_prof.tags.back() == g_prof.only || g_prof.tags.back() == P_EVENT_PAIR)))
+    return;
   if (g_prof.used == g_prof.ev.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -643,9 +650,23 @@ const char* empose_arch(void) { return "gfx950"; }
 
 int empose_profile_enable(int on) {
   g_prof.on = on != 0;
+  g_prof.only = -1;
   g_prof.used = 0;
   g_prof.tags.clear();
   return EMPOSE_OK;
+}
+
+int empose_profile_enable_only(const char* tag_name) {
+  if (!tag_name) return fail(EMPOSE_EINVAL, "null tag name");
+  for (int i = 0; i < P_NTAGS; ++i)
+    if (std::strcmp(tag_name, kProfNames[i]) == 0) {
+      g_prof.on = true;
+      g_prof.only = i;
+      g_prof.used = 0;
+      g_prof.tags.clear();
+      return EMPOSE_OK;
+    }
+  return fail(EMPOSE_EINVAL, "unknown profile tag '%s'", tag_name);
 }
 
 int empose_profile_ntags(void) { return P_NTAGS; }
@@ -919,6 +940,10 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream));
   }
   prof_mark(P_END, stream);
+  if (g_prof.on && g_prof.only >= 0) {   // calibration: two event packets with nothing in between
+    prof_mark(P_EVENT_PAIR, stream);
+    prof_mark(P_END, stream);
+  }
   return EMPOSE_OK;
 }
 

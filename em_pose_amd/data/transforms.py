@@ -5,8 +5,11 @@ The few transforms `evaluate_real` needs before the model sees a recording (refe
   ToTensor               reference transforms.py:51-56
   NormalizeRoot          reference transforms.py:229-256 first root orientation := identity, translation := 0
 
-Host-side NumPy/PyTorch-CPU code, once per recording; not on the accelerated path.  Training-time transforms
-(SMPLFK ground truth, SampleMarkersWithOffsets, noise) are out of scope of this round.
+  SMPLFK, SampleMarkersWithOffsets, get_end_to_end_preprocess_fn   reference transforms.py:259-282,132-226,23-48 on the
+                         HIP full-mesh kernel (pinned by tests/golden/preprocess.npz)
+
+The sensor-noise augmentation of the reference (noise_functions.py) is not part of this build; configurations that ask
+for it are refused.
 """
 import numpy as np
 import torch
@@ -213,6 +216,12 @@ def get_end_to_end_preprocess_fn(config, smpl_model, offset_files, randomize_if_
     """
     if not getattr(config, 'use_real_offsets', True):
         raise ValueError('We expect to use the real offsets.')
+    if randomize_if_configured and (getattr(config, 'spherical_noise_length', 0.0) > 0.0 or
+                                    getattr(config, 'suppression_noise_length', 0.0) > 0.0):
+        # The reference would now add its sensor-noise augmentation (noise_functions.py:14-36: spherical marker noise or
+        # marker suppression).  It is not part of this build: refuse instead of silently training without it.
+        raise NotImplementedError('sensor-noise augmentation (spherical_noise_length / suppression_noise_length > 0) '
+                                  'is not implemented in this build')
     normalize_root, fk = NormalizeRoot(), SMPLFK(smpl_model)
     noise_level = getattr(config, 'offset_noise_level', -1) if randomize_if_configured else -1
     sample_markers = SampleMarkersWithOffsets(smpl_model, list(offset_files), noise_level=noise_level)

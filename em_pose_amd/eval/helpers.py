@@ -183,52 +183,55 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
     assert isinstance(net, IterativeErrorFeedback)
     # rows shorter than the chunk are padded: average the shape over their valid frames only, which is what the
     # unpadded one-recording chunk of the sequential driver averages over
+    was_valid_only = net.shape_avg_valid_only
     net.shape_avg_valid_only = True
-    n = len(batches)
-    lengths = [int(b.seq_lengths[0]) for b in batches]
-    engines = [MetricsEngine(smpl_model) for _ in range(n)]
-    first_shape = [None] * n
-    state = None       # (h, c) for the rows of `rows_prev`
-    rows_prev = []
-    n_chunks = (max(lengths) + window_size - 1) // window_size
-    frames = 0
-    pad = lambda t, f: torch.nn.functional.pad(t, (0, 0, 0, f - t.shape[1]))
-    # the recordings go to the device once; chunks are cut and padded there
-    fields = ('poses', 'shapes', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks', 'offset_t', 'offset_r')
-    on_dev = [{k: getattr(b, k).to(device=device, dtype=C.DTYPE) for k in fields} for b in batches]
-    for c in range(n_chunks):
-        sf = c * window_size
-        rows = [i for i in range(n) if lengths[i] > sf]
-        lens = [min(window_size, lengths[i] - sf) for i in rows]
-        f = max(lens)
-        cut = lambda name: torch.cat([pad(on_dev[i][name][:, sf:sf + f], f) for i in rows])
-        whole = lambda name: torch.cat([on_dev[i][name] for i in rows])
-        chunk = RealBatch([batches[i].ids[0] for i in rows], torch.tensor(lens), cut('poses'), whole('shapes'),
-                          cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'), cut('marker_masks'),
-                          whole('offset_t'), whole('offset_r')).to_gpu(device)
-        if net.rnn_init and c > 0:
-            keep = torch.tensor([rows_prev.index(i) for i in rows], device=device)
-            net.rnn.final_state = (state[0].index_select(1, keep).contiguous(),
-                                   state[1].index_select(1, keep).contiguous())
-        out = net(chunk, is_new_sequence=(c == 0))
-        if net.rnn_init:
-            state, rows_prev = net.rnn.final_state, rows
-        if c == 0:
+    try:
+        n = len(batches)
+        lengths = [int(b.seq_lengths[0]) for b in batches]
+        engines = [MetricsEngine(smpl_model) for _ in range(n)]
+        first_shape = [None] * n
+        state = None       # (h, c) for the rows of `rows_prev`
+        rows_prev = []
+        n_chunks = (max(lengths) + window_size - 1) // window_size
+        frames = 0
+        pad = lambda t, f: torch.nn.functional.pad(t, (0, 0, 0, f - t.shape[1]))
+        # the recordings go to the device once; chunks are cut and padded there
+        fields = ('poses', 'shapes', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks', 'offset_t', 'offset_r')
+        on_dev = [{k: getattr(b, k).to(device=device, dtype=C.DTYPE) for k in fields} for b in batches]
+        for c in range(n_chunks):
+            sf = c * window_size
+            rows = [i for i in range(n) if lengths[i] > sf]
+            lens = [min(window_size, lengths[i] - sf) for i in rows]
+            f = max(lens)
+            cut = lambda name: torch.cat([pad(on_dev[i][name][:, sf:sf + f], f) for i in rows])
+            whole = lambda name: torch.cat([on_dev[i][name] for i in rows])
+            chunk = RealBatch([batches[i].ids[0] for i in rows], torch.tensor(lens), cut('poses'), whole('shapes'),
+                              cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'), cut('marker_masks'),
+                              whole('offset_t'), whole('offset_r')).to_gpu(device)
+            if net.rnn_init and c > 0:
+                keep = torch.tensor([rows_prev.index(i) for i in rows], device=device)
+                net.rnn.final_state = (state[0].index_select(1, keep).contiguous(),
+                                       state[1].index_select(1, keep).contiguous())
+            out = net(chunk, is_new_sequence=(c == 0))
+            if net.rnn_init:
+                state, rows_prev = net.rnn.final_state, rows
+            if c == 0:
+                for k, i in enumerate(rows):
+                    first_shape[i] = out['shape_hat'][k:k + 1, 0]
+            # one metrics pass over the whole chunk; its per-frame rows come back in (row, frame) order, so each recording's
+            # rows are a contiguous slice
+            me_tmp = MetricsEngine(smpl_model)
+            me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], torch.cat([first_shape[i] for i in rows]),
+                           chunk.seq_lengths, chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
+            st = me_tmp.state()
+            counts = MetricsEngine._mask(chunk.seq_lengths, len(rows), f, chunk.marker_masks, device).sum(dim=1).tolist()
+            at = 0
             for k, i in enumerate(rows):
-                first_shape[i] = out['shape_hat'][k:k + 1, 0]
-        # one metrics pass over the whole chunk; its per-frame rows come back in (row, frame) order, so each recording's
-        # rows are a contiguous slice
-        me_tmp = MetricsEngine(smpl_model)
-        me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], torch.cat([first_shape[i] for i in rows]),
-                       chunk.seq_lengths, chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
-        st = me_tmp.state()
-        counts = MetricsEngine._mask(chunk.seq_lengths, len(rows), f, chunk.marker_masks, device).sum(dim=1).tolist()
-        at = 0
-        for k, i in enumerate(rows):
-            engines[i].merge({key: v[at:at + counts[k]] for key, v in st.items()})
-            at += counts[k]
-        frames += sum(lens)
-    net.shape_avg_valid_only = False
+                engines[i].merge({key: v[at:at + counts[k]] for key, v in st.items()})
+                at += counts[k]
+            frames += sum(lens)
+    finally:
+        net.shape_avg_valid_only = was_valid_only
     me_all = MetricsEngine(smpl_model)
     per_sequence = []
     for i in range(n):  # recording order, exactly as the sequential driver accumulates

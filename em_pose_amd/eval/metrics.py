@@ -202,11 +202,13 @@ class MetricsEngine(object):
             root_hat_f = torch.zeros_like(root_f)
         else:
             root_f, root_hat_f = pose_root[mask], pose_root_hat[mask]
-        _, kp3d = self.smpl_model.fk(pose_f.contiguous(), shape_f.contiguous(), poses_root=root_f.contiguous(),
-                                     window_size=1000)
-        _, kp3d_hat = self.smpl_model.fk(pose_hat_f.contiguous(), shape_hat_f.contiguous(),
-                                         poses_root=root_hat_f.contiguous(), window_size=1000)
-        self._add_eucl(kp3d[:, :C.N_JOINTS + 1], kp3d_hat[:, :C.N_JOINTS + 1])
+        if self.smpl_model is not None:
+            # no body model (the CPU plumbing configuration has no HIP device to evaluate SMPL-H on): angle metric only
+            _, kp3d = self.smpl_model.fk(pose_f.contiguous(), shape_f.contiguous(), poses_root=root_f.contiguous(),
+                                         window_size=1000)
+            _, kp3d_hat = self.smpl_model.fk(pose_hat_f.contiguous(), shape_hat_f.contiguous(),
+                                             poses_root=root_hat_f.contiguous(), window_size=1000)
+            self._add_eucl(kp3d[:, :C.N_JOINTS + 1], kp3d_hat[:, :C.N_JOINTS + 1])
         p = pose_f.detach().cpu().numpy().astype(np.float64)
         ph = pose_hat_f.detach().cpu().numpy().astype(np.float64)
         if self.angle_glob:

@@ -32,6 +32,9 @@ class GraphedTrainStep(object):
         # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
         # workspaces on the first call on a stream, which is not allowed while capturing).  The LSTM goes through MIOpen in
         # pieces of 16 time steps (RNNLayer.forward_torch): its RNN captures up to 31 steps and crashes from 32 on.
+        # the warm-up passes must not count as training steps: BatchNorm running statistics are put back afterwards
+        bn_state = {k: v.clone() for k, v in net.state_dict().items()
+                    if 'running_' in k or k.endswith('num_batches_tracked')}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -39,6 +42,9 @@ class GraphedTrainStep(object):
                 optimizer.zero_grad(set_to_none=True)
                 out = net(self.static)
                 net.backward(self.static, out, as_tensors=True)
+            sd = net.state_dict()
+            for k, v in bn_state.items():
+                sd[k].copy_(v)
             side.synchronize()
             optimizer.zero_grad(set_to_none=True)
             del out

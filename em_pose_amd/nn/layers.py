@@ -62,6 +62,11 @@ class _HipLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+# Bumped whenever a kernel updates BatchNorm running statistics through raw pointers (torch's tensor version counters do
+# not see such writes); part of the key of the cached inference handle (nn/models.py::_state_key).
+BN_STATS_GENERATION = [0]
+
+
 class _BnPreluFn(torch.autograd.Function):
     """Train-mode BatchNorm1d followed by PReLU (one shared slope), forward and backward as one HIP kernel each
     (`empose_bn_prelu_train_fwd/bwd`); the running statistics are updated in place like torch.nn.BatchNorm1d does."""
@@ -80,6 +85,8 @@ class _BnPreluFn(torch.autograd.Function):
             float(bn.momentum), _lib.dptr(bn.running_mean) if track else None,
             _lib.dptr(bn.running_var) if track else None, _lib.dptr(bn.num_batches_tracked) if track else None,
             _lib.dptr(z), Cn, _lib.dptr(mean), _lib.dptr(rstd), _lib.current_stream()))
+        if track:
+            BN_STATS_GENERATION[0] += 1
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
         return z
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 from em_pose_amd import _lib
 from em_pose_amd.bodymodels import tables as TB
 from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.nn import layers as _layers
 from em_pose_amd.nn.layers import MLP, FeedForwardResidualBlock, RNNLayer, fill_dense_desc, linear_hip, linear_train
 
 
@@ -420,13 +421,16 @@ class IterativeErrorFeedback(BaseModel):
     def _state_key(self, device):
         ps = self._own_parameters()
         return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N, self.shape_avg_valid_only,
-                self._rodrigues(),
+                self._rodrigues(), _layers.BN_STATS_GENERATION[0],
                 tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def release(self):
         if self._handle is not None:
             _lib.lib().empose_model_destroy(self._handle)
             self._handle, self._handle_key = None, None
+        for _, handle in getattr(self, '_alt_handles', {}).values():
+            _lib.lib().empose_model_destroy(handle)
+        self._alt_handles = {}
 
     def release_all(self):
         self.release()
@@ -449,7 +453,23 @@ class IterativeErrorFeedback(BaseModel):
         key = self._state_key(device)
         if self._handle is not None and key == self._handle_key:
             return self._handle
-        self.release()
+        # A driver may alternate between the two shape-averaging modes (eval/helpers.py::evaluate_sequences_batched):
+        # the handle of the other mode is parked instead of being destroyed and rebuilt on every switch.
+        alt = getattr(self, '_alt_handles', None)
+        if alt is None:
+            alt = self._alt_handles = {}
+        if self._handle is not None:
+            old = alt.pop(self._handle_key[4], None)
+            if old is not None:
+                _lib.lib().empose_model_destroy(old[1])
+            alt[self._handle_key[4]] = (self._handle_key, self._handle)
+            self._handle, self._handle_key = None, None
+        parked = alt.pop(self.shape_avg_valid_only, None)
+        if parked is not None:
+            if parked[0] == key:
+                self._handle_key, self._handle = parked
+                return self._handle
+            _lib.lib().empose_model_destroy(parked[1])
         return self._build_handle(device, key, smpl_only=False)
 
     def _ensure_smpl_handle(self, device):

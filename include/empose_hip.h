@@ -295,6 +295,11 @@ int empose_virtual_sensors_fwd(int T, int V, const float* vertices, int M, int m
  * empose_profile_read() waits for the recorded events, returns per-category total milliseconds and launch counts, and
  * clears the log. New in this library (the reference only has wall-clock prints, scripts/train.py:136-173). */
 int empose_profile_enable(int on);
+/* Single-kernel mode: only the launches of category `tag_name` are bracketed (start event, end event right after the
+ * launch), the rest of the step runs unperturbed; every empose_lgd_forward additionally records one empty event pair,
+ * reported as category "event_pair": what two event packets cost by themselves, to be subtracted from the bracketed
+ * duration. This is how bench.py times the dominant kernel inside the step. */
+int empose_profile_enable_only(const char* tag_name);
 int empose_profile_ntags(void);
 const char* empose_profile_tag_name(int tag);
 int empose_profile_read(double* total_ms, long long* count);

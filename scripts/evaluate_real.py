@@ -13,6 +13,14 @@ runs the same driver on the stand-in of BASELINE.json configs[3]: 36 synthetic r
 the real test set (README.md:107-142, 54 030 frames), a synthetic SMPL-H-shaped body model and random-init weights of
 the released LGD-RNN-6 architecture, streamed in 256-frame chunks with LSTM state carry.
 
+BASELINE.json configs[0] (plumbing, no GPU): the frame-wise ResNet baseline runs as plain PyTorch on CPU tensors, like
+the reference's `C.DEVICE` fallback (reference configuration.py:23, scripts/evaluate_real.py:24-61):
+
+    python scripts/evaluate_real.py --synthetic --m_type resnet --device cpu --max_sequences 1
+
+Only that model has a CPU path (the LGD models are the HIP path and refuse CPU tensors); without a device the joint
+position metrics, which need an SMPL-H evaluation, are skipped and the joint-angle metric is reported.
+
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N scripts/evaluate_real.py ...`; whole
 recordings are assigned to ranks longest-first (chunks of one recording are serially dependent), and the per-rank metric
 accumulators are combined with one all_gather over RCCL.
@@ -45,17 +53,7 @@ def sample_to_batch(sample):
     return NormalizeRoot()(RealBatch.from_sample_list([sample]))
 
 
-def synthetic_setup(args, device):
-    from em_pose_amd import synthetic
-    from em_pose_amd.bodymodels.smpl import SMPLLayer
-    from em_pose_amd.helpers.configuration import lgd_config
-    from em_pose_amd.nn.models import create_model
-    model = synthetic.make_model()
-    torch.manual_seed(args.model_id)
-    cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, lr=0.0005)
-    net = create_model(cfg, SMPLLayer(model)).to(device).eval()
-    smpl = SMPLLayer(model).to(device)
-
+def _hip_sensors(net, device):
     def sensors(poses, betas, o_r, o_t):
         n = poses.shape[0]
         pos, ori, _ = net.get_estimated_real_markers(torch.from_numpy(poses).to(device),
@@ -63,6 +61,41 @@ def synthetic_setup(args, device):
                                                      torch.from_numpy(o_r[:1].copy()).to(device),
                                                      torch.from_numpy(o_t[:1].copy()).to(device), frames_per_window=n)
         return pos.cpu().numpy(), ori.cpu().numpy()
+    return sensors
+
+
+def synthetic_setup(args, device):
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.helpers.configuration import Configuration, lgd_config
+    from em_pose_amd.nn.models import create_model
+    torch.manual_seed(args.model_id)
+    if args.m_type == 'resnet':
+        # the frame-wise baseline (reference models.py:166-262); hyper-parameters of the released ResNet are not
+        # published (its config.json is part of models.zip), so a 3-block, 512-wide stand-in
+        cfg = Configuration.defaults(m_type='resnet', m_hidden_size=512, m_num_layers=3, use_marker_pos=True,
+                                     use_marker_ori=True, n_markers=args.n_markers, window_size=32,
+                                     m_estimate_shape=False, m_fk_loss=0.0)
+        net = create_model(cfg, None).to(device).eval()
+        if device.type == 'cpu':
+            # no device, no body model: sensor readings of the stand-in recordings are random (plumbing only)
+            smpl = None
+            rng = np.random.default_rng(args.model_id)
+
+            def sensors(poses, betas, o_r, o_t):
+                n = poses.shape[0]
+                ori = synthetic._exp_so3(rng.normal(0, 0.5, size=(n, 12, 3))).astype(np.float32)
+                return rng.normal(0, 0.3, size=(n, 12, 3)).astype(np.float32), ori
+        else:
+            smpl = SMPLLayer(synthetic.make_model()).to(device)
+            lgd = create_model(lgd_config(12, False, 1, hidden=32), SMPLLayer(synthetic.make_model())).to(device).eval()
+            sensors = _hip_sensors(lgd, device)
+    else:
+        model = synthetic.make_model()
+        cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, lr=0.0005)
+        net = create_model(cfg, SMPLLayer(model)).to(device).eval()
+        smpl = SMPLLayer(model).to(device)
+        sensors = _hip_sensors(net, device)
 
     lengths = synthetic.README_SEQUENCE_LENGTHS[:args.max_sequences] if args.max_sequences else \
         synthetic.README_SEQUENCE_LENGTHS
@@ -101,6 +134,9 @@ def main():
     p.add_argument('--n_markers', type=int, default=6)
     p.add_argument('--iterations', type=int, default=2)
     p.add_argument('--no_rnn', action='store_true')
+    p.add_argument('--m_type', default='ief', choices=['ief', 'resnet'], help='--synthetic only: which model to build.')
+    p.add_argument('--device', default='cuda', choices=['cuda', 'cpu'],
+                   help="'cpu' runs the ResNet baseline as plain PyTorch (BASELINE configs[0]); the LGD models need 'cuda'.")
     p.add_argument('--max_sequences', type=int, default=0)
     p.add_argument('--json', action='store_true', help='Also print one machine-readable JSON line.')
     p.add_argument('--sequential', action='store_true',
@@ -115,10 +151,19 @@ def main():
 
     world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('evaluate_real.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    on_cpu = args.device == 'cpu'
+    if on_cpu:
+        if not (args.synthetic and args.m_type == 'resnet') or world > 1:
+            raise SystemExit("--device cpu is the single-process plumbing configuration of the ResNet baseline "
+                             "(--synthetic --m_type resnet); the LGD models run the HIP path and need an MI355X.")
+        device = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('evaluate_real.py runs the HIP path and needs an MI355X; there is no CPU fallback '
+                             '(the ResNet plumbing configuration: --synthetic --m_type resnet --device cpu).')
+        device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(device)
+    sync = (lambda: None) if on_cpu else torch.cuda.synchronize
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -138,7 +183,7 @@ def main():
         else:
             evaluate_sequences_batched(net, [next(iter(window_generator(b, 256))) for b in batches], smpl, device,
                                        window_size=256)
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
     log = print if world == 1 else None
@@ -150,7 +195,7 @@ def main():
                                                          log=log if rep == 0 else None)
         else:
             me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256)
-        torch.cuda.synchronize()
+        sync()
         passes.append(time.perf_counter() - t0)
     elapsed = passes[-1]
     rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]
@@ -167,8 +212,8 @@ def main():
         table = [[i, sid] + list(m.values()) for i, sid, m in rows]
         table.append([len(table), 'Overall average'] + list(metrics.values()))
         print(tabulate(table, headers=['Nr', 'E2E {}'.format(name)] + list(metrics.keys())))
-        print('{} frames in {:.3f} s on {} GPU(s): {:.0f} frames/s (model forward + metrics)'
-              .format(frames, elapsed, world, frames / elapsed))
+        print('{} frames in {:.3f} s on {}: {:.0f} frames/s (model forward + metrics)'
+              .format(frames, elapsed, 'the host CPU' if on_cpu else '{} GPU(s)'.format(world), frames / elapsed))
         if args.json:
             print(json.dumps({'frames': frames, 'seconds': elapsed, 'n_gpus': world, 'frames_per_sec': frames / elapsed,
                               'seconds_per_pass': passes, 'metrics': metrics}))

@@ -66,12 +66,24 @@ def train_on_amass(args, dev, rank, world):
         raise SystemExit('need at least two AMASS sequences under ' + args.amass_dir)
     n_valid = max(1, int(round(len(files) * args.valid_fraction)))
     valid_files, train_files = files[::max(1, len(files) // n_valid)][:n_valid], None
-    train_files = [f for f in files if f not in valid_files][rank::world]     # sequences sharded over the ranks
+    # Sequences sharded over the ranks.  Every rank must run the same number of steps per epoch (each step ends in a
+    # gradient all-reduce): the list is cut to a multiple of world x batch size before it is dealt out.
+    train_all = [f for f in files if f not in valid_files]
+    usable = (len(train_all) // (world * args.bs_train)) * world * args.bs_train
+    if usable == 0:
+        raise SystemExit('{} training sequences are fewer than one batch of {} on each of {} ranks'
+                         .format(len(train_all), args.bs_train, world))
+    train_files = train_all[:usable][rank::world]
     win = lambda mode, rng=None: (lambda smp: ToTensor()(ExtractWindow(args.window_size, rng=rng, mode=mode)(smp)))
-    train_data = AMASSNpzDataset(None, win('random', np.random.RandomState(args.seed + rank)), files=train_files)
+    window_rng = np.random.RandomState(args.seed + rank)
+
+    def seed_worker(worker_id):   # every DataLoader worker owns a copy of window_rng: give each its own stream
+        window_rng.seed(args.seed + 1000 * (rank + 1) + worker_id)
+    train_data = AMASSNpzDataset(None, win('random', window_rng), files=train_files)
     valid_data = AMASSNpzDataset(None, win('middle'), files=valid_files)
     loader = lambda data, bs, shuffle: DataLoader(data, batch_size=bs, shuffle=shuffle, num_workers=args.data_workers,
-                                                 collate_fn=AMASSBatch.from_sample_list, drop_last=shuffle)
+                                                 collate_fn=AMASSBatch.from_sample_list, drop_last=shuffle,
+                                                 worker_init_fn=seed_worker if shuffle else None)
     train_loader, valid_loader = loader(train_data, args.bs_train, True), loader(valid_data, args.bs_train, False)
 
     model_dir = checkpoint = None

@@ -148,6 +148,31 @@ def test_resnet_plumbing_on_cpu():
     assert out['pose_hat'].shape == (1, 32, 63) and out['root_ori_hat'].shape == (1, 32, 3)
 
 
+def test_evaluate_real_cli_runs_the_resnet_baseline_on_cpu():
+    """BASELINE config 0 through the CLI: `scripts/evaluate_real.py` runs the frame-wise ResNet on CPU tensors without a
+    GPU (plumbing only, as reference scripts/evaluate_real.py:24-61 does on `C.DEVICE` = cpu); the LGD models refuse."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'scripts', 'evaluate_real.py'), '--synthetic', '--device', 'cpu']
+    ok = subprocess.run(cmd + ['--m_type', 'resnet', '--n_markers', '12', '--max_sequences', '1', '--json'],
+                        capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    res = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert res['frames'] == 3460 and res['metrics']['MPJAE [deg]'] > 0.0 and res['metrics']['MPJPE [mm]'] == 0.0
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and 'need an MI355X' in (bad.stderr + bad.stdout)
+
+
+def test_preprocess_refuses_unimplemented_noise_augmentation():
+    from em_pose_amd.data.transforms import get_end_to_end_preprocess_fn
+    from em_pose_amd.helpers.configuration import lgd_config
+    cfg = lgd_config(12, True, 2, suppression_noise_length=0.1)
+    with pytest.raises(NotImplementedError):
+        get_end_to_end_preprocess_fn(cfg, None, [], randomize_if_configured=True)
+
+
 def test_offsets_npz_file_format(tmp_path):
     """`*_offsets.npz` as the reference stores them (data/transforms.py:145-155) load into the transform's offset sets."""
     from em_pose_amd.data.transforms import load_offsets_npz
