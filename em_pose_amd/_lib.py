@@ -68,6 +68,15 @@ class LgdIO(C.Structure):
                 ('trace_g_pose', C.c_void_p), ('trace_g_shape', C.c_void_p)]
 
 
+class LstmParams(C.Structure):   # empose_lstm_params: DEVICE pointers
+    _fields_ = [('num_layers', C.c_int), ('input_size', C.c_int), ('hidden_size', C.c_int),
+                ('w_ih', C.c_void_p * 4), ('w_hh', C.c_void_p * 4), ('b_ih', C.c_void_p * 4), ('b_hh', C.c_void_p * 4)]
+
+
+class LstmGrads(C.Structure):    # empose_lstm_grads
+    _fields_ = [('w_ih', C.c_void_p * 4), ('w_hh', C.c_void_p * 4), ('b_ih', C.c_void_p * 4), ('b_hh', C.c_void_p * 4)]
+
+
 class MeshDesc(C.Structure):
     _fields_ = [('n_vertices', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
                 ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p),
@@ -115,6 +124,18 @@ SIGNATURES = {
     'empose_bn_prelu_train_bwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'empose_gemm_atb_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'empose_gemm_atb_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_transpose_f32': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'empose_lstm_train_save_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'empose_lstm_train_workspace_bytes': (C.c_size_t, [C.POINTER(LstmParams), C.c_int, C.c_int]),
+    'empose_lstm_train_fwd': (C.c_int, [C.POINTER(LstmParams), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_lstm_train_bwd': (C.c_int, [C.POINTER(LstmParams), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LstmGrads), C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
     'empose_rnn_create': (C.c_int, [C.POINTER(RnnDesc), C.POINTER(C.c_void_p)]),
     'empose_rnn_destroy': (None, [C.c_void_p]),
     'empose_rnn_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -1157,6 +1157,207 @@ int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float
   return EMPOSE_OK;
 }
 
+// ---- training backward building blocks ------------------------------------------------------------------------
+size_t empose_gemm_atb_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return atb_workspace_floats(M, N, K) * sizeof(float) + 256;
+}
+
+int empose_gemm_atb_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        float* bias, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  if (!A || !B || !C) return fail(EMPOSE_EINVAL, "null argument");
+  if (M <= 0 || N <= 0 || K <= 0 || lda < N || ldb < K || ldc < K) return fail(EMPOSE_EINVAL, "bad sizes");
+  const size_t need = atb_workspace_floats(M, N, K) * sizeof(float);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  AtbArgs a{};
+  a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.bias = bias; a.M = M; a.N = N; a.K = K;
+  hipError_t e = launch_gemm_atb(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "A^T B gemm: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_transpose_f32(int rows, int cols, const float* src, int ld_src, float* dst, int ld_dst,
+                         empose_stream_t stream_) {
+  if (!src || !dst) return fail(EMPOSE_EINVAL, "null argument");
+  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_transpose(src, ld_src, dst, ld_dst, rows, cols, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+size_t empose_lstm_train_save_floats(int L, int B, int F, int H) {
+  return (size_t)L * B * F * 7 * H;
+}
+
+namespace {
+struct TrainLstmWs {
+  LstmWs st;               // h[l][2], c[l]
+  float* bias[4];          // b_ih + b_hh
+  float* dgates;           // [B*F][4H]
+  float* dyl;              // [B*F][H] cotangent of the layer below's output
+  float* dh[2]; float* carry; float* dc;   // [B][H]
+  float* wt;               // transposed weights, max(H, in) x 4H
+  float* atb;              // A^T B partials
+  size_t atb_floats;
+};
+int check_lstm_params(const empose_lstm_params* p) {
+  if (!p) return fail(EMPOSE_EINVAL, "null argument");
+  if (p->num_layers < 1 || p->num_layers > 4 || p->hidden_size % 4 != 0 || p->input_size % 4 != 0 ||
+      p->hidden_size <= 0 || p->input_size <= 0)
+    return fail(EMPOSE_EINVAL, "unsupported LSTM configuration");
+  for (int l = 0; l < p->num_layers; ++l)
+    if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return fail(EMPOSE_EINVAL, "null LSTM parameter");
+  return EMPOSE_OK;
+}
+Lstm lstm_view(const empose_lstm_params* p) {   // device pointers as they are: nothing is uploaded
+  Lstm r;
+  r.num_layers = p->num_layers; r.input_size = p->input_size; r.H = p->hidden_size; r.dirs = 1;
+  return r;
+}
+TrainLstmWs carve_train_lstm(Carver& c, const empose_lstm_params* p, int B, int F) {
+  TrainLstmWs w;
+  const int H = p->hidden_size, L = p->num_layers;
+  const int in_max = p->input_size > H ? p->input_size : H;
+  Lstm r = lstm_view(p);
+  w.st = carve_lstm_of(c, r, B, F);   // B > LSTM_PERSIST_B or not, the exchange buffer is unused here
+  for (int l = 0; l < 4; ++l) w.bias[l] = l < L ? c.f((size_t)4 * H) : nullptr;
+  w.dgates = c.f((size_t)B * F * 4 * H);
+  w.dyl = c.f((size_t)B * F * H);
+  w.dh[0] = c.f((size_t)B * H); w.dh[1] = c.f((size_t)B * H); w.carry = c.f((size_t)B * H); w.dc = c.f((size_t)B * H);
+  w.wt = c.f((size_t)in_max * 4 * H);
+  w.atb_floats = atb_workspace_floats(B * F, 4 * H, in_max);
+  w.atb = c.f(w.atb_floats + 64);
+  return w;
+}
+}  // namespace
+
+size_t empose_lstm_train_workspace_bytes(const empose_lstm_params* p, int B, int F) {
+  if (!p || B <= 0 || F <= 0) return 0;
+  Carver c(nullptr);
+  carve_train_lstm(c, p, B, F);
+  return c.off;
+}
+
+int empose_lstm_train_fwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                          const float* h0, const float* c0, float* y, float* h_n, float* c_n, float* save,
+                          void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_lstm_params(p));
+  if (!x || !y || !save || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0 || ldx < p->input_size || ldx % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (workspace_bytes < empose_lstm_train_workspace_bytes(p, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int H = p->hidden_size, L = p->num_layers;
+  const size_t bh = (size_t)B * H, bfh = (size_t)B * F * H;
+  if ((size_t)B * F * (size_t)(ldx > 4 * H ? ldx : 4 * H) * sizeof(float) >= ((size_t)1 << 32))
+    return fail(EMPOSE_EINVAL, "LSTM batch of %d x %d frames is too large for one call; split the batch", B, F);
+  Carver c(workspace);
+  TrainLstmWs w = carve_train_lstm(c, p, B, F);
+  LstmWaveArgs a;
+  a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H; a.n_units = L;
+  for (int l = 0; l < L; ++l) {
+    hipError_t e = launch_add2(p->b_ih[l], p->b_hh[l], w.bias[l], 4 * H, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "bias sum: %s", hipGetErrorString(e));
+    float* sv = save + (size_t)l * 7 * bfh;
+    LstmUnitArgs& ua = a.unit[l];
+    ua.w_ih = p->w_ih[l]; ua.w_hh = p->w_hh[l]; ua.bias = w.bias[l];
+    ua.h[0] = w.st.h[l][0]; ua.h[1] = w.st.h[l][1]; ua.c = w.st.c[l];
+    ua.in_k = l == 0 ? p->input_size : H;
+    ua.in_seq = l == 0 ? x : nullptr; ua.in_ld = l == 0 ? ldx : 0; ua.in_from = l == 0 ? -1 : l - 1;
+    ua.t_offset = l; ua.reverse = 0;
+    ua.y = l == L - 1 ? y : sv + 6 * bfh; ua.y_ld = H; ua.y_col = 0;
+    ua.sv_gates = sv; ua.sv_c = sv + 4 * bfh; ua.sv_hprev = sv + 5 * bfh;
+    if (h0) {
+      HIP_TRY(hipMemcpyAsync(ua.h[0], h0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      HIP_TRY(hipMemcpy2DAsync(ua.sv_hprev, (size_t)F * H * sizeof(float), h0 + l * bh, (size_t)H * sizeof(float),
+                               (size_t)H * sizeof(float), B, hipMemcpyDeviceToDevice, stream));
+    } else {
+      HIP_TRY(hipMemsetAsync(ua.h[0], 0, bh * sizeof(float), stream));
+      HIP_TRY(hipMemset2DAsync(ua.sv_hprev, (size_t)F * H * sizeof(float), 0, (size_t)H * sizeof(float), B, stream));
+    }
+    if (c0) HIP_TRY(hipMemcpyAsync(ua.c, c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    else HIP_TRY(hipMemsetAsync(ua.c, 0, bh * sizeof(float), stream));
+  }
+  for (int s = 0; s < F + L - 1; ++s) {
+    a.s = s;
+    hipError_t e = launch_lstm_wave(a, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));
+  }
+  for (int l = 0; l < L; ++l) {
+    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + l * bh, w.st.h[l][F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (c_n) HIP_TRY(hipMemcpyAsync(c_n + l * bh, w.st.c[l], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  }
+  return EMPOSE_OK;
+}
+
+int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                          const float* c0, const float* save, const float* dy, float* dx,
+                          const empose_lstm_grads* grads, void* workspace, size_t workspace_bytes,
+                          empose_stream_t stream_) {
+  TRY(check_lstm_params(p));
+  if (!x || !save || !dy || !grads || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0 || ldx < p->input_size || ldx % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (workspace_bytes < empose_lstm_train_workspace_bytes(p, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int H = p->hidden_size, L = p->num_layers;
+  const size_t bh = (size_t)B * H, bfh = (size_t)B * F * H;
+  for (int l = 0; l < L; ++l)
+    if (!grads->w_ih[l] || !grads->w_hh[l] || !grads->b_ih[l] || !grads->b_hh[l])
+      return fail(EMPOSE_EINVAL, "null gradient output");
+  Carver c(workspace);
+  TrainLstmWs w = carve_train_lstm(c, p, B, F);
+  auto gemm = [&](const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                  const float* resid, int ldr) -> hipError_t {
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& g = b.p[0];
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.scale = nullptr; g.shift = nullptr; g.resid = resid; g.ldr = ldr; g.act = 0; g.slope = 0.f;
+    return launch_gemm(b, stream);
+  };
+  for (int l = L - 1; l >= 0; --l) {
+    const float* sv = save + (size_t)l * 7 * bfh;
+    const int in_l = l == 0 ? p->input_size : H;
+    const float* x_l = l == 0 ? x : save + (size_t)(l - 1) * 7 * bfh + 6 * bfh;
+    const int ldx_l = l == 0 ? ldx : H;
+    const float* dy_l = l == L - 1 ? dy : w.dyl;
+    // W_hh^T for the recurrent product dh_{t-1} = dG_t . W_hh on the forward GEMM kernel
+    hipError_t e = launch_transpose(p->w_hh[l], H, w.wt, 4 * H, 4 * H, H, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(w.dc, 0, bh * sizeof(float), stream));
+    const float* dh_in = nullptr;
+    for (int t = F - 1; t >= 0; --t) {
+      LstmCellBwdArgs ca;
+      ca.gates = sv; ca.c_all = sv + 4 * bfh; ca.c0 = c0 ? c0 + l * bh : nullptr;
+      ca.dy = dy_l; ca.ld_dy = H; ca.dh_in = dh_in; ca.dc = w.dc; ca.dgates = w.dgates; ca.dh_carry = w.carry;
+      ca.seq_lengths = seq_lengths; ca.B = B; ca.F = F; ca.H = H; ca.t = t;
+      e = launch_lstm_cell_bwd(ca, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm cell backward: %s", hipGetErrorString(e));
+      if (t == 0) break;
+      float* out = w.dh[t & 1];
+      e = gemm(w.dgates + (size_t)t * 4 * H, F * 4 * H, w.wt, 4 * H, out, H, B, H, 4 * H, w.carry, H);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward gemm: %s", hipGetErrorString(e));
+      dh_in = out;
+    }
+    AtbArgs ab{};
+    ab.A = w.dgates; ab.lda = 4 * H; ab.B = x_l; ab.ldb = ldx_l; ab.C = grads->w_ih[l]; ab.ldc = in_l;
+    ab.bias = grads->b_ih[l]; ab.M = B * F; ab.N = 4 * H; ab.K = in_l;
+    e = launch_gemm_atb(ab, w.atb, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_ih: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(grads->b_hh[l], grads->b_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    ab.B = sv + 5 * bfh; ab.ldb = H; ab.C = grads->w_hh[l]; ab.ldc = H; ab.bias = nullptr; ab.K = H;
+    e = launch_gemm_atb(ab, w.atb, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_hh: %s", hipGetErrorString(e));
+    float* dx_l = l > 0 ? w.dyl : dx;
+    if (dx_l) {
+      e = launch_transpose(p->w_ih[l], in_l, w.wt, 4 * H, 4 * H, in_l, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+      e = gemm(w.dgates, 4 * H, w.wt, 4 * H, dx_l, in_l, B * F, in_l, 4 * H, nullptr, 0);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
+    }
+  }
+  return EMPOSE_OK;
+}
+
 int empose_linear_f32(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                       const float* scale, const float* shift, int prelu, float slope, empose_stream_t stream_) {
   if (!A || !W || !C) return fail(EMPOSE_EINVAL, "null argument");

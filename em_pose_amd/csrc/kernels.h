@@ -102,6 +102,10 @@ struct LstmUnitArgs {        // one (layer, direction), selected by blockIdx.z
   float* h[2];         // [B][H] ping-pong: step k reads h[k & 1], writes h[(k + 1) & 1]
   float* c;            // [B][H] updated in place
   float* y; int y_ld; int y_col;   // output sequence [B][F][y_ld], columns [y_col, y_col + H), or nullptr
+  // Training forward (forward units only): what back-propagation through time needs, batch-major like y.
+  float* sv_gates = nullptr;       // [B][F][4H] activated gates (i | f | g | o) of every step, or nullptr
+  float* sv_c = nullptr;           // [B][F][H] cell state after the step (unchanged past a row's length)
+  float* sv_hprev = nullptr;       // [B][F][H] hidden state BEFORE the step; the caller fills slot t = 0 (h_0)
 };
 struct LstmSeg {             // one operand segment (input part / recurrent part) of a unit's step; built on the host
   const float* a;            // A rows: a + row * lda (+ per-row time offset, below)
@@ -129,6 +133,37 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
 constexpr int LSTM_PERSIST_B = 16;   // largest batch of the whole-sequence kernel
 size_t lstm_persist_xch_floats(int n_units, int B, int H);   // its exchange buffer (8-byte aligned)
 hipError_t launch_lstm_persist(const LstmWaveArgs& a, float* xch, hipStream_t stream, bool* done);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training backward (train.hip)
+// ---------------------------------------------------------------------------------------------------------------
+struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] = sum_m A[m][n])
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  float* bias;               // [N] or nullptr
+  int M, N, K;
+  // set by launch_gemm_atb
+  int S; float* partial; float* bias_partial;
+};
+int atb_splits(int M, int N, int K);
+size_t atb_workspace_floats(int M, int N, int K);
+hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream);
+hipError_t launch_transpose(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t stream);
+hipError_t launch_add2(const float* a, const float* b, float* out, int n, hipStream_t stream);
+struct LstmCellBwdArgs {
+  const float* gates;        // [B][F][4H] saved activations
+  const float* c_all;        // [B][F][H]
+  const float* c0;           // [B][H] or nullptr (zeros)
+  const float* dy; int ld_dy;   // [B][F][ld_dy] cotangent of the layer's output sequence, or nullptr
+  const float* dh_in;        // [B][H] from step t + 1, or nullptr (zeros)
+  float* dc;                 // [B][H] in: from step t + 1, out: for step t - 1
+  float* dgates;             // [B][F][4H] pre-activation gradients (this step's rows are written)
+  float* dh_carry;           // [B][H] out: dh_in of rows that had ended at this step, else 0
+  const int* seq_lengths;
+  int B, F, H, t;
+};
+hipError_t launch_lstm_cell_bwd(const LstmCellBwdArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------------------------
 // SMPL sub-mesh kernels

@@ -211,12 +211,20 @@ __global__ __launch_bounds__(256) void lstm_chain_kernel(LstmWaveArgs a) {
       const size_t hc = (size_t)row * H + e_unit;
       const bool live = t < e_len[e];
       const int t_out = (rev && live) ? e_len[e] - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
-      const float c_new = fsigmoid(acc[i][1][r] + e_bias[1]) * e_c[e] +
-                          fsigmoid(acc[i][0][r] + e_bias[0]) * ftanh(acc[i][2][r] + e_bias[2]);
-      const float h_new = fsigmoid(acc[i][3][r] + e_bias[3]) * ftanh(c_new);
+      const float g_i = fsigmoid(acc[i][0][r] + e_bias[0]), g_f = fsigmoid(acc[i][1][r] + e_bias[1]);
+      const float g_g = ftanh(acc[i][2][r] + e_bias[2]), g_o = fsigmoid(acc[i][3][r] + e_bias[3]);
+      const float c_new = g_f * e_c[e] + g_i * g_g;
+      const float h_new = g_o * ftanh(c_new);
       if (live) cst[hc] = c_new;
       h_next[hc] = live ? h_new : e_hp[e];
       if (yout) yout[((size_t)row * F + t_out) * y_ld + y_col + e_unit] = live ? h_new : 0.f;
+      if (L.sv_gates) {   // training forward: what back-propagation through time reads
+        const size_t rt = (size_t)row * F + t;
+        float* sg = L.sv_gates + rt * 4 * H + e_unit;
+        sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
+        L.sv_c[rt * H + e_unit] = live ? c_new : e_c[e];
+        if (t + 1 < F) L.sv_hprev[(rt + 1) * H + e_unit] = live ? h_new : e_hp[e];
+      }
     }
   };
 
@@ -471,11 +479,20 @@ __global__ __launch_bounds__(256) void lstm_mid_kernel(LstmWaveArgs a) {
     const size_t hc = (size_t)row * H + e_unit;
     const bool live = t < e_len[x];
     const int t_out = (rev && live) ? e_len[x] - 1 - t : t;
-    const float c_new = fsigmoid(gs[1] + e_bias[1]) * e_c[x] + fsigmoid(gs[0] + e_bias[0]) * ftanh(gs[2] + e_bias[2]);
-    const float h_new = fsigmoid(gs[3] + e_bias[3]) * ftanh(c_new);
+    const float g_i = fsigmoid(gs[0] + e_bias[0]), g_f = fsigmoid(gs[1] + e_bias[1]);
+    const float g_g = ftanh(gs[2] + e_bias[2]), g_o = fsigmoid(gs[3] + e_bias[3]);
+    const float c_new = g_f * e_c[x] + g_i * g_g;
+    const float h_new = g_o * ftanh(c_new);
     if (live) L.c[hc] = c_new;
     L.h[(t + 1) & 1][hc] = live ? h_new : e_hp[x];
     if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + e_unit] = live ? h_new : 0.f;
+    if (L.sv_gates) {   // training forward
+      const size_t rt = (size_t)row * F + t;
+      float* sg = L.sv_gates + rt * 4 * H + e_unit;
+      sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
+      L.sv_c[rt * H + e_unit] = live ? c_new : e_c[x];
+      if (t + 1 < F) L.sv_hprev[(rt + 1) * H + e_unit] = live ? h_new : e_hp[x];
+    }
   }
 }
 
@@ -557,15 +574,26 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
     const bool live = t < len;
     const int t_out = (rev && live) ? len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
     float h_new = 0.f;
+    const float g_i = fsigmoid(gi + bias[unit]), g_f = fsigmoid(gf + bias[H + unit]);
+    const float g_g = ftanh(gg + bias[2 * H + unit]), g_o = fsigmoid(go + bias[3 * H + unit]);
+    const float c_old = cst[hc];
+    const float c_new = g_f * c_old + g_i * g_g;
+    float h_carry;
     if (live) {
-      const float c_new = fsigmoid(gf + bias[H + unit]) * cst[hc] + fsigmoid(gi + bias[unit]) * ftanh(gg + bias[2 * H + unit]);
-      h_new = fsigmoid(go + bias[3 * H + unit]) * ftanh(c_new);
+      h_new = g_o * ftanh(c_new);
       cst[hc] = c_new;
-      h_next[hc] = h_new;
+      h_next[hc] = h_carry = h_new;
     } else {
-      h_next[hc] = h_prev[hc];
+      h_next[hc] = h_carry = h_prev[hc];
     }
     if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + unit] = h_new;
+    if (L.sv_gates) {   // training forward
+      const size_t rt = (size_t)row * F + t;
+      float* sg = L.sv_gates + rt * 4 * H + unit;
+      sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
+      L.sv_c[rt * H + unit] = live ? c_new : c_old;
+      if (t + 1 < F) L.sv_hprev[(rt + 1) * H + unit] = h_carry;
+    }
   }
 }
 

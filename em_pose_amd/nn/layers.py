@@ -110,6 +110,103 @@ class _BnPreluFn(torch.autograd.Function):
         return dx, dgamma, dbeta, dslope, None
 
 
+class _HipLinearLargeFn(torch.autograd.Function):
+    """y = x W^T + b for any batch: forward on the fp32 matrix-core GEMM (`empose_linear_f32`), dX = dY . W on the same
+    kernel against a transposed copy of W (`empose_transpose_f32`), dW = dY^T X and db = column sums of dY in one
+    `empose_gemm_atb_f32` (operands read as they lie, reduction over the rows split across workgroups)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = x.contiguous(), w.contiguous()
+        M, K, N = x.shape[0], x.shape[1], w.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().empose_linear_f32(_lib.dptr(x), K, _lib.dptr(w), K, _lib.dptr(y), N, M, N, K, None,
+                                                _lib.dptr(b), 0, 0.0, _lib.current_stream()))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K, N = x.shape[0], x.shape[1], w.shape[0]
+        dev, lib = x.device, _lib.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(K, N, dtype=torch.float32, device=dev)
+            _lib.check(lib.empose_transpose_f32(N, K, _lib.dptr(w), K, _lib.dptr(wt), N, _lib.current_stream()))
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            _lib.check(lib.empose_linear_f32(_lib.dptr(dy), N, _lib.dptr(wt), N, _lib.dptr(dx), K, M, K, N, None, None, 0,
+                                             0.0, _lib.current_stream()))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(N, dtype=torch.float32, device=dev)
+            nbytes = lib.empose_gemm_atb_workspace_bytes(M, N, K)
+            ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+            _lib.check(lib.empose_gemm_atb_f32(M, N, K, _lib.dptr(dy), N, _lib.dptr(x), K, _lib.dptr(dw), K,
+                                               _lib.dptr(db), _lib.dptr(ws), ws.numel(), _lib.current_stream()))
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=0)
+        return dx, dw, db
+
+
+class _LstmTrainFn(torch.autograd.Function):
+    """Stacked uni-directional LSTM over ragged rows with hand-written forward and back-propagation through time
+    (`empose_lstm_train_fwd/bwd`): the forward is the inference wavefront kernel saving gates / cell states / incoming
+    hidden states; the backward one cell kernel + one recurrent GEMM per step and layer, then the weight gradients as
+    three big GEMMs per layer.  Replaces nn.LSTM (MIOpen) + pack/pad on the training path (reference layers.py:133-157)."""
+
+    @staticmethod
+    def forward(ctx, x, lens, h0, c0, n_layers, *weights):
+        x = x.contiguous()
+        B, F, K = x.shape
+        H = weights[1].shape[1]
+        dev, lib = x.device, _lib.lib()
+        p = _lib.LstmParams()
+        p.num_layers, p.input_size, p.hidden_size = n_layers, K, H
+        ws_ = [w.contiguous() for w in weights]
+        for l in range(n_layers):
+            p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [ws_[4 * l + k].data_ptr() for k in range(4)]
+        y = torch.empty(B, F, H, dtype=torch.float32, device=dev)
+        h_n = torch.empty(n_layers, B, H, dtype=torch.float32, device=dev)
+        c_n = torch.empty(n_layers, B, H, dtype=torch.float32, device=dev)
+        save = torch.empty(lib.empose_lstm_train_save_floats(n_layers, B, F, H), dtype=torch.float32, device=dev)
+        nbytes = lib.empose_lstm_train_workspace_bytes(C.byref(p), B, F)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.empose_lstm_train_fwd(C.byref(p), B, F, _lib.dptr(x), K, _lib.dptr(lens), _lib.dptr(h0),
+                                             _lib.dptr(c0), _lib.dptr(y), _lib.dptr(h_n), _lib.dptr(c_n), _lib.dptr(save),
+                                             _lib.dptr(ws), nbytes, _lib.current_stream()))
+        ctx.save_for_backward(x, lens, c0, save, *ws_)
+        ctx.n_layers = n_layers
+        ctx.mark_non_differentiable(h_n, c_n)
+        return y, h_n, c_n
+
+    @staticmethod
+    def backward(ctx, dy, _dh, _dc):
+        x, lens, c0, save = ctx.saved_tensors[:4]
+        weights = ctx.saved_tensors[4:]
+        L = ctx.n_layers
+        B, F, K = x.shape
+        H = weights[1].shape[1]
+        dev, lib = x.device, _lib.lib()
+        p, g = _lib.LstmParams(), _lib.LstmGrads()
+        p.num_layers, p.input_size, p.hidden_size = L, K, H
+        grads = [torch.empty_like(w) for w in weights]
+        for l in range(L):
+            p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [weights[4 * l + k].data_ptr() for k in range(4)]
+            g.w_ih[l], g.w_hh[l], g.b_ih[l], g.b_hh[l] = [grads[4 * l + k].data_ptr() for k in range(4)]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nbytes = lib.empose_lstm_train_workspace_bytes(C.byref(p), B, F)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dy = dy.contiguous()
+        _lib.check(lib.empose_lstm_train_bwd(C.byref(p), B, F, _lib.dptr(x), K, _lib.dptr(lens), _lib.dptr(c0),
+                                             _lib.dptr(save), _lib.dptr(dy), _lib.dptr(dx), C.byref(g), _lib.dptr(ws),
+                                             nbytes, _lib.current_stream()))
+        return (dx, None, None, None, None) + tuple(grads)
+
+
 def bn_prelu_train(x, bn, act):
     """`act(bn(x))` for the training path: the fused kernels for a train-mode BatchNorm1d with a momentum and a PReLU
     with one slope on GPU tensors, the torch modules otherwise."""
@@ -126,8 +223,11 @@ def linear_train(x, lin):
     x2 = x.reshape(-1, x.shape[-1])
     M, K, N = x2.shape[0], lin.in_features, lin.out_features
     ok = _lib.lib().empose_gemm_strided_applicable
-    if x2.is_cuda and x2.dtype == torch.float32 and ok(M, N) and ok(M, K) and ok(N, K):
-        return _HipLinearFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))
+    if x2.is_cuda and x2.dtype == torch.float32:
+        if ok(M, N) and ok(M, K) and ok(N, K):
+            return _HipLinearFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))
+        if K % 4 == 0 and N % 4 == 0:
+            return _HipLinearLargeFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))
     return lin(x)
 
 
@@ -408,6 +508,17 @@ class RNNLayer(nn.Module):
         `full_length=True` (every row spans all F frames, checked by the caller on the host) skips the packing, which
         is the same computation without its host round trip -- required inside a captured HIP graph."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+        if x.is_cuda and not self.is_bidirectional and self.num_layers <= 4 and x.dtype == torch.float32 and \
+                x.shape[2] % 4 == 0:
+            # hand-written forward + back-propagation through time; no packing, no host round trip, capturable
+            lens = None if full_length else seq_lengths.to(device=x.device, dtype=torch.int32).contiguous()
+            h0 = c0 = None
+            if self.init_state is not None:
+                h0, c0 = [t.detach().to(device=x.device, dtype=torch.float32).contiguous() for t in self.init_state]
+            weights = [w for unit in self._unit_params() for w in unit]
+            y, h_n, c_n = _LstmTrainFn.apply(x, lens, h0, c0, self.num_layers, *weights)
+            self.final_state = (h_n, c_n)
+            return y
         if full_length:   # the module is time-major (batch_first=False, like the reference's); the packing hid that
             xt = x.transpose(0, 1).contiguous()
             # Pieces of at most 16 time steps with the state carried: MIOpen's RNN captures into a HIP graph up to 31

@@ -262,6 +262,51 @@ int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float
                               float* dx, int lddx, float* dgamma, float* dbeta, float* dslope, float* dslope_partial,
                               int* counter, empose_stream_t stream);
 
+/* ---- training backward: building blocks (BASELINE.json configs[4]) ------------------------------------------------ */
+/* The reference trains through torch.autograd (reference nn/models.py:634-688, scripts/train.py:133-152); these are the
+ * hand-written pieces the Python autograd Functions of em_pose_amd/nn call instead of library kernels.  All pointers are
+ * DEVICE pointers (the parameters live in torch tensors and change every optimiser step: nothing is packed or cached). */
+
+/* C[N][ldc] = A[M][lda]^T . B[M][ldb], optionally bias[n] = sum_m A[m][n]: the weight and bias gradient of a linear
+ * layer y = x W^T + b (dW = dY^T X, db = column sums of dY; torch.nn.functional.linear's backward).  The reduction over
+ * M is split over workgroups and summed in a fixed order (deterministic).  workspace: empose_gemm_atb_workspace_bytes. */
+size_t empose_gemm_atb_workspace_bytes(int M, int N, int K);
+int empose_gemm_atb_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        float* bias, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+/* dst[c][r] = src[r][c] (rows x cols): W^T copies so that dX = dY . W runs on the forward GEMM (empose_linear_f32). */
+int empose_transpose_f32(int rows, int cols, const float* src, int ld_src, float* dst, int ld_dst,
+                         empose_stream_t stream);
+
+/* Stacked uni-directional LSTM with autograd support (reference nn/layers.py:133-157 in training mode: nn.LSTM over
+ * packed ragged sequences, its backward through cuDNN/MIOpen).  Parameters as torch.nn.LSTM holds them. */
+typedef struct {
+  int num_layers, input_size, hidden_size;   /* num_layers <= 4 */
+  const float* w_ih[4];   /* [4H][in]  (in = input_size for layer 0, H above) */
+  const float* w_hh[4];   /* [4H][H] */
+  const float* b_ih[4];   /* [4H] */
+  const float* b_hh[4];
+} empose_lstm_params;
+typedef struct {          /* gradient outputs, same shapes; every pointer required */
+  float* w_ih[4];
+  float* w_hh[4];
+  float* b_ih[4];
+  float* b_hh[4];
+} empose_lstm_grads;
+/* floats of the `save` buffer the forward fills for the backward: per layer gates [B][F][4H], cell states [B][F][H],
+ * incoming hidden states [B][F][H], output sequence [B][F][H] */
+size_t empose_lstm_train_save_floats(int num_layers, int B, int F, int hidden_size);
+size_t empose_lstm_train_workspace_bytes(const empose_lstm_params* p, int B, int F);
+/* x [B][F][ldx], seq_lengths [B] or NULL, h0/c0 [L][B][H] or NULL -> y [B][F][H], h_n/c_n [L][B][H] (may be NULL). */
+int empose_lstm_train_fwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                          const float* h0, const float* c0, float* y, float* h_n, float* c_n, float* save,
+                          void* workspace, size_t workspace_bytes, empose_stream_t stream);
+/* dy [B][F][H] -> parameter gradients (overwritten) and, if dx != NULL, dx [B][F][input_size].  The final state is not
+ * differentiated (it only seeds the next chunk, detached, reference models.py:489-492). */
+int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
+                          const float* c0, const float* save, const float* dy, float* dx,
+                          const empose_lstm_grads* grads, void* workspace, size_t workspace_bytes,
+                          empose_stream_t stream);
+
 /* ---- stand-alone (Bi)LSTM: the RNNLayer of the BiRNN baseline --------------------------------- */
 /* reference nn/layers.py:80-157 (nn.LSTM, optionally bidirectional, packed ragged sequences). Parameter index
  * u = layer * dirs + direction (direction 1 = reverse), as PyTorch orders `*_l{k}` / `*_l{k}_reverse`; layer k > 0 of

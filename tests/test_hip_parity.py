@@ -1183,3 +1183,106 @@ def test_ground_truth_preprocessing_round_trip(big_model):
     with pytest.raises(ValueError):
         SampleMarkersWithOffsets(smpl, sets, noise_level=4)
     assert det_pos.shape == b3.marker_pos_synth.shape and det_ori.shape == b3.marker_ori_synth.shape
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Training backward building blocks (BASELINE configs[4]): hand-written kernels against torch.autograd
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(384, 512, 512), (8192, 512, 296), (1000, 66, 512), (50, 10, 512), (4096, 2048, 144),
+                                   (7, 5, 3), (130, 200, 320)])
+def test_gemm_atb_vs_float64(M, N, K):
+    """C = A^T B (+ column sums of A): the weight / bias gradient of a linear layer."""
+    rng = np.random.default_rng(M + N)
+    lda, ldb, ldc = N + 3, K + 5, K + 2
+    a = rng.normal(size=(M, lda)).astype(np.float32)
+    b = rng.normal(size=(M, ldb)).astype(np.float32)
+    want = a[:, :N].astype(np.float64).T @ b[:, :K].astype(np.float64)
+    A_, B_ = gpu(a), gpu(b)
+    Cm = torch.full((N, ldc), -7.0, device=DEV)
+    bias = torch.full((N,), -7.0, device=DEV)
+    lib = _lib.lib()
+    nbytes = lib.empose_gemm_atb_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=DEV)
+    for _ in range(2):   # twice: bitwise reproducible
+        _lib.check(lib.empose_gemm_atb_f32(M, N, K, _lib.dptr(A_), lda, _lib.dptr(B_), ldb, _lib.dptr(Cm), ldc,
+                                           _lib.dptr(bias), _lib.dptr(ws), ws.numel(), _lib.current_stream()))
+        torch.cuda.synchronize()
+        got, gb = Cm.cpu().numpy(), bias.cpu().numpy()
+        np.testing.assert_allclose(got[:, :K], want, atol=2e-5 * np.sqrt(M), rtol=1e-5)
+        np.testing.assert_allclose(gb, a[:, :N].astype(np.float64).sum(0), atol=2e-5 * np.sqrt(M))
+        assert (got[:, K:] == -7.0).all()
+        if _ == 0:
+            first = got.copy()
+    assert np.array_equal(first, got)
+
+
+def test_transpose_f32():
+    rng = np.random.default_rng(1)
+    for rows, cols in ((2048, 512), (66, 512), (33, 7)):
+        a = rng.normal(size=(rows, cols + 4)).astype(np.float32)
+        A_ = gpu(a)
+        out = torch.zeros(cols, rows + 2, device=DEV)
+        _lib.check(_lib.lib().empose_transpose_f32(rows, cols, _lib.dptr(A_), cols + 4, _lib.dptr(out), rows + 2,
+                                                   _lib.current_stream()))
+        assert np.array_equal(out.cpu().numpy()[:, :rows], a[:, :cols].T)
+
+
+@pytest.mark.parametrize('M,K,N', [(8192, 296, 512), (2048, 512, 512), (3000, 512, 66), (1536, 512, 10)])
+def test_linear_train_large_batch_vs_torch_autograd(M, K, N):
+    from em_pose_amd.nn.layers import linear_train, _HipLinearLargeFn  # noqa: F401
+    torch.manual_seed(M + N)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    x = torch.randn(M, K, device=DEV, requires_grad=True)
+    dy = torch.randn(M, N, device=DEV)
+    y = linear_train(x, lin)
+    y.backward(dy)
+    got = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    x.grad = None
+    lin.zero_grad()
+    y2 = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+    y2.backward(dy.double())
+    want = [y2.detach(), x.grad.double(), None, None]
+    np.testing.assert_allclose(got[0].cpu().numpy(), want[0].cpu().numpy(), atol=3e-5 * np.sqrt(K / 32))
+    np.testing.assert_allclose(got[1].cpu().numpy(), want[1].cpu().numpy(), atol=3e-5 * np.sqrt(N / 32))
+    dw = dy.double().t() @ x.detach().double()
+    np.testing.assert_allclose(got[2].cpu().numpy(), dw.cpu().numpy(), atol=3e-5 * np.sqrt(M))
+    np.testing.assert_allclose(got[3].cpu().numpy(), dy.double().sum(0).cpu().numpy(), atol=3e-5 * np.sqrt(M))
+
+
+@pytest.mark.parametrize('B,F,K,H,L,ragged,carry', [(12, 32, 144, 512, 2, False, False), (5, 9, 72, 64, 2, True, True),
+                                                    (40, 16, 144, 128, 1, True, False), (300, 8, 144, 256, 2, False, True),
+                                                    (3, 4, 8, 16, 3, True, False)])
+def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
+    """empose_lstm_train_fwd/bwd (all three step kernels: B <= 16, <= 256, larger) against torch.nn.LSTM over packed
+    sequences with autograd, in float64 on the CPU: outputs, final state, dx and every parameter gradient."""
+    from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+    from em_pose_amd.nn.layers import _LstmTrainFn
+    torch.manual_seed(B * 7 + F)
+    ref = torch.nn.LSTM(K, H, L).double()
+    x = torch.randn(B, F, K, dtype=torch.float64)
+    lens = torch.randint(1, F + 1, (B,)) if ragged else torch.full((B,), F)
+    lens[0] = F
+    state = (0.5 * torch.randn(L, B, H, dtype=torch.float64), 0.5 * torch.randn(L, B, H, dtype=torch.float64)) if carry else None
+    dy = torch.randn(B, F, H, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    packed = pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=False)
+    out, (hn, cn) = ref(packed, state)
+    out, _ = pad_packed_sequence(out, batch_first=True, total_length=F)
+    (out * dy).sum().backward()
+    weights = [getattr(ref, '%s_l%d' % (n, l)) for l in range(L) for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    wg = [w.detach().float().to(DEV).requires_grad_(True) for w in weights]
+    xg = x.float().to(DEV).requires_grad_(True)
+    h0 = c0 = None
+    if carry:
+        h0, c0 = state[0].float().to(DEV), state[1].float().to(DEV)
+    y, h_n, c_n = _LstmTrainFn.apply(xg, lens.to(DEV, torch.int32) if ragged else None, h0, c0, L, *wg)
+    (y * dy.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    tol = 2e-5
+    np.testing.assert_allclose(y.detach().cpu().numpy(), out.detach().numpy(), atol=tol)
+    np.testing.assert_allclose(h_n.cpu().numpy(), hn.detach().numpy(), atol=tol)
+    np.testing.assert_allclose(c_n.cpu().numpy(), cn.detach().numpy(), atol=tol)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), atol=5e-5)
+    for g_, w in zip(wg, weights):
+        scale = max(1.0, float(w.grad.abs().max()))
+        np.testing.assert_allclose(g_.grad.cpu().numpy(), w.grad.numpy(), atol=1e-4 * scale)
