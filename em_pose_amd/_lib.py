@@ -77,6 +77,33 @@ class LstmGrads(C.Structure):    # empose_lstm_grads
     _fields_ = [('w_ih', C.c_void_p * 4), ('w_hh', C.c_void_p * 4), ('b_ih', C.c_void_p * 4), ('b_hh', C.c_void_p * 4)]
 
 
+class MlpParams(C.Structure):    # empose_mlp_params: DEVICE pointers
+    _fields_ = [('n_layers', C.c_int), ('in_dim', C.c_int), ('hidden', C.c_int), ('out_dim', C.c_int),
+                ('weight', C.c_void_p * MAX_DENSE), ('bias', C.c_void_p * MAX_DENSE),
+                ('bn_weight', C.c_void_p * MAX_DENSE), ('bn_bias', C.c_void_p * MAX_DENSE),
+                ('bn_running_mean', C.c_void_p * MAX_DENSE), ('bn_running_var', C.c_void_p * MAX_DENSE),
+                ('bn_num_batches', C.c_void_p * MAX_DENSE), ('prelu', C.c_void_p * MAX_DENSE),
+                ('bn_eps', C.c_float), ('bn_momentum', C.c_float)]
+
+
+class MlpGrads(C.Structure):     # empose_mlp_grads
+    _fields_ = [('weight', C.c_void_p * MAX_DENSE), ('bias', C.c_void_p * MAX_DENSE),
+                ('bn_weight', C.c_void_p * MAX_DENSE), ('bn_bias', C.c_void_p * MAX_DENSE),
+                ('prelu', C.c_void_p * MAX_DENSE)]
+
+
+class LossIO(C.Structure):       # empose_loss_io
+    _fields_ = [('B', C.c_int), ('F', C.c_int), ('n_hist', C.c_int), ('n_markers', C.c_int),
+                ('marker_idx', C.c_int * 12),
+                ('pose_hist', C.c_void_p), ('shape_hist', C.c_void_p), ('markers_hist', C.c_void_p),
+                ('markers_ori_hist', C.c_void_p), ('joints_final', C.c_void_p), ('pose_gt', C.c_void_p),
+                ('shape_gt', C.c_void_p), ('joints_gt', C.c_void_p), ('inputs', C.c_void_p), ('ld_inputs', C.c_int),
+                ('seq_lengths', C.c_void_p), ('marker_masks', C.c_void_p),
+                ('w_pose', C.c_float), ('w_shape', C.c_float), ('w_fk', C.c_float), ('w_rec', C.c_float),
+                ('d_pose', C.c_void_p), ('d_shape', C.c_void_p), ('d_markers', C.c_void_p),
+                ('d_markers_ori', C.c_void_p), ('d_joints', C.c_void_p), ('loss_vals', C.c_void_p)]
+
+
 class MeshDesc(C.Structure):
     _fields_ = [('n_vertices', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
                 ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p),
@@ -118,16 +145,31 @@ SIGNATURES = {
     'empose_gemm_strided_applicable': (C.c_int, [C.c_int, C.c_int]),
     'empose_gemm_strided_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long,
                                            C.c_long, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'empose_bn_prelu_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int]),
     'empose_bn_prelu_train_fwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_bn_prelu_train_bwd': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p]),
     'empose_gemm_atb_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'empose_gemm_atb_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_transpose_f32': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'empose_mlp_train_save_floats': (C.c_size_t, [C.POINTER(MlpParams), C.c_int]),
+    'empose_mlp_train_workspace_bytes': (C.c_size_t, [C.POINTER(MlpParams), C.c_int]),
+    'empose_mlp_train_fwd': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_mlp_train_bwd': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.POINTER(MlpGrads), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_window_mean': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'empose_axpby2d': (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
+    'empose_lgd_losses_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'empose_lgd_losses': (C.c_int, [C.POINTER(LossIO), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_adam_step': (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     'empose_lstm_train_save_floats': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'empose_lstm_train_workspace_bytes': (C.c_size_t, [C.POINTER(LstmParams), C.c_int, C.c_int]),
     'empose_lstm_train_fwd': (C.c_int, [C.POINTER(LstmParams), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

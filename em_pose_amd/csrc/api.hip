@@ -1124,17 +1124,24 @@ int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long
 
 int empose_gemm_strided_applicable(int M, int N) { return strided_gemm_applicable(M, N) ? 1 : 0; }
 
+size_t empose_bn_prelu_workspace_bytes(int M, int C) {
+  return (M > 0 && C > 0) ? bn_prelu_workspace_floats(M, C) * sizeof(float) : 0;
+}
+
 int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float* gamma, const float* beta,
                               const float* slope, float eps, float momentum, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float* z, int ldz, float* save_mean, float* save_rstd,
-                              empose_stream_t stream_) {
+                              void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   if (!x || !gamma || !beta || !slope || !z || !save_mean || !save_rstd) return fail(EMPOSE_EINVAL, "null argument");
   if (M <= 0 || C <= 0 || ldx < C || ldz < C) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (bn_prelu_workspace_floats(M, C) * sizeof(float) > (workspace ? workspace_bytes : 0))
+    return fail(EMPOSE_ENOMEM, "workspace too small (empose_bn_prelu_workspace_bytes)");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(EMPOSE_EINVAL, "running_mean and running_var go together");
   BnPreluArgs a{};
   a.M = M; a.C = C; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.slope = slope; a.eps = eps;
   a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var;
   a.num_batches_tracked = num_batches_tracked; a.z = z; a.ldz = ldz; a.save_mean = save_mean; a.save_rstd = save_rstd;
+  a.workspace = static_cast<float*>(workspace);
   hipError_t e = launch_bn_prelu(a, false, static_cast<hipStream_t>(stream_));
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu forward: %s", hipGetErrorString(e));
   return EMPOSE_OK;
@@ -1143,12 +1150,15 @@ int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float
 int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
                               const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
                               float* dx, int lddx, float* dgamma, float* dbeta, float* dslope, float* dslope_partial,
-                              int* counter, empose_stream_t stream_) {
+                              int* counter, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   if (!x || !dz || !gamma || !beta || !slope || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !dslope ||
       !dslope_partial || !counter)
     return fail(EMPOSE_EINVAL, "null argument");
   if (M <= 0 || C <= 0 || ldx < C || lddz < C || lddx < C) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (bn_prelu_workspace_floats(M, C) * sizeof(float) > (workspace ? workspace_bytes : 0))
+    return fail(EMPOSE_ENOMEM, "workspace too small (empose_bn_prelu_workspace_bytes)");
   BnPreluArgs a{};
+  a.workspace = static_cast<float*>(workspace);
   a.M = M; a.C = C; a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.save_mean = const_cast<float*>(save_mean); a.save_rstd = const_cast<float*>(save_rstd);
   a.dz = dz; a.lddz = lddz; a.dx = dx; a.lddx = lddx; a.dgamma = dgamma; a.dbeta = dbeta; a.dslope_partial = dslope_partial; a.dslope = dslope; a.counter = counter;
@@ -1171,6 +1181,7 @@ int empose_gemm_atb_f32(int M, int N, int K, const float* A, int lda, const floa
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(EMPOSE_ENOMEM, "workspace too small");
   AtbArgs a{};
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.bias = bias; a.M = M; a.N = N; a.K = K;
+  a.accumulate = 0;
   hipError_t e = launch_gemm_atb(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream_));
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "A^T B gemm: %s", hipGetErrorString(e));
   return EMPOSE_OK;
@@ -1182,6 +1193,230 @@ int empose_transpose_f32(int rows, int cols, const float* src, int ld_src, float
   if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return fail(EMPOSE_EINVAL, "bad sizes");
   hipError_t e = launch_transpose(src, ld_src, dst, ld_dst, rows, cols, static_cast<hipStream_t>(stream_));
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* out, int ld_out, empose_stream_t stream_) {
+  if (!in || !out) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0 || F <= 0 || C <= 0 || T % F != 0 || ld_in < C || ld_out < C) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_window_mean(in, ld_in, out, ld_out, T, F, C, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "window mean: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
+                   float* out, int ldo, empose_stream_t stream_) {
+  if (!out) return fail(EMPOSE_EINVAL, "null argument");
+  if (rows <= 0 || cols <= 0 || ldo < cols || (x && ldx < cols) || (y && ldy < cols)) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_axpby2d(rows, cols, alpha, x, ldx, beta, y, ldy, out, ldo, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "axpby: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+size_t empose_lgd_losses_workspace_bytes(int B, int F, int n_hist) {
+  if (B <= 0 || F <= 0 || n_hist <= 0) return 0;
+  return (size_t)4 * n_hist * B * F * sizeof(float) + 256;
+}
+
+int empose_lgd_losses(const empose_loss_io* io, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  if (!io || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (io->B <= 0 || io->F <= 0 || io->n_hist <= 0 || (io->n_markers != 6 && io->n_markers != 12))
+    return fail(EMPOSE_EINVAL, "bad sizes");
+  if (!io->pose_hist || !io->shape_hist || !io->markers_hist || !io->markers_ori_hist || !io->joints_final ||
+      !io->pose_gt || !io->shape_gt || !io->inputs || !io->d_pose || !io->d_shape || !io->d_markers ||
+      !io->d_markers_ori || !io->d_joints || !io->loss_vals)
+    return fail(EMPOSE_EINVAL, "null tensor");
+  if (workspace_bytes < empose_lgd_losses_workspace_bytes(io->B, io->F, io->n_hist)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  LossArgs a;
+  a.B = io->B; a.F = io->F; a.N1 = io->n_hist; a.n_markers = io->n_markers;
+  for (int m = 0; m < 12; ++m) a.used_slot[m] = -1;
+  for (int i = 0; i < io->n_markers; ++i) {
+    if (io->marker_idx[i] < 0 || io->marker_idx[i] >= 12) return fail(EMPOSE_EINVAL, "marker_idx out of range");
+    a.used_slot[io->marker_idx[i]] = i;
+  }
+  a.pose_hist = io->pose_hist; a.shape_hist = io->shape_hist; a.pos_hist = io->markers_hist; a.ori_hist = io->markers_ori_hist;
+  a.joints_final = io->joints_final; a.pose_gt = io->pose_gt; a.shape_gt = io->shape_gt; a.joints_gt = io->joints_gt;
+  a.x_in = io->inputs; a.ldx = io->ld_inputs; a.seq_lengths = io->seq_lengths; a.masks = io->marker_masks;
+  a.w_pose = io->w_pose; a.w_shape = io->w_shape; a.w_fk = io->w_fk; a.w_rec = io->w_rec;
+  a.d_pose = io->d_pose; a.d_shape = io->d_shape; a.d_pos = io->d_markers; a.d_ori = io->d_markers_ori;
+  a.d_joints = io->d_joints; a.partial = static_cast<float*>(workspace); a.loss_vals = io->loss_vals;
+  hipError_t e = launch_lgd_losses(a, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "loss kernels: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_adam_step(int n_chunks, const void* params, const void* grads, const void* exp_avg, const void* exp_avg_sq,
+                     const void* sizes, const void* chunk_tensor, const void* chunk_offset, float lr, float beta1,
+                     float beta2, float eps, int step, empose_stream_t stream_) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !chunk_tensor || !chunk_offset)
+    return fail(EMPOSE_EINVAL, "null argument");
+  if (n_chunks <= 0 || step < 1) return fail(EMPOSE_EINVAL, "bad sizes");
+  AdamArgs a;
+  a.params = static_cast<void* const*>(params); a.grads = static_cast<void* const*>(grads);
+  a.exp_avg = static_cast<void* const*>(exp_avg); a.exp_avg_sq = static_cast<void* const*>(exp_avg_sq);
+  a.sizes = static_cast<const long long*>(sizes); a.chunk_tensor = static_cast<const int*>(chunk_tensor);
+  a.chunk_offset = static_cast<const long long*>(chunk_offset);
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+  hipError_t e = launch_adam(a, n_chunks, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "adam: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+// ---- one MLP in training mode -------------------------------------------------------------------------------------
+namespace {
+int check_mlp_params(const empose_mlp_params* p) {
+  if (!p) return fail(EMPOSE_EINVAL, "null argument");
+  if (p->n_layers < 2 || p->n_layers > EMPOSE_MAX_DENSE || p->in_dim <= 0 || p->hidden <= 0 || p->out_dim <= 0 ||
+      p->in_dim % 4 != 0 || p->hidden % 4 != 0)
+    return fail(EMPOSE_EINVAL, "unsupported MLP configuration");
+  for (int l = 0; l < p->n_layers; ++l) {
+    if (!p->weight[l] || !p->bias[l]) return fail(EMPOSE_EINVAL, "null MLP parameter");
+    if (l < p->n_layers - 1 && (!p->bn_weight[l] || !p->bn_bias[l] || !p->prelu[l]))
+      return fail(EMPOSE_EINVAL, "the training MLP needs BatchNorm + PReLU on every hidden layer");
+  }
+  return EMPOSE_OK;
+}
+struct MlpTrainWs {
+  float* d[2];       // [M][hidden] cotangent ping-pong
+  float* wt;         // transposed weight [hidden][max(hidden, out_pad)]
+  float* atb; float* bn; float* slope_partial; int* counter;
+};
+MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
+  MlpTrainWs w;
+  const int H = p->hidden, op = (p->out_dim + 3) & ~3;
+  w.d[0] = c.f((size_t)M * H); w.d[1] = c.f((size_t)M * H);
+  w.wt = c.f((size_t)H * (H > op ? H : op));
+  size_t atbf = atb_workspace_floats(M, H, H > p->in_dim ? H : p->in_dim);
+  const size_t atb2 = atb_workspace_floats(M, p->out_dim, H);
+  atbf = atbf > atb2 ? atbf : atb2;
+  w.atb = c.f(atbf + 64);
+  w.bn = c.f(bn_prelu_workspace_floats(M, H) + 64);
+  w.slope_partial = c.f((size_t)(H + 31) / 32 + 8);
+  w.counter = reinterpret_cast<int*>(c.f(64));
+  return w;
+}
+size_t mlp_layer_save(const empose_mlp_params* p, int M) { return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden; }
+}  // namespace
+
+size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M) {
+  if (!p || M <= 0) return 0;
+  return (size_t)(p->n_layers - 1) * mlp_layer_save(p, M);
+}
+
+size_t empose_mlp_train_workspace_bytes(const empose_mlp_params* p, int M) {
+  if (!p || M <= 0) return 0;
+  Carver c(nullptr);
+  carve_mlp_train(c, p, M);
+  return c.off;
+}
+
+int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int ldx, float* out, int ld_out,
+                         float* save, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_mlp_params(p));
+  if (!x || !out || !save || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (M <= 0 || ldx < p->in_dim || ldx % 4 != 0 || ld_out < p->out_dim) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (workspace_bytes < empose_mlp_train_workspace_bytes(p, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Carver c(workspace);
+  MlpTrainWs w = carve_mlp_train(c, p, M);
+  const int H = p->hidden, L = p->n_layers;
+  const float* in = x;
+  int ld_in = ldx, k_in = p->in_dim;
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    float* sv = save + (size_t)l * mlp_layer_save(p, M);
+    float* z = last ? out : sv;
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& g = b.p[0];
+    g.A = in; g.lda = ld_in; g.W = p->weight[l]; g.ldw = k_in; g.C = z; g.ldc = last ? ld_out : H;
+    g.M = M; g.N = last ? p->out_dim : H; g.K = k_in;
+    g.scale = nullptr; g.shift = p->bias[l]; g.resid = nullptr; g.ldr = 0; g.act = 0; g.slope = 0.f;
+    hipError_t e = launch_gemm(b, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "mlp forward gemm: %s", hipGetErrorString(e));
+    if (last) break;
+    float* act = sv + (size_t)M * H;
+    BnPreluArgs a{};
+    a.M = M; a.C = H; a.x = z; a.ldx = H; a.gamma = p->bn_weight[l]; a.beta = p->bn_bias[l]; a.slope = p->prelu[l];
+    a.eps = p->bn_eps; a.momentum = p->bn_momentum; a.running_mean = p->bn_running_mean[l];
+    a.running_var = p->bn_running_var[l]; a.num_batches_tracked = p->bn_num_batches[l];
+    a.z = act; a.ldz = H; a.save_mean = sv + (size_t)2 * M * H; a.save_rstd = a.save_mean + H;
+    a.workspace = w.bn;
+    e = launch_bn_prelu(a, false, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu forward: %s", hipGetErrorString(e));
+    in = act; ld_in = H; k_in = H;
+  }
+  return EMPOSE_OK;
+}
+
+int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
+                         const float* save, const empose_mlp_grads* gr, int accumulate, void* workspace,
+                         size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_mlp_params(p));
+  if (!x || !d_out || !save || !gr || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  const int H = p->hidden, L = p->n_layers, op = (p->out_dim + 3) & ~3;
+  if (M <= 0 || ldx < p->in_dim || ld_dout < op || ld_dout % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (workspace_bytes < empose_mlp_train_workspace_bytes(p, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  for (int l = 0; l < L; ++l) {
+    if (!gr->weight[l] || !gr->bias[l]) return fail(EMPOSE_EINVAL, "null gradient output");
+    if (l < L - 1 && (!gr->bn_weight[l] || !gr->bn_bias[l] || !gr->prelu[l])) return fail(EMPOSE_EINVAL, "null gradient output");
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Carver c(workspace);
+  MlpTrainWs w = carve_mlp_train(c, p, M);
+  HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
+  auto gemm = [&](const float* A, int lda, const float* W, int ldw, float* C, int ldc, int N, int K) -> hipError_t {
+    GemmBatch b;
+    b.count = 1;
+    GemmProb& g = b.p[0];
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.scale = nullptr; g.shift = nullptr; g.resid = nullptr; g.ldr = 0; g.act = 0; g.slope = 0.f;
+    return launch_gemm(b, stream);
+  };
+  auto layer_save = [&](int l) { return save + (size_t)l * mlp_layer_save(p, M); };
+  // output layer: dW = d_out^T a_{L-2}, db, dA = d_out . W
+  {
+    const int l = L - 1;
+    AtbArgs ab{};
+    ab.A = d_out; ab.lda = ld_dout; ab.B = layer_save(l - 1) + (size_t)M * H; ab.ldb = H; ab.C = gr->weight[l]; ab.ldc = H;
+    ab.bias = gr->bias[l]; ab.M = M; ab.N = p->out_dim; ab.K = H; ab.accumulate = accumulate;
+    hipError_t e = launch_gemm_atb(ab, w.atb, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
+    e = launch_transpose(p->weight[l], H, w.wt, op, p->out_dim, H, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+    e = gemm(d_out, ld_dout, w.wt, op, w.d[0], H, H, op);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
+  }
+  int cur = 0;
+  for (int l = L - 2; l >= 0; --l) {
+    const float* sv = layer_save(l);
+    BnPreluArgs a{};
+    a.M = M; a.C = H; a.x = sv; a.ldx = H; a.gamma = p->bn_weight[l]; a.beta = p->bn_bias[l]; a.slope = p->prelu[l];
+    a.save_mean = const_cast<float*>(sv + (size_t)2 * M * H); a.save_rstd = a.save_mean + H;
+    a.dz = w.d[cur]; a.lddz = H; a.dx = w.d[cur ^ 1]; a.lddx = H;
+    a.dgamma = gr->bn_weight[l]; a.dbeta = gr->bn_bias[l]; a.dslope = gr->prelu[l];
+    a.dslope_partial = w.slope_partial; a.counter = w.counter; a.workspace = w.bn; a.accumulate = accumulate;
+    hipError_t e = launch_bn_prelu(a, true, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu backward: %s", hipGetErrorString(e));
+    cur ^= 1;   // w.d[cur] = dZ_l
+    const float* in = l == 0 ? x : layer_save(l - 1) + (size_t)M * H;
+    const int ld_in = l == 0 ? ldx : H, k_in = l == 0 ? p->in_dim : H;
+    AtbArgs ab{};
+    ab.A = w.d[cur]; ab.lda = H; ab.B = in; ab.ldb = ld_in; ab.C = gr->weight[l]; ab.ldc = k_in;
+    ab.bias = gr->bias[l]; ab.M = M; ab.N = H; ab.K = k_in; ab.accumulate = accumulate;
+    e = launch_gemm_atb(ab, w.atb, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    if (l == 0) break;
+    e = launch_transpose(p->weight[l], H, w.wt, H, H, H, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+    e = gemm(w.d[cur], H, w.wt, H, w.d[cur ^ 1], H, H, H);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
+    cur ^= 1;
+  }
   return EMPOSE_OK;
 }
 

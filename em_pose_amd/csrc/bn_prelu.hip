@@ -104,7 +104,7 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
       __threadfence();
       float total = 0.f;
       for (unsigned i = 0; i < gridDim.x; ++i) total += __hip_atomic_load(a.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.dslope[0] = total;
+      a.dslope[0] = total + (a.accumulate ? a.dslope[0] : 0.f);
       a.counter[0] = 0;
     }
   }
@@ -118,10 +118,185 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
     const float dy = y > 0.f ? dz : slope * dz;
     a.dx[(size_t)m * a.lddx + col] = k * ((float)a.M * dy - dbeta - xh * dgamma);
   }
-  if (rg == 0) { a.dgamma[col] = dgamma; a.dbeta[col] = dbeta; }
+  if (rg == 0) {
+    a.dgamma[col] = dgamma + (a.accumulate ? a.dgamma[col] : 0.f);
+    a.dbeta[col] = dbeta + (a.accumulate ? a.dbeta[col] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Large batches (M > BN_SINGLE_PASS_ROWS: training with hundreds of windows per GPU): a workgroup per 32 columns and
+// ALL rows leaves a 512-column layer on 16 workgroups (144 us per backward call at M = 8192).  Here the rows are split
+// over workgroups too: pass 1 writes per-(row split, column) partial sums to a caller-provided workspace, pass 2 adds
+// them in split order (deterministic) and transforms its rows.  The variance uses sums shifted by the column's first
+// element, which keeps the one-pass form accurate.
+// ---------------------------------------------------------------------------------------------------------------
+namespace bpl {
+constexpr int COLS = 64, RG = 4, NT = COLS * RG;   // 256 threads: 4 row groups x 64 columns
+constexpr int ROWS = 128;                          // rows per workgroup
+}
+
+__device__ __forceinline__ float bpl_reduce(float v, float* red, int rg, int c) {
+  red[rg * bpl::COLS + c] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < bpl::RG; ++g) s += red[g * bpl::COLS + c];
+  __syncthreads();
+  return s;
+}
+
+// pass 1 forward: part[split][0][col] = sum (x - k), part[split][1][col] = sum (x - k)^2, k = x[0][col]
+__global__ __launch_bounds__(bpl::NT) void bn_stats_fwd_kernel(BnPreluArgs a) {
+  using namespace bpl;
+  __shared__ float red[RG * COLS];
+  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  const int cc = col < a.C ? col : a.C - 1;
+  const int m0 = blockIdx.y * ROWS, m1 = min(a.M, m0 + ROWS);
+  const float k = a.x[cc];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int m = m0 + rg; m < m1; m += RG) { const float d = a.x[(size_t)m * a.ldx + cc] - k; s1 += d; s2 += d * d; }
+  s1 = bpl_reduce(s1, red, rg, c);
+  s2 = bpl_reduce(s2, red, rg, c);
+  if (rg == 0 && col < a.C) {
+    float* p = a.workspace + (size_t)blockIdx.y * 3 * a.C;
+    p[col] = s1; p[a.C + col] = s2;
+  }
+}
+
+// pass 2 forward
+__global__ __launch_bounds__(bpl::NT) void bn_apply_fwd_kernel(BnPreluArgs a, int n_split) {
+  using namespace bpl;
+  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  if (col >= a.C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < n_split; ++s) { const float* p = a.workspace + (size_t)s * 3 * a.C; s1 += p[col]; s2 += p[a.C + col]; }
+  const float inv_m = 1.f / (float)a.M;
+  const float d = s1 * inv_m;
+  const float mean = a.x[col] + d;
+  const float var = fmaxf(s2 * inv_m - d * d, 0.f);
+  const float rstd = 1.f / sqrtf(var + a.eps);
+  const float g = a.gamma[col], b = a.beta[col], slope = a.slope[0];
+  const int m0 = blockIdx.y * ROWS, m1 = min(a.M, m0 + ROWS);
+#pragma unroll 4
+  for (int m = m0 + rg; m < m1; m += RG) {
+    const float y = g * ((a.x[(size_t)m * a.ldx + col] - mean) * rstd) + b;
+    a.z[(size_t)m * a.ldz + col] = y > 0.f ? y : slope * y;
+  }
+  if (blockIdx.y == 0 && rg == 0) {
+    a.save_mean[col] = mean;
+    a.save_rstd[col] = rstd;
+    if (a.running_mean) {
+      const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+      a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * mean;
+      a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * unbiased;
+    }
+    if (col == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+  }
+}
+
+// pass 1 backward: part[split][0..2][col] = sum dy, sum dy * xhat, sum_{y <= 0} dz * y
+__global__ __launch_bounds__(bpl::NT) void bn_stats_bwd_kernel(BnPreluArgs a) {
+  using namespace bpl;
+  __shared__ float red[RG * COLS];
+  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  const int cc = col < a.C ? col : a.C - 1;
+  const int m0 = blockIdx.y * ROWS, m1 = min(a.M, m0 + ROWS);
+  const float mean = a.save_mean[cc], rstd = a.save_rstd[cc];
+  const float g = a.gamma[cc], b = a.beta[cc], slope = a.slope[0];
+  float s_b = 0.f, s_g = 0.f, s_a = 0.f;
+#pragma unroll 4
+  for (int m = m0 + rg; m < m1; m += RG) {
+    const float xh = (a.x[(size_t)m * a.ldx + cc] - mean) * rstd;
+    const float y = g * xh + b;
+    const float dz = a.dz[(size_t)m * a.lddz + cc];
+    const float dy = y > 0.f ? dz : slope * dz;
+    s_b += dy;
+    s_g += dy * xh;
+    s_a += y > 0.f ? 0.f : dz * y;
+  }
+  s_b = bpl_reduce(s_b, red, rg, c);
+  s_g = bpl_reduce(s_g, red, rg, c);
+  s_a = bpl_reduce(s_a, red, rg, c);
+  if (rg == 0 && col < a.C) {
+    float* p = a.workspace + (size_t)blockIdx.y * 3 * a.C;
+    p[col] = s_b; p[a.C + col] = s_g; p[2 * a.C + col] = s_a;
+  }
+}
+
+// pass 2 backward
+__global__ __launch_bounds__(bpl::NT) void bn_apply_bwd_kernel(BnPreluArgs a, int n_split) {
+  using namespace bpl;
+  __shared__ float red[RG * COLS];
+  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  const bool ok = col < a.C;
+  const int cc = ok ? col : a.C - 1;
+  float dbeta = 0.f, dgamma = 0.f, da = 0.f;
+  for (int s = 0; s < n_split; ++s) {
+    const float* p = a.workspace + (size_t)s * 3 * a.C;
+    dbeta += p[cc]; dgamma += p[a.C + cc]; da += p[2 * a.C + cc];
+  }
+  if (blockIdx.y == 0) {
+    // slope gradient: sum over this workgroup's columns, then the last of these workgroups adds the partial sums in
+    // index order and re-arms the counter
+    red[threadIdx.x] = (rg == 0 && ok) ? da : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int i = 0; i < COLS; ++i) t += red[i];
+      a.dslope_partial[blockIdx.x] = t;
+      __threadfence();
+      if (atomicAdd(a.counter, 1) == (int)gridDim.x - 1) {
+        __threadfence();
+        float total = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) total += __hip_atomic_load(a.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.dslope[0] = total + (a.accumulate ? a.dslope[0] : 0.f);
+        a.counter[0] = 0;
+      }
+    }
+    if (rg == 0 && ok) {
+      a.dgamma[col] = dgamma + (a.accumulate ? a.dgamma[col] : 0.f);
+      a.dbeta[col] = dbeta + (a.accumulate ? a.dbeta[col] : 0.f);
+    }
+  }
+  if (!ok) return;
+  const float mean = a.save_mean[col], rstd = a.save_rstd[col];
+  const float g = a.gamma[col], b = a.beta[col], slope = a.slope[0];
+  const float k = g * rstd / (float)a.M;
+  const int m0 = blockIdx.y * ROWS, m1 = min(a.M, m0 + ROWS);
+#pragma unroll 4
+  for (int m = m0 + rg; m < m1; m += RG) {
+    const float xh = (a.x[(size_t)m * a.ldx + col] - mean) * rstd;
+    const float y = g * xh + b;
+    const float dz = a.dz[(size_t)m * a.lddz + col];
+    const float dy = y > 0.f ? dz : slope * dz;
+    a.dx[(size_t)m * a.lddx + col] = k * ((float)a.M * dy - dbeta - xh * dgamma);
+  }
+}
+
+size_t bn_prelu_workspace_floats(int M, int C) {
+  if (M <= BN_SINGLE_PASS_ROWS) return 0;
+  return (size_t)((M + bpl::ROWS - 1) / bpl::ROWS) * 3 * C;
 }
 
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream) {
+  if (a.M > BN_SINGLE_PASS_ROWS) {
+    const int n_split = (a.M + bpl::ROWS - 1) / bpl::ROWS;
+    dim3 grid((a.C + bpl::COLS - 1) / bpl::COLS, n_split);
+    if (backward) {
+      hipLaunchKernelGGL(bn_stats_bwd_kernel, grid, dim3(bpl::NT), 0, stream, a);
+      hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, dim3(bpl::NT), 0, stream, a, n_split);
+    } else {
+      hipLaunchKernelGGL(bn_stats_fwd_kernel, grid, dim3(bpl::NT), 0, stream, a);
+      hipLaunchKernelGGL(bn_apply_fwd_kernel, grid, dim3(bpl::NT), 0, stream, a, n_split);
+    }
+    return hipGetLastError();
+  }
   const int blocks = (a.C + bp::COLS - 1) / bp::COLS;
   if (backward) hipLaunchKernelGGL(bn_prelu_bwd_kernel, dim3(blocks), dim3(bp::NT), 0, stream, a);
   else hipLaunchKernelGGL(bn_prelu_fwd_kernel, dim3(blocks), dim3(bp::NT), 0, stream, a);

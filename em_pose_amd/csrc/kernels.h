@@ -58,7 +58,11 @@ struct BnPreluArgs {
   const float* dz; int lddz; float* dx; int lddx;                            // backward
   float* dgamma; float* dbeta; float* dslope_partial;                        // [C], [C], [ceil(C / 32)] scratch
   float* dslope; int* counter;   // slope gradient (one float); arrival counter, zero before the first launch, self re-arming
+  float* workspace = nullptr;    // bn_prelu_workspace_floats(M, C) floats: partial sums of the row-split path (large M)
+  int accumulate = 0;            // backward: add to dgamma / dbeta / dslope instead of overwriting them
 };
+constexpr int BN_SINGLE_PASS_ROWS = 1024;   // up to here one workgroup per 32 columns walks all rows
+size_t bn_prelu_workspace_floats(int M, int C);
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream);
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
@@ -143,9 +147,34 @@ struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] 
   float* C; int ldc;
   float* bias;               // [N] or nullptr
   int M, N, K;
+  int accumulate;            // 1: C += A^T B, bias += column sums (gradient accumulation over the LGD iterations)
   // set by launch_gemm_atb
   int S; float* partial; float* bias_partial;
 };
+hipError_t launch_window_mean(const float* in, int ld_in, float* out, int ld_out, int T, int F, int C, hipStream_t stream);
+hipError_t launch_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
+                          float* out, int ldo, hipStream_t stream);
+struct LossArgs {
+  int B, F, N1, n_markers;
+  int used_slot[12];                       // column slot of virtual sensor m in the network input, or -1
+  const float* pose_hist; const float* shape_hist; const float* pos_hist; const float* ori_hist;   // [N1][T][66|10|36|108]
+  const float* joints_final;               // [T][66]
+  const float* pose_gt; const float* shape_gt; const float* joints_gt;   // [T][66], [B][10], [T][66] or nullptr
+  const float* x_in; int ldx;              // measured sensors in the network input layout
+  const int* seq_lengths; const float* masks;   // [B] or nullptr, [T][12] or nullptr
+  float w_pose, w_shape, w_fk, w_rec;
+  float* d_pose; float* d_shape; float* d_pos; float* d_ori; float* d_joints;
+  float* partial;                          // [4][N1 * T]
+  float* loss_vals;                        // [5]
+};
+hipError_t launch_lgd_losses(const LossArgs& a, hipStream_t stream);
+constexpr int ADAM_CHUNK = 4096;
+struct AdamArgs {
+  void* const* params; void* const* grads; void* const* exp_avg; void* const* exp_avg_sq;   // device pointer tables
+  const long long* sizes; const int* chunk_tensor; const long long* chunk_offset;
+  float beta1, beta2, eps, step_size, inv_sqrt_bc2;
+};
+hipError_t launch_adam(const AdamArgs& a, int n_chunks, hipStream_t stream);
 int atb_splits(int M, int N, int K);
 size_t atb_workspace_floats(int M, int N, int K);
 hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream);

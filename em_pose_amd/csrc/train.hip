@@ -79,6 +79,7 @@ __global__ __launch_bounds__(atb::NT) void gemm_atb_kernel(AtbArgs a) {
   // C/D layout of the 32x32 instruction: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float* out = a.S > 1 ? a.partial + (size_t)blockIdx.y * a.N * a.K : a.C;
   const int ldo = a.S > 1 ? a.K : a.ldc;
+  const bool acc_c = a.S == 1 && a.accumulate;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(atb::NT) void gemm_atb_kernel(AtbArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < a.N) out[(size_t)n * ldo + k] = acc[i][j][r];
+        if (n < a.N) out[(size_t)n * ldo + k] = acc[i][j][r] + (acc_c ? out[(size_t)n * ldo + k] : 0.f);
       }
     }
   if (do_bias) {
@@ -96,7 +97,10 @@ __global__ __launch_bounds__(atb::NT) void gemm_atb_kernel(AtbArgs a) {
     for (int i = 0; i < 2; ++i) {
       const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);   // the two row parities
       const int n = n0 + i * 32 + l31;
-      if (lh == 0 && n < a.N) (a.S > 1 ? a.bias_partial + (size_t)blockIdx.y * a.N : a.bias)[n] = v;
+      if (lh == 0 && n < a.N) {
+        float* bo = a.S > 1 ? a.bias_partial + (size_t)blockIdx.y * a.N : a.bias;
+        bo[n] = v + (acc_c ? bo[n] : 0.f);
+      }
     }
   }
 }
@@ -109,12 +113,12 @@ __global__ void atb_reduce_kernel(AtbArgs a) {
     float v = 0.f;
     for (int s = 0; s < a.S; ++s) v += a.partial[(size_t)s * nk + i];
     const size_t n = i / a.K, k = i - n * a.K;
-    a.C[n * a.ldc + k] = v;
+    a.C[n * a.ldc + k] = v + (a.accumulate ? a.C[n * a.ldc + k] : 0.f);
   }
   if (a.bias_partial && i < (size_t)a.N) {
     float v = 0.f;
     for (int s = 0; s < a.S; ++s) v += a.bias_partial[(size_t)s * a.N + i];
-    a.bias[i] = v;
+    a.bias[i] = v + (a.accumulate ? a.bias[i] : 0.f);
   }
 }
 
@@ -221,6 +225,217 @@ __global__ void lstm_cell_bwd_kernel(LstmCellBwdArgs a) {
   dG[3 * H] = d_o * go * (1.f - go);
   a.dc[idx] = dc * gf;
   a.dh_carry[idx] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Elementwise pieces of the training step
+// ---------------------------------------------------------------------------------------------------------------
+// out[t][c] = mean over the window of t (F consecutive rows) of in[.][c]; its adjoint is the same operator.
+__global__ void window_mean_kernel(const float* in, int ld_in, float* out, int ld_out, int T, int F, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * C) return;
+  const int t = idx / C, c = idx - t * C;
+  const int w0 = (t / F) * F;
+  float s = 0.f;
+  for (int f = 0; f < F; ++f) s += in[(size_t)(w0 + f) * ld_in + c];
+  out[(size_t)t * ld_out + c] = s / (float)F;
+}
+hipError_t launch_window_mean(const float* in, int ld_in, float* out, int ld_out, int T, int F, int C, hipStream_t stream) {
+  const long n = (long)T * C;
+  hipLaunchKernelGGL(window_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, ld_in, out, ld_out,
+                     T, F, C);
+  return hipGetLastError();
+}
+
+// out[r][c] = alpha * x[r][c] + beta * y[r][c] over a [rows][cols] block with row strides (out may alias x or y)
+__global__ void axpby2d_kernel(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
+                               float* out, int ldo) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx - (long)r * cols);
+  const float xv = x ? x[(size_t)r * ldx + c] : 0.f;
+  const float yv = y ? y[(size_t)r * ldy + c] : 0.f;
+  out[(size_t)r * ldo + c] = alpha * xv + beta * yv;
+}
+hipError_t launch_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
+                          float* out, int ldo, hipStream_t stream) {
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(axpby2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rows, cols, alpha, x, ldx,
+                     beta, y, ldy, out, ldo);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Losses of IterativeErrorFeedback.backward and their cotangents (reference models.py:634-688, loss.py:13-41):
+//   total = (w_pose sum_i L1(pose_i) + w_shape sum_i L1(shape_i) + w_fk (N+1) FK(joints_N) + w_rec sum_i REC_i) / (N+1)
+//   L1: |hat - gt| averaged over the features, summed over the valid frames / len_b, averaged over the batch
+//   FK / REC: sum of Euclidean norms per frame (joints; sensor positions + 9-vector orientations of the sensors fed to
+//   the network), frames with a missing sensor dropped, summed over the valid frames / len_b, averaged over the batch.
+// 16 lanes per (history entry, frame): lane 0 pose, 1 shape, 2..13 one sensor each, 14 the joints (last entry only).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lgd_losses_kernel(LossArgs a) {
+  const int T = a.B * a.F;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long item = gid >> 4;
+  const int part = (int)(gid & 15);
+  const bool in_range = item < (long)a.N1 * T;
+  const long it = in_range ? item : 0;
+  const int i = (int)(it / T), t = (int)(it - (long)i * T);
+  const int b = t / a.F, f = t - b * a.F;
+  const int len = a.seq_lengths ? a.seq_lengths[b] : a.F;
+  const bool live = in_range && f < len;
+  bool frame_ok = true;
+  if (a.masks)
+    for (int m = 0; m < 12; ++m) frame_ok = frame_ok && a.masks[(size_t)t * 12 + m] != 0.f;
+  const float inv = 1.f / ((float)len * (float)a.B);
+  const float inv_n1 = 1.f / (float)a.N1;
+  float l_pose = 0.f, l_shape = 0.f, l_rec = 0.f, l_fk = 0.f;
+  const size_t row = (size_t)i * T + t;
+  if (in_range && part == 0) {
+    const float* h = a.pose_hist + row * 66;
+    const float* g = a.pose_gt + (size_t)t * 66;
+    float* d = a.d_pose + row * 66;
+    const float k = live ? a.w_pose * inv_n1 * inv / 66.f : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < 66; ++c) {
+      const float df = h[c] - g[c];
+      s += fabsf(df);
+      d[c] = df > 0.f ? k : (df < 0.f ? -k : 0.f);
+    }
+    l_pose = live ? s / 66.f * inv : 0.f;
+  } else if (in_range && part == 1) {
+    const float* h = a.shape_hist + row * 10;
+    const float* g = a.shape_gt + (size_t)b * 10;
+    float* d = a.d_shape + row * 10;
+    const float k = live ? a.w_shape * inv_n1 * inv / 10.f : 0.f;
+    float s = 0.f;
+    for (int c = 0; c < 10; ++c) {
+      const float df = h[c] - g[c];
+      s += fabsf(df);
+      d[c] = df > 0.f ? k : (df < 0.f ? -k : 0.f);
+    }
+    l_shape = live ? s / 10.f * inv : 0.f;
+  } else if (in_range && part >= 2 && part < 14) {
+    const int m = part - 2;
+    const int slot = a.used_slot[m];
+    float* dp = a.d_pos + (row * 12 + m) * 3;
+    float* dq = a.d_ori + (row * 12 + m) * 9;
+    const bool on = live && frame_ok && slot >= 0;
+    if (!on) {
+      for (int c = 0; c < 3; ++c) dp[c] = 0.f;
+      for (int c = 0; c < 9; ++c) dq[c] = 0.f;
+    } else {
+      const float* hp = a.pos_hist + (row * 12 + m) * 3;
+      const float* hq = a.ori_hist + (row * 12 + m) * 9;
+      const float* gp = a.x_in + (size_t)t * a.ldx + slot * 3;
+      const float* gq = a.x_in + (size_t)t * a.ldx + a.n_markers * 3 + slot * 9;
+      const float k = a.w_rec * inv_n1 * inv;
+      float r[9], q = 0.f;
+      for (int c = 0; c < 3; ++c) { r[c] = hp[c] - gp[c]; q += r[c] * r[c]; }
+      float nrm = sqrtf(q);
+      for (int c = 0; c < 3; ++c) dp[c] = k * r[c] / nrm;
+      l_rec = nrm * inv;
+      q = 0.f;
+      for (int c = 0; c < 9; ++c) { r[c] = hq[c] - gq[c]; q += r[c] * r[c]; }
+      nrm = sqrtf(q);
+      for (int c = 0; c < 9; ++c) dq[c] = k * r[c] / nrm;
+      l_rec += nrm * inv;
+    }
+  } else if (in_range && part == 14 && i == a.N1 - 1 && a.d_joints) {
+    float* d = a.d_joints + (size_t)t * 66;
+    const bool on = live && frame_ok && a.joints_gt != nullptr;
+    if (!on) {
+      for (int c = 0; c < 66; ++c) d[c] = 0.f;
+    } else {
+      const float* h = a.joints_final + (size_t)t * 66;
+      const float* g = a.joints_gt + (size_t)t * 66;
+      const float k = a.w_fk * inv;   // added N + 1 times, divided by N + 1
+      float s = 0.f;
+      for (int j = 0; j < 22; ++j) {
+        const float r0 = h[j * 3] - g[j * 3], r1 = h[j * 3 + 1] - g[j * 3 + 1], r2 = h[j * 3 + 2] - g[j * 3 + 2];
+        const float nrm = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+        d[j * 3] = k * r0 / nrm; d[j * 3 + 1] = k * r1 / nrm; d[j * 3 + 2] = k * r2 / nrm;
+        s += nrm;
+      }
+      l_fk = s * inv;
+    }
+  }
+  // per (entry, frame) sums over the 16 lanes -> partial[kind][item]
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    l_pose += __shfl_xor(l_pose, off, 16);
+    l_shape += __shfl_xor(l_shape, off, 16);
+    l_rec += __shfl_xor(l_rec, off, 16);
+    l_fk += __shfl_xor(l_fk, off, 16);
+  }
+  if (in_range && part == 0) {
+    const size_t n = (size_t)a.N1 * T;
+    a.partial[item] = l_pose; a.partial[n + item] = l_shape; a.partial[2 * n + item] = l_rec; a.partial[3 * n + item] = l_fk;
+  }
+}
+
+// loss_vals = (pose, shape, reconstruction, fk, total) from the per-frame contributions, summed in index order
+__global__ __launch_bounds__(1024) void lgd_losses_reduce_kernel(LossArgs a) {
+  __shared__ double red[1024];
+  const size_t n = (size_t)a.N1 * a.B * a.F;
+  double sums[4];
+  for (int k = 0; k < 4; ++k) {
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) s += (double)a.partial[k * n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    sums[k] = red[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n1 = (double)a.N1;
+    const double fk_sum = sums[3] * n1;   // the same FK term is added once per history entry
+    a.loss_vals[0] = (float)(sums[0] / n1);
+    a.loss_vals[1] = (float)(sums[1] / n1);
+    a.loss_vals[2] = (float)(sums[2] / n1);
+    a.loss_vals[3] = (float)(fk_sum / n1);
+    a.loss_vals[4] = (float)((a.w_pose * sums[0] + a.w_fk * fk_sum + a.w_shape * sums[1] + a.w_rec * sums[2]) / n1);
+  }
+}
+
+hipError_t launch_lgd_losses(const LossArgs& a, hipStream_t stream) {
+  const long n = (long)a.N1 * a.B * a.F * 16;
+  hipLaunchKernelGGL(lgd_losses_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(lgd_losses_reduce_kernel, dim3(1), dim3(1024), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam over a list of tensors in one launch (torch.optim.Adam semantics, amsgrad off, weight_decay 0):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// chunk c covers elements [off, off + ADAM_CHUNK) of tensor `tensor_of_chunk[c]`.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const int ch = blockIdx.x;
+  const int ti = a.chunk_tensor[ch];
+  const long base = (long)a.chunk_offset[ch];
+  const long n = a.sizes[ti];
+  float* p = reinterpret_cast<float*>(a.params[ti]);
+  const float* g = reinterpret_cast<const float*>(a.grads[ti]);
+  float* m = reinterpret_cast<float*>(a.exp_avg[ti]);
+  float* v = reinterpret_cast<float*>(a.exp_avg_sq[ti]);
+  for (int k = threadIdx.x; k < ADAM_CHUNK; k += 256) {
+    const long i = base + k;
+    if (i >= n) break;
+    const float gi = g[i];
+    const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+    const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= a.step_size * mi / (sqrtf(vi) * a.inv_sqrt_bc2 + a.eps);
+  }
+}
+hipError_t launch_adam(const AdamArgs& a, int n_chunks, hipStream_t stream) {
+  hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_lstm_cell_bwd(const LstmCellBwdArgs& a, hipStream_t stream) {

@@ -80,11 +80,13 @@ class _BnPreluFn(torch.autograd.Function):
         z = torch.empty(M, Cn, dtype=torch.float32, device=dev)
         mean, rstd = torch.empty(Cn, dtype=torch.float32, device=dev), torch.empty(Cn, dtype=torch.float32, device=dev)
         track = bn.track_running_stats and bn.running_mean is not None
+        nbytes = _lib.lib().empose_bn_prelu_workspace_bytes(M, Cn)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
         _lib.check(_lib.lib().empose_bn_prelu_train_fwd(
             M, Cn, _lib.dptr(x), Cn, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(slope), float(bn.eps),
             float(bn.momentum), _lib.dptr(bn.running_mean) if track else None,
             _lib.dptr(bn.running_var) if track else None, _lib.dptr(bn.num_batches_tracked) if track else None,
-            _lib.dptr(z), Cn, _lib.dptr(mean), _lib.dptr(rstd), _lib.current_stream()))
+            _lib.dptr(z), Cn, _lib.dptr(mean), _lib.dptr(rstd), _lib.dptr(ws), nbytes, _lib.current_stream()))
         if track:
             BN_STATS_GENERATION[0] += 1
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
@@ -103,10 +105,12 @@ class _BnPreluFn(torch.autograd.Function):
         counter = _BnPreluFn._counters.get(dev)
         if counter is None:   # arrival counter of the kernel's last-workgroup reduction: zero once, self re-arming
             counter = _BnPreluFn._counters[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        nbytes = _lib.lib().empose_bn_prelu_workspace_bytes(M, Cn)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
         _lib.check(_lib.lib().empose_bn_prelu_train_bwd(
             M, Cn, _lib.dptr(x), Cn, _lib.dptr(dz), Cn, _lib.dptr(gamma), _lib.dptr(beta), _lib.dptr(slope),
             _lib.dptr(mean), _lib.dptr(rstd), _lib.dptr(dx), Cn, _lib.dptr(dgamma), _lib.dptr(dbeta), _lib.dptr(dslope),
-            _lib.dptr(partial), _lib.dptr(counter), _lib.current_stream()))
+            _lib.dptr(partial), _lib.dptr(counter), _lib.dptr(ws), nbytes, _lib.current_stream()))
         return dx, dgamma, dbeta, dslope, None
 
 

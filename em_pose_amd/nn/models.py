@@ -751,9 +751,20 @@ class IterativeErrorFeedback(BaseModel):
                 'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
 
     def _forward_with_graph(self, batch, window_size):
+        from em_pose_amd.nn.train_engine import LgdTrainEngine
         outs, hists = [], []
-        for batch_inputs in self.window_generator(batch, window_size=window_size):
-            out, hist = self._forward_train(batch_inputs)
+        windows = list(self.window_generator(batch, window_size=window_size))
+        # one window per forward and a released architecture: the hand-written forward / reverse sweep
+        # (nn/train_engine.py); anything else builds an autograd graph over the same kernels
+        use_engine = len(windows) == 1 and self.training and getattr(self, 'use_train_engine', True) and \
+            LgdTrainEngine.supported(self)
+        self._engine = None
+        for batch_inputs in windows:
+            if use_engine:
+                self._engine = LgdTrainEngine(self)
+                out, hist = self._engine.forward(batch_inputs)
+            else:
+                out, hist = self._forward_train(batch_inputs)
             outs.append(out)
             hists.append(hist)
         bsz = batch.batch_size
@@ -786,6 +797,13 @@ class IterativeErrorFeedback(BaseModel):
         `as_tensors=True` returns the loss values as device tensors (no host read-back: capturable in a HIP graph)."""
         if self.pose_hat_history is None:
             raise RuntimeError('backward() needs the histories of the preceding forward() (keep_history=True)')
+        if self.training and getattr(self, '_engine', None) is not None:
+            # hand-written losses + reverse sweep (nn/train_engine.py); parameter gradients are added to `.grad`
+            engine, self._engine = self._engine, None
+            total, loss_vals = engine.backward(batch, as_tensors=as_tensors)
+            if writer is not None:
+                self.log_loss_vals(loss_vals, writer, global_step)
+            return total, loss_vals
         bs, f = batch.batch_size, batch.seq_length
         dev = model_out['pose_hat'].device
         inputs_ = self.prepare_inputs(batch.get_inputs()).to(dev)

@@ -1,0 +1,385 @@
+"""
+Hand-written training step of the LGD models (BASELINE.json configs[4]).
+
+The reference trains `IterativeErrorFeedback` through torch.autograd: `forward` builds a graph over the LSTM, the N
+update-network applications and N + 1 body-model evaluations, `backward` sums the loss terms and calls
+`total_loss.backward()` (reference nn/models.py:485-688).  The graph has a fixed, simple shape -- the update networks see
+DETACHED inputs (models.py:549-551), so a parameter gradient only needs the cotangent of that application's output, and
+estimates are chained by plain additions `pose_{i+1} = pose_i + step * delta_i` -- so this module runs the same
+computation as an explicit forward sweep and an explicit reverse sweep over the library's own kernels, without autograd:
+
+  forward   LSTM (empose_lstm_train_fwd) or init MLPs, heads, then per iteration: body model + residual gradient
+            (empose_smpl_sensors_fwd_bwd, writing the gradient features straight into the network input rows), the two
+            update MLPs in training mode (empose_mlp_train_fwd: GEMMs + train-mode BatchNorm/PReLU kernels), window mean of
+            the shape update, additive update; every estimate goes into stacked history buffers.
+  backward  all loss terms and their cotangents in one kernel (empose_lgd_losses), then for i = N .. 0: body-model
+            vector-Jacobian product (empose_smpl_sensors_vjp), accumulation of the estimate's cotangent (including the
+            reference's `E_i.backward()` deposit, models.py:576), update-MLP parameter gradients accumulated over the
+            iterations (empose_mlp_train_bwd), finally the heads and back-propagation through time
+            (empose_lstm_train_bwd).  Gradients are added to `param.grad` like autograd's AccumulateGrad.
+
+Covers the released configurations (no skip connections, BatchNorm on, dropout 0, one window per forward); anything
+else stays on the autograd path of nn/models.py.
+"""
+import ctypes as C
+
+import torch
+
+from em_pose_amd import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class _MlpView(object):
+    """Device-pointer view of one MLP (reference layers.py:46-77) for empose_mlp_train_*."""
+
+    def __init__(self, mlp):
+        self.mlp = mlp
+        self.specs = mlp.dense_specs()
+        self.n_layers = len(self.specs)
+        self.in_dim = self.specs[0][0].in_features
+        self.hidden = self.specs[0][0].out_features
+        self.out_dim = self.specs[-1][0].out_features
+
+    @staticmethod
+    def supported(mlp):
+        specs = mlp.dense_specs()
+        if getattr(mlp, 'skip_connection', False) or not getattr(mlp, 'use_batch_norm', True):
+            return False
+        if len(specs) > _lib.MAX_DENSE or getattr(mlp.dropout, 'p', 0.0) > 0:
+            return False
+        h = specs[0][0].out_features
+        for lin, bn, act in specs[:-1]:
+            if bn is None or act is None or lin.out_features != h or act.weight.numel() != 1 or bn.momentum is None:
+                return False
+        return specs[0][0].in_features % 4 == 0 and h % 4 == 0
+
+    def params(self):
+        p = _lib.MlpParams()
+        p.n_layers, p.in_dim, p.hidden, p.out_dim = self.n_layers, self.in_dim, self.hidden, self.out_dim
+        for l, (lin, bn, act) in enumerate(self.specs):
+            p.weight[l], p.bias[l] = lin.weight.data_ptr(), lin.bias.data_ptr()
+            if bn is not None:
+                p.bn_weight[l], p.bn_bias[l] = bn.weight.data_ptr(), bn.bias.data_ptr()
+                if bn.track_running_stats and bn.running_mean is not None:
+                    p.bn_running_mean[l], p.bn_running_var[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                    p.bn_num_batches[l] = bn.num_batches_tracked.data_ptr()
+                p.prelu[l] = act.weight.data_ptr()
+                p.bn_eps, p.bn_momentum = float(bn.eps), float(bn.momentum)
+        return p
+
+    def parameter_list(self):
+        out = []
+        for lin, bn, act in self.specs:
+            out += [lin.weight, lin.bias]
+            if bn is not None:
+                out += [bn.weight, bn.bias, act.weight]
+        return out
+
+    def grads(self, tensors):
+        g = _lib.MlpGrads()
+        k = 0
+        for l, (lin, bn, act) in enumerate(self.specs):
+            g.weight[l], g.bias[l] = tensors[k].data_ptr(), tensors[k + 1].data_ptr()
+            k += 2
+            if bn is not None:
+                g.bn_weight[l], g.bn_bias[l], g.prelu[l] = [t.data_ptr() for t in tensors[k:k + 3]]
+                k += 3
+        return g
+
+
+class LgdTrainEngine(object):
+    def __init__(self, net):
+        self.net = net
+        self.ctx = None
+
+    @staticmethod
+    def supported(net):
+        if net.skip_connections or getattr(net.config, 'm_dropout_hidden', 0.0) > 0 or \
+                getattr(net.config, 'm_dropout', 0.0) > 0:
+            return False
+        mlps = [net.pose_net_iter, net.shape_net_iter] + ([] if net.rnn_init else [net.pose_net_init, net.shape_net_init])
+        if not all(_MlpView.supported(m) for m in mlps):
+            return False
+        if net.rnn_init and (net.rnn.is_bidirectional or net.rnn.num_layers > 4 or net.rnn.learn_init_state):
+            return False
+        return net.input_size % 4 == 0 and net.input_iter_size % 4 == 0
+
+    # ---- small helpers over the C ABI -------------------------------------------------------------------------
+    def _axpby(self, rows, cols, alpha, x, ldx, beta, y, ldy, out, ldo):
+        _lib.check(self.lib.empose_axpby2d(rows, cols, alpha, x, ldx, beta, y, ldy, out, ldo, self.stream))
+
+    def _mlp_fwd(self, view, x, ldx, out, ld_out, M):
+        p = view.params()
+        save = self.new(self.lib.empose_mlp_train_save_floats(C.byref(p), M))
+        nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
+        ws = self.ws(nbytes)
+        _lib.check(self.lib.empose_mlp_train_fwd(C.byref(p), M, x, ldx, out, ld_out, save.data_ptr(), ws.data_ptr(),
+                                                 nbytes, self.stream))
+        from em_pose_amd.nn import layers as _layers
+        _layers.BN_STATS_GENERATION[0] += 1
+        return save
+
+    def _mlp_bwd(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M):
+        p = view.params()
+        g = view.grads(grads)
+        nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
+        ws = self.ws(nbytes)
+        _lib.check(self.lib.empose_mlp_train_bwd(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(), C.byref(g),
+                                                 int(accumulate), ws.data_ptr(), nbytes, self.stream))
+
+    def ws(self, nbytes):
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.dev)
+
+    def new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    # ---- forward ------------------------------------------------------------------------------------------------
+    def forward(self, batch_inputs):
+        net = self.net
+        inputs_ = net.prepare_inputs(batch_inputs)
+        if not inputs_.is_cuda:
+            raise _lib.EmposeError('IterativeErrorFeedback needs GPU tensors; there is no CPU fallback')
+        dev = self.dev = inputs_.device
+        lib = self.lib = _lib.lib()
+        self.stream = _lib.current_stream()
+        B, F = inputs_.shape[0], inputs_.shape[1]
+        T, N, s = B * F, net.N, float(net.step_size)
+        d_in, d_x = net.input_size, net.input_iter_size
+        x0 = inputs_.reshape(T, d_in).contiguous().float()
+        seq_lengths = batch_inputs['seq_lengths'].to(dev)
+        lens32 = seq_lengths.to(torch.int32).contiguous()
+        masks = batch_inputs['marker_masks']
+        masks = None if masks is None else masks.to(dev, torch.float32).reshape(T, 12).contiguous()
+        offset_r = batch_inputs['offset_r'].to(dev, torch.float32).contiguous()
+        offset_t = batch_inputs['offset_t'].to(dev, torch.float32).contiguous()
+        # per-frame weight of the in-loop residual (reference loss.py:36-39 times the B * F rescale of models.py:578-579)
+        live = (torch.arange(F, device=dev)[None, :] < seq_lengths[:, None]).float()
+        scale = live * (float(F) / seq_lengths.float())[:, None]
+        if masks is not None:
+            scale = scale * masks.reshape(B, F, 12).ne(0).all(dim=-1).float()
+        scale = scale.reshape(T).contiguous()
+
+        ctx = self.ctx = {'B': B, 'F': F, 'x0': x0, 'lens32': lens32, 'masks': masks, 'offset_r': offset_r,
+                          'offset_t': offset_t}
+        pose_hist, shape_hist = self.new(N + 1, T, 66), self.new(N + 1, T, 10)
+        markers_hist, ori_hist = self.new(N + 1, T, 36), self.new(N + 1, T, 108)
+        joints_hist = self.new(N + 1, T, 66)
+        tmp10 = self.new(T, 10)
+        with torch.cuda.device(dev):
+            smpl_h = net._ensure_smpl_handle(dev)
+            if net.rnn_init:
+                rnn = net.rnn
+                rnn.init_state = rnn.final_state
+                L, H = rnn.num_layers, rnn.hidden_size
+                weights = [w for unit in rnn._unit_params() for w in unit]
+                p = _lib.LstmParams()
+                p.num_layers, p.input_size, p.hidden_size = L, d_in, H
+                for l in range(L):
+                    p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [weights[4 * l + k].data_ptr() for k in range(4)]
+                h0 = c0 = None
+                if rnn.init_state is not None:
+                    h0, c0 = [t.detach().to(dev, torch.float32).contiguous() for t in rnn.init_state]
+                y = self.new(T, H)
+                h_n, c_n = self.new(L, B, H), self.new(L, B, H)
+                save = self.new(lib.empose_lstm_train_save_floats(L, B, F, H))
+                nbytes = lib.empose_lstm_train_workspace_bytes(C.byref(p), B, F)
+                ws = self.ws(nbytes)
+                _lib.check(lib.empose_lstm_train_fwd(C.byref(p), B, F, x0.data_ptr(), d_in, lens32.data_ptr(), _ptr(h0),
+                                                     _ptr(c0), y.data_ptr(), h_n.data_ptr(), c_n.data_ptr(),
+                                                     save.data_ptr(), ws.data_ptr(), nbytes, self.stream))
+                rnn.final_state = (h_n, c_n)
+                ctx.update({'lstm_save': save, 'y': y, 'c0': c0})
+                for lin, out, ld in ((net.pose_net_init, pose_hist[0], 66), (net.shape_net_init, tmp10, 10)):
+                    _lib.check(lib.empose_linear_f32(y.data_ptr(), H, lin.weight.data_ptr(), H, out.data_ptr(), ld, T,
+                                                     lin.out_features, H, None, lin.bias.data_ptr(), 0, 0.0, self.stream))
+            else:
+                ctx['init_views'] = (_MlpView(net.pose_net_init), _MlpView(net.shape_net_init))
+                ctx['init_saves'] = (self._mlp_fwd(ctx['init_views'][0], x0.data_ptr(), d_in, pose_hist[0].data_ptr(), 66, T),
+                                     self._mlp_fwd(ctx['init_views'][1], x0.data_ptr(), d_in, tmp10.data_ptr(), 10, T))
+            if net.shape_avg:
+                _lib.check(lib.empose_window_mean(T, F, 10, tmp10.data_ptr(), 10, shape_hist[0].data_ptr(), 10, self.stream))
+            else:
+                self._axpby(T, 10, 1.0, tmp10.data_ptr(), 10, 0.0, None, 0, shape_hist[0].data_ptr(), 10)
+
+            views = (_MlpView(net.pose_net_iter), _MlpView(net.shape_net_iter))
+            X = self.new(max(N, 1), T, d_x)
+            dp, ds = self.new(T, 66), self.new(T, 10)
+            saves = []
+            nb_smpl = lib.empose_smpl_workspace_bytes(smpl_h, T)
+            ws_smpl = self.ws(nb_smpl)
+            for i in range(N + 1):
+                want_g = i < N and net.use_gradient
+                Xi = X[i] if i < N else None
+                _lib.check(lib.empose_smpl_sensors_fwd_bwd(
+                    smpl_h, T, F, pose_hist[i].data_ptr(), 66, shape_hist[i].data_ptr(), 10, offset_r.data_ptr(),
+                    offset_t.data_ptr(), x0.data_ptr() if want_g else None, d_in, scale.data_ptr() if want_g else None,
+                    markers_hist[i].data_ptr(), ori_hist[i].data_ptr(), joints_hist[i].data_ptr(),
+                    Xi[:, d_in + 76:].data_ptr() if want_g else None, d_x,
+                    Xi[:, d_in + 142:].data_ptr() if want_g else None, d_x, ws_smpl.data_ptr(), nb_smpl, self.stream))
+                if i == N:
+                    break
+                self._axpby(T, d_in, 1.0, x0.data_ptr(), d_in, 0.0, None, 0, Xi.data_ptr(), d_x)
+                self._axpby(T, 66, 1.0, pose_hist[i].data_ptr(), 66, 0.0, None, 0, Xi[:, d_in:].data_ptr(), d_x)
+                self._axpby(T, 10, 1.0, shape_hist[i].data_ptr(), 10, 0.0, None, 0, Xi[:, d_in + 66:].data_ptr(), d_x)
+                sp = self._mlp_fwd(views[0], Xi.data_ptr(), d_x, dp.data_ptr(), 66, T)
+                ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T)
+                saves.append((sp, ss))
+                if net.shape_avg:
+                    _lib.check(lib.empose_window_mean(T, F, 10, tmp10.data_ptr(), 10, ds.data_ptr(), 10, self.stream))
+                    d_shape = ds
+                else:
+                    d_shape = tmp10
+                self._axpby(T, 66, s, dp.data_ptr(), 66, 1.0, pose_hist[i].data_ptr(), 66, pose_hist[i + 1].data_ptr(), 66)
+                self._axpby(T, 10, s, d_shape.data_ptr(), 10, 1.0, shape_hist[i].data_ptr(), 10,
+                            shape_hist[i + 1].data_ptr(), 10)
+        ctx.update({'pose_hist': pose_hist, 'shape_hist': shape_hist, 'markers_hist': markers_hist, 'ori_hist': ori_hist,
+                    'joints_hist': joints_hist, 'X': X, 'views': views, 'saves': saves, 'smpl_h': smpl_h})
+        hist = {'pose': list(pose_hist), 'shape': list(shape_hist), 'joints': list(joints_hist),
+                'markers': list(markers_hist), 'markers_ori': list(ori_hist)}
+        out = {'pose': pose_hist[N].reshape(B, F, 66), 'shape': shape_hist[N].reshape(B, F, 10),
+               'joints': joints_hist[N].reshape(B, F, 66)}
+        return out, hist
+
+    # ---- backward -----------------------------------------------------------------------------------------------
+    def backward(self, batch, as_tensors=False):
+        """Loss values + parameter gradients (added to `.grad`).  :return: (total loss tensor, loss_vals dict)"""
+        net, ctx = self.net, self.ctx
+        if ctx is None:
+            raise RuntimeError('backward() needs the preceding training-mode forward()')
+        lib, dev = self.lib, self.dev
+        B, F = ctx['B'], ctx['F']
+        T, N, s = B * F, net.N, float(net.step_size)
+        d_in, d_x = net.input_size, net.input_iter_size
+        f32 = lambda t: t.to(dev, torch.float32).contiguous()
+        io = _lib.LossIO()
+        io.B, io.F, io.n_hist, io.n_markers = B, F, N + 1, net.n_markers
+        for k, v in enumerate(net.marker_idxs):
+            io.marker_idx[k] = v
+        pose_gt, shape_gt = f32(batch.poses).reshape(T, 66), f32(batch.shapes)
+        joints_gt = f32(batch.joints_gt).reshape(T, 66) if net.do_fk else None
+        d_pose, d_shape = self.new(N + 1, T, 66), self.new(N + 1, T, 10)
+        d_mark, d_ori, d_joints = self.new(N + 1, T, 36), self.new(N + 1, T, 108), self.new(T, 66)
+        loss_vals = self.new(5)
+        io.pose_hist, io.shape_hist = ctx['pose_hist'].data_ptr(), ctx['shape_hist'].data_ptr()
+        io.markers_hist, io.markers_ori_hist = ctx['markers_hist'].data_ptr(), ctx['ori_hist'].data_ptr()
+        io.joints_final = ctx['joints_hist'][N].data_ptr()
+        io.pose_gt, io.shape_gt, io.joints_gt = pose_gt.data_ptr(), shape_gt.data_ptr(), _ptr(joints_gt)
+        io.inputs, io.ld_inputs = ctx['x0'].data_ptr(), d_in
+        io.seq_lengths, io.marker_masks = ctx['lens32'].data_ptr(), _ptr(ctx['masks'])
+        io.w_pose, io.w_shape = float(net.pose_weight), float(net.shape_weight)
+        io.w_fk, io.w_rec = float(net.fk_loss_weight) if net.do_fk else 0.0, float(net.r_weight)
+        io.d_pose, io.d_shape, io.d_markers, io.d_markers_ori = [t.data_ptr() for t in (d_pose, d_shape, d_mark, d_ori)]
+        io.d_joints, io.loss_vals = d_joints.data_ptr(), loss_vals.data_ptr()
+        with torch.cuda.device(dev):
+            self.stream = _lib.current_stream()
+            nbytes = lib.empose_lgd_losses_workspace_bytes(B, F, N + 1)
+            ws = self.ws(nbytes)
+            _lib.check(lib.empose_lgd_losses(C.byref(io), ws.data_ptr(), nbytes, self.stream))
+
+            smpl_h = ctx['smpl_h']
+            nb_vjp = lib.empose_smpl_vjp_workspace_bytes(smpl_h, T)
+            ws_vjp = self.ws(nb_vjp)
+            Dp, Ds = self.new(T, 66), self.new(T, 10)
+            vp, vs = self.new(T, 66), self.new(T, 10)
+            dpad = torch.zeros(T, 68, dtype=torch.float32, device=dev)     # zero padding columns for the GEMMs
+            dspad = torch.zeros(T, 12, dtype=torch.float32, device=dev)
+            tmp10 = self.new(T, 10)
+            views = ctx['views']
+            grads = [[torch.empty_like(p) for p in v.parameter_list()] for v in views]
+            X = ctx['X']
+            for i in range(N, -1, -1):
+                _lib.check(lib.empose_smpl_sensors_vjp(
+                    smpl_h, T, F, ctx['pose_hist'][i].data_ptr(), 66, ctx['shape_hist'][i].data_ptr(), 10,
+                    ctx['offset_r'].data_ptr(), ctx['offset_t'].data_ptr(), d_mark[i].data_ptr(), d_ori[i].data_ptr(),
+                    d_joints.data_ptr() if i == N else None, vp.data_ptr(), vs.data_ptr(), ws_vjp.data_ptr(), nb_vjp,
+                    self.stream))
+                first = i == N
+                self._axpby(T, 66, 1.0, d_pose[i].data_ptr(), 66, 0.0 if first else 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
+                self._axpby(T, 10, 1.0, d_shape[i].data_ptr(), 10, 0.0 if first else 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
+                self._axpby(T, 66, 1.0, vp.data_ptr(), 66, 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
+                self._axpby(T, 10, 1.0, vs.data_ptr(), 10, 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
+                if i < N and net.use_gradient:
+                    # the reference's `E_i.backward()` inside forward (models.py:576): dE_i/d(pose_i) = g_i / (B F) flows
+                    # into everything that produced pose_i
+                    self._axpby(T, 66, 1.0 / T, X[i][:, d_in + 76:].data_ptr(), d_x, 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
+                    self._axpby(T, 10, 1.0 / T, X[i][:, d_in + 142:].data_ptr(), d_x, 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
+                if i == 0:
+                    break
+                # cotangents of the update networks' outputs of iteration i - 1
+                self._axpby(T, 66, s, Dp.data_ptr(), 66, 0.0, None, 0, dpad.data_ptr(), 68)
+                if net.shape_avg:
+                    _lib.check(lib.empose_window_mean(T, F, 10, Ds.data_ptr(), 10, tmp10.data_ptr(), 10, self.stream))
+                    self._axpby(T, 10, s, tmp10.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
+                else:
+                    self._axpby(T, 10, s, Ds.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
+                sp, ss = ctx['saves'][i - 1]
+                acc = i < N
+                self._mlp_bwd(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp, grads[0], acc, T)
+                self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)
+            # ---- initial estimate
+            self._axpby(T, 66, 1.0, Dp.data_ptr(), 66, 0.0, None, 0, dpad.data_ptr(), 68)
+            if net.shape_avg:
+                _lib.check(lib.empose_window_mean(T, F, 10, Ds.data_ptr(), 10, tmp10.data_ptr(), 10, self.stream))
+                self._axpby(T, 10, 1.0, tmp10.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
+            else:
+                self._axpby(T, 10, 1.0, Ds.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
+            named = []
+            if N > 0:
+                for v, g in zip(views, grads):
+                    named += list(zip(v.parameter_list(), g))
+            if net.rnn_init:
+                rnn, y = net.rnn, ctx['y']
+                H, L = rnn.hidden_size, rnn.num_layers
+                dy = self.new(T, H)
+                first = True
+                for lin, dpd, ld, n_out in ((net.pose_net_init, dpad, 68, 66), (net.shape_net_init, dspad, 12, 10)):
+                    gw, gb = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
+                    nb = lib.empose_gemm_atb_workspace_bytes(T, n_out, H)
+                    wsa = self.ws(nb)
+                    _lib.check(lib.empose_gemm_atb_f32(T, n_out, H, dpd.data_ptr(), ld, y.data_ptr(), H, gw.data_ptr(), H,
+                                                       gb.data_ptr(), wsa.data_ptr(), wsa.numel(), self.stream))
+                    named += [(lin.weight, gw), (lin.bias, gb)]
+                    wt = torch.zeros(H, ld, dtype=torch.float32, device=dev)
+                    _lib.check(lib.empose_transpose_f32(n_out, H, lin.weight.data_ptr(), H, wt.data_ptr(), ld, self.stream))
+                    _lib.check(lib.empose_linear_f32_ex(dpd.data_ptr(), ld, wt.data_ptr(), ld, dy.data_ptr(), H, T, H, ld,
+                                                        None, None, None if first else dy.data_ptr(), H, 0, 0.0,
+                                                        self.stream))
+                    first = False
+                weights = [w for unit in rnn._unit_params() for w in unit]
+                p, g = _lib.LstmParams(), _lib.LstmGrads()
+                p.num_layers, p.input_size, p.hidden_size = L, d_in, H
+                lg = [torch.empty_like(w) for w in weights]
+                for l in range(L):
+                    p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [weights[4 * l + k].data_ptr() for k in range(4)]
+                    g.w_ih[l], g.w_hh[l], g.b_ih[l], g.b_hh[l] = [lg[4 * l + k].data_ptr() for k in range(4)]
+                nbytes = lib.empose_lstm_train_workspace_bytes(C.byref(p), B, F)
+                ws = self.ws(nbytes)
+                _lib.check(lib.empose_lstm_train_bwd(C.byref(p), B, F, ctx['x0'].data_ptr(), d_in, ctx['lens32'].data_ptr(),
+                                                     _ptr(ctx['c0']), ctx['lstm_save'].data_ptr(), dy.data_ptr(), None,
+                                                     C.byref(g), ws.data_ptr(), nbytes, self.stream))
+                named += list(zip(weights, lg))
+            else:
+                for v, sv, dpd, ld in zip(ctx['init_views'], ctx['init_saves'], (dpad, dspad), (68, 12)):
+                    gi = [torch.empty_like(p_) for p_ in v.parameter_list()]
+                    self._mlp_bwd(v, ctx['x0'].data_ptr(), d_in, dpd.data_ptr(), ld, sv, gi, False, T)
+                    named += list(zip(v.parameter_list(), gi))
+            for p_, g_ in named:   # autograd's AccumulateGrad
+                if not p_.requires_grad:
+                    continue
+                if p_.grad is None:
+                    p_.grad = g_
+                else:
+                    self._axpby(1, g_.numel(), 1.0, g_.data_ptr(), g_.numel(), 1.0, p_.grad.data_ptr(), g_.numel(),
+                                p_.grad.data_ptr(), g_.numel())
+        self.ctx = None
+        total = loss_vals[4]
+        keys = ('pose', 'shape', 'reconstruction', 'fk', 'total_loss')
+        if as_tensors:
+            vals = {k: loss_vals[j] for j, k in enumerate(keys)}
+        else:
+            host = loss_vals.tolist()
+            vals = {k: host[j] for j, k in enumerate(keys)}
+        return total, vals

@@ -252,15 +252,18 @@ int empose_gemm_strided_f32(int M, int N, int K, const float* A, long a_rs, long
  * the normalisation, running statistics updated with `momentum` and the unbiased variance, num_batches_tracked + 1).
  * x, z, dz, dx are [M][ld] row-major; gamma, beta, save_mean, save_rstd, dgamma, dbeta are [C]; slope is one device float;
  * dslope receives the slope gradient; dslope_partial (ceil(C / 32) floats) and counter (one int, zero before the first
- * call, left at zero by every call) are scratch. running_mean / running_var / num_batches_tracked may be NULL. */
+ * call, left at zero by every call) are scratch. running_mean / running_var / num_batches_tracked may be NULL.
+ * Batches of more than 1024 rows split the rows over workgroups and need empose_bn_prelu_workspace_bytes(M, C) bytes of
+ * workspace for the partial sums (0 for smaller batches, workspace may then be NULL). */
+size_t empose_bn_prelu_workspace_bytes(int M, int C);
 int empose_bn_prelu_train_fwd(int M, int C, const float* x, int ldx, const float* gamma, const float* beta,
                               const float* slope, float eps, float momentum, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float* z, int ldz, float* save_mean, float* save_rstd,
-                              empose_stream_t stream);
+                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
 int empose_bn_prelu_train_bwd(int M, int C, const float* x, int ldx, const float* dz, int lddz, const float* gamma,
                               const float* beta, const float* slope, const float* save_mean, const float* save_rstd,
                               float* dx, int lddx, float* dgamma, float* dbeta, float* dslope, float* dslope_partial,
-                              int* counter, empose_stream_t stream);
+                              int* counter, void* workspace, size_t workspace_bytes, empose_stream_t stream);
 
 /* ---- training backward: building blocks (BASELINE.json configs[4]) ------------------------------------------------ */
 /* The reference trains through torch.autograd (reference nn/models.py:634-688, scripts/train.py:133-152); these are the
@@ -276,6 +279,80 @@ int empose_gemm_atb_f32(int M, int N, int K, const float* A, int lda, const floa
 /* dst[c][r] = src[r][c] (rows x cols): W^T copies so that dX = dY . W runs on the forward GEMM (empose_linear_f32). */
 int empose_transpose_f32(int rows, int cols, const float* src, int ld_src, float* dst, int ld_dst,
                          empose_stream_t stream);
+
+/* One MLP of the LGD model (reference nn/layers.py:46-77) in TRAINING mode: Linear -> BatchNorm1d (batch statistics) ->
+ * PReLU for every layer but the last, which is a plain Linear.  Device pointers to the parameters as torch holds them. */
+typedef struct {
+  int n_layers;                 /* 2 + 2 * blocks, <= EMPOSE_MAX_DENSE; no skip connections */
+  int in_dim, hidden, out_dim;  /* in_dim and hidden multiples of 4 */
+  const float* weight[EMPOSE_MAX_DENSE];   /* [out_l][in_l] */
+  const float* bias[EMPOSE_MAX_DENSE];
+  const float* bn_weight[EMPOSE_MAX_DENSE];   /* layers 0 .. n_layers-2 */
+  const float* bn_bias[EMPOSE_MAX_DENSE];
+  float* bn_running_mean[EMPOSE_MAX_DENSE];   /* updated in place like torch.nn.BatchNorm1d, may be NULL */
+  float* bn_running_var[EMPOSE_MAX_DENSE];
+  long long* bn_num_batches[EMPOSE_MAX_DENSE];
+  const float* prelu[EMPOSE_MAX_DENSE];       /* one device float per layer */
+  float bn_eps, bn_momentum;
+} empose_mlp_params;
+typedef struct {                /* gradient outputs, shapes of the parameters */
+  float* weight[EMPOSE_MAX_DENSE];
+  float* bias[EMPOSE_MAX_DENSE];
+  float* bn_weight[EMPOSE_MAX_DENSE];
+  float* bn_bias[EMPOSE_MAX_DENSE];
+  float* prelu[EMPOSE_MAX_DENSE];
+} empose_mlp_grads;
+/* `save`: per hidden layer the pre-BatchNorm and the activated outputs [M][hidden] and the batch mean / rstd. */
+size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M);
+size_t empose_mlp_train_workspace_bytes(const empose_mlp_params* p, int M);
+/* x [M][ldx] -> out [M][ld_out] (out_dim columns written). */
+int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int ldx, float* out, int ld_out,
+                         float* save, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+/* d_out [M][ld_dout]: ld_dout a multiple of 4 and >= out_dim, columns past out_dim ZERO.  Parameter gradients are
+ * overwritten (accumulate = 0) or added to (1: the same network applied N times in the LGD loop).  The input x is not
+ * differentiated: the LGD loop feeds the update networks detached values (reference models.py:549-551). */
+int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
+                         const float* save, const empose_mlp_grads* grads, int accumulate, void* workspace,
+                         size_t workspace_bytes, empose_stream_t stream);
+
+/* out[t][c] = mean of in[.][c] over the window of frame t (F consecutive rows); the operator is its own adjoint, so
+ * the same call back-propagates (`_to_single_shape`, reference models.py:529-535,588-589). */
+int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* out, int ld_out, empose_stream_t stream);
+/* out = alpha x + beta y over a [rows][cols] block with row strides; x or y may be NULL (treated as 0), out may alias. */
+int empose_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
+                   float* out, int ldo, empose_stream_t stream);
+
+/* The loss of IterativeErrorFeedback.backward (reference models.py:634-688, loss.py:13-41) and the cotangents of the
+ * total loss with respect to every history entry, in one pass. */
+typedef struct {
+  int B, F, n_hist, n_markers;  /* n_hist = N + 1 */
+  int marker_idx[12];           /* first n_markers entries: which virtual sensors feed the network */
+  const float* pose_hist;       /* [n_hist][T][66] */
+  const float* shape_hist;      /* [n_hist][T][10] */
+  const float* markers_hist;    /* [n_hist][T][36] */
+  const float* markers_ori_hist;/* [n_hist][T][108] */
+  const float* joints_final;    /* [T][66] */
+  const float* pose_gt;         /* [T][66] */
+  const float* shape_gt;        /* [B][10] */
+  const float* joints_gt;       /* [T][66] or NULL (no FK loss) */
+  const float* inputs; int ld_inputs;   /* network input rows: n_markers*3 positions then n_markers*9 orientations */
+  const int* seq_lengths;       /* [B] or NULL */
+  const float* marker_masks;    /* [T][12] or NULL */
+  float w_pose, w_shape, w_fk, w_rec;
+  float* d_pose; float* d_shape; float* d_markers; float* d_markers_ori;   /* like the histories */
+  float* d_joints;              /* [T][66] */
+  float* loss_vals;             /* [5] device floats: pose, shape, reconstruction, fk, total_loss */
+} empose_loss_io;
+size_t empose_lgd_losses_workspace_bytes(int B, int F, int n_hist);
+int empose_lgd_losses(const empose_loss_io* io, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+/* torch.optim.Adam (amsgrad off, no weight decay) over n tensors in one launch.  The pointer tables are DEVICE arrays:
+ * params/grads/exp_avg/exp_avg_sq [n] (void*), sizes [n] (int64), and the chunk tables chunk_tensor [n_chunks] (int32),
+ * chunk_offset [n_chunks] (int64): chunk c covers elements [offset, offset + 4096) of tensor chunk_tensor[c].
+ * step is the 1-based step count (bias correction). */
+int empose_adam_step(int n_chunks, const void* params, const void* grads, const void* exp_avg, const void* exp_avg_sq,
+                     const void* sizes, const void* chunk_tensor, const void* chunk_offset, float lr, float beta1,
+                     float beta2, float eps, int step, empose_stream_t stream);
 
 /* Stacked uni-directional LSTM with autograd support (reference nn/layers.py:133-157 in training mode: nn.LSTM over
  * packed ragged sequences, its backward through cuDNN/MIOpen).  Parameters as torch.nn.LSTM holds them. */

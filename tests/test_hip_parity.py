@@ -640,7 +640,7 @@ def test_smpl_sensors_vjp_vs_autograd(big_model):
     np.testing.assert_allclose(s.grad.cpu().numpy(), want_be.numpy(), atol=2e-4 * want_be.abs().max().item(), rtol=1e-3)
 
 
-@pytest.mark.parametrize('M,Cn', [(384, 512), (48, 32), (7, 100), (2, 5)])
+@pytest.mark.parametrize('M,Cn', [(384, 512), (48, 32), (7, 100), (2, 5), (8192, 512), (3001, 100)])
 def test_bn_prelu_train_function_vs_torch_autograd(M, Cn):
     """nn/layers.py::bn_prelu_train (train-mode BatchNorm1d + PReLU, one kernel forward, one backward) against the torch
     modules and their autograd in float64: output, dx, dgamma, dbeta, dslope, running statistics, batch counter."""
@@ -707,6 +707,7 @@ def test_training_step_matches_reference_gradients(name):
     batch.joints_gt = gpu(w['joints_gt'])
     net.zero_grad()
     out = net(batch)
+    assert net._engine is not None   # the hand-written forward / reverse sweep (nn/train_engine.py), not autograd
     total, loss_vals = net.backward(batch, out)
     # Train mode is ill-conditioned (residual direction r/|r|, BatchNorm statistics over 48 frames): the reference's own
     # outputs move by `sens` when its inputs change by one unit in the last place (tests/golden/train_sensitivity.json,
