@@ -128,7 +128,7 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
 // Large batches (M > BN_SINGLE_PASS_ROWS: training with hundreds of windows per GPU): a workgroup per 32 columns and
 // ALL rows leaves a 512-column layer on 16 workgroups (144 us per backward call at M = 8192).  Here the rows are split
 // over workgroups too: pass 1 writes per-(row split, column) partial sums to a caller-provided workspace, pass 2 adds
-// them in split order (deterministic) and transforms its rows.  The variance uses sums shifted by the column's first
+// them in split order (deterministic), pass 3 transforms the rows.  The variance uses sums shifted by the column's first
 // element, which keeps the one-pass form accurate.
 // ---------------------------------------------------------------------------------------------------------------
 namespace bpl {
@@ -166,35 +166,49 @@ __global__ __launch_bounds__(bpl::NT) void bn_stats_fwd_kernel(BnPreluArgs a) {
   }
 }
 
-// pass 2 forward
-__global__ __launch_bounds__(bpl::NT) void bn_apply_fwd_kernel(BnPreluArgs a, int n_split) {
-  using namespace bpl;
-  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
-  const int col = blockIdx.x * COLS + c;
-  if (col >= a.C) return;
+// pass 2 forward: a workgroup per 64 columns; 16 row groups each add a strided quarter of the partial sums, the row
+// groups meet in LDS in a fixed order -> mean, rstd, running statistics
+constexpr int BN_CG = 16;   // split groups of the combine kernels
+__global__ __launch_bounds__(64 * BN_CG) void bn_combine_fwd_kernel(BnPreluArgs a, int n_split) {
+  __shared__ float red[2][BN_CG][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int cc = col < a.C ? col : a.C - 1;
   float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < n_split; ++s) { const float* p = a.workspace + (size_t)s * 3 * a.C; s1 += p[col]; s2 += p[a.C + col]; }
+  for (int s = rg; s < n_split; s += BN_CG) { const float* p = a.workspace + (size_t)s * 3 * a.C; s1 += p[cc]; s2 += p[a.C + cc]; }
+  red[0][rg][c] = s1; red[1][rg][c] = s2;
+  __syncthreads();
+  if (rg != 0 || col >= a.C) return;
+  s1 = 0.f; s2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < BN_CG; ++g) { s1 += red[0][g][c]; s2 += red[1][g][c]; }
   const float inv_m = 1.f / (float)a.M;
   const float d = s1 * inv_m;
   const float mean = a.x[col] + d;
   const float var = fmaxf(s2 * inv_m - d * d, 0.f);
-  const float rstd = 1.f / sqrtf(var + a.eps);
+  a.save_mean[col] = mean;
+  a.save_rstd[col] = 1.f / sqrtf(var + a.eps);
+  if (a.running_mean) {
+    const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+    a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * mean;
+    a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * unbiased;
+  }
+  if (col == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+}
+
+// pass 3 forward: the transform
+__global__ __launch_bounds__(bpl::NT) void bn_apply_fwd_kernel(BnPreluArgs a) {
+  using namespace bpl;
+  const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
+  const int col = blockIdx.x * COLS + c;
+  if (col >= a.C) return;
+  const float mean = a.save_mean[col], rstd = a.save_rstd[col];
   const float g = a.gamma[col], b = a.beta[col], slope = a.slope[0];
   const int m0 = blockIdx.y * ROWS, m1 = min(a.M, m0 + ROWS);
 #pragma unroll 4
   for (int m = m0 + rg; m < m1; m += RG) {
     const float y = g * ((a.x[(size_t)m * a.ldx + col] - mean) * rstd) + b;
     a.z[(size_t)m * a.ldz + col] = y > 0.f ? y : slope * y;
-  }
-  if (blockIdx.y == 0 && rg == 0) {
-    a.save_mean[col] = mean;
-    a.save_rstd[col] = rstd;
-    if (a.running_mean) {
-      const float unbiased = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
-      a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * mean;
-      a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * unbiased;
-    }
-    if (col == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
   }
 }
 
@@ -228,43 +242,50 @@ __global__ __launch_bounds__(bpl::NT) void bn_stats_bwd_kernel(BnPreluArgs a) {
   }
 }
 
-// pass 2 backward
+// pass 2 backward: a workgroup per 64 columns, split groups as in the forward; writes this call's (dbeta, dgamma)
+// behind the partial sums for pass 3, the parameter gradients, and the workgroup's share of the slope gradient
+__global__ __launch_bounds__(64 * BN_CG) void bn_combine_bwd_kernel(BnPreluArgs a, int n_split) {
+  __shared__ float red[3][BN_CG][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int cc = col < a.C ? col : a.C - 1;
+  float s_b = 0.f, s_g = 0.f, s_a = 0.f;
+  for (int s = rg; s < n_split; s += BN_CG) {
+    const float* p = a.workspace + (size_t)s * 3 * a.C;
+    s_b += p[cc]; s_g += p[a.C + cc]; s_a += p[2 * a.C + cc];
+  }
+  red[0][rg][c] = s_b; red[1][rg][c] = s_g; red[2][rg][c] = col < a.C ? s_a : 0.f;
+  __syncthreads();
+  if (rg != 0) return;
+  s_b = 0.f; s_g = 0.f; s_a = 0.f;
+#pragma unroll
+  for (int g = 0; g < BN_CG; ++g) { s_b += red[0][g][c]; s_g += red[1][g][c]; s_a += red[2][g][c]; }
+  if (col < a.C) {
+    float* fin = a.workspace + (size_t)n_split * 3 * a.C;
+    fin[col] = s_b; fin[a.C + col] = s_g;
+    a.dgamma[col] = s_g + (a.accumulate ? a.dgamma[col] : 0.f);
+    a.dbeta[col] = s_b + (a.accumulate ? a.dbeta[col] : 0.f);
+  }
+  // slope: the 64 columns of this workgroup in lane order (one wave)
+  float t = s_a;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (c == 0) a.dslope_partial[blockIdx.x] = t;
+}
+
+// pass 3 backward
 __global__ __launch_bounds__(bpl::NT) void bn_apply_bwd_kernel(BnPreluArgs a, int n_split) {
   using namespace bpl;
-  __shared__ float red[RG * COLS];
   const int c = threadIdx.x & (COLS - 1), rg = threadIdx.x / COLS;
   const int col = blockIdx.x * COLS + c;
-  const bool ok = col < a.C;
-  const int cc = ok ? col : a.C - 1;
-  float dbeta = 0.f, dgamma = 0.f, da = 0.f;
-  for (int s = 0; s < n_split; ++s) {
-    const float* p = a.workspace + (size_t)s * 3 * a.C;
-    dbeta += p[cc]; dgamma += p[a.C + cc]; da += p[2 * a.C + cc];
+  if (col >= a.C) return;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // slope gradient: the combine workgroups' shares in order
+    float t = 0.f;
+    for (unsigned i = 0; i < gridDim.x; ++i) t += a.dslope_partial[i];
+    a.dslope[0] = t + (a.accumulate ? a.dslope[0] : 0.f);
   }
-  if (blockIdx.y == 0) {
-    // slope gradient: sum over this workgroup's columns, then the last of these workgroups adds the partial sums in
-    // index order and re-arms the counter
-    red[threadIdx.x] = (rg == 0 && ok) ? da : 0.f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-      for (int i = 0; i < COLS; ++i) t += red[i];
-      a.dslope_partial[blockIdx.x] = t;
-      __threadfence();
-      if (atomicAdd(a.counter, 1) == (int)gridDim.x - 1) {
-        __threadfence();
-        float total = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) total += __hip_atomic_load(a.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.dslope[0] = total + (a.accumulate ? a.dslope[0] : 0.f);
-        a.counter[0] = 0;
-      }
-    }
-    if (rg == 0 && ok) {
-      a.dgamma[col] = dgamma + (a.accumulate ? a.dgamma[col] : 0.f);
-      a.dbeta[col] = dbeta + (a.accumulate ? a.dbeta[col] : 0.f);
-    }
-  }
-  if (!ok) return;
+  const float* fin = a.workspace + (size_t)n_split * 3 * a.C;
+  const float dbeta = fin[col], dgamma = fin[a.C + col];
   const float mean = a.save_mean[col], rstd = a.save_rstd[col];
   const float g = a.gamma[col], b = a.beta[col], slope = a.slope[0];
   const float k = g * rstd / (float)a.M;
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(bpl::NT) void bn_apply_bwd_kernel(BnPreluArgs a, in
 
 size_t bn_prelu_workspace_floats(int M, int C) {
   if (M <= BN_SINGLE_PASS_ROWS) return 0;
-  return (size_t)((M + bpl::ROWS - 1) / bpl::ROWS) * 3 * C;
+  return (size_t)((M + bpl::ROWS - 1) / bpl::ROWS + 1) * 3 * C;   // partial sums per row split + the combined sums
 }
 
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream) {
@@ -290,10 +311,12 @@ hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stre
     dim3 grid((a.C + bpl::COLS - 1) / bpl::COLS, n_split);
     if (backward) {
       hipLaunchKernelGGL(bn_stats_bwd_kernel, grid, dim3(bpl::NT), 0, stream, a);
+      hipLaunchKernelGGL(bn_combine_bwd_kernel, dim3(grid.x), dim3(64 * BN_CG), 0, stream, a, n_split);
       hipLaunchKernelGGL(bn_apply_bwd_kernel, grid, dim3(bpl::NT), 0, stream, a, n_split);
     } else {
       hipLaunchKernelGGL(bn_stats_fwd_kernel, grid, dim3(bpl::NT), 0, stream, a);
-      hipLaunchKernelGGL(bn_apply_fwd_kernel, grid, dim3(bpl::NT), 0, stream, a, n_split);
+      hipLaunchKernelGGL(bn_combine_fwd_kernel, dim3(grid.x), dim3(64 * BN_CG), 0, stream, a, n_split);
+      hipLaunchKernelGGL(bn_apply_fwd_kernel, grid, dim3(bpl::NT), 0, stream, a);
     }
     return hipGetLastError();
   }

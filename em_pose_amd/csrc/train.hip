@@ -105,6 +105,121 @@ __global__ __launch_bounds__(atb::NT) void gemm_atb_kernel(AtbArgs a) {
   }
 }
 
+// The same product with the operands staged through LDS: 16-byte coalesced global loads (a quarter of the load
+// instructions and of the texture-addresser time of the register version, which issues one 4-byte load per lane and
+// MFMA operand), each element fetched once per workgroup and read by the waves that need it from LDS in the layout it
+// has in memory -- [row m][column]: lane (column = lane & 31, m parity = lane >> 5) is exactly the 32x32x2 operand
+// order, consecutive lanes hit consecutive banks.  Chunks of 32 rows, double-buffered.  Needs 16-byte aligned rows
+// (lda, ldb multiples of 4, aligned bases); the register kernel takes the rest.
+namespace atbl {
+constexpr int NT = 256, BN = 128, BK = 128, MC = 32;
+constexpr int LDS_FLOATS = 2 * MC * (BN + BK);
+}  // namespace atbl
+
+__global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
+  using namespace atbl;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int tiles_k = (a.K + BK - 1) / BK;
+  const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nw = (wave >> 1) * 64, kw = (wave & 1) * 64;      // this wave's 64 x 64 inside the tile
+  const int n_base = tn * BN, k_base = tk * BK;
+  const int chunk = (((a.M + a.S - 1) / a.S) + MC - 1) / MC * MC;
+  const int ms = blockIdx.y * chunk, me = min(a.M, ms + chunk);
+  f32x16t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // staging: thread (row r8 = tid / 32, 16-byte piece c4 = tid % 32) moves rows r8 + 8 p, p = 0..3, of both operands
+  const int r8 = tid >> 5, c4 = (tid & 31) * 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 ga[4], gb[4];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int mm = m0 + r8 + 8 * p;
+      const bool row_ok = mm < me;
+      f4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (row_ok) {
+        const float* pa = a.A + (size_t)mm * a.lda + n_base + c4;
+        const float* pb = a.B + (size_t)mm * a.ldb + k_base + c4;
+        if (n_base + c4 + 4 <= a.N) va = *reinterpret_cast<const f4*>(pa);
+        else
+          for (int e = 0; e < 4; ++e) if (n_base + c4 + e < a.N) va[e] = pa[e];
+        if (k_base + c4 + 4 <= a.K) vb = *reinterpret_cast<const f4*>(pb);
+        else
+          for (int e = 0; e < 4; ++e) if (k_base + c4 + e < a.K) vb[e] = pb[e];
+      }
+      ga[p] = va; gb[p] = vb;
+    }
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f4*>(st + (r8 + 8 * p) * BN + c4) = ga[p];
+      *reinterpret_cast<f4*>(st + MC * BN + (r8 + 8 * p) * BK + c4) = gb[p];
+    }
+  };
+  float bsum[2] = {0.f, 0.f};
+  const bool do_bias = a.bias_partial != nullptr && tk == 0 && (wave & 1) == 0;
+  constexpr int STAGE = MC * (BN + BK);
+  gload(ms);
+  lwrite(lds);
+  __syncthreads();
+  int buf = 0;
+  for (int m = ms; m < me; m += MC) {
+    const bool more = m + MC < me;
+    if (more) gload(m + MC);
+    const float* sA = lds + buf * STAGE + nw + l31;
+    const float* sB = lds + buf * STAGE + MC * BN + kw + l31;
+#pragma unroll
+    for (int q = 0; q < MC / 2; ++q) {
+      const int row = 2 * q + lh;
+      const float a0 = sA[row * BN], a1 = sA[row * BN + 32];
+      const float b0 = sB[row * BK], b1 = sB[row * BK + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (do_bias) { bsum[0] += a0; bsum[1] += a1; }
+    }
+    if (more) lwrite(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int n0 = n_base + nw, k0 = k_base + kw;
+  float* out = a.S > 1 ? a.partial + (size_t)blockIdx.y * a.N * a.K : a.C;
+  const int ldo = a.S > 1 ? a.K : a.ldc;
+  const bool acc_c = a.S == 1 && a.accumulate;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + j * 32 + l31;
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < a.N) out[(size_t)n * ldo + k] = acc[i][j][r] + (acc_c ? out[(size_t)n * ldo + k] : 0.f);
+      }
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int n = n0 + i * 32 + l31;
+      if (lh == 0 && n < a.N) {
+        float* bo = a.S > 1 ? a.bias_partial + (size_t)blockIdx.y * a.N : a.bias;
+        bo[n] = v + (acc_c ? bo[n] : 0.f);
+      }
+    }
+  }
+}
+
 // C[i] = sum_s partial[s][i] in split order; the same for the bias partials
 __global__ void atb_reduce_kernel(AtbArgs a) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,7 +239,7 @@ __global__ void atb_reduce_kernel(AtbArgs a) {
 
 int atb_splits(int M, int N, int K) {
   const int tiles = ((N + atb::BN - 1) / atb::BN) * ((K + atb::BK - 1) / atb::BK);
-  int s = (768 + tiles - 1) / tiles;
+  int s = (options().atb_target + tiles - 1) / tiles;
   s = std::min(s, std::max(1, M / 64));
   return std::max(1, std::min(s, 256));
 }
@@ -143,7 +258,9 @@ hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream) {
     a.bias_partial = a.bias ? workspace + (size_t)a.S * a.N * a.K : nullptr;
   }
   const int tiles = ((a.N + atb::BN - 1) / atb::BN) * ((a.K + atb::BK - 1) / atb::BK);
-  hipLaunchKernelGGL(gemm_atb_kernel, dim3(tiles, a.S), dim3(atb::NT), 0, stream, a);
+  const bool aligned = a.lda % 4 == 0 && a.ldb % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
+  if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
+  else hipLaunchKernelGGL(gemm_atb_kernel, dim3(tiles, a.S), dim3(atb::NT), 0, stream, a);
   if (a.S > 1) {
     const size_t n = (size_t)a.N * a.K;
     hipLaunchKernelGGL(atb_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);

@@ -9,8 +9,8 @@ model.backward -> optimizer.step, Adam, per-step loss line) on SYNTHETIC windows
     python -m torch.distributed.run --nproc-per-node 8 scripts/train.py --steps 20
 
 Data parallel over windows; gradients averaged with bucketed RCCL all-reduces (em_pose_amd/helpers/distributed.py).
-SMPL forward / reverse are the HIP kernels; the LSTM / MLP forward+backward of the training path run as PyTorch-ROCm
-autograd ops (the inference path does not use them).
+Forward, losses, backward and the optimiser step are the library's own kernels (em_pose_amd/nn/train_engine.py,
+em_pose_amd/helpers/optim.py): no autograd graph, no library GEMM / RNN / elementwise kernel on the step.
 """
 import argparse
 import json
@@ -179,7 +179,8 @@ def main():
     cfg = lgd_config(args.n_markers, not args.no_rnn, args.iterations, window_size=args.window_size, lr=args.lr)
     net = create_model(cfg, SMPLLayer(model)).to(dev)
     params = [q for n, q in net.named_parameters() if not n.startswith('smpl.')]
-    opt = torch.optim.Adam(params, lr=args.lr)
+    from em_pose_amd.helpers.optim import HipAdam
+    opt = HipAdam(params, lr=args.lr)   # torch.optim.Adam semantics, one kernel launch per step
     if rank == 0:
         print('Model created with {} trainable parameters'.format(sum(q.numel() for q in net.parameters())))
 

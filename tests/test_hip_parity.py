@@ -1287,3 +1287,22 @@ def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
     for g_, w in zip(wg, weights):
         scale = max(1.0, float(w.grad.abs().max()))
         np.testing.assert_allclose(g_.grad.cpu().numpy(), w.grad.numpy(), atol=1e-4 * scale)
+
+
+def test_hip_adam_equals_torch_adam():
+    """empose_adam_step (one launch over all tensors) against torch.optim.Adam, three steps."""
+    from em_pose_amd.helpers.optim import HipAdam
+    torch.manual_seed(3)
+    shapes = [(512, 512), (66,), (5000,), (1,), (2048, 144)]
+    ours = [torch.randn(*s, device=DEV).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in ours]
+    oa, ob = HipAdam(ours, lr=5e-4), torch.optim.Adam(ref, lr=5e-4)
+    for step in range(3):
+        for p, q in zip(ours, ref):
+            g = torch.randn_like(p)
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ours, ref):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=1e-6, rtol=1e-6)
