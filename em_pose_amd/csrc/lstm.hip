@@ -573,25 +573,25 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
     const int len = lens ? lens[row] : F;
     const bool live = t < len;
     const int t_out = (rev && live) ? len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
-    float h_new = 0.f;
-    const float g_i = fsigmoid(gi + bias[unit]), g_f = fsigmoid(gf + bias[H + unit]);
-    const float g_g = ftanh(gg + bias[2 * H + unit]), g_o = fsigmoid(go + bias[3 * H + unit]);
-    const float c_old = cst[hc];
-    const float c_new = g_f * c_old + g_i * g_g;
-    float h_carry;
-    if (live) {
-      h_new = g_o * ftanh(c_new);
+    float h_new = 0.f, c_old = 0.f, c_keep = 0.f, h_carry;
+    if (live) {   // (these expressions are kept as they are: lstm_persist_kernel must give the same bits)
+      c_old = cst[hc];
+      const float c_new = fsigmoid(gf + bias[H + unit]) * c_old + fsigmoid(gi + bias[unit]) * ftanh(gg + bias[2 * H + unit]);
+      h_new = fsigmoid(go + bias[3 * H + unit]) * ftanh(c_new);
       cst[hc] = c_new;
       h_next[hc] = h_carry = h_new;
+      c_keep = c_new;
     } else {
       h_next[hc] = h_carry = h_prev[hc];
+      if (L.sv_gates) c_keep = cst[hc];
     }
     if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + unit] = h_new;
-    if (L.sv_gates) {   // training forward
+    if (L.sv_gates) {   // training forward: what back-propagation through time reads
       const size_t rt = (size_t)row * F + t;
       float* sg = L.sv_gates + rt * 4 * H + unit;
-      sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
-      L.sv_c[rt * H + unit] = live ? c_new : c_old;
+      sg[0] = fsigmoid(gi + bias[unit]); sg[H] = fsigmoid(gf + bias[H + unit]);
+      sg[2 * H] = ftanh(gg + bias[2 * H + unit]); sg[3 * H] = fsigmoid(go + bias[3 * H + unit]);
+      L.sv_c[rt * H + unit] = c_keep;
       if (t + 1 < F) L.sv_hprev[(rt + 1) * H + unit] = h_carry;
     }
   }
