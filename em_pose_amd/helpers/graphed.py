@@ -1,11 +1,12 @@
 """
 One training step (forward + loss + backward) captured in a HIP graph.
 
-The reference's batch of 12 windows is launch-bound on an MI355X: about 2000 small kernels per step, 11 ms of kernel time
-inside a 22 ms step.  Capturing forward + backward once and replaying it removes the per-launch host cost; the gradient
-all-reduce and the optimizer stay outside the graph.  Static shapes only: every batch must have the shape of the batch
-the graph was captured with, and every window must span all F frames (the LSTM then runs without sequence packing,
-which needs a host round trip, and in pieces short enough for MIOpen's RNN to be captured).
+The reference's batch of 12 windows is launch-bound on an MI355X: hundreds of small kernels per step.  Capturing forward
++ backward once and replaying it removes the per-launch host cost; the gradient all-reduce and the optimizer stay
+outside the graph.  Static shapes only: every batch must have the shape of the batch the graph was captured with.  With
+the hand-written training step (nn/train_engine.py) nothing on the step needs the host -- sequence lengths stay on the
+device -- so ragged windows are captured like full ones; only the autograd fallback (configurations the engine does not
+cover) still needs full-length windows, because packing sequences is a host round trip.
 """
 import torch
 
@@ -16,9 +17,11 @@ class GraphedTrainStep(object):
 
     def __init__(self, net, optimizer, example_batch, warmup=3):
         import copy
+        from em_pose_amd.nn.train_engine import LgdTrainEngine
         F = example_batch.seq_length
-        if int(example_batch.seq_lengths.min()) != F:
-            raise ValueError('a captured training step needs full-length windows')
+        engine = getattr(net, 'use_train_engine', True) and hasattr(net, 'N') and LgdTrainEngine.supported(net)
+        if not engine and int(example_batch.seq_lengths.min()) != F:
+            raise ValueError('a captured training step on the autograd fallback needs full-length windows')
         self.net, self.optimizer = net, optimizer
         self.static = copy.copy(example_batch)
         for k in self.FIELDS:
@@ -27,11 +30,7 @@ class GraphedTrainStep(object):
                 setattr(self.static, k, v.clone())
         was_full = getattr(net, 'full_windows', False)
         net.full_windows = True   # only while the step is traced: the replayed graph does not go through Python again
-        # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
-        # workspaces on the first call on a stream, which is not allowed while capturing).
-        # Warm-up and capture on the SAME side stream: libraries keep per-stream state (MIOpen / hipBLASLt create
-        # workspaces on the first call on a stream, which is not allowed while capturing).  The LSTM goes through MIOpen in
-        # pieces of 16 time steps (RNNLayer.forward_torch): its RNN captures up to 31 steps and crashes from 32 on.
+        # Warm-up and capture on the SAME side stream (allocator pools and any library state are per stream).
         # the warm-up passes must not count as training steps: BatchNorm running statistics are put back afterwards
         bn_state = {k: v.clone() for k, v in net.state_dict().items()
                     if 'running_' in k or k.endswith('num_batches_tracked')}

@@ -413,7 +413,6 @@ class RNNLayer(nn.Module):
             self.to_init_state_h = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
             self.to_init_state_c = nn.Linear(input_size, hidden_size * num_layers * self.num_directions)
         self.lstm = nn.LSTM(input_size, hidden_size, num_layers, bidirectional=bidirectional)
-        self.graph_chunk = 16   # time steps per nn.LSTM call on the capturable training path (forward_torch)
         self.to_out = nn.Linear(hidden_size * self.num_directions, output_size) if output_size is not None \
             else nn.Identity()
         self._handle, self._handle_key = None, None
@@ -508,9 +507,9 @@ class RNNLayer(nn.Module):
         return y
 
     def forward_torch(self, x, seq_lengths, full_length=False):
-        """Training path only: nn.LSTM over packed sequences with the carried state (reference layers.py:133-157).
-        `full_length=True` (every row spans all F frames, checked by the caller on the host) skips the packing, which
-        is the same computation without its host round trip -- required inside a captured HIP graph."""
+        """Training path with an autograd graph (configurations nn/train_engine.py does not cover): the hand-written
+        LSTM forward + back-propagation through time as one autograd Function (reference layers.py:133-157).
+        `full_length=True`: every row spans all F frames (no lengths needed)."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         if x.is_cuda and not self.is_bidirectional and self.num_layers <= 4 and x.dtype == torch.float32 and \
                 x.shape[2] % 4 == 0:
@@ -523,16 +522,10 @@ class RNNLayer(nn.Module):
             y, h_n, c_n = _LstmTrainFn.apply(x, lens, h0, c0, self.num_layers, *weights)
             self.final_state = (h_n, c_n)
             return y
-        if full_length:   # the module is time-major (batch_first=False, like the reference's); the packing hid that
-            xt = x.transpose(0, 1).contiguous()
-            # Pieces of at most 16 time steps with the state carried: MIOpen's RNN captures into a HIP graph up to 31
-            # steps and crashes the capture from 32 on (scripts/dev/dbg_lstm_graph.py); the arithmetic is unchanged.
-            outs, state = [], self.init_state
-            for t0 in range(0, xt.shape[0], self.graph_chunk):
-                o, state = self.lstm(xt[t0:t0 + self.graph_chunk], state)
-                outs.append(o)
-            self.final_state = state
-            return (outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)).transpose(0, 1).contiguous()
+        # fallback (bidirectional stacks, CPU tensors): nn.LSTM over packed sequences, as the reference
+        if full_length:
+            out, self.final_state = self.lstm(x.transpose(0, 1).contiguous(), self.init_state)
+            return out.transpose(0, 1).contiguous()
         packed = pack_padded_sequence(x, seq_lengths.cpu(), batch_first=True, enforce_sorted=False)
         out, self.final_state = self.lstm(packed, self.init_state)
         out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])
