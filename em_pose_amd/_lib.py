@@ -107,7 +107,7 @@ class LossIO(C.Structure):       # empose_loss_io
 class MeshDesc(C.Structure):
     _fields_ = [('n_vertices', C.c_int), ('j_off', C.c_int), ('ncp', C.c_int), ('kb', C.c_int),
                 ('wc', c_float_p), ('skin_idx', c_int_p), ('skin_w', c_float_p), ('parents', c_int_p),
-                ('n_joints', C.c_int), ('rodrigues', C.c_int)]
+                ('n_joints', C.c_int), ('rodrigues', C.c_int), ('with_bf16x3', C.c_int)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests check against the header.
@@ -201,6 +201,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     'empose_mesh_vertices_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_mesh_vertices_fwd_bf16x3': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

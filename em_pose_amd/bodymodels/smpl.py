@@ -57,13 +57,16 @@ class _BodyModelBuffers(nn.Module):
 
 
 class SMPLLayer(nn.Module):
-    def __init__(self, smpl_path, device=None, vposer_path=None, rodrigues_convention='smplx'):
+    def __init__(self, smpl_path, device=None, vposer_path=None, rodrigues_convention='smplx', arithmetic='f32'):
         super(SMPLLayer, self).__init__()
         if vposer_path is not None:
             raise NotImplementedError('VPoser is not part of the LGD path')
         if rodrigues_convention not in _lib.RODRIGUES:
             raise ValueError('rodrigues_convention must be one of {}'.format(sorted(_lib.RODRIGUES)))
         self.rodrigues_convention = rodrigues_convention
+        if arithmetic not in ('f32', 'bf16x3'):
+            raise ValueError("arithmetic must be 'f32' (exact fp32 matrix cores, the default) or 'bf16x3'")
+        self.arithmetic = arithmetic   # 'bf16x3': blend-shape contraction in split bf16 (explicit opt-in, not the reference's)
         self.num_betas = C.N_SHAPE_PARAMS
         self.model = load_model_npz(smpl_path)
         self.bm = _BodyModelBuffers(self.model, self.num_betas)
@@ -103,7 +106,7 @@ class SMPLLayer(nn.Module):
         return int(np.asarray(self.model['J_regressor']).shape[0])
 
     def _mesh_handle(self, device):
-        key = (device.index, self.rodrigues_convention)
+        key = (device.index, self.rodrigues_convention, self.arithmetic)
         if self._mesh is not None and self._mesh[1] == key:
             return self._mesh[0]
         self._release()
@@ -113,6 +116,7 @@ class SMPLLayer(nn.Module):
         desc.wc, desc.skin_idx = _lib.fptr(tab['wc']), _lib.iptr(tab['skin_idx'])
         desc.skin_w, desc.parents = _lib.fptr(tab['skin_w']), _lib.iptr(tab['parents'])
         desc.n_joints, desc.rodrigues = tab['n_joints'], _lib.RODRIGUES[self.rodrigues_convention]
+        desc.with_bf16x3 = int(self.arithmetic == 'bf16x3')
         handle = _lib.C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.lib().empose_mesh_create(_lib.C.byref(desc), _lib.C.byref(handle)))
@@ -151,7 +155,8 @@ class SMPLLayer(nn.Module):
             joints = torch.empty(n, self.n_joints, 3, dtype=torch.float32, device=dev)
             ws_bytes = lib.empose_mesh_workspace_bytes(handle, n)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.empose_mesh_vertices_fwd(handle, n, _lib.dptr(poses), _lib.dptr(betas), _lib.dptr(trans),
+            fwd = lib.empose_mesh_vertices_fwd_bf16x3 if self.arithmetic == 'bf16x3' else lib.empose_mesh_vertices_fwd
+            _lib.check(fwd(handle, n, _lib.dptr(poses), _lib.dptr(betas), _lib.dptr(trans),
                                                     _lib.dptr(vertices), _lib.dptr(joints), _lib.dptr(ws), ws_bytes,
                                                     _lib.current_stream()))
         return vertices, joints

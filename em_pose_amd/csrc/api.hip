@@ -128,6 +128,7 @@ struct empose_mesh {
   int* skin_idx4 = nullptr;     // first four bones / weights per vertex, padded to whole tiles
   float* skin_w4 = nullptr;
   int* parents = nullptr;
+  unsigned short* wc_bf16 = nullptr;   // split-bf16 pieces of wc in fragment order (only when the handle asked for them)
 };
 
 namespace {
@@ -1676,6 +1677,50 @@ static int pack_mesh_tiles(empose_mesh* m, const empose_mesh_desc* d) {
   return EMPOSE_OK;
 }
 
+// Tables of mesh_rows_bf16_kernel: per 32-vertex tile, k-step of 16, coordinate plane and (hi, lo) piece, lane
+// (v = lane & 31, half = lane >> 5) owns the eight values k = kstep * 16 + half * 8 .. + 7 of row (tile * 32 + v) * 3 + c.
+// Columns (mesh.hip): 0..188 pose, (hi, lo) = (w0, w1); 189..199 shape/template, (b0, b2); 200..210 the same
+// coefficients again, (b1, b0); zero up to 223.
+static unsigned short host_bf16_rne(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float host_bf16_f32(unsigned short h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+static int pack_mesh_tiles_bf16(empose_mesh* m, const empose_mesh_desc* d) {
+  const int V = d->n_vertices, NT = (V + 31) / 32, K = 200, KS = 14;
+  const size_t tile_shorts = MESH_BF16_TILE_BYTES / 2;
+  std::vector<unsigned short> buf((size_t)NT * tile_shorts, 0);
+  for (int t = 0; t < NT; ++t)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int v = t * 32 + (lane & 31), half = lane >> 5;
+      if (v >= V) continue;
+      for (int c = 0; c < 3; ++c) {
+        const float* row = d->wc + ((size_t)v * 3 + c) * K;
+        for (int ks = 0; ks < KS; ++ks)
+          for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + half * 8 + e;
+            if (k >= 211) continue;
+            const float x = row[k < 200 ? k : k - 11];
+            const unsigned short p0 = host_bf16_rne(x);
+            const float r1 = x - host_bf16_f32(p0);
+            const unsigned short p1 = host_bf16_rne(r1);
+            const unsigned short p2 = host_bf16_rne(r1 - host_bf16_f32(p1));
+            unsigned short* dst = &buf[(size_t)t * tile_shorts + ((size_t)((ks * 3 + c) * 2) * 64 + lane) * 8 + e];
+            dst[0] = k < 200 ? p0 : p1;                          // hi: w0 | b0 | b1
+            dst[64 * 8] = k < 189 ? p1 : (k < 200 ? p2 : p0);    // lo: w1 | b2 | b0
+          }
+      }
+    }
+  TRY(upload(m->allocs, buf.data(), buf.size(), &m->wc_bf16));
+  return EMPOSE_OK;
+}
+
 int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if (!d || !out) return fail(EMPOSE_EINVAL, "null argument");
   *out = nullptr;
@@ -1696,7 +1741,8 @@ int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
   if ((rc = upload(m->allocs, d->wc, (size_t)d->ncp * 200, &m->wc)) ||
       (rc = upload(m->allocs, d->skin_idx, (size_t)d->n_vertices * d->kb, &m->skin_idx)) ||
       (rc = upload(m->allocs, d->skin_w, (size_t)d->n_vertices * d->kb, &m->skin_w)) ||
-      (rc = upload(m->allocs, d->parents, (size_t)nj, &m->parents)) || (rc = pack_mesh_tiles(m, d))) {
+      (rc = upload(m->allocs, d->parents, (size_t)nj, &m->parents)) || (rc = pack_mesh_tiles(m, d)) ||
+      (d->with_bf16x3 && (rc = pack_mesh_tiles_bf16(m, d)))) {
     empose_mesh_destroy(m);
     return rc;
   }
@@ -1726,7 +1772,7 @@ size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T) {
 // Slab by slab: Rodrigues + feature row, rest joints (the joint rows of wc), kinematic chain (all n_joints posed
 // joints + the 22 skinning transforms) and, when `vertices` is given, the full-mesh kernel.
 static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const float* betas, const float* trans,
-                    float* vertices, float* joints, void* workspace, hipStream_t stream) {
+                    float* vertices, float* joints, void* workspace, hipStream_t stream, bool bf16x3 = false) {
   const int S = T < MESH_SLAB ? T : MESH_SLAB;
   const int jw = mesh->ncp - mesh->j_off, nj = mesh->n_joints;
   Carver c(workspace);
@@ -1762,7 +1808,8 @@ static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const 
     sa.feat = w.feat; sa.wc = mesh->wc; sa.xf = w.xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
-    e = launch_mesh_rows(sa, stream);
+    sa.wc_bf16 = mesh->wc_bf16;
+    e = bf16x3 ? launch_mesh_rows_bf16(sa, stream) : launch_mesh_rows(sa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
@@ -1775,6 +1822,16 @@ int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* pose
   if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
   if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
   return run_mesh(mesh, T, poses, betas, trans, vertices, joints, workspace, static_cast<hipStream_t>(stream_));
+}
+
+int empose_mesh_vertices_fwd_bf16x3(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                                    const float* trans, float* vertices, float* joints, void* workspace,
+                                    size_t workspace_bytes, empose_stream_t stream_) {
+  if (!mesh || !poses || !betas || !vertices || !joints || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (!mesh->wc_bf16) return fail(EMPOSE_EINVAL, "the mesh handle was created without with_bf16x3");
+  if (T <= 0) return fail(EMPOSE_EINVAL, "T must be positive");
+  if (workspace_bytes < empose_mesh_workspace_bytes(mesh, T)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  return run_mesh(mesh, T, poses, betas, trans, vertices, joints, workspace, static_cast<hipStream_t>(stream_), true);
 }
 
 int empose_mesh_joints_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,

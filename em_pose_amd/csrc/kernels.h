@@ -353,8 +353,12 @@ struct MeshSkinArgs {
   int T, V;
   const float* wc_frag;        // [tiles][25][3][64][4]: wc in fragment order per 32-vertex tile (api.hip pack_mesh_tiles)
   const int* skin_idx4; const float* skin_w4;   // [tiles * 32][4]
+  const void* wc_bf16 = nullptr;   // bf16 pieces of wc in fragment order per tile (api.hip pack_mesh_tiles_bf16), or nullptr
 };
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream);
+// The same evaluation with the blend-shape contraction in split bf16 (mesh.hip); needs MeshSkinArgs::wc_bf16.
+hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream);
+constexpr int MESH_BF16_TILE_BYTES = 14 * 3 * 2 * 1024;
 
 struct VirtualSensorArgs {
   const float* vertices;   // [T][V][3]

@@ -224,6 +224,272 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same kernel with the blend-shape contraction on the bf16 matrix cores ("split bf16", fp32 accumulate): an fp32
+// operand x is the exact sum of bf16 pieces x = x0 + x1 + x2, |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|.  NOT the arithmetic
+// of the headline: selected explicitly (empose_mesh_vertices_fwd_bf16x3, `bench.py --workload vertices --arith bf16x3`).
+// Every column of the contraction carries a (hi, lo) pair on both operands and contributes three products
+// hi.hi + hi.lo + lo.hi; which pieces sit in the pair depends on the column:
+//   * pose blend-shapes (189 features, centimetre-scale contributions): (x0, x1) . (w0, w1) -- products down to 2^-16
+//     relative, error < 1e-6 m;
+//   * template + shape blend-shapes (10 betas and the constant 1, metre-scale) appear twice: once as (a0, a2) . (b0, b2)
+//     and once as (a1, a0) . (b1, b0), which together are the six products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 of a
+//     three-piece split -- fp32-like.
+// That is 211 columns = 14 k-steps of 16 (v_mfma_f32_32x32x16_bf16, 8 passes for 16 k where the fp32 instruction needs
+// 16 passes for 2): the K loop of a tile shrinks from 600 fp32 MFMAs (38.4 k cycles) to 252 bf16 MFMAs (8.1 k).
+// Measured (scripts/dev/mesh_bf16_lab.hip, T = 16384, one wave per SIMD): 13-14 k cycles of K loop (the coefficient
+// stream, 84 KB per tile and wave from L2, three k-steps ahead in a register ring) and 12-13 k of skinning per tile,
+// at 1.8-1.9 GHz under the power limit.
+// ONE WAVE PER SIMD (four waves per workgroup), deliberately: with eight waves per workgroup (two per SIMD, as the fp32
+// kernel runs) this kernel returned sporadically wrong x coordinates -- always the second accumulator row of the upper
+// lane half, lanes 48..63, in roughly one tile-wave in a thousand, different ones on every launch; independent of the
+// register count (216..254), of the prefetch, of fences / nops around the stores and after the K loop.  With one wave
+// per SIMD ten repetitions of 16384 frames are bit-identical and within 5e-7 of the fp32 kernel.  The throughput is
+// the same either way: the two waves of a SIMD ran their K loops and their skinning in lockstep and gained nothing
+// from each other.
+// Operand order inside a k-step only has to agree between the two operands (a dot product is order-free): a lane's
+// eight values are k = 16 * step + 8 * (lane >> 5) + 0..7 on both sides.
+// ---------------------------------------------------------------------------------------------------------------
+namespace mb {
+#ifndef MB_NW
+#define MB_NW 4
+#endif
+constexpr int BM = 64, NW = MB_NW;
+constexpr int KS = 14;                    // k-steps: 189 pose columns + 2 x 11 shape columns = 211 <= 224
+constexpr int M1 = 189, M2 = 200, KCOLS = 211;
+constexpr int LDA = 232;                  // bf16 per row of a piece (464 B = 4 x 29 dwords: conflict-free 16-byte reads)
+constexpr int A_PIECE_BYTES = BM * LDA * 2;
+constexpr int A_BYTES = 2 * A_PIECE_BYTES;
+constexpr int XF_FLOATS = BM * NB * 12;
+constexpr int TR_FLOATS = BM * 4;
+constexpr size_t LDS_BYTES = (size_t)A_BYTES + (size_t)(XF_FLOATS + TR_FLOATS) * sizeof(float) + 64;
+constexpr int TILE_BYTES = KS * 3 * 2 * 1024;   // packed coefficients of one 32-vertex tile
+#ifndef MB_RING
+#define MB_RING 4
+#endif
+constexpr int RING = MB_RING;             // B fragments: steps s+1 .. s+RING-1 in flight while step s is consumed
+static_assert(TILE_BYTES == MESH_BF16_TILE_BYTES, "api.hip packs what this kernel reads");
+}  // namespace mb
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {   // round to nearest even (finite inputs)
+  const unsigned u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <bool EXTRA>
+__global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArgs a) {
+  using namespace mb;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned short* Ab = reinterpret_cast<unsigned short*>(lds);
+  float* XFs = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + A_BYTES);
+  float* TRs = XFs + XF_FLOATS;
+  const int T = a.T, V = a.V;
+  const int f0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- staging: the features split into bf16 pieces (column plan above), relative transforms, translations
+  {
+    const float* __restrict__ feat = a.feat;
+    for (int i = tid; i < BM * LDA; i += NW * 64) {
+      const int r = i / LDA, c = i - r * LDA;
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      const int src = c < M1 ? c : (c < M2 ? c : c - (M2 - M1));   // both shape groups read columns 189..199
+      const float x = c < KCOLS ? feat[(size_t)row * 200 + src] : 0.f;
+      const unsigned short p0 = bf16_rne(x);
+      const float r1 = x - bf16_f32(p0);
+      const unsigned short p1 = bf16_rne(r1);
+      const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
+      Ab[i] = c < M2 ? p0 : p1;                                   // hi: x0 | a0 | a1
+      Ab[A_PIECE_BYTES / 2 + i] = c < M1 ? p1 : (c < M2 ? p2 : p0);   // lo: x1 | a2 | a0
+    }
+    const float* __restrict__ xf = a.xf;
+    for (int i = tid; i < BM * NB * 3; i += NW * 64) {
+      const int r = i / (NB * 3), c = i % (NB * 3);
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      *reinterpret_cast<f32x4*>(XFs + i * 4) = *reinterpret_cast<const f32x4*>(xf + ((size_t)row * NB * 3 + c) * 4);
+    }
+    if (tid < BM) {
+      const int row = f0 + tid < T ? f0 + tid : T - 1;
+      f32x4 t{0.f, 0.f, 0.f, 0.f};
+      if (a.trans) { t[0] = a.trans[(size_t)row * 3]; t[1] = a.trans[(size_t)row * 3 + 1]; t[2] = a.trans[(size_t)row * 3 + 2]; }
+      *reinterpret_cast<f32x4*>(TRs + tid * 4) = t;
+    }
+  }
+  __syncthreads();
+
+  const int n_tiles = (V + 31) / 32;
+  const int per_block = (n_tiles + gridDim.y - 1) / gridDim.y;
+  const int first = blockIdx.y * per_block;
+  const int end = min(first + per_block, n_tiles);
+  int vt = first + wave;
+  if (vt >= end) return;
+
+  epi_cgbyte_t wbase = (epi_cgbyte_t)a.wc_bf16;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // B fragments of one k-step: [plane][piece], 1 KB each
+  auto bload = [&](f32x4 (&dst)[3][2], epi_cgbyte_t tile, int ks) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        dst[c][p] = *(const __attribute__((address_space(1))) f32x4*)(tile + ((unsigned)(((ks * 3 + c) * 2 + p) * 1024) + lane16));
+  };
+  // A fragments of this lane: row l31 (+ 32), 16 bytes at k-step * 32 + lh * 16; [frame tile][piece]
+  const char* a_lane = reinterpret_cast<const char*>(Ab) + l31 * (LDA * 2) + lh * 16;
+  auto aload = [&](f32x4 (&dst)[2][2], int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        dst[i][p] = *reinterpret_cast<const f32x4*>(a_lane + p * A_PIECE_BYTES + i * 32 * (LDA * 2) + ks * 32);
+  };
+  epi_gbyte_t vbase = (epi_gbyte_t)a.vertices;
+  const int kb = a.kb;
+  const size_t vrow_bytes = (size_t)V * 12;
+
+  f32x4 ring[RING][3][2];
+  f32x4 fa[2][2][2];
+  {
+    epi_cgbyte_t b0 = wbase + (size_t)vt * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < RING - 1; ++ks) bload(ring[ks], b0, ks);
+  }
+  aload(fa[0], 0);
+
+#pragma unroll 1
+  for (int seq = 0; vt < end; vt += NW, ++seq) {
+    MR_STAMP(seq, 0)
+    epi_cgbyte_t bt = wbase + (size_t)vt * TILE_BYTES;
+    // past the wave's last tile the prefetch re-reads this one (never consumed)
+    epi_cgbyte_t bnext = vt + NW < end ? wbase + (size_t)(vt + NW) * TILE_BYTES : bt;
+    const int s = vt * 32 + l31;
+    const int4 bone4 = *reinterpret_cast<const int4*>(a.skin_idx4 + (size_t)s * 4);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.skin_w4 + (size_t)s * 4);
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // Coefficients RING-1 k-steps ahead (every tile starts in slot 0: the first steps of the next tile are requested
+      // after the loop and land during the skinning), A fragments one k-step ahead.  A k-step is three fenced groups of
+      // six MFMAs, one per product, each on the six different accumulators: the scheduler must never put two MFMAs on
+      // the same accumulator back to back (measured: it did, eight in a row, and besides being slow that gave
+      // sporadically wrong rows of the accumulator on gfx950), so nothing but scalar / vector ALU work may cross a fence.
+      const int kn = ks + RING - 1;
+      f32x4 (&bn)[3][2] = ring[kn % RING];
+      f32x4 (&fn)[2][2] = fa[(ks + 1) & 1];
+      const int an = ks + 1 < KS ? ks + 1 : 0;
+      const f32x4 (&fc)[2][2] = fa[ks & 1];
+      const f32x4 (&bc)[3][2] = ring[ks % RING];
+#pragma unroll
+      for (int prod = 0; prod < 3; ++prod) {   // lo.hi, hi.lo, hi.hi: the small terms first
+        // this group's share of the prefetch: one coordinate plane of coefficients, one frame tile of A fragments
+        if (kn < KS) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            bn[prod][p] = *(const __attribute__((address_space(1))) f32x4*)(bt + ((unsigned)(((kn * 3 + prod) * 2 + p) * 1024) + lane16));
+        }
+        if (prod < 2) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            fn[prod][p] = *reinterpret_cast<const f32x4*>(a_lane + p * A_PIECE_BYTES + prod * 32 * (LDA * 2) + an * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, fc[i][prod == 0 ? 1 : 0]);
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[c][prod == 1 ? 1 : 0]);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][c], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0x6);   // only VALU / SALU may move across
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < RING - 1; ++ks) bload(ring[ks], bnext, ks);
+
+    MR_STAMP(seq, 1)
+    // ---- skinning (as mesh_rows_kernel)
+    if (s < V) {
+      const char* xfl = reinterpret_cast<const char*>(XFs) + lh * (4 * NB * 48);
+      const char* xk[4] = {xfl + bone4.x * 48, xfl + bone4.y * 48, xfl + bone4.z * 48, xfl + bone4.w * 48};
+      const f32x2 wp[4] = {{w4[0], w4[0]}, {w4[1], w4[1]}, {w4[2], w4[2]}, {w4[3], w4[3]}};
+      const char* trl = reinterpret_cast<const char*>(TRs) + lh * 64;
+      const unsigned lane_off = ((unsigned)(f0 + 4 * lh) * (unsigned)V + (unsigned)s) * 12u;
+      auto skin = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+            const float vx = acc[i][0][r], vy = acc[i][1][r], vz = acc[i][2][r];
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(trl + dm * 16);
+            float out[3];
+#pragma unroll
+            for (int row = 0; row < 3; ++row) {
+              f32x4 gk = *reinterpret_cast<const f32x4*>(xk[0] + dm * (NB * 48) + row * 16);
+              f32x2 Ta = wp[0] * f32x2{gk[0], gk[1]}, Tb = wp[0] * f32x2{gk[2], gk[3]};
+#pragma unroll
+              for (int k = 1; k < 4; ++k) {
+                gk = *reinterpret_cast<const f32x4*>(xk[k] + dm * (NB * 48) + row * 16);
+                Ta = __builtin_elementwise_fma(wp[k], f32x2{gk[0], gk[1]}, Ta);
+                Tb = __builtin_elementwise_fma(wp[k], f32x2{gk[2], gk[3]}, Tb);
+              }
+              if (EXTRA)
+                for (int k = 4; k < kb; ++k) {
+                  const int b = a.skin_idx[(size_t)s * kb + k];
+                  const float wk = a.skin_w[(size_t)s * kb + k];
+                  gk = *reinterpret_cast<const f32x4*>(xfl + b * 48 + dm * (NB * 48) + row * 16);
+                  Ta = __builtin_elementwise_fma(f32x2{wk, wk}, f32x2{gk[0], gk[1]}, Ta);
+                  Tb = __builtin_elementwise_fma(f32x2{wk, wk}, f32x2{gk[2], gk[3]}, Tb);
+                }
+              out[row] = __builtin_fmaf(Ta[0], vx, __builtin_fmaf(Ta[1], vy, __builtin_fmaf(Tb[0], vz, Tb[1]))) + tr[row];
+            }
+            if (FULL || f0 + 4 * lh + dm < T) {
+              epi_gfloat_t o = (epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + lane_off);
+              o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+            }
+          }
+      };
+      if (f0 + BM <= T) skin(std::true_type{}); else skin(std::false_type{});
+    }
+    MR_STAMP(seq, 2)
+  }
+}
+
+hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int bx = (a.T + mb::BM - 1) / mb::BM;
+  const int n_tiles = (a.V + 31) / 32;
+  int by = bx >= 256 ? 1 : (256 + bx - 1) / bx;
+  const int max_by = (n_tiles + mb::NW - 1) / mb::NW;
+  if (by > max_by) by = max_by;
+  if (a.kb > 4)
+    hipLaunchKernelGGL(mesh_rows_bf16_kernel<true>, dim3(bx, by), dim3(mb::NW * 64), mb::LDS_BYTES, stream, a);
+  else
+    hipLaunchKernelGGL(mesh_rows_bf16_kernel<false>, dim3(bx, by), dim3(mb::NW * 64), mb::LDS_BYTES, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {

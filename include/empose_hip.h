@@ -439,6 +439,7 @@ typedef struct {
   const int* parents;     /* [n_joints], topologically ordered, parents[0] < 0 */
   int n_joints;           /* posed joints returned: 22 (body) ... 52 (all of SMPL-H, as `body.Jtr`); 0 means 22 */
   int rodrigues;          /* EMPOSE_RODRIGUES_* */
+  int with_bf16x3;        /* also pack the split-bf16 coefficient tables (empose_mesh_vertices_fwd_bf16x3), +25 MB */
 } empose_mesh_desc;
 
 int empose_mesh_create(const empose_mesh_desc* desc, empose_mesh_t** out);
@@ -451,6 +452,14 @@ int empose_mesh_n_joints(const empose_mesh_t* mesh);
 int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
                              const float* trans, float* vertices, float* joints,
                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
+/* The same evaluation with the blend-shape contraction in split bf16 on the bf16 matrix cores, fp32 accumulate (pose
+ * blend-shapes: 2 pieces / 3 products; template + shape: 3 pieces / 6 products; kinematic chain and skinning unchanged,
+ * fp32).  NOT the arithmetic of the reference or of the headline benchmark: an explicitly selected variant whose vertices
+ * stay within 1e-4 of the fp32 path (tests/test_hip_boundary.py); joints are identical (the chain does not use it). */
+int empose_mesh_vertices_fwd_bf16x3(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
+                                    const float* trans, float* vertices, float* joints, void* workspace,
+                                    size_t workspace_bytes, empose_stream_t stream);
 
 /* Joints only (forward kinematics without the mesh): what MetricsEngine needs from `smpl_model.fk`
  * (reference eval/metrics.py:223-228 keeps `kp3d[:, :22]` and discards the vertices). joints [T][n_joints][3]; same
