@@ -630,7 +630,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"gemm_wide", &o.gemm_wide}, {"smpl_fused", &o.smpl_fused}, {"lstm_seq", &o.lstm_seq},
+      {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -642,7 +642,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"gemm_wide", o.gemm_wide}, {"smpl_fused", o.smpl_fused}, {"lstm_seq", o.lstm_seq},
+      {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;

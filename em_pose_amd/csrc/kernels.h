@@ -13,8 +13,6 @@ struct Options {
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
-  int smpl_fused = 1;     // one kernel per SMPL evaluation of the LGD loop (0: feat / GEMM / chain / GEMM^T / rodrigues)
-  int lstm_seq = 1;       // whole-sequence large-batch LSTM kernel (0: one launch per wavefront step)
   int atb_target = 256;   // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction
 };
 Options& options();

@@ -7,6 +7,12 @@
 #include <cstdio>
 #include <vector>
 using namespace empose;
+namespace empose { Options& options() { static Options o; return o; } }
+#ifdef LAB_PIPE   // scripts/dev/experiments/mesh_bf16_pipe.hip pasted into mesh.hip
+#define LAB_KERNEL mesh_rows_bf16_pipe_kernel
+#else
+#define LAB_KERNEL mesh_rows_bf16_kernel<false>
+#endif
 
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -40,9 +46,9 @@ int main(int argc, char** argv) {
   a.vertices = out;
   const int bx = (T + 63) / 64;
   auto launch = [&]() {
-    hipLaunchKernelGGL(mesh_rows_bf16_kernel<false>, dim3(bx, 1), dim3(mb::NW * 64), mb::LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(LAB_KERNEL, dim3(bx, 1), dim3(mb::NW * 64), mb::LDS_BYTES, 0, a);
   };
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<false>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(LAB_KERNEL),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb::LDS_BYTES);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) launch();

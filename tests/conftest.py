@@ -26,5 +26,5 @@ def _reset_kernel_variant_options():
     yield
     from em_pose_amd import _lib
     if _lib._lib is not None:
-        for name in (b'mlp_fused', b'lstm_persist', b'lstm_seq', b'gemm_splitk', b'gemm_wide', b'smpl_fused'):
+        for name in (b'mlp_fused', b'lstm_persist', b'gemm_splitk', b'gemm_wide'):
             _lib._lib.empose_set_option(name, 1)
