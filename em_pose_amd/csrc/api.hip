@@ -1355,9 +1355,14 @@ int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int 
   return EMPOSE_OK;
 }
 
-int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
-                         const float* save, const empose_mlp_grads* gr, int accumulate, void* workspace,
-                         size_t workspace_bytes, empose_stream_t stream_) {
+namespace {
+// stash of one application: dZ of the hidden layers [M][hidden] each, then a copy of d_out [M][out_pad]
+size_t mlp_stash_floats(const empose_mlp_params* p, int M) {
+  return (size_t)M * ((size_t)(p->n_layers - 1) * p->hidden + ((p->out_dim + 3) & ~3));
+}
+int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
+                       const float* save, const empose_mlp_grads* gr, int accumulate, float* stash, void* workspace,
+                       size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p));
   if (!x || !d_out || !save || !gr || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   const int H = p->hidden, L = p->n_layers, op = (p->out_dim + 3) & ~3;
@@ -1383,42 +1388,119 @@ int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int 
   // output layer: dW = d_out^T a_{L-2}, db, dA = d_out . W
   {
     const int l = L - 1;
-    AtbArgs ab{};
-    ab.A = d_out; ab.lda = ld_dout; ab.B = layer_save(l - 1) + (size_t)M * H; ab.ldb = H; ab.C = gr->weight[l]; ab.ldc = H;
-    ab.bias = gr->bias[l]; ab.M = M; ab.N = p->out_dim; ab.K = H; ab.accumulate = accumulate;
-    hipError_t e = launch_gemm_atb(ab, w.atb, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    if (stash) {   // weight gradients deferred: keep d_out for empose_mlp_train_wgrad
+      e = launch_axpby2d(M, op, 1.f, d_out, ld_dout, 0.f, nullptr, 0, stash + (size_t)M * (L - 1) * H, op, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "stash: %s", hipGetErrorString(e));
+    } else {
+      AtbArgs ab{};
+      ab.A = d_out; ab.lda = ld_dout; ab.B = layer_save(l - 1) + (size_t)M * H; ab.ldb = H; ab.C = gr->weight[l]; ab.ldc = H;
+      ab.bias = gr->bias[l]; ab.M = M; ab.N = p->out_dim; ab.K = H; ab.accumulate = accumulate;
+      e = launch_gemm_atb(ab, w.atb, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    }
     HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
     e = launch_transpose(p->weight[l], H, w.wt, op, p->out_dim, H, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
     e = gemm(d_out, ld_dout, w.wt, op, w.d[0], H, H, op);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
   }
-  int cur = 0;
+  const int cur = 0;   // w.d[0]: cotangent of the current layer's activation; w.d[1]: dZ when it is not stashed
   for (int l = L - 2; l >= 0; --l) {
     const float* sv = layer_save(l);
     BnPreluArgs a{};
     a.M = M; a.C = H; a.x = sv; a.ldx = H; a.gamma = p->bn_weight[l]; a.beta = p->bn_bias[l]; a.slope = p->prelu[l];
     a.save_mean = const_cast<float*>(sv + (size_t)2 * M * H); a.save_rstd = a.save_mean + H;
-    a.dz = w.d[cur]; a.lddz = H; a.dx = w.d[cur ^ 1]; a.lddx = H;
+    float* dz = stash ? stash + (size_t)M * l * H : w.d[cur ^ 1];   // dZ_l: into the stash when the dW are deferred
+    a.dz = w.d[cur]; a.lddz = H; a.dx = dz; a.lddx = H;
     a.dgamma = gr->bn_weight[l]; a.dbeta = gr->bn_bias[l]; a.dslope = gr->prelu[l];
     a.dslope_partial = w.slope_partial; a.counter = w.counter; a.workspace = w.bn; a.accumulate = accumulate;
     hipError_t e = launch_bn_prelu(a, true, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn_prelu backward: %s", hipGetErrorString(e));
-    cur ^= 1;   // w.d[cur] = dZ_l
     const float* in = l == 0 ? x : layer_save(l - 1) + (size_t)M * H;
     const int ld_in = l == 0 ? ldx : H, k_in = l == 0 ? p->in_dim : H;
-    AtbArgs ab{};
-    ab.A = w.d[cur]; ab.lda = H; ab.B = in; ab.ldb = ld_in; ab.C = gr->weight[l]; ab.ldc = k_in;
-    ab.bias = gr->bias[l]; ab.M = M; ab.N = H; ab.K = k_in; ab.accumulate = accumulate;
-    e = launch_gemm_atb(ab, w.atb, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    if (!stash) {
+      AtbArgs ab{};
+      ab.A = dz; ab.lda = H; ab.B = in; ab.ldb = ld_in; ab.C = gr->weight[l]; ab.ldc = k_in;
+      ab.bias = gr->bias[l]; ab.M = M; ab.N = H; ab.K = k_in; ab.accumulate = accumulate;
+      e = launch_gemm_atb(ab, w.atb, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    }
     if (l == 0) break;
     e = launch_transpose(p->weight[l], H, w.wt, H, H, H, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
-    e = gemm(w.d[cur], H, w.wt, H, w.d[cur ^ 1], H, H, H);
+    e = gemm(dz, H, w.wt, H, w.d[cur], H, H, H);   // the cotangent of the layer below overwrites the consumed one
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
-    cur ^= 1;
+  }
+  return EMPOSE_OK;
+}
+}  // namespace
+
+int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
+                         const float* save, const empose_mlp_grads* gr, int accumulate, void* workspace,
+                         size_t workspace_bytes, empose_stream_t stream) {
+  return mlp_train_bwd_impl(p, M, x, ldx, d_out, ld_dout, save, gr, accumulate, nullptr, workspace, workspace_bytes, stream);
+}
+
+size_t empose_mlp_train_stash_floats(const empose_mlp_params* p, int M) {
+  if (!p || M <= 0 || check_mlp_params(p) != EMPOSE_OK) return 0;
+  return mlp_stash_floats(p, M);
+}
+
+int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out,
+                                  int ld_dout, const float* save, const empose_mlp_grads* gr, int accumulate,
+                                  float* dz_stash, void* workspace, size_t workspace_bytes, empose_stream_t stream) {
+  if (!dz_stash) return fail(EMPOSE_EINVAL, "null stash");
+  return mlp_train_bwd_impl(p, M, x, ldx, d_out, ld_dout, save, gr, accumulate, dz_stash, workspace, workspace_bytes, stream);
+}
+
+size_t empose_mlp_train_wgrad_workspace_bytes(const empose_mlp_params* p, int n_app, int M) {
+  if (!p || M <= 0 || n_app <= 0 || check_mlp_params(p) != EMPOSE_OK) return 0;
+  const int H = p->hidden;
+  const size_t a = atb_workspace_floats(n_app * M, H, H > p->in_dim ? H : p->in_dim);
+  const size_t b = atb_workspace_floats(n_app * M, p->out_dim, H);
+  return ((a > b ? a : b) + 64) * sizeof(float);
+}
+
+int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const float* const* x, int ldx,
+                           const float* const* save, const float* const* dz_stash, const empose_mlp_grads* gr,
+                           int accumulate, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_mlp_params(p));
+  if (!x || !save || !dz_stash || !gr || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (n_app < 1 || n_app > ATB_MAX_SEG || M <= 0 || ldx < p->in_dim) return fail(EMPOSE_EINVAL, "bad sizes");
+  if (workspace_bytes < empose_mlp_train_wgrad_workspace_bytes(p, n_app, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  const int H = p->hidden, L = p->n_layers, op = (p->out_dim + 3) & ~3;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  float* ws = static_cast<float*>(workspace);
+  // one product over all applications when their rows can be addressed as 32-row aligned segments, else one per application
+  bool batched = M % 32 == 0 && ldx % 4 == 0;
+  for (int s = 0; s < n_app && batched; ++s)
+    batched = x[s] && save[s] && dz_stash[s] && ((uintptr_t)x[s] & 15) == 0 && ((uintptr_t)save[s] & 15) == 0 &&
+              ((uintptr_t)dz_stash[s] & 15) == 0;
+  for (int s = 0; s < n_app; ++s)
+    if (!x[s] || !save[s] || !dz_stash[s]) return fail(EMPOSE_EINVAL, "null argument");
+  for (int l = 0; l < L; ++l) {
+    if (!gr->weight[l] || !gr->bias[l]) return fail(EMPOSE_EINVAL, "null gradient output");
+    const bool last = l == L - 1;
+    const int ld_a = last ? op : H, n_out = last ? p->out_dim : H;
+    const int ld_b = l == 0 ? ldx : H, k_in = l == 0 ? p->in_dim : H;
+    auto a_of = [&](int s) { return dz_stash[s] + (size_t)M * l * H; };
+    auto b_of = [&](int s) { return l == 0 ? x[s] : save[s] + (size_t)(l - 1) * mlp_layer_save(p, M) + (size_t)M * H; };
+    AtbArgs ab{};
+    ab.lda = ld_a; ab.ldb = ld_b; ab.C = gr->weight[l]; ab.ldc = k_in; ab.bias = gr->bias[l]; ab.N = n_out; ab.K = k_in;
+    if (batched) {
+      ab.A = a_of(0); ab.B = b_of(0); ab.M = n_app * M; ab.accumulate = accumulate;
+      ab.n_seg = n_app; ab.seg_rows = M;
+      for (int s = 0; s < n_app; ++s) { ab.A_seg[s] = a_of(s); ab.B_seg[s] = b_of(s); }
+      hipError_t e = launch_gemm_atb(ab, ws, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    } else {
+      for (int s = 0; s < n_app; ++s) {
+        ab.A = a_of(s); ab.B = b_of(s); ab.M = M; ab.accumulate = accumulate || s > 0;
+        hipError_t e = launch_gemm_atb(ab, ws, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+      }
+    }
   }
   return EMPOSE_OK;
 }

@@ -140,6 +140,7 @@ hipError_t launch_lstm_persist(const LstmWaveArgs& a, float* xch, hipStream_t st
 // ---------------------------------------------------------------------------------------------------------------
 // Training backward (train.hip)
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int ATB_MAX_SEG = 8;
 struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] = sum_m A[m][n])
   const float* A; int lda;
   const float* B; int ldb;
@@ -147,6 +148,11 @@ struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] 
   float* bias;               // [N] or nullptr
   int M, N, K;
   int accumulate;            // 1: C += A^T B, bias += column sums (gradient accumulation over the LGD iterations)
+  // Row segments: with n_seg > 0 the M rows are n_seg blocks of seg_rows rows (a multiple of 32) that live at
+  // A_seg[s] / B_seg[s] (same leading dimensions) -- the operands of one layer over the applications of the LGD loop.
+  int n_seg = 0, seg_rows = 0;
+  const float* A_seg[ATB_MAX_SEG] = {};
+  const float* B_seg[ATB_MAX_SEG] = {};
   // set by launch_gemm_atb
   int S; float* partial; float* bias_partial;
 };

@@ -139,14 +139,21 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 ga[4], gb[4];
   auto gload = [&](int m0) {
+    // a 32-row chunk never straddles two row segments (seg_rows is a multiple of 32)
+    const float* A0 = a.A; const float* B0 = a.B;
+    int mrel = 0;
+    if (a.n_seg > 0) {
+      const int sg = min(m0 / a.seg_rows, a.n_seg - 1);
+      A0 = a.A_seg[sg]; B0 = a.B_seg[sg]; mrel = sg * a.seg_rows;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int mm = m0 + r8 + 8 * p;
       const bool row_ok = mm < me;
       f4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       if (row_ok) {
-        const float* pa = a.A + (size_t)mm * a.lda + n_base + c4;
-        const float* pb = a.B + (size_t)mm * a.ldb + k_base + c4;
+        const float* pa = A0 + (size_t)(mm - mrel) * a.lda + n_base + c4;
+        const float* pb = B0 + (size_t)(mm - mrel) * a.ldb + k_base + c4;
         if (n_base + c4 + 4 <= a.N) va = *reinterpret_cast<const f4*>(pa);
         else
           for (int e = 0; e < 4; ++e) if (n_base + c4 + e < a.N) va[e] = pa[e];
@@ -258,7 +265,13 @@ hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream) {
     a.bias_partial = a.bias ? workspace + (size_t)a.S * a.N * a.K : nullptr;
   }
   const int tiles = ((a.N + atb::BN - 1) / atb::BN) * ((a.K + atb::BK - 1) / atb::BK);
-  const bool aligned = a.lda % 4 == 0 && a.ldb % 4 == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
+  bool aligned = a.lda % 4 == 0 && a.ldb % 4 == 0;
+  if (a.n_seg > 0) {
+    for (int s = 0; s < a.n_seg; ++s) aligned = aligned && ((uintptr_t)a.A_seg[s] & 15) == 0 && ((uintptr_t)a.B_seg[s] & 15) == 0;
+    if (!aligned || a.seg_rows % 32 != 0 || a.n_seg > ATB_MAX_SEG) return hipErrorInvalidValue;   // callers check first
+  } else {
+    aligned = aligned && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
+  }
   if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
   else hipLaunchKernelGGL(gemm_atb_kernel, dim3(tiles, a.S), dim3(atb::NT), 0, stream, a);
   if (a.S > 1) {

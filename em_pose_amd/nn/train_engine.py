@@ -91,6 +91,8 @@ class _MlpView(object):
 
 
 class LgdTrainEngine(object):
+    batched_wgrad = True   # dW / db of the update networks once over the N iterations (False: per iteration; A/B and tests)
+
     def __init__(self, net):
         self.net = net
         self.ctx = None
@@ -129,6 +131,30 @@ class LgdTrainEngine(object):
         ws = self.ws(nbytes)
         _lib.check(self.lib.empose_mlp_train_bwd(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(), C.byref(g),
                                                  int(accumulate), ws.data_ptr(), nbytes, self.stream))
+
+    def _mlp_bwd_deferred(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M):
+        """Backward of one application that keeps the layer cotangents instead of forming dW / db; returns the stash."""
+        p = view.params()
+        g = view.grads(grads)
+        stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
+        nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
+        ws = self.ws(nbytes)
+        _lib.check(self.lib.empose_mlp_train_bwd_deferred(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(),
+                                                          C.byref(g), int(accumulate), stash.data_ptr(), ws.data_ptr(),
+                                                          nbytes, self.stream))
+        return stash
+
+    def _mlp_wgrad(self, view, xs, ldx, saves, stashes, grads, M):
+        """dW, db of one network over all its applications: one A^T B product per layer (empose_mlp_train_wgrad)."""
+        p = view.params()
+        g = view.grads(grads)
+        n = len(xs)
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+        nbytes = self.lib.empose_mlp_train_wgrad_workspace_bytes(C.byref(p), n, M)
+        ws = self.ws(nbytes)
+        _lib.check(self.lib.empose_mlp_train_wgrad(C.byref(p), n, M, arr(xs), ldx, arr([t.data_ptr() for t in saves]),
+                                                   arr([t.data_ptr() for t in stashes]), C.byref(g), 0, ws.data_ptr(),
+                                                   nbytes, self.stream))
 
     def ws(self, nbytes):
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.dev)
@@ -290,6 +316,8 @@ class LgdTrainEngine(object):
             views = ctx['views']
             grads = [[torch.empty_like(p) for p in v.parameter_list()] for v in views]
             X = ctx['X']
+            deferred = self.batched_wgrad and 1 <= N <= 8   # (row counts off the 32-row grid: per application inside)
+            pend = ([], [])
             for i in range(N, -1, -1):
                 _lib.check(lib.empose_smpl_sensors_vjp(
                     smpl_h, T, F, ctx['pose_hist'][i].data_ptr(), 66, ctx['shape_hist'][i].data_ptr(), 10,
@@ -317,8 +345,21 @@ class LgdTrainEngine(object):
                     self._axpby(T, 10, s, Ds.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
                 sp, ss = ctx['saves'][i - 1]
                 acc = i < N
-                self._mlp_bwd(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp, grads[0], acc, T)
-                self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)
+                if deferred:
+                    # weight gradients once over all N applications (one A^T B per layer instead of N)
+                    pend[0].append((X[i - 1].data_ptr(), sp,
+                                    self._mlp_bwd_deferred(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp,
+                                                           grads[0], acc, T)))
+                    pend[1].append((X[i - 1].data_ptr(), ss,
+                                    self._mlp_bwd_deferred(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss,
+                                                           grads[1], acc, T)))
+                else:
+                    self._mlp_bwd(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp, grads[0], acc, T)
+                    self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)
+            for k in (0, 1):
+                if pend[k]:
+                    self._mlp_wgrad(views[k], [q[0] for q in pend[k]], d_x, [q[1] for q in pend[k]],
+                                    [q[2] for q in pend[k]], grads[k], T)
             # ---- initial estimate
             self._axpby(T, 66, 1.0, Dp.data_ptr(), 66, 0.0, None, 0, dpad.data_ptr(), 68)
             if net.shape_avg:

@@ -315,6 +315,22 @@ int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int 
                          const float* save, const empose_mlp_grads* grads, int accumulate, void* workspace,
                          size_t workspace_bytes, empose_stream_t stream);
 
+/* Deferred weight gradients (the same network applied n_app times, as the N iterations of the LGD loop): the backward
+ * of each application keeps its layer cotangents in `dz_stash` (empose_mlp_train_stash_floats floats) instead of forming
+ * dW / db, and ONE call of empose_mlp_train_wgrad forms them over the rows of all applications -- one A^T B product of
+ * n_app * M rows per layer instead of n_app products and reductions.  BatchNorm / PReLU parameter gradients are produced
+ * by the deferred backward exactly as by empose_mlp_train_bwd.  x / save / dz_stash of wgrad: host arrays of n_app
+ * device pointers (n_app <= 8), the arguments the applications were run with.  Same sums in a different order:
+ * results agree with the per-application path to rounding, not bitwise. */
+size_t empose_mlp_train_stash_floats(const empose_mlp_params* p, int M);
+int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out,
+                                  int ld_dout, const float* save, const empose_mlp_grads* grads, int accumulate,
+                                  float* dz_stash, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+size_t empose_mlp_train_wgrad_workspace_bytes(const empose_mlp_params* p, int n_app, int M);
+int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const float* const* x, int ldx,
+                           const float* const* save, const float* const* dz_stash, const empose_mlp_grads* grads,
+                           int accumulate, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+
 /* out[t][c] = mean of in[.][c] over the window of frame t (F consecutive rows); the operator is its own adjoint, so
  * the same call back-propagates (`_to_single_shape`, reference models.py:529-535,588-589). */
 int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* out, int ld_out, empose_stream_t stream);

@@ -809,6 +809,46 @@ def test_training_step_matches_reference_gradients(name):
     assert net._smpl_handle.value == h1
 
 
+def test_training_weight_gradients_once_over_all_iterations_equal_per_iteration_sums():
+    """The reverse sweep forms dW / db of the update networks once over the N applications (empose_mlp_train_wgrad: one
+    A^T B product of N * T rows per layer, row segments addressed in the kernel); the per-application products + sums
+    (empose_mlp_train_bwd with accumulate) give the same gradients up to the order of the additions."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    case = H.load_case('train_lgdrnn12_n2')
+    meta = dict(case['meta'])
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    net.train()
+    g = torch.Generator().manual_seed(9)
+    Bn, Fn = 6, 32                      # 192 rows: on the 32-row grid, so the batched product is taken
+    w = {k: v for k, v in case['in'].items()}
+    rep = lambda a: np.concatenate([a] * 8, axis=0)[:Bn] if a.shape[0] < Bn else a[:Bn]
+    def fit(a):   # tile the recorded window batch along batch and time to (6, 32, ...)
+        a = rep(a)
+        if a.ndim >= 2 and a.shape[1] == case['in']['marker_pos'].shape[1]:
+            a = np.concatenate([a] * 4, axis=1)[:, :Fn]
+        return np.ascontiguousarray(a)
+    w = {k: fit(v) for k, v in w.items() if k != 'seq_lengths'}
+    batch = SyntheticBatch(w, torch.tensor([32, 32, 20, 32, 7, 32], device=DEV), device=DEV)
+    batch.joints_gt = gpu(w['joints_gt'])
+    grads = {}
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    for mode in (True, False):
+        LgdTrainEngine.batched_wgrad = mode
+        try:
+            net.load_state_dict(bn_state, strict=False)
+            net.zero_grad()
+            net.backward(batch, net(batch))
+            grads[mode] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        finally:
+            LgdTrainEngine.batched_wgrad = True
+    assert len(grads[True]) >= 14
+    gmax = max(float(v.abs().max()) for v in grads[False].values())
+    for k, v in grads[False].items():
+        np.testing.assert_allclose(grads[True][k].cpu().numpy(), v.cpu().numpy(),
+                                   atol=2e-5 * max(float(v.abs().max()), 1e-3 * gmax), rtol=1e-4, err_msg=k)
+
+
 @pytest.mark.parametrize('rnn,n_markers', [(True, 12), (False, 6)])
 def test_graphed_training_step_equals_eager(rnn, n_markers):
     """helpers/graphed.py: forward + backward captured in a HIP graph and replayed on new batches gives the losses and,
