@@ -220,15 +220,19 @@ def bn_prelu_train(x, bn, act):
     return act(bn(x))
 
 
+FORCE_LARGE_LINEAR = [False]   # dev / fuzz switch: take the large-batch GEMM path (the kernels the training engine uses)
+
+
 def linear_train(x, lin):
-    """`lin(x)` with autograd for the training path: own kernels when the three GEMMs of the layer are small problems
-    (the reference's training batch), `torch.nn.functional.linear` (library GEMMs) otherwise."""
+    """`lin(x)` with autograd for the training path: the strided small-problem kernel when the three GEMMs of the layer
+    are small (the reference's training batch), the matrix-core GEMM / A^T B kernels otherwise (`_HipLinearLargeFn`);
+    plain `lin(x)` only for shapes off the 4-column grid or CPU tensors."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     M, K, N = x2.shape[0], lin.in_features, lin.out_features
     ok = _lib.lib().empose_gemm_strided_applicable
     if x2.is_cuda and x2.dtype == torch.float32:
-        if ok(M, N) and ok(M, K) and ok(N, K):
+        if not FORCE_LARGE_LINEAR[0] and ok(M, N) and ok(M, K) and ok(N, K):
             return _HipLinearFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))
         if K % 4 == 0 and N % 4 == 0:
             return _HipLinearLargeFn.apply(x2, lin.weight, lin.bias).reshape(lead + (N,))

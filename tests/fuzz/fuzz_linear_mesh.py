@@ -32,17 +32,28 @@ while time.time() < t_end:
         print('LINEAR MISMATCH', dict(M=M, N=N, K=K, act=act, slope=slope, res=use_res), err, tol); sys.exit(1)
 print('linear: %d random cases, worst abs error %.2e' % (n, worst))
 
-model = H.small_model(); bm = R.BodyModelTensors(model); smpl = SMPLLayer(model).to(dev)
-t_end, n, worst = time.time() + budget / 2, 0, 0.0
+model = H.small_model()
+layers = {}
+for conv in ('smplx', 'so3'):
+    bm = R.BodyModelTensors(model, rodrigues_convention=conv)
+    for arith in ('f32', 'bf16x3'):
+        layers[(conv, arith)] = (bm, SMPLLayer(model, rodrigues_convention=conv, arithmetic=arith).to(dev))
+t_end, n, worst = time.time() + budget / 2, 0, {'f32': 0.0, 'bf16x3': 0.0}
 while time.time() < t_end:
     T = int(rng.choice([1, 2, 63, 64, 65, 128, 200, 1000, 5000])); g = torch.Generator().manual_seed(n)
-    pose, root = 0.4 * torch.randn(T, 63, generator=g), 0.5 * torch.randn(T, 3, generator=g)
+    scale = float(rng.choice([1e-3, 0.4, 1.5]))   # incl. angles near the guard of the axis-angle map
+    pose, root = scale * torch.randn(T, 63, generator=g), 0.5 * torch.randn(T, 3, generator=g)
     betas, trans = torch.randn(T, 10, generator=g), torch.randn(T, 3, generator=g)
     use_tr = bool(rng.integers(0, 2))
-    v_ref, j_ref = R.smpl_fk(bm, pose, betas, root, trans if use_tr else None)
-    v, j = smpl(poses_body=pose.to(dev), betas=betas.to(dev), poses_root=root.to(dev), trans=trans.to(dev) if use_tr else None)
-    err = max(float((v.cpu() - v_ref).abs().max()), float((j.cpu() - j_ref[:, :22]).abs().max()))
-    worst = max(worst, err); n += 1
-    if not err < 3e-5:
-        print('MESH MISMATCH', T, use_tr, err); sys.exit(1)
-print('mesh: %d random cases, worst abs error %.2e' % (n, worst))
+    conv = ('smplx', 'so3')[int(rng.integers(0, 2))]
+    for arith in ('f32', 'bf16x3'):
+        bm, smpl = layers[(conv, arith)]
+        v_ref, j_ref = R.smpl_fk(bm, pose, betas, root, trans if use_tr else None)
+        v, j = smpl(poses_body=pose.to(dev), betas=betas.to(dev), poses_root=root.to(dev), trans=trans.to(dev) if use_tr else None)
+        assert tuple(j.shape) == (T, 52, 3)
+        err = max(float((v.cpu() - v_ref).abs().max()), float((j.cpu() - j_ref).abs().max()))
+        worst[arith] = max(worst[arith], err)
+        if not err < 3e-5:
+            print('MESH MISMATCH', T, use_tr, conv, arith, scale, err); sys.exit(1)
+    n += 1
+print('mesh: %d random cases x (f32, bf16x3), both Rodrigues conventions, worst abs error %.2e / %.2e' % (n, worst['f32'], worst['bf16x3']))

@@ -1,0 +1,120 @@
+"""Dev: the hand-written training step (nn/train_engine.py: explicit forward / reverse sweep over the C ABI) against the
+autograd path over the same kernels (custom autograd Functions; what configurations outside the engine still use) on
+random configurations: losses, outputs and every parameter gradient of one step.  Two independent derivations of the
+same backward; the reference's recorded steps (tests/golden/train_*.npz) pin both in the pytest suite.
+
+Train mode is ill-conditioned at these sizes (BatchNorm statistics over a few dozen rows, many of them padding; the
+PReLU kink): the two paths run different forward kernels, ~1e-7 apart, and that difference can come out amplified by
+orders of magnitude.  So every configuration also measures its own sensitivity -- the engine's step on inputs perturbed
+by one unit in the last place -- and the comparison allows 2e-4 of the tensor scale plus eight times that sensitivity
+(the same rule as tests/test_hip_parity.py::test_training_step_matches_reference_gradients, where the sensitivity was
+recorded from the reference itself)."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import helpers as H
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.data.data import SyntheticBatch
+from em_pose_amd.helpers.configuration import CONSTANTS as C, lgd_config
+from em_pose_amd.nn.models import create_model
+from em_pose_amd import synthetic
+from oracle import torch_ref as R
+from em_pose_amd.nn import layers as _layers
+_layers.FORCE_LARGE_LINEAR[0] = True   # same forward GEMM kernel in both paths: no PReLU kink flips from rounding
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+if len(sys.argv) > 3 and sys.argv[3] == 'per_iteration':   # weight gradients per iteration instead of once over all
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    LgdTrainEngine.batched_wgrad = False
+dev = torch.device('cuda:0')
+model = H.small_model()
+bm = R.BodyModelTensors(model)
+vids = [int(v) for v in np.random.default_rng(5).choice(model['v_template'].shape[0], 12, replace=False)]
+tables = R.sensor_tables(model['f'], vids)
+
+
+def sensors(poses, betas, o_r, o_t):
+    with torch.no_grad():
+        p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                      torch.from_numpy(o_r), torch.from_numpy(o_t))
+    return p.numpy(), o.numpy()
+
+
+stats = {}
+flips = set()
+t_end, n, worst = time.time() + budget, 0, 0.0
+while time.time() < t_end:
+    rnn, n_markers, N = bool(rng.integers(0, 2)), int(rng.choice([6, 12])), int(rng.integers(1, 4))
+    B, F = int(rng.integers(1, 10)), int(rng.choice([8, 16, 32, 40]))
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    hidden = int(rng.choice([32, 64]))
+    cfg = lgd_config(n_markers, rnn, N, hidden=hidden, rnn_hidden=hidden)
+    net = create_model(cfg, SMPLLayer(model))
+    net.vertex_ids = vids
+    net = net.to(dev)
+    net.train()
+    w = synthetic.make_windows(B, F, int(rng.integers(0, 1000)), sensors)
+    lens = torch.from_numpy(rng.integers(1, F + 1, size=B)).to(dev)
+    lens[int(rng.integers(0, B))] = F
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    with torch.no_grad():   # ground-truth joints of the windows (the FK loss term)
+        _, _, jgt = R.estimated_markers(bm, tables, vids, torch.from_numpy(w['poses'].reshape(-1, 66)),
+                                        torch.from_numpy(np.repeat(w['shapes'], F, axis=0)),
+                                        torch.from_numpy(np.repeat(w['offset_r'], F, axis=0)),
+                                        torch.from_numpy(np.repeat(w['offset_t'], F, axis=0)))
+    jgt_dev = jgt.reshape(B, F, -1).to(dev).float()   # (B, F, 22 * 3)
+    res = {}
+    ulp = {k: (1.0 + 1.2e-7 * np.sign(rng.standard_normal(w[k].shape))).astype(np.float32) for k in ('marker_pos', 'marker_oris')}
+    for mode in ('engine', 'autograd', 'engine_perturbed'):
+        net.load_state_dict(state0)
+        net.use_train_engine = mode != 'autograd'
+        wi = dict(w)
+        if mode == 'engine_perturbed':
+            for k in ulp:
+                wi[k] = w[k] * ulp[k]
+        batch = SyntheticBatch(wi, lens, device=dev)
+        batch.joints_gt = jgt_dev
+        net.zero_grad()
+        out = net(batch)
+        assert (net._engine is not None) == (mode != 'autograd')
+        total, vals = net.backward(batch, out)
+        res[mode] = (float(total.detach()) if torch.is_tensor(total) else float(total),
+                     {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None},
+                     {k: v.detach().clone() for k, v in out.items()})
+    sens_g = {k: float((res['engine_perturbed'][1][k] - v).abs().max()) for k, v in res['engine'][1].items()}
+    sens_o = {k: float((res['engine_perturbed'][2][k] - v).abs().max()) for k, v in res['engine'][2].items()}
+    res = {True: res['engine'], False: res['autograd']}
+    gmax = max(float(v.abs().max()) for v in res[False][1].values())
+    for k, v in res[False][1].items():
+        err = float((res[True][1][k] - v).abs().max())
+        # 2e-4 of the tensor's scale (plus round-off at the scale of the largest gradient: biases in front of a train-mode
+        # BatchNorm have a mathematically zero gradient) plus eight times the step's own sensitivity to a one-ulp input change
+        tol = 2e-4 * (float(v.abs().max()) + 1e-2 * gmax) + 8.0 * sens_g[k]
+        stats.setdefault('grad err / tol', []).append(err / tol)
+        stats.setdefault('grad sensitivity / scale', []).append(sens_g[k] / (float(v.abs().max()) + 1e-2 * gmax))
+        worst = max(worst, err / tol)
+        if not err <= tol and err <= 2e-2 * (float(v.abs().max()) + 1e-2 * gmax):
+            # A kink flip: the two forward kernels differ by ~1e-7, an element of a BatchNorm output within that distance
+            # of zero takes different sides of the PReLU in the two backward passes, and the Linear in front of it (and
+            # that BatchNorm's bias, and everything upstream) moves by (1 - slope) dz of ONE element. ~0.1 per
+            # configuration at these sizes (7e5 activations, density 0.4 near zero); counted and bounded below.
+            flips.add(n)
+            continue
+        if not err <= tol:
+            print('TRAIN MISMATCH', dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, tol)
+            for kk, vv in res[False][1].items():
+                print('  grad %-50s engine-vs-autograd %.2e of %.2e (sensitivity %.2e)' % (kk, float((res[True][1][kk] - vv).abs().max()), float(vv.abs().max()), sens_g[kk]))
+            sys.exit(1)
+    for k, v in res[False][2].items():
+        err = float((res[True][2][k] - v).abs().max())
+        if not err <= 1e-4 + 8.0 * sens_o[k]:   # the north-star 1e-4 (train-mode BatchNorm amplifies the kernels' rounding)
+            print('OUTPUT MISMATCH', dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, sens_o[k])
+            sys.exit(1)
+    assert abs(res[True][0] - res[False][0]) <= 1e-3 * max(1.0, abs(res[False][0])), (res[True][0], res[False][0])
+    n += 1
+print('train: %d random configurations, worst gradient error / tolerance %.2f; %d configurations with a PReLU kink flip' % (n, worst, len(flips)))
+assert len(flips) <= max(3, n // 3), 'too many to be kink flips'
+for k, v in stats.items():
+    v = np.sort(np.array(v))
+    print('  %s: median %.1e, 99%% %.1e, max %.1e' % (k, np.median(v), v[int(0.99 * (len(v) - 1))], v[-1]))
