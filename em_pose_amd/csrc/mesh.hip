@@ -328,16 +328,25 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
   int vt = first + wave;
   if (vt >= end) return;
 
-  epi_cgbyte_t wbase = (epi_cgbyte_t)a.wc_bf16;
-  const unsigned lane16 = (unsigned)lane * 16u;
+  // The coefficient table as a raw buffer: a fragment load is one buffer_load_dwordx4 with the lane offset in a VGPR, the
+  // tile / k-step offset in an SGPR and the (plane, piece) offset in the instruction -- no address arithmetic in VGPRs
+  // (flat global loads made the compiler keep a 64-bit address pair per 4 KB of the 84 KB tile).
+  const __amdgpu_buffer_rsrc_t wtab = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.wc_bf16), 0, (int)((size_t)((V + 31) / 32) * TILE_BYTES), 0x00020000);
+  const int lane16 = lane * 16;
+  auto wload = [&](int tile_off, int ks, int c, int p) {
+    const int f = c * 2 + p;   // fragment of the k-step: the part below 4 KB rides in the instruction's offset field
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wtab, lane16 + (f & 3) * 1024,
+                                                                           tile_off + ks * 6144 + (f >> 2) * 4096, 0));
+  };
   // B fragments of one k-step: [plane][piece], 1 KB each
-  auto bload = [&](f32x4 (&dst)[3][2], epi_cgbyte_t tile, int ks) {
+  auto bload = [&](f32x4 (&dst)[3][2], int tile_off, int ks) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-        dst[c][p] = *(const __attribute__((address_space(1))) f32x4*)(tile + ((unsigned)(((ks * 3 + c) * 2 + p) * 1024) + lane16));
+      for (int p = 0; p < 2; ++p) dst[c][p] = wload(tile_off, ks, c, p);
   };
+  auto tile_off_of = [&](int t) { return __builtin_amdgcn_readfirstlane(t) * TILE_BYTES; };   // wave-uniform
   // A fragments of this lane: row l31 (+ 32), 16 bytes at k-step * 32 + lh * 16; [frame tile][piece]
   const char* a_lane = reinterpret_cast<const char*>(Ab) + l31 * (LDA * 2) + lh * 16;
   auto aload = [&](f32x4 (&dst)[2][2], int ks) {
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
   f32x4 ring[RING][3][2];
   f32x4 fa[2][2][2];
   {
-    epi_cgbyte_t b0 = wbase + (size_t)vt * TILE_BYTES;
+    const int b0 = tile_off_of(vt);
 #pragma unroll
     for (int ks = 0; ks < RING - 1; ++ks) bload(ring[ks], b0, ks);
   }
@@ -363,9 +372,9 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
 #pragma unroll 1
   for (int seq = 0; vt < end; vt += NW, ++seq) {
     MR_STAMP(seq, 0)
-    epi_cgbyte_t bt = wbase + (size_t)vt * TILE_BYTES;
+    const int bt = tile_off_of(vt);
     // past the wave's last tile the prefetch re-reads this one (never consumed)
-    epi_cgbyte_t bnext = vt + NW < end ? wbase + (size_t)(vt + NW) * TILE_BYTES : bt;
+    const int bnext = vt + NW < end ? tile_off_of(vt + NW) : bt;
     const int s = vt * 32 + l31;
     const int4 bone4 = *reinterpret_cast<const int4*>(a.skin_idx4 + (size_t)s * 4);
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.skin_w4 + (size_t)s * 4);
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
         if (kn < KS) {
 #pragma unroll
           for (int p = 0; p < 2; ++p)
-            bn[prod][p] = *(const __attribute__((address_space(1))) f32x4*)(bt + ((unsigned)(((kn * 3 + prod) * 2 + p) * 1024) + lane16));
+            bn[prod][p] = wload(bt, kn, prod, p);
         }
         if (prod < 2) {
 #pragma unroll
