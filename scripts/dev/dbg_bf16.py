@@ -1,3 +1,7 @@
+"""Dev: the split-bf16 full-mesh kernel against the fp32 kernel on several frame counts, four launches each (count,
+location and coordinate of every element off by more than 1e-4), then ten repetitions of 2048 and 16384 frames compared
+bit for bit.  This is the harness that showed the two-waves-per-SIMD build of the kernel returning sporadically wrong
+x coordinates (mesh.hip); optional argv[1]: path of an alternative libempose_hip.so build to load."""
 import numpy as np, torch, sys, os
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import em_pose_amd._lib as L
