@@ -265,15 +265,22 @@ hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream) {
 //   P5c combine chunks per bone                       P6 subtree sums (bit mask)      P7 d R, d J -> global
 // Every accumulation is a gather in a fixed order: results are bitwise reproducible and independent of the batch.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int CH_THREADS = 192;
-constexpr int CH_FRAMES = 2;
-static_assert(CH_FRAMES == 2, "frame_split() assumes at most two frames per block");
+// Two shapes of the workgroup, picked by the launch (launch_chain_sensors): 4 frames on 256 threads when the launch is
+// many workgroups per CU deep (T >= 16384: 231 us against 253 for the other shape at T = 32768 -- the 24 KB of tables
+// are staged once per four frames and the narrow phases fill more lanes), 2 frames on 192 threads below (twice as many
+// workgroups: at T = 8192 the larger shape leaves a third wave of workgroups mostly empty and costs 7 % of the step).
+// Measured and rejected: 3 x 192 (236), 3 x 256 (241), 4 x 192 (257), 4 x 224 (243), 5 x 256 (261), 8 x 512 (255),
+// anything with more than 256 threads per workgroup (320-390 us: the register budget halves).
 
-// (frame, item) of flat index i < 2 * n without an integer division (n is a run-time value in most phases, and a
-// division costs ~25 instructions in a kernel whose limit is instruction issue).
-__device__ __forceinline__ void frame_split(int i, int n, int& f, int& o) {
-  f = i >= n ? 1 : 0;
-  o = i - (f ? n : 0);
+// (frame, item) of flat index i < FR * n without an integer division (n is a run-time value in most phases, and
+// a division costs ~25 instructions in a kernel whose limit is instruction issue).
+template <int FR>
+__device__ __forceinline__ void frame_split_t(int i, int n, int& f, int& o) {
+  static_assert(FR >= 1 && FR <= 8, "a chain of compares");
+  f = 0;
+#pragma unroll
+  for (int k = 1; k < FR; ++k) f += i >= k * n ? 1 : 0;
+  o = i - f * n;
 }
 constexpr int CHUNK = CHAIN_CHUNK;  // (vertex, weight) pairs per partial-sum chunk, lists padded with weight 0
 
@@ -304,8 +311,10 @@ __device__ long long g_chain_trace[2][32];
 #define CH_STAMP(i)
 #endif
 
+template <int CH_FRAMES, int CH_THREADS>
 __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  auto frame_split = [](int i, int n, int& f, int& o) { frame_split_t<CH_FRAMES>(i, n, f, o); };
   CH_STAMP(0)
   const SmplTables& tb = a.tab;
   const ChainTabs& O = tb.off;
@@ -331,7 +340,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
     const int n16 = (O.total + 3) >> 2;   // the blob is padded to a multiple of 4 words
     const int row = NB * 9 + tb.ncp;
     const int n = nf * row;
-    constexpr int TB = 8, FB = 6;   // 8 x 192 x 16 B = 24 KB of tables; 2 frames x (198 + ncp ~ 320) floats / 192 threads
+    // 8 x 192 x 16 B = 24 KB of tables; CH_FRAMES frames x (198 + ncp ~ 320) floats over the workgroup's threads
+    constexpr int TB = (8 * 192 + CH_THREADS - 1) / CH_THREADS, FB = (CH_FRAMES * 520 + CH_THREADS - 1) / CH_THREADS;
     auto frame_src = [&](int i) -> float {
       int f, o;
       frame_split(i, row, f, o);
@@ -782,19 +792,24 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
   CH_STAMP(11)
 }
 
-hipError_t launch_chain_sensors(const ChainArgs& a_in, hipStream_t stream) {
-  ChainArgs a = a_in;
-  const size_t lds = chain_lds_bytes(a.tab, CH_FRAMES);
+template <int FR, int NT>
+static hipError_t launch_chain_cfg(const ChainArgs& a, hipStream_t stream) {
+  const size_t lds = chain_lds_bytes(a.tab, FR);
   static size_t attr_set = 0;
   if (lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel<FR, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = lds;
   }
-  const int blocks = (a.T + CH_FRAMES - 1) / CH_FRAMES;
-  hipLaunchKernelGGL(chain_sensors_kernel, dim3(blocks), dim3(CH_THREADS), lds, stream, a);
+  const int blocks = (a.T + FR - 1) / FR;
+  hipLaunchKernelGGL((chain_sensors_kernel<FR, NT>), dim3(blocks), dim3(NT), lds, stream, a);
   return hipGetLastError();
+}
+
+hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream) {
+  if (a.T >= 16384 && chain_lds_bytes(a.tab, 4) <= 64 * 1024) return launch_chain_cfg<4, 256>(a, stream);
+  return launch_chain_cfg<2, 192>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
