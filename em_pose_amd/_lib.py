@@ -163,6 +163,13 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_mlp_train_bwd': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.POINTER(MlpGrads), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_lgd_assemble_inputs': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_void_p]),
+    'empose_lgd_additive_update': (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'empose_lgd_cotangent_step': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'empose_mlp_train_stash_floats': (C.c_size_t, [C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_bwd_deferred': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                C.c_void_p, C.POINTER(MlpGrads), C.c_int, C.c_void_p, C.c_void_p,

@@ -1223,6 +1223,39 @@ int empose_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, flo
   return EMPOSE_OK;
 }
 
+int empose_lgd_assemble_inputs(int T, int d_in, const float* x0, int ld_x0, const float* pose, const float* shape,
+                               float* X, int ldx, empose_stream_t stream_) {
+  if (!x0 || !pose || !shape || !X) return fail(EMPOSE_EINVAL, "null argument");
+  if (T <= 0 || d_in <= 0 || ld_x0 < d_in || ldx < d_in + 76) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_lgd_assemble(T, d_in, x0, ld_x0, pose, shape, X, ldx, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "assemble: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_lgd_additive_update(int B, int F, float step, int shape_avg, const float* pose, const float* d_pose,
+                               const float* shape, const float* d_shape, float* pose_next, float* shape_next,
+                               empose_stream_t stream_) {
+  if (!pose || !d_pose || !shape || !d_shape || !pose_next || !shape_next) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_lgd_update(B, F, step, shape_avg, pose, d_pose, shape, d_shape, pose_next, shape_next,
+                                   static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "update: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
+int empose_lgd_cotangent_step(int B, int F, int first, const float* d_pose, const float* d_shape, const float* vp,
+                              const float* vs, const float* g_theta, int ld_g, const float* g_beta, int ld_gb, float* Dp,
+                              float* Ds, float step, int shape_avg, float* dpad, float* dspad, empose_stream_t stream_) {
+  if (!d_pose || !d_shape || !vp || !vs || !Dp || !Ds) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0 || (size_t)F * 10 * sizeof(float) > 48 * 1024) return fail(EMPOSE_EINVAL, "bad sizes");
+  if ((g_theta && ld_g < 66) || (g_beta && ld_gb < 10) || ((dpad == nullptr) != (dspad == nullptr)))
+    return fail(EMPOSE_EINVAL, "bad arguments");
+  hipError_t e = launch_lgd_cotangent(B, F, first, d_pose, d_shape, vp, vs, g_theta, ld_g, g_beta, ld_gb, Dp, Ds, step,
+                                      shape_avg, dpad, dspad, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "cotangent step: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
 size_t empose_lgd_losses_workspace_bytes(int B, int F, int n_hist) {
   if (B <= 0 || F <= 0 || n_hist <= 0) return 0;
   return (size_t)4 * n_hist * B * F * sizeof(float) + 256;

@@ -159,6 +159,14 @@ struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] 
 hipError_t launch_window_mean(const float* in, int ld_in, float* out, int ld_out, int T, int F, int C, hipStream_t stream);
 hipError_t launch_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
                           float* out, int ldo, hipStream_t stream);
+hipError_t launch_lgd_assemble(int T, int d_in, const float* x0, int ld0, const float* pose, const float* shape, float* X,
+                               int ldx, hipStream_t stream);
+hipError_t launch_lgd_update(int B, int F, float step, int shape_avg, const float* pose, const float* d_pose,
+                             const float* shape, const float* d_shape, float* pose_next, float* shape_next,
+                             hipStream_t stream);
+hipError_t launch_lgd_cotangent(int B, int F, int first, const float* d_pose, const float* d_shape, const float* vp,
+                                const float* vs, const float* g_theta, int ld_g, const float* g_beta, int ld_gb, float* Dp,
+                                float* Ds, float step, int shape_avg, float* dpad, float* dspad, hipStream_t stream);
 struct LossArgs {
   int B, F, N1, n_markers;
   int used_slot[12];                       // column slot of virtual sensor m in the network input, or -1

@@ -396,6 +396,120 @@ hipError_t launch_axpby2d(int rows, int cols, float alpha, const float* x, int l
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The bookkeeping of the LGD loop around the update networks, one launch each instead of a handful of axpby / mean
+// launches (at the reference's training batch of 12 windows a step is launch-bound: every launch saved is ~5 us).
+// Same operations in the same order as the separate kernels they replace.
+// ---------------------------------------------------------------------------------------------------------------
+// X[t] = [ x0[t] (d_in) | pose[t] (66) | shape[t] (10) | (the gradient columns are written by the body-model kernel) ]
+__global__ void lgd_assemble_kernel(int T, int d_in, const float* x0, int ld0, const float* pose, const float* shape,
+                                    float* X, int ldx) {
+  const int w = d_in + 76;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)T * w) return;
+  const int t = (int)(idx / w), c = (int)(idx - (long)t * w);
+  float v;
+  if (c < d_in) v = x0[(size_t)t * ld0 + c];
+  else if (c < d_in + 66) v = pose[(size_t)t * 66 + (c - d_in)];
+  else v = shape[(size_t)t * 10 + (c - d_in - 66)];
+  X[(size_t)t * ldx + c] = v;
+}
+hipError_t launch_lgd_assemble(int T, int d_in, const float* x0, int ld0, const float* pose, const float* shape, float* X,
+                               int ldx, hipStream_t stream) {
+  const long n = (long)T * (d_in + 76);
+  hipLaunchKernelGGL(lgd_assemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, T, d_in, x0, ld0, pose,
+                     shape, X, ldx);
+  return hipGetLastError();
+}
+
+// pose_next = pose + step * d_pose;  shape_next = shape + step * (shape_avg ? window mean of d_shape : d_shape).
+// One workgroup per window of F frames (reference models.py:529-535, 588-600).
+__global__ __launch_bounds__(256) void lgd_update_kernel(int F, float step, int shape_avg, const float* pose,
+                                                         const float* d_pose, const float* shape, const float* d_shape,
+                                                         float* pose_next, float* shape_next) {
+  __shared__ float mean[10];
+  const size_t t0 = (size_t)blockIdx.x * F;
+  if (shape_avg && threadIdx.x < 10) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += d_shape[(t0 + f) * 10 + threadIdx.x];
+    mean[threadIdx.x] = s / (float)F;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < F * 76; i += 256) {
+    const int f = i / 76, c = i - f * 76;
+    const size_t t = t0 + f;
+    if (c < 66) pose_next[t * 66 + c] = step * d_pose[t * 66 + c] + pose[t * 66 + c];
+    else {
+      const int k = c - 66;
+      const float d = shape_avg ? mean[k] : d_shape[t * 10 + k];
+      shape_next[t * 10 + k] = step * d + shape[t * 10 + k];
+    }
+  }
+}
+hipError_t launch_lgd_update(int B, int F, float step, int shape_avg, const float* pose, const float* d_pose,
+                             const float* shape, const float* d_shape, float* pose_next, float* shape_next,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(lgd_update_kernel, dim3(B), dim3(256), 0, stream, F, step, shape_avg, pose, d_pose, shape, d_shape,
+                     pose_next, shape_next);
+  return hipGetLastError();
+}
+
+// Reverse sweep, entry i of the histories: the running cotangents of the estimates
+//   Dp = [Dp +] d_pose_i + vp_i [+ g_theta_i / T],   Ds likewise           (loss terms, body-model VJP, the reference's
+//   in-forward E_i.backward() deposit, models.py:576)
+// and, for i > 0, the cotangents of the update networks' outputs of iteration i - 1, zero-padded to the GEMM grid:
+//   dpad[:, :66] = step * Dp,   dspad[:, :10] = step * (shape_avg ? window mean of Ds : Ds)   (adjoint of the mean = mean)
+__global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, int first, const float* d_pose,
+                                                            const float* d_shape, const float* vp, const float* vs,
+                                                            const float* g_theta, int ld_g, const float* g_beta, int ld_gb,
+                                                            float* Dp, float* Ds, float step, int shape_avg, float* dpad,
+                                                            float* dspad) {
+  extern __shared__ float sds[];   // [F][10]
+  const size_t t0 = (size_t)blockIdx.x * F;
+  for (int i = threadIdx.x; i < F * 76; i += 256) {
+    const int f = i / 76, c = i - f * 76;
+    const size_t t = t0 + f;
+    if (c < 66) {
+      float v = d_pose[t * 66 + c];
+      if (!first) v = v + Dp[t * 66 + c];
+      v = vp[t * 66 + c] + v;
+      if (g_theta) v = inv_T * g_theta[t * ld_g + c] + v;
+      Dp[t * 66 + c] = v;
+      if (dpad) dpad[t * 68 + c] = step * v;
+    } else {
+      const int k = c - 66;
+      float v = d_shape[t * 10 + k];
+      if (!first) v = v + Ds[t * 10 + k];
+      v = vs[t * 10 + k] + v;
+      if (g_beta) v = inv_T * g_beta[t * ld_gb + k] + v;
+      Ds[t * 10 + k] = v;
+      sds[f * 10 + k] = v;
+    }
+  }
+  if (!dspad) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < F * 10; i += 256) {
+    const int f = i / 10, k = i - f * 10;
+    float v;
+    if (shape_avg) {
+      float s = 0.f;
+      for (int ff = 0; ff < F; ++ff) s += sds[ff * 10 + k];
+      v = s / (float)F;
+    } else {
+      v = sds[i];
+    }
+    dspad[(t0 + f) * 12 + k] = step * v;
+  }
+}
+hipError_t launch_lgd_cotangent(int B, int F, int first, const float* d_pose, const float* d_shape, const float* vp,
+                                const float* vs, const float* g_theta, int ld_g, const float* g_beta, int ld_gb, float* Dp,
+                                float* Ds, float step, int shape_avg, float* dpad, float* dspad, hipStream_t stream) {
+  const float inv_T = 1.f / (float)((long)B * F);
+  hipLaunchKernelGGL(lgd_cotangent_kernel, dim3(B), dim3(256), (size_t)F * 10 * sizeof(float), stream, F, inv_T, first,
+                     d_pose, d_shape, vp, vs, g_theta, ld_g, g_beta, ld_gb, Dp, Ds, step, shape_avg, dpad, dspad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Losses of IterativeErrorFeedback.backward and their cotangents (reference models.py:634-688, loss.py:13-41):
 //   total = (w_pose sum_i L1(pose_i) + w_shape sum_i L1(shape_i) + w_fk (N+1) FK(joints_N) + w_rec sum_i REC_i) / (N+1)
 //   L1: |hat - gt| averaged over the features, summed over the valid frames / len_b, averaged over the batch

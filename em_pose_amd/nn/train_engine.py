@@ -247,20 +247,17 @@ class LgdTrainEngine(object):
                     Xi[:, d_in + 142:].data_ptr() if want_g else None, d_x, ws_smpl.data_ptr(), nb_smpl, self.stream))
                 if i == N:
                     break
-                self._axpby(T, d_in, 1.0, x0.data_ptr(), d_in, 0.0, None, 0, Xi.data_ptr(), d_x)
-                self._axpby(T, 66, 1.0, pose_hist[i].data_ptr(), 66, 0.0, None, 0, Xi[:, d_in:].data_ptr(), d_x)
-                self._axpby(T, 10, 1.0, shape_hist[i].data_ptr(), 10, 0.0, None, 0, Xi[:, d_in + 66:].data_ptr(), d_x)
+                # network input rows [x0 | pose_i | shape_i | g_pose | g_shape] (the gradients are already there)
+                _lib.check(lib.empose_lgd_assemble_inputs(T, d_in, x0.data_ptr(), d_in, pose_hist[i].data_ptr(),
+                                                          shape_hist[i].data_ptr(), Xi.data_ptr(), d_x, self.stream))
                 sp = self._mlp_fwd(views[0], Xi.data_ptr(), d_x, dp.data_ptr(), 66, T)
                 ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T)
                 saves.append((sp, ss))
-                if net.shape_avg:
-                    _lib.check(lib.empose_window_mean(T, F, 10, tmp10.data_ptr(), 10, ds.data_ptr(), 10, self.stream))
-                    d_shape = ds
-                else:
-                    d_shape = tmp10
-                self._axpby(T, 66, s, dp.data_ptr(), 66, 1.0, pose_hist[i].data_ptr(), 66, pose_hist[i + 1].data_ptr(), 66)
-                self._axpby(T, 10, s, d_shape.data_ptr(), 10, 1.0, shape_hist[i].data_ptr(), 10,
-                            shape_hist[i + 1].data_ptr(), 10)
+                # pose_{i+1} = pose_i + s dp, shape_{i+1} = shape_i + s (window mean of) ds
+                _lib.check(lib.empose_lgd_additive_update(B, F, s, int(bool(net.shape_avg)), pose_hist[i].data_ptr(),
+                                                          dp.data_ptr(), shape_hist[i].data_ptr(), tmp10.data_ptr(),
+                                                          pose_hist[i + 1].data_ptr(), shape_hist[i + 1].data_ptr(),
+                                                          self.stream))
         ctx.update({'pose_hist': pose_hist, 'shape_hist': shape_hist, 'markers_hist': markers_hist, 'ori_hist': ori_hist,
                     'joints_hist': joints_hist, 'X': X, 'views': views, 'saves': saves, 'smpl_h': smpl_h})
         hist = {'pose': list(pose_hist), 'shape': list(shape_hist), 'joints': list(joints_hist),
@@ -324,25 +321,18 @@ class LgdTrainEngine(object):
                     ctx['offset_r'].data_ptr(), ctx['offset_t'].data_ptr(), d_mark[i].data_ptr(), d_ori[i].data_ptr(),
                     d_joints.data_ptr() if i == N else None, vp.data_ptr(), vs.data_ptr(), ws_vjp.data_ptr(), nb_vjp,
                     self.stream))
-                first = i == N
-                self._axpby(T, 66, 1.0, d_pose[i].data_ptr(), 66, 0.0 if first else 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
-                self._axpby(T, 10, 1.0, d_shape[i].data_ptr(), 10, 0.0 if first else 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
-                self._axpby(T, 66, 1.0, vp.data_ptr(), 66, 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
-                self._axpby(T, 10, 1.0, vs.data_ptr(), 10, 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
-                if i < N and net.use_gradient:
-                    # the reference's `E_i.backward()` inside forward (models.py:576): dE_i/d(pose_i) = g_i / (B F) flows
-                    # into everything that produced pose_i
-                    self._axpby(T, 66, 1.0 / T, X[i][:, d_in + 76:].data_ptr(), d_x, 1.0, Dp.data_ptr(), 66, Dp.data_ptr(), 66)
-                    self._axpby(T, 10, 1.0 / T, X[i][:, d_in + 142:].data_ptr(), d_x, 1.0, Ds.data_ptr(), 10, Ds.data_ptr(), 10)
+                # running cotangents of the estimates (loss terms + body-model VJP + the reference's in-forward
+                # `E_i.backward()` deposit, models.py:576: dE_i/d(pose_i) = g_i / (B F) flows into everything that produced
+                # pose_i) and, for i > 0, the zero-padded cotangents of the update networks' outputs of iteration i - 1
+                deposit = i < N and net.use_gradient
+                _lib.check(lib.empose_lgd_cotangent_step(
+                    B, F, int(i == N), d_pose[i].data_ptr(), d_shape[i].data_ptr(), vp.data_ptr(), vs.data_ptr(),
+                    X[i][:, d_in + 76:].data_ptr() if deposit else None, d_x,
+                    X[i][:, d_in + 142:].data_ptr() if deposit else None, d_x, Dp.data_ptr(), Ds.data_ptr(), s,
+                    int(bool(net.shape_avg)), dpad.data_ptr() if i > 0 else None, dspad.data_ptr() if i > 0 else None,
+                    self.stream))
                 if i == 0:
                     break
-                # cotangents of the update networks' outputs of iteration i - 1
-                self._axpby(T, 66, s, Dp.data_ptr(), 66, 0.0, None, 0, dpad.data_ptr(), 68)
-                if net.shape_avg:
-                    _lib.check(lib.empose_window_mean(T, F, 10, Ds.data_ptr(), 10, tmp10.data_ptr(), 10, self.stream))
-                    self._axpby(T, 10, s, tmp10.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
-                else:
-                    self._axpby(T, 10, s, Ds.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
                 sp, ss = ctx['saves'][i - 1]
                 acc = i < N
                 if deferred:

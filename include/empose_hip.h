@@ -338,6 +338,25 @@ int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* o
 int empose_axpby2d(int rows, int cols, float alpha, const float* x, int ldx, float beta, const float* y, int ldy,
                    float* out, int ldo, empose_stream_t stream);
 
+/* Bookkeeping of the LGD loop around the update networks as single launches (each replaces 3-9 axpby / mean launches; at
+ * the reference's training batch a step is launch-bound):
+ *   assemble_inputs   X[t] = [x0[t] (d_in) | pose[t] (66) | shape[t] (10)]; the gradient columns d_in+76.. are written by
+ *                     empose_smpl_sensors_fwd_bwd (reference models.py:584)
+ *   additive_update   pose_next = pose + step d_pose, shape_next = shape + step (mean over the window of) d_shape
+ *                     (reference models.py:588-600)
+ *   cotangent_step    reverse sweep at history entry i: Dp = [Dp +] d_pose + vp [+ g_theta / (B F)], Ds likewise (loss
+ *                     terms, body-model VJP, the in-forward E_i.backward() deposit of models.py:576), and with dpad / dspad
+ *                     the zero-padded cotangents [T][68] / [T][12] of the update networks' outputs:
+ *                     step * Dp, step * (window mean of) Ds.  `first`: Dp / Ds are overwritten, not accumulated. */
+int empose_lgd_assemble_inputs(int T, int d_in, const float* x0, int ld_x0, const float* pose, const float* shape,
+                               float* X, int ldx, empose_stream_t stream);
+int empose_lgd_additive_update(int B, int F, float step, int shape_avg, const float* pose, const float* d_pose,
+                               const float* shape, const float* d_shape, float* pose_next, float* shape_next,
+                               empose_stream_t stream);
+int empose_lgd_cotangent_step(int B, int F, int first, const float* d_pose, const float* d_shape, const float* vp,
+                              const float* vs, const float* g_theta, int ld_g, const float* g_beta, int ld_gb, float* Dp,
+                              float* Ds, float step, int shape_avg, float* dpad, float* dspad, empose_stream_t stream);
+
 /* The loss of IterativeErrorFeedback.backward (reference models.py:634-688, loss.py:13-41) and the cotangents of the
  * total loss with respect to every history entry, in one pass. */
 typedef struct {
