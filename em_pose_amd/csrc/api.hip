@@ -1637,7 +1637,15 @@ int empose_lstm_train_fwd(const empose_lstm_params* p, int B, int F, const float
     if (c0) HIP_TRY(hipMemcpyAsync(ua.c, c0 + l * bh, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
     else HIP_TRY(hipMemsetAsync(ua.c, 0, bh * sizeof(float), stream));
   }
-  for (int s = 0; s < F + L - 1; ++s) {
+  // Small batches (the reference's training batch of 12 windows): the whole sequence in one cooperative launch with the
+  // weights in registers, as in inference -- the step-by-step kernel streams 13.8 MB of weights per wavefront step.
+  bool done = false;
+  if (w.st.xch && F >= 4 && options().lstm_persist != 0) {
+    a.s = 0;
+    hipError_t e = launch_lstm_persist(a, w.st.xch, stream, &done);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel: %s", hipGetErrorString(e));
+  }
+  for (int s = 0; !done && s < F + L - 1; ++s) {
     a.s = s;
     hipError_t e = launch_lstm_wave(a, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step: %s", hipGetErrorString(e));

@@ -821,6 +821,14 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
           __hip_atomic_store(a.xch + (size_t)(s & 1) * xch_buf + (size_t)l * xch_layer + hc,
                              xch_pack(failed ? poison : h_reg, (unsigned)(s + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (U.y) U.y[((size_t)lane * F + k) * U.y_ld + U.y_col + unit] = failed ? poison : h_new;
+          if (U.sv_gates) {   // training forward: what back-propagation through time reads (as lstm_small_kernel)
+            const size_t rt = (size_t)lane * F + k;
+            float* sg = U.sv_gates + rt * 4 * H + unit;
+            sg[0] = fsigmoid(gi + bias[0]); sg[H] = fsigmoid(gf + bias[1]);
+            sg[2 * H] = ftanh(gg + bias[2]); sg[3 * H] = fsigmoid(go + bias[3]);
+            U.sv_c[rt * H + unit] = failed ? poison : c_reg;
+            if (k + 1 < F) U.sv_hprev[(rt + 1) * H + unit] = failed ? poison : h_reg;
+          }
         }
       }
     }

@@ -1386,6 +1386,38 @@ def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
         np.testing.assert_allclose(g_.grad.cpu().numpy(), w.grad.numpy(), atol=1e-4 * scale)
 
 
+def test_lstm_training_forward_whole_sequence_kernel_equals_step_launches():
+    """Small batches run the training forward as one cooperative launch too (lstm_persist_kernel now stores the gates /
+    cell states / incoming hidden states that back-propagation through time reads): same bits as the step-by-step
+    launches (option lstm_persist = 0) for outputs, final state and every gradient, ragged lengths and carried state."""
+    from em_pose_amd.nn.layers import _LstmTrainFn
+    torch.manual_seed(11)
+    B, F, K, H, L = 12, 32, 144, 512, 2
+    x = torch.randn(B, F, K, device=DEV)
+    lens = torch.randint(1, F + 1, (B,), dtype=torch.int32)
+    lens[3] = F
+    h0, c0 = 0.5 * torch.randn(L, B, H, device=DEV), 0.5 * torch.randn(L, B, H, device=DEV)
+    dy = torch.randn(B, F, H, device=DEV)
+    ws = [0.05 * torch.randn(*shape, device=DEV) for l in range(L)
+          for shape in ((4 * H, K if l == 0 else H), (4 * H, H), (4 * H,), (4 * H,))]
+    lib = _lib.lib()
+    res = {}
+    for mode in (1, 0):
+        _lib.check(lib.empose_set_option(b'lstm_persist', mode))
+        try:
+            wg = [w.clone().requires_grad_(True) for w in ws]
+            xg = x.clone().requires_grad_(True)
+            y, h_n, c_n = _LstmTrainFn.apply(xg, lens.to(DEV), h0, c0, L, *wg)
+            (y * dy).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = [y.detach(), h_n, c_n, xg.grad] + [w.grad for w in wg]
+        finally:
+            _lib.check(lib.empose_set_option(b'lstm_persist', 1))
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[1][0]).all()
+
+
 def test_hip_adam_equals_torch_adam():
     """empose_adam_step (one launch over all tensors) against torch.optim.Adam, three steps."""
     from em_pose_amd.helpers.optim import HipAdam
