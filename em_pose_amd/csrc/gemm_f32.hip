@@ -553,7 +553,113 @@ hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK };
+// ---------------------------------------------------------------------------------------------------------------
+// A handful of rows against a long K (back-propagation through time at the reference's training batch: dh = dG . W_hh
+// is 12 x 2048 . 2048 x 512, sixty-four times per step): a matrix-vector problem bound by streaming W once.  The 32 x 32
+// split-K tile leaves it on 16 workgroups that each walk 256 KB (19.9 us per call); here a wave owns ONE output column,
+// its lanes split K in 16-byte pieces (coalesced 1 KB reads of the weight row, all in flight at once), the rows of A
+// are staged in LDS once per workgroup, and the lane sums meet in a butterfly -- a fixed order: reproducible results.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FEWROWS_MAX_M = 16;
+constexpr size_t FEWROWS_MAX_LDS = 128 * 1024;   // the rows of A (M x K floats) are staged in LDS once per workgroup
+__global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
+  extern __shared__ __attribute__((aligned(16))) float arow[];   // [M][K]
+  const GemmProb& p = b.p[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x * 4 + wave;
+  const int M = p.M, N = p.N, K = p.K;
+  const int k4n = K >> 2;
+  {
+    const float* __restrict__ A = p.A;
+    constexpr int SB = 8;   // 16-byte pieces per thread in flight: a round trip per batch, not per piece
+    for (int i0 = threadIdx.x; i0 < M * k4n; i0 += 256 * SB) {
+      f32x4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int i = i0 + u * 256;
+        const int m = i / k4n, c = i - m * k4n;
+        v[u] = i < M * k4n ? *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int i = i0 + u * 256;
+        const int m = i / k4n, c = i - m * k4n;
+        if (i < M * k4n) *reinterpret_cast<f32x4*>(arow + (size_t)m * K + c * 4) = v[u];
+      }
+    }
+  }
+  // this wave's weight row: all of its 16-byte pieces requested before the barrier
+  constexpr int WMAX = 8;   // K <= 64 lanes x 4 x 8 = 2048 per pass
+  const float* __restrict__ wrow = p.W + (size_t)(n < N ? n : N - 1) * p.ldw;
+  float acc[FEWROWS_MAX_M];
+#pragma unroll
+  for (int m = 0; m < FEWROWS_MAX_M; ++m) acc[m] = 0.f;
+  for (int kb = 0; kb < K; kb += 256 * WMAX) {
+    f32x4 w[WMAX];
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) {
+      const int k4 = kb + j * 256 + lane * 4;
+      w[j] = k4 < K ? *reinterpret_cast<const f32x4*>(wrow + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (kb == 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) {
+      const int k4 = kb + j * 256 + lane * 4;
+      if (kb + j * 256 >= K) break;        // uniform
+      const int kk = k4 < K ? k4 : 0;      // (lanes past a ragged K multiply zeros)
+#pragma unroll
+      for (int m = 0; m < FEWROWS_MAX_M; ++m) {
+        if (m >= M) break;                 // uniform
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (size_t)m * K + kk);
+        acc[m] = __builtin_fmaf(a[3], w[j][3], __builtin_fmaf(a[2], w[j][2], __builtin_fmaf(a[1], w[j][1], __builtin_fmaf(a[0], w[j][0], acc[m]))));
+      }
+    }
+  }
+  if (n >= N) return;
+  float out = 0.f;   // lane m ends up with row m
+#pragma unroll
+  for (int m = 0; m < FEWROWS_MAX_M; ++m) {
+    if (m >= M) break;
+    float v = acc[m];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == m) out = v;
+  }
+  if (lane < M) {
+    float y = out * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+    if (p.act == 2) {
+      if (p.resid) y += p.resid[(size_t)lane * p.ldr + n];
+      y = y > 0.f ? y : 0.f;
+    } else {
+      if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
+      if (p.resid) y += p.resid[(size_t)lane * p.ldr + n];
+    }
+    p.C[(size_t)lane * p.ldc + n] = y;
+  }
+}
+
+static hipError_t launch_fewrows(const GemmBatch& batch, hipStream_t stream) {
+  int maxN = 0;
+  size_t lds = 0;
+  for (int i = 0; i < batch.count; ++i) {
+    maxN = batch.p[i].N > maxN ? batch.p[i].N : maxN;
+    const size_t l = (size_t)batch.p[i].M * batch.p[i].K * sizeof(float);
+    lds = l > lds ? l : lds;
+  }
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fewrows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FEWROWS_MAX_LDS);
+    if (e != hipSuccess) return e;
+    attr = FEWROWS_MAX_LDS;
+  }
+  dim3 grid((maxN + 3) / 4, batch.count);
+  hipLaunchKernelGGL(gemm_fewrows_kernel, grid, dim3(256), lds, stream, batch);
+  return hipGetLastError();
+}
+
+enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK, PICK_FEWROWS };
 
 static GemmPick pick_gemm(const GemmBatch& batch) {
   int maxM = 0, maxN = 0;
@@ -575,6 +681,13 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
   const bool splitk_on = options().gemm_splitk != 0;
   int minK = 1 << 30;
   for (int i = 0; i < batch.count; ++i) minK = batch.p[i].K < minK ? batch.p[i].K : minK;
+  {   // matrix-vector shape
+    int maxK = 0;
+    for (int i = 0; i < batch.count; ++i) maxK = batch.p[i].K > maxK ? batch.p[i].K : maxK;
+    if (splitk_on && maxM <= FEWROWS_MAX_M && minK >= 1024 && maxN >= 64 &&
+        (size_t)maxM * maxK * sizeof(float) <= FEWROWS_MAX_LDS)
+      return PICK_FEWROWS;
+  }
   if (splitk_on && minK >= 64 && nblocks(32, 32) <= SPLITK_MAX_TILES) return PICK_SPLITK;
   if (shortm && narrow) return PICK_S11;
   if (shortm) return PICK_S12;
@@ -601,6 +714,7 @@ const char* gemm_kernel_name(int M, int N, int K, int count, int role) {
   for (int i = 0; i < count && i < 2; ++i) { b.p[i] = GemmProb{}; b.p[i].M = M; b.p[i].N = N; b.p[i].K = K; }
   switch (pick_gemm(b)) {
     case PICK_SPLITK: return "gemm_splitk_f32_kernel";
+    case PICK_FEWROWS: return "gemm_fewrows_kernel";
     case PICK_S11: return "gemm_tn_f32_kernel<Cfg<2,2,1,1,32,false>,0>";
     case PICK_S12: return "gemm_tn_f32_kernel<Cfg<2,2,1,2,32,false>,0>";
     case PICK_S21: return "gemm_tn_f32_kernel<Cfg<2,2,2,1,32,false>,0>";
@@ -614,6 +728,7 @@ hipError_t launch_gemm(const GemmBatch& batch_in, hipStream_t stream) {
   batch.xcd_swizzle = 1;
   switch (pick_gemm(batch)) {
     case PICK_SPLITK: return launch_splitk(batch, stream);
+    case PICK_FEWROWS: return launch_fewrows(batch, stream);
     case PICK_S11: return launch_cfg<CfgS11>(batch, stream);
     case PICK_S12: return launch_cfg<CfgS12>(batch, stream);
     case PICK_S21: return launch_cfg<CfgS21>(batch, stream);
