@@ -83,7 +83,7 @@ class MlpParams(C.Structure):    # empose_mlp_params: DEVICE pointers
                 ('bn_weight', C.c_void_p * MAX_DENSE), ('bn_bias', C.c_void_p * MAX_DENSE),
                 ('bn_running_mean', C.c_void_p * MAX_DENSE), ('bn_running_var', C.c_void_p * MAX_DENSE),
                 ('bn_num_batches', C.c_void_p * MAX_DENSE), ('prelu', C.c_void_p * MAX_DENSE),
-                ('bn_eps', C.c_float), ('bn_momentum', C.c_float)]
+                ('bn_eps', C.c_float), ('bn_momentum', C.c_float), ('weight_t', C.c_void_p * MAX_DENSE)]
 
 
 class MlpGrads(C.Structure):     # empose_mlp_grads

@@ -1439,10 +1439,14 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       e = launch_gemm_atb(ab, w.atb, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
     }
-    HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
-    e = launch_transpose(p->weight[l], H, w.wt, op, p->out_dim, H, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
-    e = gemm(d_out, ld_dout, w.wt, op, w.d[0], H, H, op);
+    const float* wt = p->weight_t[l];
+    if (!wt) {
+      HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
+      e = launch_transpose(p->weight[l], H, w.wt, op, p->out_dim, H, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+      wt = w.wt;
+    }
+    e = gemm(d_out, ld_dout, wt, op, w.d[0], H, H, op);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
   }
   const int cur = 0;   // w.d[0]: cotangent of the current layer's activation; w.d[1]: dZ when it is not stashed
@@ -1467,9 +1471,13 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
     }
     if (l == 0) break;
-    e = launch_transpose(p->weight[l], H, w.wt, H, H, H, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
-    e = gemm(dz, H, w.wt, H, w.d[cur], H, H, H);   // the cotangent of the layer below overwrites the consumed one
+    const float* wt = p->weight_t[l];
+    if (!wt) {
+      e = launch_transpose(p->weight[l], H, w.wt, H, H, H, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+      wt = w.wt;
+    }
+    e = gemm(dz, H, wt, H, w.d[cur], H, H, H);   // the cotangent of the layer below overwrites the consumed one
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;

@@ -42,6 +42,7 @@ class _MlpView(object):
         self.in_dim = self.specs[0][0].in_features
         self.hidden = self.specs[0][0].out_features
         self.out_dim = self.specs[-1][0].out_features
+        self.weight_t = None
 
     @staticmethod
     def supported(mlp):
@@ -68,7 +69,21 @@ class _MlpView(object):
                     p.bn_num_batches[l] = bn.num_batches_tracked.data_ptr()
                 p.prelu[l] = act.weight.data_ptr()
                 p.bn_eps, p.bn_momentum = float(bn.eps), float(bn.momentum)
+        for l, t in enumerate(self.weight_t or ()):   # transposed once per step (prepare_backward)
+            if t is not None:
+                p.weight_t[l] = t.data_ptr()
         return p
+
+    def prepare_backward(self, lib, stream):
+        """W^T of layers 1.. (what dX = dY . W needs on the K-contiguous GEMM): once per step instead of once per
+        application of the network -- the weights do not change inside a step."""
+        self.weight_t = [None]
+        for lin, _, _ in self.specs[1:]:
+            n_out, n_in = lin.weight.shape
+            ld = (n_out + 3) & ~3
+            t = torch.zeros(n_in, ld, dtype=torch.float32, device=lin.weight.device)
+            _lib.check(lib.empose_transpose_f32(n_out, n_in, lin.weight.data_ptr(), n_in, t.data_ptr(), ld, stream))
+            self.weight_t.append(t)
 
     def parameter_list(self):
         out = []
@@ -314,6 +329,8 @@ class LgdTrainEngine(object):
             grads = [[torch.empty_like(p) for p in v.parameter_list()] for v in views]
             X = ctx['X']
             deferred = self.batched_wgrad and 1 <= N <= 8   # (row counts off the 32-row grid: per application inside)
+            for v in views:
+                v.prepare_backward(lib, self.stream)
             pend = ([], [])
             for i in range(N, -1, -1):
                 _lib.check(lib.empose_smpl_sensors_vjp(

@@ -294,6 +294,11 @@ typedef struct {
   long long* bn_num_batches[EMPOSE_MAX_DENSE];
   const float* prelu[EMPOSE_MAX_DENSE];       /* one device float per layer */
   float bn_eps, bn_momentum;
+  /* Optional, backward only: the weights of layers 1 .. n_layers-1 transposed, [in_l][out_l] with the leading dimension
+   * of the last layer padded to a multiple of 4 and its padding columns ZERO (empose_transpose_f32 into a zeroed buffer).
+   * With NULL entries the backward transposes the weights itself on every call; a caller that applies the network
+   * several times per step (the LGD loop) transposes once per step instead. */
+  const float* weight_t[EMPOSE_MAX_DENSE];
 } empose_mlp_params;
 typedef struct {                /* gradient outputs, shapes of the parameters */
   float* weight[EMPOSE_MAX_DENSE];
