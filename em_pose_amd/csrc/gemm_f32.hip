@@ -399,8 +399,9 @@ static hipError_t launch_large(const GemmBatch& batch, hipStream_t stream) {
 // MLP kernel, no LDS, no barrier), the four partial tiles meet in LDS and are added in wave order, each wave finishes a
 // quarter of the tile.  Four times as many workgroups, a quarter of the MFMA chain per wave.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_splitk_f32_kernel(GemmBatch batch) {
-  __shared__ float red[4 * 16 * 64];
+template <int NW>   // waves that split K: 4, or 8 for a long K on few tiles (256 x 512 x 2048: 24.5 -> see DESIGN)
+__global__ __launch_bounds__(NW * 64) void gemm_splitk_f32_kernel(GemmBatch batch) {
+  __shared__ float red[NW * 16 * 64];
   const GemmProb& p = batch.p[blockIdx.y];
   const int M = p.M, N = p.N, K = p.K;
   const int nt_n = (N + 31) / 32, nt_m = (M + 31) / 32;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_f32_kernel(GemmBatch batch) {
   const int m0 = ((int)blockIdx.x / nt_n) * 32, n0 = ((int)blockIdx.x % nt_n) * 32;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int KG = (K + 7) / 8, gq = (KG + 3) / 4;
+  const int KG = (K + 7) / 8, gq = (KG + NW - 1) / NW;
   const int g_beg = wave * gq, g_end = min(g_beg + gq, KG);
   const float* __restrict__ arow = p.A + (size_t)min(m0 + l31, M - 1) * p.lda + lh * 4;
   const float* __restrict__ wrow = p.W + (size_t)min(n0 + l31, N - 1) * p.ldw + lh * 4;
@@ -440,13 +441,13 @@ __global__ __launch_bounds__(256) void gemm_splitk_f32_kernel(GemmBatch batch) {
   const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
   const float slope = p.act == 1 ? p.slope : 1.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 4 + i;
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int r = wave * (16 / NW) + i;
     const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // C/D layout of the 32x32 MFMA
     if (row >= M) continue;
     float v = red[(0 * 16 + r) * 64 + lane];
 #pragma unroll
-    for (int w2 = 1; w2 < 4; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
+    for (int w2 = 1; w2 < NW; ++w2) v += red[(w2 * 16 + r) * 64 + lane];
     float y = v * sc + sh;
     if (p.act == 2) {          // relu(W x + b + x), reference layers.py:170-182
       if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
@@ -466,7 +467,13 @@ static hipError_t launch_splitk(const GemmBatch& batch, hipStream_t stream) {
     blocks = t > blocks ? t : blocks;
   }
   if (blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(gemm_splitk_f32_kernel, dim3(blocks, batch.count), dim3(256), 0, stream, batch);
+  int minK = 1 << 30;
+  for (int i = 0; i < batch.count; ++i) minK = batch.p[i].K < minK ? batch.p[i].K : minK;
+  // a long K on few tiles (the recurrent products of back-propagation through time at a few hundred rows): eight waves
+  if (minK >= 1024 && (long)blocks * batch.count <= 256)
+    hipLaunchKernelGGL(gemm_splitk_f32_kernel<8>, dim3(blocks, batch.count), dim3(512), 0, stream, batch);
+  else
+    hipLaunchKernelGGL(gemm_splitk_f32_kernel<4>, dim3(blocks, batch.count), dim3(256), 0, stream, batch);
   return hipGetLastError();
 }
 

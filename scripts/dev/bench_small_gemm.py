@@ -5,7 +5,7 @@ import torch
 from em_pose_amd import _lib
 lib = _lib.lib(); dev = 'cuda:0'
 for M, N, K in ((384, 512, 512), (384, 512, 296), (384, 66, 512), (384, 296, 512), (12, 512, 2048), (12, 2048, 512),
-                (384, 2048, 144), (384, 2048, 512), (8192, 512, 512)):
+                (384, 2048, 144), (384, 2048, 512), (256, 512, 2048), (64, 512, 2048), (8192, 512, 512)):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); y = torch.empty(M, N, device=dev)
     def run():
         _lib.check(lib.empose_linear_f32(_lib.dptr(x), K, _lib.dptr(w), K, _lib.dptr(y), N, M, N, K, None, None, 0, 0.0, None))

@@ -61,7 +61,8 @@ def test_library_reports_gfx950():
 
 @pytest.mark.parametrize('M,N,K', [(1, 4, 4), (64, 64, 32), (100, 66, 296), (257, 10, 512), (1000, 512, 144),
                                    (4096, 512, 512), (333, 200, 320), (130, 2048, 72),
-                                   (12, 512, 2048), (1, 67, 1024), (16, 130, 1100)])   # the last three: gemm_fewrows_kernel
+                                   (12, 512, 2048), (1, 67, 1024), (16, 130, 1100),    # these three: gemm_fewrows_kernel
+                                   (256, 512, 2048), (100, 64, 1024)])                 # eight-wave split-K
 def test_linear_f32(M, N, K):
     rng = np.random.default_rng(M * 7 + N)
     lda = K + 8
