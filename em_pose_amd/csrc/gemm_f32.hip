@@ -569,55 +569,66 @@ hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int FEWROWS_MAX_M = 16;
 constexpr size_t FEWROWS_MAX_LDS = 128 * 1024;   // the rows of A (M x K floats) are staged in LDS once per workgroup
+template <int MB>   // rows computed (M rounded up to a multiple of 4; rows past M are staged as zeros, never stored)
 __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
-  extern __shared__ __attribute__((aligned(16))) float arow[];   // [M][K]
+  extern __shared__ __attribute__((aligned(16))) float arow[];   // [MB][K]
   const GemmProb& p = b.p[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = blockIdx.x * 4 + wave;
   const int M = p.M, N = p.N, K = p.K;
   const int k4n = K >> 2;
-  {
-    const float* __restrict__ A = p.A;
-    constexpr int SB = 8;   // 16-byte pieces per thread in flight: a round trip per batch, not per piece
-    for (int i0 = threadIdx.x; i0 < M * k4n; i0 += 256 * SB) {
-      f32x4 v[SB];
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int i = i0 + u * 256;
-        const int m = i / k4n, c = i - m * k4n;
-        v[u] = i < M * k4n ? *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < SB; ++u) {
-        const int i = i0 + u * 256;
-        const int m = i / k4n, c = i - m * k4n;
-        if (i < M * k4n) *reinterpret_cast<f32x4*>(arow + (size_t)m * K + c * 4) = v[u];
-      }
-    }
-  }
-  // this wave's weight row: all of its 16-byte pieces requested before the barrier
+  // this wave's weight row first: its 16-byte pieces are in flight while the rows of A are staged
   constexpr int WMAX = 8;   // K <= 64 lanes x 4 x 8 = 2048 per pass
   const float* __restrict__ wrow = p.W + (size_t)(n < N ? n : N - 1) * p.ldw;
-  float acc[FEWROWS_MAX_M];
+  f32x4 w[WMAX];
 #pragma unroll
-  for (int m = 0; m < FEWROWS_MAX_M; ++m) acc[m] = 0.f;
-  for (int kb = 0; kb < K; kb += 256 * WMAX) {
-    f32x4 w[WMAX];
+  for (int j = 0; j < WMAX; ++j) {
+    const int k4 = j * 256 + lane * 4;
+    w[j] = k4 < K ? *reinterpret_cast<const f32x4*>(wrow + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    // (row, piece) of this thread's pieces tid, tid + 256, ... without a division per piece: k4n >= 256 (K >= 1024),
+    // so a step of 256 pieces wraps to the next row at most once.  Rows M .. MB-1 are zeros.
+    const float* __restrict__ A = p.A;
+    constexpr int SB = 8;   // 16-byte pieces per thread in flight
+    int m = (int)threadIdx.x / k4n, c = (int)threadIdx.x - m * k4n;
+    for (int i0 = threadIdx.x; i0 < MB * k4n; i0 += 256 * SB) {
+      f32x4 v[SB];
+      int mu[SB], cu[SB];
 #pragma unroll
-    for (int j = 0; j < WMAX; ++j) {
-      const int k4 = kb + j * 256 + lane * 4;
-      w[j] = k4 < K ? *reinterpret_cast<const f32x4*>(wrow + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < SB; ++u) {
+        mu[u] = m; cu[u] = c;
+        const int mr = m < M ? m : M - 1;   // (clamped address, value discarded below)
+        v[u] = *reinterpret_cast<const f32x4*>(A + (size_t)mr * p.lda + (c < k4n ? c : 0) * 4);
+        if (m >= M) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        c += 256;
+        if (c >= k4n) { c -= k4n; ++m; }
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (mu[u] < MB) *reinterpret_cast<f32x4*>(arow + (size_t)mu[u] * K + cu[u] * 4) = v[u];
     }
-    if (kb == 0) __syncthreads();
+  }
+  __syncthreads();
+  float acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+  for (int kb = 0; kb < K; kb += 256 * WMAX) {
+    if (kb > 0) {
+#pragma unroll
+      for (int j = 0; j < WMAX; ++j) {
+        const int k4 = kb + j * 256 + lane * 4;
+        w[j] = k4 < K ? *reinterpret_cast<const f32x4*>(wrow + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // branch-free inner loops: pieces past K multiply zero weights (w) with whatever row 0.. holds at piece 0
 #pragma unroll
     for (int j = 0; j < WMAX; ++j) {
       const int k4 = kb + j * 256 + lane * 4;
-      if (kb + j * 256 >= K) break;        // uniform
-      const int kk = k4 < K ? k4 : 0;      // (lanes past a ragged K multiply zeros)
+      const int kk = k4 < K ? k4 : 0;
 #pragma unroll
-      for (int m = 0; m < FEWROWS_MAX_M; ++m) {
-        if (m >= M) break;                 // uniform
+      for (int m = 0; m < MB; ++m) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (size_t)m * K + kk);
         acc[m] = __builtin_fmaf(a[3], w[j][3], __builtin_fmaf(a[2], w[j][2], __builtin_fmaf(a[1], w[j][1], __builtin_fmaf(a[0], w[j][0], acc[m]))));
       }
@@ -626,8 +637,7 @@ __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
   if (n >= N) return;
   float out = 0.f;   // lane m ends up with row m
 #pragma unroll
-  for (int m = 0; m < FEWROWS_MAX_M; ++m) {
-    if (m >= M) break;
+  for (int m = 0; m < MB; ++m) {
     float v = acc[m];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -646,24 +656,32 @@ __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
   }
 }
 
-static hipError_t launch_fewrows(const GemmBatch& batch, hipStream_t stream) {
-  int maxN = 0;
-  size_t lds = 0;
-  for (int i = 0; i < batch.count; ++i) {
-    maxN = batch.p[i].N > maxN ? batch.p[i].N : maxN;
-    const size_t l = (size_t)batch.p[i].M * batch.p[i].K * sizeof(float);
-    lds = l > lds ? l : lds;
-  }
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fewrows_kernel),
+template <int MB>
+static hipError_t launch_fewrows_cfg(const GemmBatch& batch, int maxN, int maxK, hipStream_t stream) {
+  const size_t lds = (size_t)MB * maxK * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fewrows_kernel<MB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)FEWROWS_MAX_LDS);
     if (e != hipSuccess) return e;
-    attr = FEWROWS_MAX_LDS;
+    attr = true;
   }
   dim3 grid((maxN + 3) / 4, batch.count);
-  hipLaunchKernelGGL(gemm_fewrows_kernel, grid, dim3(256), lds, stream, batch);
+  hipLaunchKernelGGL(gemm_fewrows_kernel<MB>, grid, dim3(256), lds, stream, batch);
   return hipGetLastError();
+}
+
+static hipError_t launch_fewrows(const GemmBatch& batch, hipStream_t stream) {
+  int maxN = 0, maxM = 0, maxK = 0;
+  for (int i = 0; i < batch.count; ++i) {
+    maxN = batch.p[i].N > maxN ? batch.p[i].N : maxN;
+    maxM = batch.p[i].M > maxM ? batch.p[i].M : maxM;
+    maxK = batch.p[i].K > maxK ? batch.p[i].K : maxK;
+  }
+  if (maxM <= 4) return launch_fewrows_cfg<4>(batch, maxN, maxK, stream);
+  if (maxM <= 8) return launch_fewrows_cfg<8>(batch, maxN, maxK, stream);
+  if (maxM <= 12) return launch_fewrows_cfg<12>(batch, maxN, maxK, stream);
+  return launch_fewrows_cfg<16>(batch, maxN, maxK, stream);
 }
 
 enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK, PICK_FEWROWS };
@@ -692,7 +710,7 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
     int maxK = 0;
     for (int i = 0; i < batch.count; ++i) maxK = batch.p[i].K > maxK ? batch.p[i].K : maxK;
     if (splitk_on && maxM <= FEWROWS_MAX_M && minK >= 1024 && maxN >= 64 &&
-        (size_t)maxM * maxK * sizeof(float) <= FEWROWS_MAX_LDS)
+        (size_t)((maxM + 3) & ~3) * maxK * sizeof(float) <= FEWROWS_MAX_LDS)
       return PICK_FEWROWS;
   }
   if (splitk_on && minK >= 64 && nblocks(32, 32) <= SPLITK_MAX_TILES) return PICK_SPLITK;
