@@ -1567,6 +1567,8 @@ struct TrainLstmWs {
   float* wt;               // transposed weights, max(H, in) x 4H
   float* atb;              // A^T B partials
   size_t atb_floats;
+  float* ksplit;           // partial tiles of the K-split recurrent product, or nullptr
+  size_t ksplit_floats;
 };
 int check_lstm_params(const empose_lstm_params* p) {
   if (!p) return fail(EMPOSE_EINVAL, "null argument");
@@ -1595,6 +1597,8 @@ TrainLstmWs carve_train_lstm(Carver& c, const empose_lstm_params* p, int B, int 
   w.wt = c.f((size_t)in_max * 4 * H);
   w.atb_floats = atb_workspace_floats(B * F, 4 * H, in_max);
   w.atb = c.f(w.atb_floats + 64);
+  w.ksplit_floats = gemm_ksplit_applicable(B, H, 4 * H) ? gemm_ksplit_workspace_floats(B, H, 4 * H) : 0;
+  w.ksplit = w.ksplit_floats ? c.f(w.ksplit_floats) : nullptr;
   return w;
 }
 }  // namespace
@@ -1710,6 +1714,13 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm cell backward: %s", hipGetErrorString(e));
       if (t == 0) break;
       float* out = w.dh[t & 1];
+      if (w.ksplit) {   // a few hundred rows: K split over the workgroups (gemm_ksplit_kernel)
+        GemmProb g;
+        g.A = w.dgates + (size_t)t * 4 * H; g.lda = F * 4 * H; g.W = w.wt; g.ldw = 4 * H; g.C = out; g.ldc = H;
+        g.M = B; g.N = H; g.K = 4 * H; g.scale = nullptr; g.shift = nullptr; g.resid = w.carry; g.ldr = H; g.act = 0;
+        g.slope = 0.f;
+        e = launch_gemm_ksplit(g, w.ksplit, stream);
+      } else
       e = gemm(w.dgates + (size_t)t * 4 * H, F * 4 * H, w.wt, 4 * H, out, H, B, H, 4 * H, w.carry, H);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward gemm: %s", hipGetErrorString(e));
       dh_in = out;

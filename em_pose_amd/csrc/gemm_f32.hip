@@ -561,6 +561,126 @@ hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A few hundred rows against a long K with a small output (back-propagation through time at 256 windows: dh = dG . W_hh
+// is 256 x 2048 . 2048 x 512, sixty-two times per step): 32 x 32 tiles that each walk the whole K leave it at 22 us per
+// call (128 workgroups, strided 16-byte operand reads).  Here K is split over the workgroups: a workgroup owns a
+// 64 x 64 output tile for a K slice of 256, stages both operand slices in LDS with coalesced row reads in one round
+// trip, runs 128 MFMAs per wave (four waves, a 32 x 32 quadrant each) without a barrier, and writes its partial tile;
+// a small second kernel adds the partial tiles in slice order (fixed order: reproducible) and applies the epilogue.
+// 32 tiles x 8 slices = 256 workgroups.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FEWROWS_MAX_M_DECL = 16;   // (= FEWROWS_MAX_M below)
+namespace ks {
+constexpr int BT = 64, KS = 256, LDK = KS + 4;   // tile, K slice per workgroup, LDS row stride (floats)
+constexpr size_t LDS_BYTES = (size_t)2 * BT * LDK * sizeof(float);
+}
+__global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmProb p, float* partial) {
+  using namespace ks;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;
+  float* sW = sm + BT * LDK;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nt_n = (N + BT - 1) / BT;
+  const int tile = blockIdx.x, m0 = (tile / nt_n) * BT, n0 = (tile % nt_n) * BT;
+  const int k0 = blockIdx.y * KS;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // staging: 64 rows x 256 floats of each operand = 2 x 4096 16-byte pieces over 256 threads, all in flight at once
+  {
+    f32x4 va[16], vw[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = tid + u * 256, r = i >> 6, c = (i & 63) * 4;
+      const bool kin = k0 + c < K;   // K % 4 == 0
+      va[u] = kin ? *reinterpret_cast<const f32x4*>(p.A + (size_t)min(m0 + r, M - 1) * p.lda + k0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vw[u] = kin ? *reinterpret_cast<const f32x4*>(p.W + (size_t)min(n0 + r, N - 1) * p.ldw + k0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = tid + u * 256, r = i >> 6, c = (i & 63) * 4;
+      *reinterpret_cast<f32x4*>(sA + r * LDK + c) = va[u];
+      *reinterpret_cast<f32x4*>(sW + r * LDK + c) = vw[u];
+    }
+  }
+  __syncthreads();
+  const int mq = (wave >> 1) * 32, nq = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ar = sA + (mq + l31) * LDK + lh * 4;
+  const float* wr = sW + (nq + l31) * LDK + lh * 4;
+#pragma unroll 8
+  for (int g = 0; g < KS / 8; ++g) {   // k-groups of 8: lane half lh holds k = 8 g + 4 lh .. + 3 of both operands
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(ar + g * 8);
+    const f32x4 fb = *reinterpret_cast<const f32x4*>(wr + g * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+  }
+  // partial tile of this slice: [slice][tile][wave][reg][lane]; a second kernel adds the slices in order (a last-arriver
+  // reduction inside this kernel was measured: the agent-scope fences it needs write back and invalidate the whole L2
+  // of every workgroup's XCD -- 60 us per call instead of 22)
+  float* pt = partial + (((size_t)blockIdx.y * gridDim.x + tile) * 4 + wave) * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pt[r * 64 + lane] = acc[r];
+}
+
+// C = epilogue(sum over the K slices, in slice order): one thread per output element, its S partial values requested
+// together (one round trip) and added in slice order
+constexpr int KSPLIT_MAX_S = 16;
+__global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(GemmProb p, const float* partial, int S, int tiles) {
+  using namespace ks;
+  const int M = p.M, N = p.N;
+  const int nt_n = (N + BT - 1) / BT;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // position inside one slice's partial buffer
+  if (idx >= (size_t)tiles * 4096) return;
+  float ps[KSPLIT_MAX_S];
+#pragma unroll
+  for (int s2 = 0; s2 < KSPLIT_MAX_S; ++s2) ps[s2] = s2 < S ? partial[(size_t)s2 * tiles * 4096 + idx] : 0.f;
+  float v = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < KSPLIT_MAX_S; ++s2) v += ps[s2];   // (slices past S add 0: the same bits as stopping at S)
+  const int tile = (int)(idx >> 12), wave = (int)(idx >> 10) & 3, r = (int)(idx >> 6) & 15, lane = (int)idx & 63;
+  const int m0 = (tile / nt_n) * BT, n0 = (tile % nt_n) * BT;
+  const int mq = (wave >> 1) * 32, nq = (wave & 1) * 32, l31 = lane & 31, lh = lane >> 5;
+  const int row = m0 + mq + (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nq + l31;
+  if (row >= M || n >= N) return;
+  float y = v * (p.scale ? p.scale[n] : 1.f) + (p.shift ? p.shift[n] : 0.f);
+  if (p.act == 2) {
+    if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
+    y = y > 0.f ? y : 0.f;
+  } else {
+    if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
+    if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
+  }
+  p.C[(size_t)row * p.ldc + n] = y;
+}
+
+bool gemm_ksplit_applicable(int M, int N, int K) {
+  const long tiles = (long)((M + ks::BT - 1) / ks::BT) * ((N + ks::BT - 1) / ks::BT);
+  const int S = (K + ks::KS - 1) / ks::KS;
+  return K % 4 == 0 && M > FEWROWS_MAX_M_DECL && S >= 4 && S <= KSPLIT_MAX_S && tiles * S >= 32 && tiles * S <= 1024;
+}
+size_t gemm_ksplit_workspace_floats(int M, int N, int K) {
+  const size_t tiles = (size_t)((M + ks::BT - 1) / ks::BT) * ((N + ks::BT - 1) / ks::BT);
+  const size_t S = (K + ks::KS - 1) / ks::KS;
+  return tiles * S * 4096 + 64;   // partial tiles
+}
+hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream) {
+  const int tiles = ((p.M + ks::BT - 1) / ks::BT) * ((p.N + ks::BT - 1) / ks::BT);
+  const int S = (p.K + ks::KS - 1) / ks::KS;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ksplit_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gemm_ksplit_kernel, dim3(tiles, S), dim3(256), ks::LDS_BYTES, stream, p, workspace);
+  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3(tiles * 16), dim3(256), 0, stream, p, (const float*)workspace, S, tiles);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // A handful of rows against a long K (back-propagation through time at the reference's training batch: dh = dG . W_hh
 // is 12 x 2048 . 2048 x 512, sixty-four times per step): a matrix-vector problem bound by streaming W once.  The 32 x 32
 // split-K tile leaves it on 16 workgroups that each walk 256 KB (19.9 us per call); here a wave owns ONE output column,

@@ -33,6 +33,13 @@ struct GemmProb {
 };
 struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
 
+// The same product with K split over workgroups (a few hundred rows, long K, small output: the recurrent products of
+// back-propagation through time); `workspace`: gemm_ksplit_workspace_floats floats.  Deterministic (partials added in
+// slice order by a second kernel).
+bool gemm_ksplit_applicable(int M, int N, int K);
+size_t gemm_ksplit_workspace_floats(int M, int N, int K);
+hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream);
+
 // C[M][N] = A . W^T (+ bias) with strided operands: A(m, k) = A[m * a_rs + k * a_ks], W(n, k) = W[n * w_rs + k * w_ks]
 // (small problems only, split-K tile; `strided_gemm_applicable`).
 struct StridedGemm {
