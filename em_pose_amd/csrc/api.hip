@@ -1705,21 +1705,31 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
     HIP_TRY(hipMemsetAsync(w.dc, 0, bh * sizeof(float), stream));
     const float* dh_in = nullptr;
-    for (int t = F - 1; t >= 0; --t) {
+    auto cell_args = [&](int t, const float* dh) {
       LstmCellBwdArgs ca;
       ca.gates = sv; ca.c_all = sv + 4 * bfh; ca.c0 = c0 ? c0 + l * bh : nullptr;
-      ca.dy = dy_l; ca.ld_dy = H; ca.dh_in = dh_in; ca.dc = w.dc; ca.dgates = w.dgates; ca.dh_carry = w.carry;
+      ca.dy = dy_l; ca.ld_dy = H; ca.dh_in = dh; ca.dc = w.dc; ca.dgates = w.dgates; ca.dh_carry = w.carry;
       ca.seq_lengths = seq_lengths; ca.B = B; ca.F = F; ca.H = H; ca.t = t;
-      e = launch_lstm_cell_bwd(ca, stream);
-      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm cell backward: %s", hipGetErrorString(e));
+      return ca;
+    };
+    bool cell_done = false;   // the cell of step t already ran inside the previous step's reduce kernel
+    for (int t = F - 1; t >= 0; --t) {
+      if (!cell_done) {
+        LstmCellBwdArgs ca = cell_args(t, dh_in);
+        e = launch_lstm_cell_bwd(ca, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm cell backward: %s", hipGetErrorString(e));
+      }
+      cell_done = false;
       if (t == 0) break;
       float* out = w.dh[t & 1];
-      if (w.ksplit) {   // a few hundred rows: K split over the workgroups (gemm_ksplit_kernel)
-        GemmProb g;
+      if (w.ksplit) {   // a few hundred rows: K split over the workgroups (gemm_ksplit_kernel); its reduce kernel
+        GemmProb g;     // feeds dh straight into the cell of step t - 1 (the carry of step t is the residual)
         g.A = w.dgates + (size_t)t * 4 * H; g.lda = F * 4 * H; g.W = w.wt; g.ldw = 4 * H; g.C = out; g.ldc = H;
         g.M = B; g.N = H; g.K = 4 * H; g.scale = nullptr; g.shift = nullptr; g.resid = w.carry; g.ldr = H; g.act = 0;
         g.slope = 0.f;
-        e = launch_gemm_ksplit(g, w.ksplit, stream);
+        LstmCellBwdArgs cn = cell_args(t - 1, nullptr);
+        e = launch_gemm_ksplit(g, w.ksplit, stream, &cn);
+        cell_done = true;
       } else
       e = gemm(w.dgates + (size_t)t * 4 * H, F * 4 * H, w.wt, 4 * H, out, H, B, H, 4 * H, w.carry, H);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward gemm: %s", hipGetErrorString(e));

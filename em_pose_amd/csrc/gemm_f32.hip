@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "gemm_epilogue.h"
+#include "lstm_cell_bwd.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -627,7 +628,8 @@ __global__ __launch_bounds__(256) void gemm_ksplit_kernel(GemmProb p, float* par
 // C = epilogue(sum over the K slices, in slice order): one thread per output element, its S partial values requested
 // together (one round trip) and added in slice order
 constexpr int KSPLIT_MAX_S = 16;
-__global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(GemmProb p, const float* partial, int S, int tiles) {
+__global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(GemmProb p, const float* partial, int S, int tiles,
+                                                                 LstmCellBwdArgs cell, int with_cell) {
   using namespace ks;
   const int M = p.M, N = p.N;
   const int nt_n = (N + BT - 1) / BT;
@@ -652,7 +654,9 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(GemmProb p, con
     if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
     if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
   }
-  p.C[(size_t)row * p.ldc + n] = y;
+  // back-propagation through time: y is dh of (row, unit n) for the step below; run that step's cell right here
+  if (with_cell) lstm_cell_bwd_elem(cell, row * cell.H + n, y);
+  else p.C[(size_t)row * p.ldc + n] = y;
 }
 
 bool gemm_ksplit_applicable(int M, int N, int K) {
@@ -665,7 +669,7 @@ size_t gemm_ksplit_workspace_floats(int M, int N, int K) {
   const size_t S = (K + ks::KS - 1) / ks::KS;
   return tiles * S * 4096 + 64;   // partial tiles
 }
-hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream) {
+hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream, const LstmCellBwdArgs* cell) {
   const int tiles = ((p.M + ks::BT - 1) / ks::BT) * ((p.N + ks::BT - 1) / ks::BT);
   const int S = (p.K + ks::KS - 1) / ks::KS;
   static bool attr = false;
@@ -676,7 +680,8 @@ hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t s
     attr = true;
   }
   hipLaunchKernelGGL(gemm_ksplit_kernel, dim3(tiles, S), dim3(256), ks::LDS_BYTES, stream, p, workspace);
-  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3(tiles * 16), dim3(256), 0, stream, p, (const float*)workspace, S, tiles);
+  hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3(tiles * 16), dim3(256), 0, stream, p, (const float*)workspace, S, tiles,
+                     cell ? *cell : LstmCellBwdArgs{}, cell ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -38,7 +38,10 @@ struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; 
 // slice order by a second kernel).
 bool gemm_ksplit_applicable(int M, int N, int K);
 size_t gemm_ksplit_workspace_floats(int M, int N, int K);
-hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream);
+struct LstmCellBwdArgs;
+// `cell` (back-propagation through time): the product is dh of the step below (N = H, one value per (row, unit)); the
+// reduce kernel runs that step's cell on it instead of storing C.
+hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream, const LstmCellBwdArgs* cell = nullptr);
 
 // C[M][N] = A . W^T (+ bias) with strided operands: A(m, k) = A[m * a_rs + k * a_ks], W(n, k) = W[n * w_rs + k * w_ks]
 // (small problems only, split-K tile; `strided_gemm_applicable`).
