@@ -1730,6 +1730,13 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
         LstmCellBwdArgs cn = cell_args(t - 1, nullptr);
         e = launch_gemm_ksplit(g, w.ksplit, stream, &cn);
         cell_done = true;
+      } else if (gemm_fewrows_applicable(B, H, 4 * H)) {   // the reference's batch: matrix-vector kernel, same fusion
+        GemmProb g;
+        g.A = w.dgates + (size_t)t * 4 * H; g.lda = F * 4 * H; g.W = w.wt; g.ldw = 4 * H; g.C = out; g.ldc = H;
+        g.M = B; g.N = H; g.K = 4 * H; g.scale = nullptr; g.shift = nullptr; g.resid = w.carry; g.ldr = H; g.act = 0;
+        g.slope = 0.f;
+        e = launch_gemm_fewrows_cell(g, cell_args(t - 1, nullptr), stream);
+        cell_done = true;
       } else
       e = gemm(w.dgates + (size_t)t * 4 * H, F * 4 * H, w.wt, 4 * H, out, H, B, H, 4 * H, w.carry, H);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward gemm: %s", hipGetErrorString(e));

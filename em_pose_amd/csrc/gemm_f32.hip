@@ -695,7 +695,7 @@ hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t s
 constexpr int FEWROWS_MAX_M = 16;
 constexpr size_t FEWROWS_MAX_LDS = 128 * 1024;   // the rows of A (M x K floats) are staged in LDS once per workgroup
 template <int MB>   // rows computed (M rounded up to a multiple of 4; rows past M are staged as zeros, never stored)
-__global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
+__global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b, LstmCellBwdArgs cell, int with_cell) {
   extern __shared__ __attribute__((aligned(16))) float arow[];   // [MB][K]
   const GemmProb& p = b.p[blockIdx.y];
   const int lane = threadIdx.x & 63;
@@ -777,12 +777,15 @@ __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b) {
       if (p.act == 1) y = y >= 0.f ? y : p.slope * y;
       if (p.resid) y += p.resid[(size_t)lane * p.ldr + n];
     }
-    p.C[(size_t)lane * p.ldc + n] = y;
+    // back-propagation through time: y is dh of (row, unit n) for the step below; run that step's cell right here
+    if (with_cell) lstm_cell_bwd_elem(cell, lane * cell.H + n, y);
+    else p.C[(size_t)lane * p.ldc + n] = y;
   }
 }
 
 template <int MB>
-static hipError_t launch_fewrows_cfg(const GemmBatch& batch, int maxN, int maxK, hipStream_t stream) {
+static hipError_t launch_fewrows_cfg(const GemmBatch& batch, int maxN, int maxK, hipStream_t stream,
+                                     const LstmCellBwdArgs* cell = nullptr) {
   const size_t lds = (size_t)MB * maxK * sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -792,21 +795,34 @@ static hipError_t launch_fewrows_cfg(const GemmBatch& batch, int maxN, int maxK,
     attr = true;
   }
   dim3 grid((maxN + 3) / 4, batch.count);
-  hipLaunchKernelGGL(gemm_fewrows_kernel<MB>, grid, dim3(256), lds, stream, batch);
+  hipLaunchKernelGGL(gemm_fewrows_kernel<MB>, grid, dim3(256), lds, stream, batch, cell ? *cell : LstmCellBwdArgs{},
+                     cell ? 1 : 0);
   return hipGetLastError();
 }
 
-static hipError_t launch_fewrows(const GemmBatch& batch, hipStream_t stream) {
+static hipError_t launch_fewrows(const GemmBatch& batch, hipStream_t stream, const LstmCellBwdArgs* cell = nullptr) {
   int maxN = 0, maxM = 0, maxK = 0;
   for (int i = 0; i < batch.count; ++i) {
     maxN = batch.p[i].N > maxN ? batch.p[i].N : maxN;
     maxM = batch.p[i].M > maxM ? batch.p[i].M : maxM;
     maxK = batch.p[i].K > maxK ? batch.p[i].K : maxK;
   }
-  if (maxM <= 4) return launch_fewrows_cfg<4>(batch, maxN, maxK, stream);
-  if (maxM <= 8) return launch_fewrows_cfg<8>(batch, maxN, maxK, stream);
-  if (maxM <= 12) return launch_fewrows_cfg<12>(batch, maxN, maxK, stream);
-  return launch_fewrows_cfg<16>(batch, maxN, maxK, stream);
+  if (maxM <= 4) return launch_fewrows_cfg<4>(batch, maxN, maxK, stream, cell);
+  if (maxM <= 8) return launch_fewrows_cfg<8>(batch, maxN, maxK, stream, cell);
+  if (maxM <= 12) return launch_fewrows_cfg<12>(batch, maxN, maxK, stream, cell);
+  return launch_fewrows_cfg<16>(batch, maxN, maxK, stream, cell);
+}
+
+// The matrix-vector kernel with the LSTM cell of the step below as its epilogue (back-propagation through time at the
+// reference's training batch); false when the shape is not this kernel's.
+bool gemm_fewrows_applicable(int M, int N, int K) {
+  return options().gemm_splitk != 0 && M <= FEWROWS_MAX_M && K >= 1024 && K % 4 == 0 && N >= 64 &&
+         (size_t)((M + 3) & ~3) * K * sizeof(float) <= FEWROWS_MAX_LDS;
+}
+hipError_t launch_gemm_fewrows_cell(const GemmProb& p, const LstmCellBwdArgs& cell, hipStream_t stream) {
+  GemmBatch b;
+  b.count = 1; b.p[0] = p;
+  return launch_fewrows(b, stream, &cell);
 }
 
 enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK, PICK_FEWROWS };

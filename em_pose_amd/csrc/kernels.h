@@ -42,6 +42,9 @@ struct LstmCellBwdArgs;
 // `cell` (back-propagation through time): the product is dh of the step below (N = H, one value per (row, unit)); the
 // reduce kernel runs that step's cell on it instead of storing C.
 hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream, const LstmCellBwdArgs* cell = nullptr);
+// At most 16 rows: the matrix-vector kernel, same epilogue.
+bool gemm_fewrows_applicable(int M, int N, int K);
+hipError_t launch_gemm_fewrows_cell(const GemmProb& p, const LstmCellBwdArgs& cell, hipStream_t stream);
 
 // C[M][N] = A . W^T (+ bias) with strided operands: A(m, k) = A[m * a_rs + k * a_ks], W(n, k) = W[n * w_rs + k * w_ks]
 // (small problems only, split-K tile; `strided_gemm_applicable`).
