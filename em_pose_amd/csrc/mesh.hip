@@ -244,7 +244,10 @@ __global__ __launch_bounds__(mr::NW * 64) void mesh_rows_kernel(MeshSkinArgs a) 
 // kernel runs) this kernel returned sporadically wrong x coordinates -- always the second accumulator row of the upper
 // lane half, lanes 48..63, in roughly one tile-wave in a thousand, different ones on every launch; independent of the
 // register count (216..254), of the prefetch, of fences / nops around the stores and after the K loop.  With one wave
-// per SIMD ten repetitions of 16384 frames are bit-identical and within 5e-7 of the fp32 kernel.  The throughput is
+// per SIMD ten repetitions of 16384 frames are bit-identical and within 5e-7 of the fp32 kernel.  Narrowed down with
+// diagnostic builds: eight waves per workgroup of which four idle after the staging -> clean (it is two ACTIVE waves per
+// SIMD, not the workgroup size); scalar instead of packed skinning arithmetic -> still wrong; the fp32 MFMA instruction
+// in place of v_mfma_f32_32x32x16_bf16 (same kernel otherwise, two waves per SIMD) -> clean.  The throughput is
 // the same either way: the two waves of a SIMD ran their K loops and their skinning in lockstep and gained nothing
 // from each other.
 // Operand order inside a k-step only has to agree between the two operands (a dot product is order-free): a lane's
