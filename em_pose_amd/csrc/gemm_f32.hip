@@ -570,7 +570,7 @@ hipError_t launch_strided_gemm(const StridedGemm& p, hipStream_t stream) {
 // a small second kernel adds the partial tiles in slice order (fixed order: reproducible) and applies the epilogue.
 // 32 tiles x 8 slices = 256 workgroups.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int FEWROWS_MAX_M_DECL = 16;   // (= FEWROWS_MAX_M below)
+constexpr int FEWROWS_MAX_M = 16;   // rows of the matrix-vector kernel further down; more rows can take the K-split kernel
 namespace ks {
 constexpr int BT = 64, KS = 256, LDK = KS + 4;   // tile, K slice per workgroup, LDS row stride (floats)
 constexpr size_t LDS_BYTES = (size_t)2 * BT * LDK * sizeof(float);
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void gemm_ksplit_reduce_kernel(GemmProb p, con
 bool gemm_ksplit_applicable(int M, int N, int K) {
   const long tiles = (long)((M + ks::BT - 1) / ks::BT) * ((N + ks::BT - 1) / ks::BT);
   const int S = (K + ks::KS - 1) / ks::KS;
-  return K % 4 == 0 && M > FEWROWS_MAX_M_DECL && S >= 4 && S <= KSPLIT_MAX_S && tiles * S >= 32 && tiles * S <= 1024;
+  return K % 4 == 0 && M > FEWROWS_MAX_M && S >= 4 && S <= KSPLIT_MAX_S && tiles * S >= 32 && tiles * S <= 1024;
 }
 size_t gemm_ksplit_workspace_floats(int M, int N, int K) {
   const size_t tiles = (size_t)((M + ks::BT - 1) / ks::BT) * ((N + ks::BT - 1) / ks::BT);
@@ -692,7 +692,6 @@ hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t s
 // its lanes split K in 16-byte pieces (coalesced 1 KB reads of the weight row, all in flight at once), the rows of A
 // are staged in LDS once per workgroup, and the lane sums meet in a butterfly -- a fixed order: reproducible results.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int FEWROWS_MAX_M = 16;
 constexpr size_t FEWROWS_MAX_LDS = 128 * 1024;   // the rows of A (M x K floats) are staged in LDS once per workgroup
 template <int MB>   // rows computed (M rounded up to a multiple of 4; rows past M are staged as zeros, never stored)
 __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b, LstmCellBwdArgs cell, int with_cell) {
