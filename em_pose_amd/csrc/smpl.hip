@@ -265,10 +265,10 @@ hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream) {
 //   P5c combine chunks per bone                       P6 subtree sums (bit mask)      P7 d R, d J -> global
 // Every accumulation is a gather in a fixed order: results are bitwise reproducible and independent of the batch.
 // ---------------------------------------------------------------------------------------------------------------
-// Two shapes of the workgroup, picked by the launch (launch_chain_sensors): 4 frames on 256 threads when the launch is
-// many workgroups per CU deep (T >= 16384: 231 us against 253 for the other shape at T = 32768 -- the 24 KB of tables
-// are staged once per four frames and the narrow phases fill more lanes), 2 frames on 192 threads below (twice as many
-// workgroups: at T = 8192 the larger shape leaves a third wave of workgroups mostly empty and costs 7 % of the step).
+// Two shapes of the workgroup, picked by the launch (launch_chain_sensors): 4 frames on 256 threads from 4096 frames up
+// (the 24 KB of tables are staged once per four frames and the narrow phases fill more lanes: 231 us against 253 for the
+// other shape at T = 32768, 126 against 137 at 16384, 69 against 74 at 8192; whole forwards at 128 / 256 / 512 windows
+// 1-2 % faster), 2 frames on 192 threads below (twice as many workgroups for the short launches of the streaming drivers).
 // Measured and rejected: 3 x 192 (236), 3 x 256 (241), 4 x 192 (257), 4 x 224 (243), 5 x 256 (261), 8 x 512 (255),
 // anything with more than 256 threads per workgroup (320-390 us: the register budget halves).
 
@@ -808,7 +808,7 @@ static hipError_t launch_chain_cfg(const ChainArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream) {
-  if (a.T >= 16384 && chain_lds_bytes(a.tab, 4) <= 64 * 1024) return launch_chain_cfg<4, 256>(a, stream);
+  if (a.T >= 4096 && chain_lds_bytes(a.tab, 4) <= 64 * 1024) return launch_chain_cfg<4, 256>(a, stream);
   return launch_chain_cfg<2, 192>(a, stream);
 }
 
