@@ -21,4 +21,8 @@ for r in seg:
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
     print('  %-52s %4d  %8.1f us  avg %6.1f' % (k, n, t, t / n))
+# launch sequence of that step (name, us), for locating the copies / fills by their neighbours
+with open('$OUT.seq.txt', 'w') as o:
+    for r in seg:
+        o.write('%-60s %7.1f\n' % (r['Kernel_Name'].split('(')[0][-60:], (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
 PY
