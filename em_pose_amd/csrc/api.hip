@@ -330,7 +330,7 @@ struct Carver {
 
 // ---- workspace layouts ------------------------------------------------------------------------------------------
 struct SmplWs {
-  float *rot, *feat, *out, *d_out, *d_feat, *d_rot, *theta, *beta;
+  float *rot, *feat, *out, *d_out, *d_feat, *d_rot;
 };
 SmplWs carve_smpl(Carver& c, const empose_model* m, int T) {
   SmplWs w;
@@ -340,8 +340,6 @@ SmplWs carve_smpl(Carver& c, const empose_model* m, int T) {
   w.d_out = c.f((size_t)T * m->tab.ncp);
   w.d_feat = c.f((size_t)T * 200);
   w.d_rot = c.f((size_t)T * 198);
-  w.theta = c.f((size_t)T * 66);
-  w.beta = c.f((size_t)T * 10);
   return w;
 }
 
@@ -970,12 +968,8 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   Carver c(workspace);
   SmplWs ws = carve_smpl(c, m, T);
-  HIP_TRY(hipMemcpy2DAsync(ws.theta, 66 * sizeof(float), theta, (size_t)ld_theta * sizeof(float), 66 * sizeof(float), T,
-                           hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemcpy2DAsync(ws.beta, 10 * sizeof(float), beta, (size_t)ld_beta * sizeof(float), 10 * sizeof(float), T,
-                           hipMemcpyDeviceToDevice, stream));
-  FeatArgs fa;
-  fa.theta = ws.theta; fa.ld_theta = 66; fa.beta = ws.beta; fa.ld_beta = 10;
+  FeatArgs fa;   // the caller's rows are read in place (no update: the kernel does not write them back)
+  fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
@@ -986,7 +980,7 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
                     nullptr, stream));
   if (tgt) {
     RodBwdArgs ra;
-    ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
+    ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
     ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
     ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
     e = launch_rodrigues_bwd(ra, stream);
@@ -1010,12 +1004,8 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   float* pos = c.f((size_t)T * 36);
   float* ori = c.f((size_t)T * 108);
   float* joints = c.f((size_t)T * 66);
-  HIP_TRY(hipMemcpy2DAsync(ws.theta, 66 * sizeof(float), theta, (size_t)ld_theta * sizeof(float), 66 * sizeof(float), T,
-                           hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemcpy2DAsync(ws.beta, 10 * sizeof(float), beta, (size_t)ld_beta * sizeof(float), 10 * sizeof(float), T,
-                           hipMemcpyDeviceToDevice, stream));
-  FeatArgs fa;
-  fa.theta = ws.theta; fa.ld_theta = 66; fa.beta = ws.beta; fa.ld_beta = 10;
+  FeatArgs fa;   // the caller's rows are read in place (no update: the kernel does not write them back)
+  fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
@@ -1025,7 +1015,7 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, pos, ori, joints, nullptr, nullptr, nullptr,
                     stream, d_pos, d_ori, d_joints));
   RodBwdArgs ra;
-  ra.theta = ws.theta; ra.ld_theta = 66; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
+  ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
   ra.g_theta = g_theta; ra.ld_g = 66; ra.g_beta = g_beta; ra.ld_gb = 10;
   ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
   e = launch_rodrigues_bwd(ra, stream);
@@ -1415,7 +1405,8 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
-  HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
+  // the last-arriver counter of the single-pass BatchNorm reverse kernel (it re-arms itself; the workspace may be fresh)
+  if (M <= BN_SINGLE_PASS_ROWS) HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
   auto gemm = [&](const float* A, int lda, const float* W, int ldw, float* C, int ldc, int N, int K) -> hipError_t {
     GemmBatch b;
     b.count = 1;
@@ -1429,9 +1420,13 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
   {
     const int l = L - 1;
     hipError_t e = hipSuccess;
-    if (stash) {   // weight gradients deferred: keep d_out for empose_mlp_train_wgrad
-      e = launch_axpby2d(M, op, 1.f, d_out, ld_dout, 0.f, nullptr, 0, stash + (size_t)M * (L - 1) * H, op, stream);
-      if (e != hipSuccess) return fail(EMPOSE_EHIP, "stash: %s", hipGetErrorString(e));
+    if (stash) {   // weight gradients deferred: keep d_out for empose_mlp_train_wgrad (no copy when the caller
+                   // produced it in its stash slot already, include/empose_hip.h)
+      float* slot = stash + (size_t)M * (L - 1) * H;
+      if (d_out != slot || ld_dout != op) {
+        e = launch_axpby2d(M, op, 1.f, d_out, ld_dout, 0.f, nullptr, 0, slot, op, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "stash: %s", hipGetErrorString(e));
+      }
     } else {
       AtbArgs ab{};
       ab.A = d_out; ab.lda = ld_dout; ab.B = layer_save(l - 1) + (size_t)M * H; ab.ldb = H; ab.C = gr->weight[l]; ab.ldc = H;
@@ -1920,11 +1915,11 @@ int empose_mesh_n_joints(const empose_mesh_t* mesh) { return mesh ? mesh->n_join
 
 static const int MESH_SLAB = 16384;  // frames per pass: bounds the scratch (rot, feat, rest joints, transforms)
 
-struct MeshWs { float *rot, *feat, *jrest, *xf, *th, *be; };
+struct MeshWs { float *rot, *feat, *jrest, *xf; };
 static MeshWs carve_mesh(Carver& c, const empose_mesh* mesh, size_t S) {
   MeshWs w;
   w.rot = c.f(S * 198); w.feat = c.f(S * 200); w.jrest = c.f(S * (size_t)(mesh->ncp - mesh->j_off));
-  w.xf = c.f(S * 264); w.th = c.f(S * 66); w.be = c.f(S * 10);
+  w.xf = c.f(S * 264);
   return w;
 }
 
@@ -1945,10 +1940,9 @@ static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const 
   const MeshWs w = carve_mesh(c, mesh, (size_t)S);
   for (int t0 = 0; t0 < T; t0 += S) {
     const int n = (T - t0) < S ? (T - t0) : S;
-    HIP_TRY(hipMemcpyAsync(w.th, poses + (size_t)t0 * 66, (size_t)n * 66 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.be, betas + (size_t)t0 * 10, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    FeatArgs fa;
-    fa.theta = w.th; fa.ld_theta = 66; fa.beta = w.be; fa.ld_beta = 10;
+    FeatArgs fa;   // plain evaluation: the caller's rows are read in place
+    fa.theta = const_cast<float*>(poses) + (size_t)t0 * 66; fa.ld_theta = 66;
+    fa.beta = const_cast<float*>(betas) + (size_t)t0 * 10; fa.ld_beta = 10;
     fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
     fa.shape_avg = 0; fa.rot = w.rot; fa.feat = w.feat;
     fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;

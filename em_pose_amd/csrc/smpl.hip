@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
         v = v + d * a.beta_step;
       }
       // The lanes of a window read d_beta of all its frames but write only beta[t][k]: no hazard.
-      *be = v;
+      if (a.d_beta || a.beta_keep != 1.f) *be = v;   // plain evaluation: the caller's rows are left alone
       if (a.out_beta) a.out_beta[(size_t)t * 10 + k] = v;
       if (a.out_beta2) a.out_beta2[(size_t)t * 10 + k] = v;
       s_feat[fl * 200 + 189 + k] = v;

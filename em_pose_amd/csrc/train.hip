@@ -434,6 +434,8 @@ hipError_t launch_lgd_update(int B, int F, float step, int shape_avg, const floa
 //   in-forward E_i.backward() deposit, models.py:576)
 // and, for i > 0, the cotangents of the update networks' outputs of iteration i - 1, zero-padded to the GEMM grid:
 //   dpad[:, :66] = step * Dp,   dspad[:, :10] = step * (shape_avg ? window mean of Ds : Ds)   (adjoint of the mean = mean)
+// (the padding columns are written too, so the destinations may be uninitialised memory: the stash slots of
+// empose_mlp_train_bwd_deferred)
 __global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, int first, const float* d_pose,
                                                             const float* d_shape, const float* vp, const float* vs,
                                                             const float* g_theta, int ld_g, const float* g_beta, int ld_gb,
@@ -450,7 +452,10 @@ __global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, 
       v = vp[t * 66 + c] + v;
       if (g_theta) v = inv_T * g_theta[t * ld_g + c] + v;
       Dp[t * 66 + c] = v;
-      if (dpad) dpad[t * 68 + c] = step * v;
+      if (dpad) {
+        dpad[t * 68 + c] = step * v;
+        if (c >= 64) dpad[t * 68 + c + 2] = 0.f;   // the two padding columns
+      }
     } else {
       const int k = c - 66;
       float v = d_shape[t * 10 + k];
@@ -474,6 +479,7 @@ __global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, 
       v = sds[i];
     }
     dspad[(t0 + f) * 12 + k] = step * v;
+    if (k >= 8) dspad[(t0 + f) * 12 + k + 2] = 0.f;   // padding columns
   }
 }
 hipError_t launch_lgd_cotangent(int B, int F, int first, const float* d_pose, const float* d_shape, const float* vp,

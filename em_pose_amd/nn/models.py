@@ -67,6 +67,11 @@ def normal_mse(x_gt, x_hat, seq_lengths=None, marker_mask=None):
     return per.mean()
 
 
+def _cat_windows(parts):
+    """Per-window results along the frame axis; a single window is returned as it is (a view, no device copy)."""
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
+
 def padded_loss(gt, hat, loss_fn, seq_lengths):
     """reference nn/loss.py:13-20"""
     unreduced = loss_fn(gt, hat).mean(-1)
@@ -737,7 +742,7 @@ class IterativeErrorFeedback(BaseModel):
                 res = []
                 for h in range(self.N + 1):
                     parts = [hw[key][h].reshape(bsz, -1, inner) for hw in hists]
-                    res.append(torch.cat(parts, dim=1))
+                    res.append(_cat_windows(parts))
                 return res
             self.pose_hat_history = merged('pose', 66)
             self.shape_hat_history = merged('shape', 10)
@@ -745,10 +750,10 @@ class IterativeErrorFeedback(BaseModel):
             self.markers_hat_history = merged('markers', 3)
             self.markers_ori_hat_history = merged('markers_ori', 3)
         self.gradient_trace = traces if self.keep_gradient_trace else None
-        pose = torch.cat([o['pose'] for o in outs], dim=1)
+        pose = _cat_windows([o['pose'] for o in outs])
         return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3],
-                'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
-                'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
+                'shape_hat': _cat_windows([o['shape'] for o in outs]),
+                'joints_hat': _cat_windows([o['joints'] for o in outs])}
 
     def _forward_with_graph(self, batch, window_size):
         from em_pose_amd.nn.train_engine import LgdTrainEngine
@@ -770,16 +775,16 @@ class IterativeErrorFeedback(BaseModel):
         bsz = batch.batch_size
 
         def merged(key, inner):
-            return [torch.cat([hw[key][h].reshape(bsz, -1, inner) for hw in hists], dim=1) for h in range(self.N + 1)]
+            return [_cat_windows([hw[key][h].reshape(bsz, -1, inner) for hw in hists]) for h in range(self.N + 1)]
         self.pose_hat_history = merged('pose', 66)
         self.shape_hat_history = merged('shape', 10)
         self.joints_hat_history = merged('joints', 3)
         self.markers_hat_history = merged('markers', 3)
         self.markers_ori_hat_history = merged('markers_ori', 3)
-        pose = torch.cat([o['pose'] for o in outs], dim=1)
+        pose = _cat_windows([o['pose'] for o in outs])
         return {'pose_hat': pose[:, :, 3:], 'root_ori_hat': pose[:, :, :3],
-                'shape_hat': torch.cat([o['shape'] for o in outs], dim=1),
-                'joints_hat': torch.cat([o['joints'] for o in outs], dim=1)}
+                'shape_hat': _cat_windows([o['shape'] for o in outs]),
+                'joints_hat': _cat_windows([o['joints'] for o in outs])}
 
     def _select_markers(self, t):
         """(bs, f, 12, d) -> the model's sensors; the index lives on the device (no host copy per call)."""

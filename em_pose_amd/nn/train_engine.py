@@ -81,7 +81,8 @@ class _MlpView(object):
         for lin, _, _ in self.specs[1:]:
             n_out, n_in = lin.weight.shape
             ld = (n_out + 3) & ~3
-            t = torch.zeros(n_in, ld, dtype=torch.float32, device=lin.weight.device)
+            alloc = torch.empty if ld == n_out else torch.zeros    # only padding columns need the zeros
+            t = alloc(n_in, ld, dtype=torch.float32, device=lin.weight.device)
             _lib.check(lib.empose_transpose_f32(n_out, n_in, lin.weight.data_ptr(), n_in, t.data_ptr(), ld, stream))
             self.weight_t.append(t)
 
@@ -147,11 +148,19 @@ class LgdTrainEngine(object):
         _lib.check(self.lib.empose_mlp_train_bwd(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(), C.byref(g),
                                                  int(accumulate), ws.data_ptr(), nbytes, self.stream))
 
-    def _mlp_bwd_deferred(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M):
+    def _new_stash(self, view, M):
+        """Stash of one deferred application + the address of its d_out slot (row stride (out_dim + 3) & ~3): the
+        cotangent kernel writes the output cotangent there directly, so the deferred backward copies nothing."""
+        p = view.params()
+        stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
+        return stash, stash.data_ptr() + 4 * M * (view.n_layers - 1) * view.hidden
+
+    def _mlp_bwd_deferred(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M, stash=None):
         """Backward of one application that keeps the layer cotangents instead of forming dW / db; returns the stash."""
         p = view.params()
         g = view.grads(grads)
-        stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
+        if stash is None:
+            stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
         nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
         ws = self.ws(nbytes)
         _lib.check(self.lib.empose_mlp_train_bwd_deferred(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(),
@@ -342,11 +351,14 @@ class LgdTrainEngine(object):
                 # `E_i.backward()` deposit, models.py:576: dE_i/d(pose_i) = g_i / (B F) flows into everything that produced
                 # pose_i) and, for i > 0, the zero-padded cotangents of the update networks' outputs of iteration i - 1
                 deposit = i < N and net.use_gradient
+                dp_ptr, ds_ptr = dpad.data_ptr(), dspad.data_ptr()
+                if deferred and i > 0:   # straight into the d_out slots of this application's stashes
+                    (st_p, dp_ptr), (st_s, ds_ptr) = self._new_stash(views[0], T), self._new_stash(views[1], T)
                 _lib.check(lib.empose_lgd_cotangent_step(
                     B, F, int(i == N), d_pose[i].data_ptr(), d_shape[i].data_ptr(), vp.data_ptr(), vs.data_ptr(),
                     X[i][:, d_in + 76:].data_ptr() if deposit else None, d_x,
                     X[i][:, d_in + 142:].data_ptr() if deposit else None, d_x, Dp.data_ptr(), Ds.data_ptr(), s,
-                    int(bool(net.shape_avg)), dpad.data_ptr() if i > 0 else None, dspad.data_ptr() if i > 0 else None,
+                    int(bool(net.shape_avg)), dp_ptr if i > 0 else None, ds_ptr if i > 0 else None,
                     self.stream))
                 if i == 0:
                     break
@@ -355,11 +367,11 @@ class LgdTrainEngine(object):
                 if deferred:
                     # weight gradients once over all N applications (one A^T B per layer instead of N)
                     pend[0].append((X[i - 1].data_ptr(), sp,
-                                    self._mlp_bwd_deferred(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp,
-                                                           grads[0], acc, T)))
+                                    self._mlp_bwd_deferred(views[0], X[i - 1].data_ptr(), d_x, dp_ptr, 68, sp,
+                                                           grads[0], acc, T, stash=st_p)))
                     pend[1].append((X[i - 1].data_ptr(), ss,
-                                    self._mlp_bwd_deferred(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss,
-                                                           grads[1], acc, T)))
+                                    self._mlp_bwd_deferred(views[1], X[i - 1].data_ptr(), d_x, ds_ptr, 12, ss,
+                                                           grads[1], acc, T, stash=st_s)))
                 else:
                     self._mlp_bwd(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp, grads[0], acc, T)
                     self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)

@@ -326,7 +326,9 @@ int empose_mlp_train_bwd(const empose_mlp_params* p, int M, const float* x, int 
  * n_app * M rows per layer instead of n_app products and reductions.  BatchNorm / PReLU parameter gradients are produced
  * by the deferred backward exactly as by empose_mlp_train_bwd.  x / save / dz_stash of wgrad: host arrays of n_app
  * device pointers (n_app <= 8), the arguments the applications were run with.  Same sums in a different order:
- * results agree with the per-application path to rounding, not bitwise. */
+ * results agree with the per-application path to rounding, not bitwise.
+ * The stash keeps d_out at dz_stash + M * (n_layers - 1) * hidden, row stride (out_dim + 3) & ~3: a caller that
+ * produces d_out there (d_out = that address, ld_dout = that stride) saves the copy. */
 size_t empose_mlp_train_stash_floats(const empose_mlp_params* p, int M);
 int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out,
                                   int ld_dout, const float* save, const empose_mlp_grads* grads, int accumulate,
