@@ -636,7 +636,8 @@ int empose_set_option(const char* name, int value) {
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
       {"gemm_wide", &o.gemm_wide},
-      {"atb_target", &o.atb_target}};
+      {"atb_target", &o.atb_target},
+      {"atb_chunk", &o.atb_chunk}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
@@ -648,7 +649,8 @@ int empose_get_option(const char* name) {
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
       {"gemm_wide", o.gemm_wide},
-      {"atb_target", o.atb_target}};
+      {"atb_target", o.atb_target},
+      {"atb_chunk", o.atb_chunk}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;

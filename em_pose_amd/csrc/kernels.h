@@ -13,7 +13,8 @@ struct Options {
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
-  int atb_target = 256;   // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction
+  int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
+  int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
 };
 Options& options();
 

@@ -112,13 +112,18 @@ __global__ __launch_bounds__(atb::NT) void gemm_atb_kernel(AtbArgs a) {
 // has in memory -- [row m][column]: lane (column = lane & 31, m parity = lane >> 5) is exactly the 32x32x2 operand
 // order, consecutive lanes hit consecutive banks.  Chunks of 32 rows, double-buffered.  Needs 16-byte aligned rows
 // (lda, ldb multiples of 4, aligned bases); the register kernel takes the rest.
+// MC = rows per chunk: 32 with one workgroup per CU, 16 when the reduction is split far enough for two or more (long
+// reductions: the second workgroup of a CU hides what a single wave per SIMD cannot -- load latency, the LDS writes;
+// measured on 32768 x 512 x 512 with scripts/dev/atb_lab.hip: 176 us at 256 workgroups x 32 rows, 138 at 512 x 16).
 namespace atbl {
-constexpr int NT = 256, BN = 128, BK = 128, MC = 32;
-constexpr int LDS_FLOATS = 2 * MC * (BN + BK);
+constexpr int NT = 256, BN = 128, BK = 128;
 }  // namespace atbl
 
+template <int MC>
 __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   using namespace atbl;
+  constexpr int LDS_FLOATS = 2 * MC * (BN + BK);
+  constexpr int P = MC / 8;   // rows a thread stages per chunk and operand
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   const int tiles_k = (a.K + BK - 1) / BK;
   const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
@@ -135,20 +140,33 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // staging: thread (row r8 = tid / 32, 16-byte piece c4 = tid % 32) moves rows r8 + 8 p, p = 0..3, of both operands
+  // staging: thread (row r8 = tid / 32, 16-byte piece c4 = tid % 32) moves rows r8 + 8 p, p < P, of both operands
   const int r8 = tid >> 5, c4 = (tid & 31) * 4;
   typedef float f4 __attribute__((ext_vector_type(4)));
-  f4 ga[4], gb[4];
+  f4 ga[P], gb[P];
+  const bool tile_full = n_base + BN <= a.N && k_base + BK <= a.K;   // uniform over the workgroup
+  // row segments (the applications of one network): a chunk never straddles two (seg_rows is a multiple of 32), and
+  // the segment is looked up again only when the walk leaves it
+  const float* A0 = a.A; const float* B0 = a.B;
+  int mrel = 0, seg_end = a.n_seg > 0 ? 0 : 0x7fffffff;
   auto gload = [&](int m0) {
-    // a 32-row chunk never straddles two row segments (seg_rows is a multiple of 32)
-    const float* A0 = a.A; const float* B0 = a.B;
-    int mrel = 0;
-    if (a.n_seg > 0) {
+    if (m0 >= seg_end) {
       const int sg = min(m0 / a.seg_rows, a.n_seg - 1);
       A0 = a.A_seg[sg]; B0 = a.B_seg[sg]; mrel = sg * a.seg_rows;
+      seg_end = sg + 1 < a.n_seg ? mrel + a.seg_rows : 0x7fffffff;
+    }
+    if (tile_full && m0 + MC <= me) {   // interior chunk (all but the edges): straight loads, no per-lane branches
+      const float* pa = A0 + (size_t)(m0 - mrel + r8) * a.lda + n_base + c4;
+      const float* pb = B0 + (size_t)(m0 - mrel + r8) * a.ldb + k_base + c4;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        ga[p] = *reinterpret_cast<const f4*>(pa + (size_t)(8 * p) * a.lda);
+        gb[p] = *reinterpret_cast<const f4*>(pb + (size_t)(8 * p) * a.ldb);
+      }
+      return;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < P; ++p) {
       const int mm = m0 + r8 + 8 * p;
       const bool row_ok = mm < me;
       f4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   };
   auto lwrite = [&](float* st) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < P; ++p) {
       *reinterpret_cast<f4*>(st + (r8 + 8 * p) * BN + c4) = ga[p];
       *reinterpret_cast<f4*>(st + MC * BN + (r8 + 8 * p) * BK + c4) = gb[p];
     }
@@ -184,16 +202,24 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
     if (more) gload(m + MC);
     const float* sA = lds + buf * STAGE + nw + l31;
     const float* sB = lds + buf * STAGE + MC * BN + kw + l31;
+    // One wave per SIMD: nothing else hides the LDS latency, so the operands of row pair q + 1 are read before the
+    // four MFMAs of row pair q (order pinned: left alone the compiler reads each pair right before its use).
+    float a0 = sA[lh * BN], a1 = sA[lh * BN + 32];
+    float b0 = sB[lh * BK], b1 = sB[lh * BK + 32];
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int q = 0; q < MC / 2; ++q) {
-      const int row = 2 * q + lh;
-      const float a0 = sA[row * BN], a1 = sA[row * BN + 32];
-      const float b0 = sB[row * BK], b1 = sB[row * BK + 32];
+      const int row = (q + 1 < MC / 2 ? 2 * (q + 1) : 0) + lh;
+      const float na0 = sA[row * BN], na1 = sA[row * BN + 32];
+      const float nb0 = sB[row * BK], nb1 = sB[row * BK + 32];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       if (do_bias) { bsum[0] += a0; bsum[1] += a1; }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two ds_read2 of the next row pair
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // this row pair's MFMAs
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
     if (more) lwrite(lds + (buf ^ 1) * STAGE);
     __syncthreads();
@@ -245,9 +271,19 @@ __global__ void atb_reduce_kernel(AtbArgs a) {
   }
 }
 
+// Long reductions (>= 768 rows per workgroup at twice the target) split twice as far and stage 16-row chunks, so that
+// two workgroups share a CU (scripts/dev/bench_atb.py: 32768 x 512 x 512 216 -> 172 us, 32768 x 512 x 296 254 -> 195,
+// 16384 x 512 x 512 and below unchanged); "atb_target" / "atb_chunk" (dev options) override both.
+static bool atb_long(int M, int tiles) { return (long)M * tiles >= (long)512 * 768; }
+int atb_chunk_rows(int M, int N, int K) {
+  const int tiles = ((N + atb::BN - 1) / atb::BN) * ((K + atb::BK - 1) / atb::BK);
+  if (options().atb_chunk == 16 || options().atb_chunk == 32) return options().atb_chunk;
+  return atb_long(M, tiles) ? 16 : 32;
+}
 int atb_splits(int M, int N, int K) {
   const int tiles = ((N + atb::BN - 1) / atb::BN) * ((K + atb::BK - 1) / atb::BK);
-  int s = (options().atb_target + tiles - 1) / tiles;
+  const int target = options().atb_target > 0 ? options().atb_target : (atb_long(M, tiles) ? 512 : 256);
+  int s = (target + tiles - 1) / tiles;
   s = std::min(s, std::max(1, M / 64));
   return std::max(1, std::min(s, 256));
 }
@@ -273,7 +309,9 @@ hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream) {
   } else {
     aligned = aligned && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
   }
-  if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
+  if (aligned && atb_chunk_rows(a.M, a.N, a.K) == 16)
+    hipLaunchKernelGGL(gemm_atb_lds_kernel<16>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
+  else if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel<32>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
   else hipLaunchKernelGGL(gemm_atb_kernel, dim3(tiles, a.S), dim3(atb::NT), 0, stream, a);
   if (a.S > 1) {
     const size_t n = (size_t)a.N * a.K;

@@ -54,7 +54,7 @@ const char* empose_arch(void);
 /* Kernel-variant selection for A/B measurements and bit-identity tests: several paths have two implementations (the
  * one-launch fused update MLPs vs layer-by-layer GEMMs, whole-sequence LSTM kernels vs step launches, ...) that must
  * give the same results.  Options are process-wide ints, default 1 = the faster variant; the library never reads the
- * environment.  Names: "mlp_fused", "lstm_persist", "gemm_splitk", "gemm_wide", "atb_target".
+ * environment.  Names: "mlp_fused", "lstm_persist", "gemm_splitk", "gemm_wide", "atb_target", "atb_chunk".
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
 int empose_set_option(const char* name, int value);
 int empose_get_option(const char* name);
