@@ -144,6 +144,10 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   const int r8 = tid >> 5, c4 = (tid & 31) * 4;
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 ga[P], gb[P];
+  // column sums of A (the bias gradient): every row passes through the staging registers exactly once, so the threads
+  // add what they write to LDS (per thread: rows r8 + 8 j of four columns); the eight row groups meet in LDS at the end
+  const bool do_bias = a.bias_partial != nullptr && tk == 0;   // uniform over the workgroup
+  f4 bs = {0.f, 0.f, 0.f, 0.f};
   const bool tile_full = n_base + BN <= a.N && k_base + BK <= a.K;   // uniform over the workgroup
   // row segments (the applications of one network): a chunk never straddles two (seg_rows is a multiple of 32), and
   // the segment is looked up again only when the walk leaves it
@@ -188,10 +192,9 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
     for (int p = 0; p < P; ++p) {
       *reinterpret_cast<f4*>(st + (r8 + 8 * p) * BN + c4) = ga[p];
       *reinterpret_cast<f4*>(st + MC * BN + (r8 + 8 * p) * BK + c4) = gb[p];
+      if (do_bias) bs += ga[p];   // here, not at the load: the loads have landed by now
     }
   };
-  float bsum[2] = {0.f, 0.f};
-  const bool do_bias = a.bias_partial != nullptr && tk == 0 && (wave & 1) == 0;
   constexpr int STAGE = MC * (BN + BK);
   gload(ms);
   lwrite(lds);
@@ -216,7 +219,6 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      if (do_bias) { bsum[0] += a0; bsum[1] += a1; }
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the two ds_read2 of the next row pair
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // this row pair's MFMAs
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
@@ -241,15 +243,15 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
         if (n < a.N) out[(size_t)n * ldo + k] = acc[i][j][r] + (acc_c ? out[(size_t)n * ldo + k] : 0.f);
       }
     }
-  if (do_bias) {
+  if (do_bias) {   // (the loop left through a barrier: the LDS stages are free)
+    *reinterpret_cast<f4*>(lds + r8 * BN + c4) = bs;
+    __syncthreads();
+    if (tid < BN && n_base + tid < a.N) {
+      float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int n = n0 + i * 32 + l31;
-      if (lh == 0 && n < a.N) {
-        float* bo = a.S > 1 ? a.bias_partial + (size_t)blockIdx.y * a.N : a.bias;
-        bo[n] = v + (acc_c ? bo[n] : 0.f);
-      }
+      for (int g = 0; g < 8; ++g) v += lds[g * BN + tid];
+      float* bo = a.S > 1 ? a.bias_partial + (size_t)blockIdx.y * a.N : a.bias;
+      bo[n_base + tid] = v + (acc_c ? bo[n_base + tid] : 0.f);
     }
   }
 }

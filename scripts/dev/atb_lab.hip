@@ -9,6 +9,7 @@ typedef float f32x16t __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // V bit 0: no global loads inside the loop   bit 1: no LDS writes   bit 2: no LDS reads (constant operands)
+// V bit 3: global_load_lds (16 bytes per lane straight into LDS, no staging registers, no ds_write)
 // TM x TK: wave tile in 32-blocks (2 x 2 = the production kernel: 64 x 64 per wave, 128 x 128 per workgroup)
 template <int V, int MC>
 __global__ __launch_bounds__(256) void atb_kernel(const float* A, const float* B, float* partial, int M, int N, int K,
@@ -46,13 +47,30 @@ __global__ __launch_bounds__(256) void atb_kernel(const float* A, const float* B
     }
   };
   constexpr int STAGE = MC * (BN + BK);
-  gload(ms);
-  lwrite(lds);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  auto gdma = [&](int m0, float* st) {   // a wave instruction fills 1 KB of LDS: its two rows of one operand
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int mm = m0 + r8 + 8 * p;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(A + (size_t)mm * N + n_base + c4),
+                                       (lds_ptr_t)(st + (2 * wave + 8 * p) * BN), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(B + (size_t)mm * K + k_base + c4),
+                                       (lds_ptr_t)(st + MC * BN + (2 * wave + 8 * p) * BK), 16, 0, 0);
+    }
+  };
+  if (V & 8) {
+    gdma(ms, lds);
+  } else {
+    gload(ms);
+    lwrite(lds);
+  }
   __syncthreads();
   int buf = 0;
   for (int m = ms; m < me; m += MC) {
     const bool more = m + MC < me;
-    if (more && !(V & 1)) gload(m + MC);
+    if (more && (V & 8)) gdma(m + MC, lds + (buf ^ 1) * STAGE);
+    if (more && !(V & 1) && !(V & 8)) gload(m + MC);
     const float* sA = lds + buf * STAGE + nw + l31;
     const float* sB = lds + buf * STAGE + MC * BN + kw + l31;
     float a0 = sA[lh * BN], a1 = sA[lh * BN + 32];
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(256) void atb_kernel(const float* A, const float* B
       }
       a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-    if (more && !(V & 2)) lwrite(lds + (buf ^ 1) * STAGE);
+    if (more && !(V & 2) && !(V & 8)) lwrite(lds + (buf ^ 1) * STAGE);
     __syncthreads();
     buf ^= 1;
   }
@@ -132,6 +150,23 @@ int main() {
     run<7, 32>("MFMAs + barriers only", A, B, partial, M, N, K, S);
     run<0, 64>("64-row chunks", A, B, partial, M, N, K, S);
     run<0, 16>("16-row chunks", A, B, partial, M, N, K, S);
+    run<8, 32>("global_load_lds", A, B, partial, M, N, K, S);
+    run<8, 16>("global_load_lds, 16-row chunks", A, B, partial, M, N, K, S);
+    run<8, 64>("global_load_lds, 64-row chunks", A, B, partial, M, N, K, S);
+  }
+  // same result with and without the direct loads?
+  float* p2; hipMalloc(&p2, (size_t)16 * N * K * 4);
+  {
+    const size_t lds = (size_t)2 * 32 * 256 * sizeof(float);
+    const dim3 grid((N / 128) * (K / 128), 16);
+    hipLaunchKernelGGL((atb_kernel<0, 32>), grid, dim3(256), lds, 0, A, B, partial, M, N, K, 16);
+    hipLaunchKernelGGL((atb_kernel<8, 32>), grid, dim3(256), lds, 0, A, B, p2, M, N, K, 16);
+    hipDeviceSynchronize();
+    const size_t n = (size_t)16 * N * K;
+    float* h0 = new float[n]; float* h1 = new float[n];
+    hipMemcpy(h0, partial, n * 4, hipMemcpyDeviceToHost); hipMemcpy(h1, p2, n * 4, hipMemcpyDeviceToHost);
+    double worst = 0; for (size_t i = 0; i < n; ++i) { double d = h0[i] - h1[i]; if (d < 0) d = -d; if (d > worst) worst = d; }
+    printf("max |staged - direct| = %g  (sample %g)\n", worst, h0[12345]);
   }
   return 0;
 }
