@@ -262,7 +262,15 @@ __global__ void atb_reduce_kernel(AtbArgs a) {
   const size_t nk = (size_t)a.N * a.K;
   if (i < nk) {
     float v = 0.f;
-    for (int s = 0; s < a.S; ++s) v += a.partial[(size_t)s * nk + i];
+    int s = 0;
+    for (; s + 8 <= a.S; s += 8) {   // eight loads in flight, added in split order
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = a.partial[(size_t)(s + j) * nk + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    for (; s < a.S; ++s) v += a.partial[(size_t)s * nk + i];
     const size_t n = i / a.K, k = i - n * a.K;
     a.C[n * a.ldc + k] = v + (a.accumulate ? a.C[n * a.ldc + k] : 0.f);
   }
