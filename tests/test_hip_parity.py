@@ -851,6 +851,41 @@ def test_training_weight_gradients_once_over_all_iterations_equal_per_iteration_
                                    atol=2e-5 * max(float(v.abs().max()), 1e-3 * gmax), rtol=1e-4, err_msg=k)
 
 
+def test_training_weight_gradients_long_reduction_of_the_full_width_networks():
+    """The released width (512 hidden units) at 256 windows: the one-product-per-layer weight gradients run the
+    long-reduction variant of A^T B over row segments (4 x 8192 rows, 512 workgroups of 16-row chunks); the
+    per-application products give the same gradients up to the order of the additions."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    model = H.small_model()
+    vids = H.load_case('train_lgdrnn12_n2')['meta']['vertex_ids']
+    B, F = 256, 32
+    torch.manual_seed(3)
+    net = build_net(lgd_config(12, False, 4), model, vids).train()
+    w = synthetic.make_windows(B, F, 11)
+    g = torch.Generator().manual_seed(11)
+    w['marker_pos'] = torch.randn(B, F, 36, generator=g).numpy()
+    w['marker_oris'] = torch.randn(B, F, 108, generator=g).numpy()
+    batch = SyntheticBatch(w, device=DEV)
+    batch.joints_gt = torch.randn(B, F, 66, generator=g).to(DEV)
+    bn_state = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    grads = {}
+    for mode in (True, False):
+        LgdTrainEngine.batched_wgrad = mode
+        try:
+            net.load_state_dict(bn_state, strict=False)
+            net.zero_grad()
+            net.backward(batch, net(batch))
+            grads[mode] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        finally:
+            LgdTrainEngine.batched_wgrad = True
+    gmax = max(float(v.abs().max()) for v in grads[False].values())
+    assert gmax > 0 and len(grads[True]) >= 14
+    for k, v in grads[False].items():
+        np.testing.assert_allclose(grads[True][k].cpu().numpy(), v.cpu().numpy(),
+                                   atol=2e-5 * max(float(v.abs().max()), 1e-3 * gmax), rtol=1e-4, err_msg=k)
+
+
 @pytest.mark.parametrize('rnn,n_markers', [(True, 12), (False, 6)])
 def test_graphed_training_step_equals_eager(rnn, n_markers):
     """helpers/graphed.py: forward + backward captured in a HIP graph and replayed on new batches gives the losses and,
@@ -1289,9 +1324,10 @@ def test_ground_truth_preprocessing_round_trip(big_model):
 # Training backward building blocks (BASELINE configs[4]): hand-written kernels against torch.autograd
 # ----------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K', [(384, 512, 512), (8192, 512, 296), (1000, 66, 512), (50, 10, 512), (4096, 2048, 144),
-                                   (7, 5, 3), (130, 200, 320)])
+                                   (7, 5, 3), (130, 200, 320), (24576, 512, 512), (20000, 515, 500)])
 def test_gemm_atb_vs_float64(M, N, K):
-    """C = A^T B (+ column sums of A): the weight / bias gradient of a linear layer."""
+    """C = A^T B (+ column sums of A): the weight / bias gradient of a linear layer.  The last two shapes are long
+    reductions (twice the split, 16-row chunks, two workgroups per CU), the last one with edge tiles and a ragged end."""
     rng = np.random.default_rng(M + N)
     lda, ldb, ldc = N + 3, K + 5, K + 2
     a = rng.normal(size=(M, lda)).astype(np.float32)
