@@ -321,8 +321,10 @@ def _check_against_record(net, rec, res, B, F, N):
         np.testing.assert_allclose(got, rec['hist_' + name], atol=ATOL)
     gp = res['trace']['g_pose'].cpu().numpy()
     gs = res['trace']['g_shape'].cpu().numpy()
-    np.testing.assert_allclose(gp, rec['g_pose'], atol=2e-3, rtol=2e-3)
-    np.testing.assert_allclose(gs, rec['g_shape'], atol=2e-3, rtol=2e-3)
+    # values hooked out of the reference's autograd, O(10): 1e-5 of the tensor's scale (measured: at most 2.1e-6 of it,
+    # 5.8e-5 absolute on values up to 27.5)
+    np.testing.assert_allclose(gp, rec['g_pose'], atol=1e-5 * np.abs(rec['g_pose']).max(), rtol=0)
+    np.testing.assert_allclose(gs, rec['g_shape'], atol=1e-5 * np.abs(rec['g_shape']).max(), rtol=0)
 
 
 def _run_case(name, tags, sl_key=None):
