@@ -285,7 +285,7 @@ __global__ void atb_reduce_kernel(AtbArgs a) {
 // two workgroups share a CU (scripts/dev/bench_atb.py: 32768 x 512 x 512 216 -> 172 us, 32768 x 512 x 296 254 -> 195,
 // 16384 x 512 x 512 and below unchanged); "atb_target" / "atb_chunk" (dev options) override both.
 static bool atb_long(int M, int tiles) { return (long)M * tiles >= (long)512 * 768; }
-int atb_chunk_rows(int M, int N, int K) {
+static int atb_chunk_rows(int M, int N, int K) {
   const int tiles = ((N + atb::BN - 1) / atb::BN) * ((K + atb::BK - 1) / atb::BK);
   if (options().atb_chunk == 16 || options().atb_chunk == 32) return options().atb_chunk;
   return atb_long(M, tiles) ? 16 : 32;
