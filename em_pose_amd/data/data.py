@@ -3,7 +3,7 @@ Batch containers: the input contract of the models (reference empose/data/data.p
 
 What the LGD path touches is restated: the attribute set of `ABatch`, `RealBatch` with its missing-sensor suppression,
 `AMASSSample` / `AMASSBatch` (the training-side containers: npz samples, padded collation), and `get_inputs(sf, ef)`
-yielding the dict the model reads.  LMDB datasets are out of scope (host-side IO, data absent).
+yielding the dict the model reads (SURVEY.md 8b).  The LMDB key schema is read by data/datasets.py::LMDBDataset.
 """
 import numpy as np
 import torch

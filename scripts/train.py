@@ -34,14 +34,21 @@ from em_pose_amd.helpers.distributed import allreduce_gradients, init_from_env  
 from em_pose_amd.nn.models import create_model  # noqa: E402
 
 
+def _body_columns(sample):
+    """LMDB records keep all 156 AMASS pose columns and 16 shape coefficients; the batch takes root + body, 10 betas."""
+    from em_pose_amd.helpers.configuration import CONSTANTS as C
+    sample.poses, sample.shape = sample.poses[:, :C.MAX_INDEX_ROOT_AND_BODY], sample.shape[:C.N_SHAPE_PARAMS]
+    return sample
+
+
 def train_on_amass(args, dev, rank, world):
     """Data-parallel training on AMASS npz sequences: random windows, offsets with the configured noise level, periodic
     validation on held-out sequences, best checkpoint + config.json in the reference's experiment layout (so that
     `scripts/evaluate_real.py --model_id <id>` / `eval.helpers.load_model` find them)."""
     import glob
-    from torch.utils.data import DataLoader
+    from torch.utils.data import DataLoader, Subset
     from em_pose_amd.data.data import AMASSBatch
-    from em_pose_amd.data.datasets import AMASSNpzDataset
+    from em_pose_amd.data.datasets import AMASSNpzDataset, LMDBDataset
     from em_pose_amd.data.transforms import ExtractWindow, ToTensor, get_end_to_end_preprocess_fn
     from em_pose_amd.eval.helpers import evaluate
     from em_pose_amd.eval.metrics import MetricsEngine
@@ -61,26 +68,44 @@ def train_on_amass(args, dev, rank, world):
     fn_train = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=True)
     fn_valid = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=False)
 
-    files = sorted(glob.glob(os.path.join(args.amass_dir, '**', '*.npz'), recursive=True))
-    if len(files) < 2:
-        raise SystemExit('need at least two AMASS sequences under ' + args.amass_dir)
-    n_valid = max(1, int(round(len(files) * args.valid_fraction)))
-    valid_files, train_files = files[::max(1, len(files) // n_valid)][:n_valid], None
+    # The sequences: AMASS npz files under --amass_dir, or the records of an LMDB database in the reference's key schema
+    # (--amass_lmdb, + optionally a separate --valid_lmdb as the reference trains on AMASS and validates on 3DPW).
+    def ex_seqs(transform, items, lmdb_path=None):
+        if lmdb_path is None:
+            return AMASSNpzDataset(None, transform, files=items)
+        return Subset(LMDBDataset(lmdb_path, transform), items)
+    valid_src = train_src = args.amass_lmdb
+    if args.amass_lmdb:
+        items = list(range(len(LMDBDataset(args.amass_lmdb))))
+    else:
+        items = sorted(glob.glob(os.path.join(args.amass_dir, '**', '*.npz'), recursive=True))
+    if args.valid_lmdb:
+        valid_src, valid_items = args.valid_lmdb, list(range(len(LMDBDataset(args.valid_lmdb))))
+    else:
+        if len(items) < 2:
+            raise SystemExit('need at least two AMASS sequences')
+        n_valid = max(1, int(round(len(items) * args.valid_fraction)))
+        valid_items = items[::max(1, len(items) // n_valid)][:n_valid]
+        held_out = set(valid_items)
+        items = [f for f in items if f not in held_out]
     # Sequences sharded over the ranks.  Every rank must run the same number of steps per epoch (each step ends in a
     # gradient all-reduce): the list is cut to a multiple of world x batch size before it is dealt out.
-    train_all = [f for f in files if f not in valid_files]
-    usable = (len(train_all) // (world * args.bs_train)) * world * args.bs_train
+    usable = (len(items) // (world * args.bs_train)) * world * args.bs_train
     if usable == 0:
         raise SystemExit('{} training sequences are fewer than one batch of {} on each of {} ranks'
-                         .format(len(train_all), args.bs_train, world))
-    train_files = train_all[:usable][rank::world]
-    win = lambda mode, rng=None: (lambda smp: ToTensor()(ExtractWindow(args.window_size, rng=rng, mode=mode)(smp)))
+                         .format(len(items), args.bs_train, world))
+    train_items = items[:usable][rank::world]
+    win = lambda mode, rng=None: (lambda smp: ToTensor()(ExtractWindow(args.window_size, rng=rng, mode=mode)(
+        _body_columns(smp))))
     window_rng = np.random.RandomState(args.seed + rank)
 
-    def seed_worker(worker_id):   # every DataLoader worker owns a copy of window_rng: give each its own stream
-        window_rng.seed(args.seed + 1000 * (rank + 1) + worker_id)
-    train_data = AMASSNpzDataset(None, win('random', window_rng), files=train_files)
-    valid_data = AMASSNpzDataset(None, win('middle'), files=valid_files)
+    def seed_worker(worker_id):
+        # Every DataLoader worker owns a copy of window_rng.  Workers are re-created every epoch; torch.initial_seed()
+        # inside a worker is that epoch's base seed + worker_id, so the crop offsets differ between epochs, workers and
+        # (through the rank term: the base seed is the same on every rank) ranks.
+        window_rng.seed((torch.initial_seed() + 1000003 * (rank + 1)) % (2 ** 32))
+    train_data = ex_seqs(win('random', window_rng), train_items, train_src)
+    valid_data = ex_seqs(win('middle'), valid_items, valid_src)
     loader = lambda data, bs, shuffle: DataLoader(data, batch_size=bs, shuffle=shuffle, num_workers=args.data_workers,
                                                  collate_fn=AMASSBatch.from_sample_list, drop_last=shuffle,
                                                  worker_init_fn=seed_worker if shuffle else None)
@@ -155,6 +180,8 @@ def main():
     # training on AMASS sequences (the loop of reference scripts/train.py:125-230 with checkpoints and validation)
     p.add_argument('--amass_dir', default=None, help='directory tree of AMASS *.npz sequences; switches from the '
                                                      'synthetic step benchmark to real training')
+    p.add_argument('--amass_lmdb', default=None, help='LMDB database in the reference key schema (needs `lmdb`)')
+    p.add_argument('--valid_lmdb', default=None, help='validation LMDB (e.g. 3DPW); default: held-out training sequences')
     p.add_argument('--offset_files', nargs='*', default=None, help='*_offsets.npz files (default: $EM_DATA_REAL/*_offsets.npz)')
     p.add_argument('--smpl_model', default=None, help='SMPL-H model.npz (default: the synthetic stand-in body model)')
     p.add_argument('--experiment_dir', default=None, help='where <id>-<name>/model.pth, config.json go ($EM_EXPERIMENTS)')
@@ -172,7 +199,7 @@ def main():
     torch.cuda.set_device(dev)
     rank, world = init_from_env(dev)
 
-    if args.amass_dir:
+    if args.amass_dir or args.amass_lmdb:
         return train_on_amass(args, dev, rank, world)
     model = synthetic.make_model()
     torch.manual_seed(args.seed)  # identical initial replicas on every rank

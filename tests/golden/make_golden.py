@@ -325,7 +325,44 @@ def train_sensitivity(vids):
     print({k: {kk: vv for kk, vv in v.items() if kk != 'grad'} for k, v in res.items()})
 
 
+def make_lmdb_schema():
+    """The LMDB key schema: a store written with the build's `encode_sequence_records` is read by the
+    UNMODIFIED reference reader (empose/data/datasets.py:19-60, over the dict-backed `lmdb` stand-in of oracle/refstubs);
+    the records and what the reference returned for every sequence are the fixture."""
+    import lmdb  # the stand-in
+    from empose.data.datasets import LMDBDataset
+    from em_pose_amd.data.datasets import LMDB_LEN_KEY, encode_sequence_records
+    rng = np.random.default_rng(4259)
+    records, out = {}, {}
+    specs = [('ACCAD/Female1General_c3d/A1 - Stand_poses', 7, 'female'), ('3dpw/courtyard_basketball_00.pkl', 1, 'male'),
+             ('BioMotionLab_NTroje/rub001/0000_treadmill_slow_poses', 33, 'unknown')]
+    for i, (sid, n, gender) in enumerate(specs):
+        poses = rng.standard_normal((n, 156 if i != 1 else 66))     # AMASS keeps 156 columns, 3DPW 66
+        betas = rng.standard_normal(16 if i != 1 else 10)
+        trans = rng.standard_normal((n, 3))
+        joints = rng.standard_normal((n, 66))
+        records.update(encode_sequence_records(i, sid, poses, betas, trans, joints, gender))
+    records[LMDB_LEN_KEY] = str(len(specs)).encode()
+    lmdb.register('/golden/lmdb', records)
+    ds = LMDBDataset('/golden/lmdb', transform=None)
+    out['n'] = np.asarray(len(ds))
+    for i in range(len(ds)):
+        s = ds[i]
+        out['seq{}/poses'.format(i)], out['seq{}/shape'.format(i)] = s.poses, s.shape
+        out['seq{}/trans'.format(i)], out['seq{}/joints'.format(i)] = s.trans, s.joints
+        out['seq{}/meta'.format(i)] = np.asarray(json.dumps({'id': s.id, 'gender': s.gender, 'fps': s.fps,
+                                                             'n_frames': int(s.n_frames)}))
+    keys = sorted(records)
+    out['keys'] = np.asarray(json.dumps([k.decode() for k in keys]))
+    for j, k in enumerate(keys):
+        out['rec/{}'.format(j)] = np.frombuffer(records[k], dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'lmdb_schema.npz'), **out)
+    print('wrote lmdb_schema.npz')
+
+
 def main():
+    if '--only-lmdb' in sys.argv:
+        return make_lmdb_schema()
     model = build_small_model()
     vids = synthetic.small_vertex_ids(160)
     if '--only-train-sensitivity' in sys.argv:
@@ -498,6 +535,7 @@ def main():
     make_preprocess(model, vids)
     make_baselines(vids)
     train_sensitivity(vids)
+    make_lmdb_schema()
 
 
 if __name__ == '__main__':

@@ -272,3 +272,65 @@ def test_amass_sample_and_batch(tmp_path):
     inp = batch.get_inputs(sf=4, ef=10)
     assert inp['marker_pos'].shape == (2, 6, 36) and float(inp['marker_pos'].min()) == 2.0   # noisy wins over synth
     assert float(inp['marker_oris'].min()) == 1.0 and inp['marker_masks'] is None and inp['joints'] is None
+
+
+def _lmdb_fixture():
+    z = np.load(os.path.join(H.GOLDEN, 'lmdb_schema.npz'))
+    keys = json.loads(str(z['keys']))
+    return z, {k.encode(): z['rec/{}'.format(j)].tobytes() for j, k in enumerate(keys)}
+
+
+def test_lmdb_key_schema_reader_equals_the_reference_reader():
+    """`LMDBDataset` over a dict store returns, for every sequence, exactly what the reference's reader
+    (empose/data/datasets.py:42-59, run by make_golden.py) returned for the same records; the key set is the one the
+    reference's conversion script writes (scripts/preprocess_amass_3dpw.py:171-189)."""
+    from em_pose_amd.data.datasets import LMDBDataset, encode_sequence_records
+    z, records = _lmdb_fixture()
+    n = int(z['n'])
+    assert set(records) == {'{}{}'.format(f, i).encode() for i in range(n) for f in
+                            ('poses', 'betas', 'trans', 'joints', 'n_frames', 'id', 'gender')} | {b'__len__'}
+    ds = LMDBDataset(records)          # a dict has get(key) -> bytes | None
+    assert len(ds) == n
+    again = {b'__len__': records[b'__len__']}
+    for i in range(n):
+        s, meta = ds[i], json.loads(str(z['seq{}/meta'.format(i)]))
+        assert (s.id, s.gender, s.fps, s.n_frames) == (meta['id'], meta['gender'], meta['fps'], meta['n_frames'])
+        for name, got in (('poses', s.poses), ('shape', s.shape), ('trans', s.trans), ('joints', s.joints)):
+            want = z['seq{}/{}'.format(i, name)]
+            assert got.dtype == np.float32 and got.shape == want.shape and np.array_equal(got, want), (i, name)
+            assert got.flags.writeable     # the reference copies out of the read-only transaction buffer
+        assert s.joints.shape == (s.n_frames, 66) and s.trans.shape == (s.n_frames, 3)
+        # the writer side: decoded arrays encode back to the very same bytes
+        back = np.frombuffer(records['joints{}'.format(i).encode()], dtype=np.float32).reshape(s.n_frames, -1)
+        again.update(encode_sequence_records(i, s.id, s.poses, s.shape, s.trans, back, s.gender))
+    assert again == records
+    # the sample feeds the training-side containers like an npz sample does
+    from em_pose_amd.data.data import AMASSBatch
+    samples = [ds[i].extract_window(0, 1) for i in (0, 2)]
+    for smp in samples:
+        smp.poses = smp.poses[:, :C.MAX_INDEX_ROOT_AND_BODY]
+        smp.shape = smp.shape[:C.N_SHAPE_PARAMS]
+        smp.to_tensor()
+    batch = AMASSBatch.from_sample_list(samples)
+    assert batch.poses.shape == (2, 1, 66) and batch.joints_gt.shape == (2, 1, 66)
+
+
+def test_lmdb_reader_errors_and_transform():
+    from em_pose_amd.data.datasets import LMDBDataset
+    _, records = _lmdb_fixture()
+    with pytest.raises(KeyError):
+        LMDBDataset({})
+    broken = dict(records)
+    del broken[b'trans1']
+    ds = LMDBDataset(broken)
+    with pytest.raises(KeyError, match='trans1'):
+        ds[1]
+    broken = dict(records)
+    broken[b'n_frames0'] = b'5'       # 7 frames of data
+    with pytest.raises(ValueError):
+        LMDBDataset(broken)[0]
+    with pytest.raises(IndexError):
+        ds[len(ds)]
+    assert LMDBDataset(records, transform=lambda s: s.n_frames)[2] == 33
+    with pytest.raises(ImportError, match='lmdb'):   # a path needs the real package, which this image lacks
+        LMDBDataset('/nonexistent/amass_lmdb')
