@@ -1184,7 +1184,8 @@ int empose_gemm_atb_f32(int M, int N, int K, const float* A, int lda, const floa
   AtbArgs a{};
   a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.bias = bias; a.M = M; a.N = N; a.K = K;
   a.accumulate = 0;
-  hipError_t e = launch_gemm_atb(a, static_cast<float*>(workspace), static_cast<hipStream_t>(stream_));
+  hipError_t e = launch_gemm_atb(a, static_cast<float*>(workspace), workspace_bytes / sizeof(float),
+                                 static_cast<hipStream_t>(stream_));
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "A^T B gemm: %s", hipGetErrorString(e));
   return EMPOSE_OK;
 }
@@ -1317,17 +1318,19 @@ int check_mlp_params(const empose_mlp_params* p) {
 struct MlpTrainWs {
   float* d[2];       // [M][hidden] cotangent ping-pong
   float* wt;         // transposed weight [hidden][max(hidden, out_pad)]
-  float* atb; float* bn; float* slope_partial; int* counter;
+  float* atb; size_t atb_floats; float* bn; float* slope_partial; int* counter;
 };
+// every A^T B product of one MLP over M rows: (H, in_dim), (H, H), (out_dim, H)
+size_t mlp_atb_floats(const empose_mlp_params* p, int M) {
+  return atb_workspace_floats_max(M, {{p->hidden, p->in_dim}, {p->hidden, p->hidden}, {p->out_dim, p->hidden}});
+}
 MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
   MlpTrainWs w;
   const int H = p->hidden, op = (p->out_dim + 3) & ~3;
   w.d[0] = c.f((size_t)M * H); w.d[1] = c.f((size_t)M * H);
   w.wt = c.f((size_t)H * (H > op ? H : op));
-  size_t atbf = atb_workspace_floats(M, H, H > p->in_dim ? H : p->in_dim);
-  const size_t atb2 = atb_workspace_floats(M, p->out_dim, H);
-  atbf = atbf > atb2 ? atbf : atb2;
-  w.atb = c.f(atbf + 64);
+  w.atb_floats = mlp_atb_floats(p, M);
+  w.atb = c.f(w.atb_floats + 64);
   w.bn = c.f(bn_prelu_workspace_floats(M, H) + 64);
   w.slope_partial = c.f((size_t)(H + 31) / 32 + 8);
   w.counter = reinterpret_cast<int*>(c.f(64));
@@ -1433,7 +1436,7 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       AtbArgs ab{};
       ab.A = d_out; ab.lda = ld_dout; ab.B = layer_save(l - 1) + (size_t)M * H; ab.ldb = H; ab.C = gr->weight[l]; ab.ldc = H;
       ab.bias = gr->bias[l]; ab.M = M; ab.N = p->out_dim; ab.K = H; ab.accumulate = accumulate;
-      e = launch_gemm_atb(ab, w.atb, stream);
+      e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
     }
     const float* wt = p->weight_t[l];
@@ -1464,7 +1467,7 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       AtbArgs ab{};
       ab.A = dz; ab.lda = H; ab.B = in; ab.ldb = ld_in; ab.C = gr->weight[l]; ab.ldc = k_in;
       ab.bias = gr->bias[l]; ab.M = M; ab.N = H; ab.K = k_in; ab.accumulate = accumulate;
-      e = launch_gemm_atb(ab, w.atb, stream);
+      e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
     }
     if (l == 0) break;
@@ -1501,9 +1504,8 @@ int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float
 
 size_t empose_mlp_train_wgrad_workspace_bytes(const empose_mlp_params* p, int n_app, int M) {
   if (!p || M <= 0 || n_app <= 0 || check_mlp_params(p) != EMPOSE_OK) return 0;
-  const int H = p->hidden;
-  const size_t a = atb_workspace_floats(n_app * M, H, H > p->in_dim ? H : p->in_dim);
-  const size_t b = atb_workspace_floats(n_app * M, p->out_dim, H);
+  // batched: one product over n_app * M rows; row counts off the 32-row grid run per application (M rows each)
+  const size_t a = mlp_atb_floats(p, n_app * M), b = mlp_atb_floats(p, M);
   return ((a > b ? a : b) + 64) * sizeof(float);
 }
 
@@ -1517,6 +1519,7 @@ int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const f
   const int H = p->hidden, L = p->n_layers, op = (p->out_dim + 3) & ~3;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   float* ws = static_cast<float*>(workspace);
+  const size_t ws_floats = workspace_bytes / sizeof(float);
   // one product over all applications when their rows can be addressed as 32-row aligned segments, else one per application
   bool batched = M % 32 == 0 && ldx % 4 == 0;
   for (int s = 0; s < n_app && batched; ++s)
@@ -1537,12 +1540,12 @@ int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const f
       ab.A = a_of(0); ab.B = b_of(0); ab.M = n_app * M; ab.accumulate = accumulate;
       ab.n_seg = n_app; ab.seg_rows = M;
       for (int s = 0; s < n_app; ++s) { ab.A_seg[s] = a_of(s); ab.B_seg[s] = b_of(s); }
-      hipError_t e = launch_gemm_atb(ab, ws, stream);
+      hipError_t e = launch_gemm_atb(ab, ws, ws_floats, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
     } else {
       for (int s = 0; s < n_app; ++s) {
         ab.A = a_of(s); ab.B = b_of(s); ab.M = M; ab.accumulate = accumulate || s > 0;
-        hipError_t e = launch_gemm_atb(ab, ws, stream);
+        hipError_t e = launch_gemm_atb(ab, ws, ws_floats, stream);
         if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
       }
     }
@@ -1592,7 +1595,7 @@ TrainLstmWs carve_train_lstm(Carver& c, const empose_lstm_params* p, int B, int 
   w.dyl = c.f((size_t)B * F * H);
   w.dh[0] = c.f((size_t)B * H); w.dh[1] = c.f((size_t)B * H); w.carry = c.f((size_t)B * H); w.dc = c.f((size_t)B * H);
   w.wt = c.f((size_t)in_max * 4 * H);
-  w.atb_floats = atb_workspace_floats(B * F, 4 * H, in_max);
+  w.atb_floats = atb_workspace_floats_max(B * F, {{4 * H, p->input_size}, {4 * H, H}});   // dW_ih (layer 0 / above), dW_hh
   w.atb = c.f(w.atb_floats + 64);
   w.ksplit_floats = gemm_ksplit_applicable(B, H, 4 * H) ? gemm_ksplit_workspace_floats(B, H, 4 * H) : 0;
   w.ksplit = w.ksplit_floats ? c.f(w.ksplit_floats) : nullptr;
@@ -1742,11 +1745,11 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
     AtbArgs ab{};
     ab.A = w.dgates; ab.lda = 4 * H; ab.B = x_l; ab.ldb = ldx_l; ab.C = grads->w_ih[l]; ab.ldc = in_l;
     ab.bias = grads->b_ih[l]; ab.M = B * F; ab.N = 4 * H; ab.K = in_l;
-    e = launch_gemm_atb(ab, w.atb, stream);
+    e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_ih: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpyAsync(grads->b_hh[l], grads->b_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
     ab.B = sv + 5 * bfh; ab.ldb = H; ab.C = grads->w_hh[l]; ab.ldc = H; ab.bias = nullptr; ab.K = H;
-    e = launch_gemm_atb(ab, w.atb, stream);
+    e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_hh: %s", hipGetErrorString(e));
     float* dx_l = l > 0 ? w.dyl : dx;
     if (dx_l) {

@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <initializer_list>
+#include <utility>
+
 namespace empose {
 
 // Kernel-variant selection for A/B and bit-identity tests (empose_set_option in the C ABI).  Plain process-wide ints set
@@ -204,7 +207,8 @@ struct AdamArgs {
 hipError_t launch_adam(const AdamArgs& a, int n_chunks, hipStream_t stream);
 int atb_splits(int M, int N, int K);
 size_t atb_workspace_floats(int M, int N, int K);
-hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream);
+size_t atb_workspace_floats_max(int M, std::initializer_list<std::pair<int, int>> products);   // over (N, K) pairs
+hipError_t launch_gemm_atb(AtbArgs a, float* workspace, size_t workspace_floats, hipStream_t stream);
 hipError_t launch_transpose(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols, hipStream_t stream);
 hipError_t launch_add2(const float* a, const float* b, float* out, int n, hipStream_t stream);
 struct LstmCellBwdArgs {

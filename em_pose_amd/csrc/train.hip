@@ -303,8 +303,24 @@ size_t atb_workspace_floats(int M, int N, int K) {
   return s > 1 ? (size_t)s * ((size_t)N * K + N) : 0;
 }
 
-hipError_t launch_gemm_atb(AtbArgs a, float* workspace, hipStream_t stream) {
+size_t atb_workspace_floats_max(int M, std::initializer_list<std::pair<int, int>> products) {
+  size_t m = 0;
+  for (const auto& nk : products)
+    if (nk.first > 0 && nk.second > 0) m = std::max(m, atb_workspace_floats(M, nk.first, nk.second));
+  return m;
+}
+
+// `workspace_floats` is what the caller carved: the split count grows as the tile count shrinks, so a workspace sized
+// for ONE product shape is not automatically large enough for a smaller one.  Callers size it over every
+// product they launch (atb_workspace_floats_max); should one ever come up short, the split count is reduced to what
+// fits instead of writing past the buffer.
+hipError_t launch_gemm_atb(AtbArgs a, float* workspace, size_t workspace_floats, hipStream_t stream) {
   a.S = atb_splits(a.M, a.N, a.K);
+  if (a.S > 1) {
+    const size_t per_split = (size_t)a.N * a.K + a.N;
+    const size_t fit = workspace ? workspace_floats / per_split : 0;
+    if (fit < (size_t)a.S) a.S = fit >= 2 ? (int)fit : 1;
+  }
   a.partial = nullptr;
   a.bias_partial = a.bias;   // S == 1: the kernel writes the bias directly (pointer doubles as the flag)
   if (a.S > 1) {

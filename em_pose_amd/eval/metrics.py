@@ -285,8 +285,11 @@ class MetricsEngine(object):
 
     # ---- reduction ------------------------------------------------------------------------------------------------
     def get_metrics(self, eucl_idxs_select=True, angle_idxs_select=True):
-        out = {'MPJPE [mm]': 0.0, 'MPJPE STD': 0.0, 'PA-MPJPE [mm]': 0.0, 'PA-MPJPE STD': 0.0, 'MPJAE [deg]': 0.0,
-               'MPJAE STD': 0.0}
+        # A metric family without a single accumulated row is NaN, not 0: "0 mm" reads as a perfect score (e.g. the
+        # position metrics of an engine built without a body model: the CPU plumbing configuration).
+        nan = float('nan')
+        out = {'MPJPE [mm]': nan, 'MPJPE STD': nan, 'PA-MPJPE [mm]': nan, 'PA-MPJPE STD': nan, 'MPJAE [deg]': nan,
+               'MPJAE STD': nan}
         if self.eucl_dists:
             e, ep = np.concatenate(self.eucl_dists, 0), np.concatenate(self.eucl_dists_pa, 0)
             idx = self.eucl_idxs if eucl_idxs_select else list(range(e.shape[1]))

@@ -70,4 +70,8 @@ class GraphedTrainStep(object):
         :return: dict of loss values as device tensors (read them after the step, not inside it)"""
         self.load(batch)
         self.graph.replay()
+        # the replay ran no Python: BatchNorm running statistics moved without anybody noticing (and an optimizer on raw
+        # pointers moves the weights the same way) -- invalidate what is cached from them (the folded inference handle)
+        from em_pose_amd.nn import layers as _layers
+        _layers.BN_STATS_GENERATION[0] += 1
         return self.loss_vals

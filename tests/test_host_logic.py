@@ -160,7 +160,9 @@ def test_evaluate_real_cli_runs_the_resnet_baseline_on_cpu():
                         capture_output=True, text=True, timeout=600)
     assert ok.returncode == 0, ok.stderr[-2000:]
     res = json.loads(ok.stdout.strip().splitlines()[-1])
-    assert res['frames'] == 3460 and res['metrics']['MPJAE [deg]'] > 0.0 and res['metrics']['MPJPE [mm]'] == 0.0
+    assert res['frames'] == 3460 and res['metrics']['MPJAE [deg]'] > 0.0
+    # no body model on the CPU plumbing path: the position metrics are NaN (not a perfect-looking 0 mm)
+    assert res['metrics']['MPJPE [mm]'] != res['metrics']['MPJPE [mm]']
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and 'need an MI355X' in (bad.stderr + bad.stdout)
 
