@@ -1199,6 +1199,23 @@ int empose_transpose_f32(int rows, int cols, const float* src, int ld_src, float
   return EMPOSE_OK;
 }
 
+int empose_pack_inputs(int B, int F, int n_markers, const int* marker_idx, const float* marker_pos,
+                       const float* marker_oris, const float* marker_masks, const int* seq_lengths, float* x, int ldx,
+                       float* frame_weight, empose_stream_t stream_) {
+  if (!marker_idx || !marker_pos || !marker_oris || !x) return fail(EMPOSE_EINVAL, "null argument");
+  if (B <= 0 || F <= 0 || n_markers < 1 || n_markers > 12 || ldx < 12 * n_markers) return fail(EMPOSE_EINVAL, "bad sizes");
+  PackArgs pa;
+  pa.marker_pos = marker_pos; pa.marker_oris = marker_oris; pa.marker_masks = marker_masks; pa.seq_lengths = seq_lengths;
+  pa.x = x; pa.ldx = ldx; pa.frame_scale = frame_weight; pa.B = B; pa.F = F; pa.n_markers = n_markers;
+  for (int i = 0; i < 12; ++i) {
+    pa.marker_idx[i] = i < n_markers ? marker_idx[i] : 0;
+    if (pa.marker_idx[i] < 0 || pa.marker_idx[i] > 11) return fail(EMPOSE_EINVAL, "sensor index out of range");
+  }
+  hipError_t e = launch_pack_inputs(pa, static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "pack kernel: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
+}
+
 int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* out, int ld_out, empose_stream_t stream_) {
   if (!in || !out) return fail(EMPOSE_EINVAL, "null argument");
   if (T <= 0 || F <= 0 || C <= 0 || T % F != 0 || ld_in < C || ld_out < C) return fail(EMPOSE_EINVAL, "bad sizes");

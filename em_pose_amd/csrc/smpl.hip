@@ -28,6 +28,7 @@ __global__ void pack_inputs_kernel(PackArgs a) {
   if (idx >= T * (d_in + 1)) return;
   const int t = idx / (d_in + 1), c = idx % (d_in + 1);
   if (c == d_in) {
+    if (!a.frame_scale) return;
     const int b = t / a.F, f = t % a.F;
     const int len = a.seq_lengths ? a.seq_lengths[b] : a.F;
     // reference: loss / n_frames, then grad * B * F  ->  F / len per valid frame (models.py:578-579, loss.py:36-39);

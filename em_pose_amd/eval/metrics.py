@@ -255,13 +255,14 @@ class MetricsEngine(object):
             if state[key].shape[0]:
                 store.append(np.asarray(state[key], dtype=np.float64))
 
-    def gather(self, group=None, device=None):
+    def gather(self, group=None, device=None, force=False):
         """
         Combine the accumulators of all ranks (torch.distributed; RCCL on GPUs, gloo on CPU). Rows are concatenated in
-        rank order, so every rank ends up with the same, order-deterministic state.
+        rank order, so every rank ends up with the same, order-deterministic state.  `force` runs the collectives even
+        in a group of one (self-test of the RCCL path on a single GPU).
         """
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
             return self
         world = dist.get_world_size(group)
         st = self.state()

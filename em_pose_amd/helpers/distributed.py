@@ -26,17 +26,7 @@ def init_from_env(device=None, backend=None):
     return rank, world
 
 
-def allreduce_gradients(parameters, bucket_bytes=8 << 20, group=None):
-    """
-    Average `.grad` of the given parameters over all ranks, in flat buckets of about `bucket_bytes` (a few large
-    collectives instead of one per tensor: ring all-reduce over xGMI is per-link bound, small messages waste it).
-    Parameters without a gradient contribute zeros so that every rank issues the same collectives.
-    """
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return 0
-    world = dist.get_world_size(group)
-    params = [p for p in parameters if p.requires_grad]
+def _bucket_plan(params, bucket_bytes):
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
         cur.append(p)
@@ -46,20 +36,131 @@ def allreduce_gradients(parameters, bucket_bytes=8 << 20, group=None):
             cur, cur_bytes = [], 0
     if cur:
         buckets.append(cur)
-    for bucket in buckets:
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat.div_(world)
-        off = 0
-        for p in bucket:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-    return len(buckets)
+    return buckets
+
+
+class GradientBuckets(object):
+    """
+    Persistent flat gradient buckets with the all-reduce overlapped with the rest of the reverse sweep.
+
+    * The parameters are laid out, in the order given (= the order in which the reverse sweep finishes their gradients:
+      update networks first, then the initial estimate's heads, the LSTM last), into flat fp32 buffers of about
+      `bucket_bytes` that live as long as this object.  `view_of(p)` is parameter p's slice of its bucket: the training
+      engine writes dW / db straight into it and installs it as `p.grad` (nn/train_engine.py), so nothing is
+      concatenated or copied, before or after the collective, and `.grad` has the same address every step.
+    * `stage(p)` says "p's gradient is final".  When the last parameter of a bucket is staged, the bucket's all-reduce
+      is enqueued on a side stream behind an event recorded on the compute stream -- it runs while the compute stream
+      continues with back-propagation through time (RCCL ring all-reduce over xGMI is per-link bound: a few multi-MB
+      messages, not one per tensor).  `finish()` makes the compute stream wait for the collectives (and stages whatever
+      was not staged explicitly, so it is also the whole story for a caller without hooks).
+    * A gradient that was produced elsewhere (autograd's own tensors on the fallback path) is copied into its slice
+      when staged; `p.grad` is re-pointed to the slice.
+    Averages over the ranks (sum, then 1 / world on the side stream).  `force=True` runs the collectives even with one
+    rank (self-test of the RCCL path on one GPU).
+    """
+
+    def __init__(self, parameters, bucket_bytes=8 << 20, group=None, force=False):
+        import torch.distributed as dist
+        self.params = [p for p in parameters if p.requires_grad]
+        if not self.params:
+            raise ValueError('no parameters')
+        self.group, self.force = group, force
+        self.active = dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1)
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        dev = self.params[0].device
+        plan = _bucket_plan(self.params, bucket_bytes)
+        self.flat, self._slot, self._members = [], {}, []
+        for members in plan:
+            # every slice starts on a 256-byte boundary (the kernels store gradients with 16-byte accesses); the
+            # padding stays zero and rides along in the collective
+            pad = lambda n: (n + 63) & ~63
+            flat = torch.zeros(sum(pad(p.numel()) for p in members), dtype=self.params[0].dtype, device=dev)
+            off = 0
+            for p in members:
+                self._slot[id(p)] = (len(self.flat), flat[off:off + p.numel()].view_as(p))
+                off += pad(p.numel())
+            self.flat.append(flat)
+            self._members.append(members)
+        self.n_buckets = len(self.flat)
+        self.side = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        self._staged = [set() for _ in self.flat]
+        self._launched = [False] * self.n_buckets
+        self._pending = []
+        self.hold = False   # True: stage() is a no-op (a step being captured into a HIP graph must not enqueue
+                            # collectives; finish() after the replay stages everything)
+
+    def view_of(self, p):
+        slot = self._slot.get(id(p))
+        return None if slot is None else slot[1]
+
+    def _launch(self, b):
+        import torch.distributed as dist
+        self._launched[b] = True
+        if not self.active:
+            return
+        flat = self.flat[b]
+        if self.side is None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            return
+        ready = torch.cuda.Event()
+        ready.record()                           # on the compute stream: the bucket's gradients are complete here
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                flat.div_(self.world)
+            done = torch.cuda.Event()
+            done.record()
+        self._pending.append(done)
+
+    def stage(self, p):
+        slot = self._slot.get(id(p))
+        if slot is None or self.hold:
+            return
+        b, view = slot
+        if p.grad is None:
+            view.zero_()                          # every rank issues the same collectives
+            p.grad = view
+        elif p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        self._staged[b].add(id(p))
+        if not self._launched[b] and len(self._staged[b]) == len(self._members[b]):
+            self._launch(b)
+
+    def finish(self):
+        """Stage what is left, wait (stream-side, not host-side) for every collective; ready for the next step."""
+        self.hold = False
+        for b, members in enumerate(self._members):
+            for p in members:
+                if id(p) not in self._staged[b]:
+                    self.stage(p)
+        for done in self._pending:
+            torch.cuda.current_stream().wait_event(done)
+        self._pending = []
+        self._staged = [set() for _ in self.flat]
+        n, self._launched = sum(self._launched), [False] * self.n_buckets
+        return n if self.active else 0
+
+
+def attach_gradient_buckets(net, buckets):
+    """The training engine of `net` writes gradients into `buckets` and stages each parameter group as the reverse sweep
+    finishes it (None detaches)."""
+    net._grad_sink = buckets
+
+
+def allreduce_gradients(parameters, bucket_bytes=8 << 20, group=None):
+    """
+    Average `.grad` of the given parameters over all ranks after the backward pass, in flat buckets of about
+    `bucket_bytes`.  One-shot form of `GradientBuckets` (which keeps the buckets and overlaps the collectives with the
+    reverse sweep); parameters without a gradient contribute zeros so that every rank issues the same collectives.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    buckets = GradientBuckets(parameters, bucket_bytes, group)
+    return buckets.finish()
 
 
 def shard_range(n_items, rank, world):

@@ -28,6 +28,11 @@ class GraphedTrainStep(object):
             v = getattr(example_batch, k, None)
             if torch.is_tensor(v):
                 setattr(self.static, k, v.clone())
+        # a gradient sink (helpers.distributed.GradientBuckets) still provides the static gradient storage, but must not
+        # enqueue collectives while the step is traced: the caller runs `buckets.finish()` after every replay
+        sink = getattr(net, '_grad_sink', None)
+        if sink is not None:
+            sink.hold = True
         was_full = getattr(net, 'full_windows', False)
         net.full_windows = True   # only while the step is traced: the replayed graph does not go through Python again
         # Warm-up and capture on the SAME side stream (allocator pools and any library state are per stream).
@@ -54,6 +59,7 @@ class GraphedTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         net.full_windows = was_full
+        self.sink = sink
 
     def load(self, batch):
         for k in self.FIELDS:
@@ -69,6 +75,8 @@ class GraphedTrainStep(object):
         """Replays forward + backward on `batch`; the parameter gradients are then in `.grad` (static tensors).
         :return: dict of loss values as device tensors (read them after the step, not inside it)"""
         self.load(batch)
+        if self.sink is not None:
+            self.sink.hold = True    # nothing of the replay goes through Python; finish() releases it
         self.graph.replay()
         # the replay ran no Python: BatchNorm running statistics moved without anybody noticing (and an optimizer on raw
         # pointers moves the weights the same way) -- invalidate what is cached from them (the folded inference handle)

@@ -128,90 +128,123 @@ class _InjectGrad(torch.autograd.Function):
         return dy + g, None
 
 
+# The per-sensor input features a configuration can switch on, in the order they are laid out in a network input row:
+# (configuration flag, key of the input dict, floats per sensor).  Every size of the models follows from this table.
+SENSOR_FEATURES = (('use_marker_pos', 'marker_pos', 3),
+                   ('use_marker_ori', 'marker_oris', 9),
+                   ('use_marker_nor', 'marker_normals', 3))
+
+
+def pack_sensor_inputs(marker_pos, marker_oris, marker_idxs, marker_masks=None, seq_lengths=None, out=None,
+                       want_frame_weight=False):
+    """
+    Device tensors (B,F,36) / (B,F,108) -> network input rows (B,F,12*len(marker_idxs)): the chosen sensors'
+    positions, then their row-major orientations -- one launch of `empose_pack_inputs` (no index_select / cat chain).
+    `out` may be a wider (B*F, ld) buffer whose leading columns are filled.  With `want_frame_weight` the per-frame
+    weight of the in-loop residual (reference loss.py:31-39, models.py:578-579) comes out of the same launch.
+    """
+    dev, (B, F) = marker_pos.device, marker_pos.shape[:2]
+    f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+    marker_pos, marker_oris = f32(marker_pos), f32(marker_oris)
+    if marker_pos.numel() != B * F * 36 or marker_oris.numel() != B * F * 108:
+        raise ValueError('expected 12 sensors per frame: marker_pos (B,F,36), marker_oris (B,F,108)')
+    width = 12 * len(marker_idxs)
+    x = torch.empty(B, F, width, dtype=torch.float32, device=dev) if out is None else out
+    ldx = x.stride(-2)
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and ldx >= width
+    weight = torch.empty(B * F, dtype=torch.float32, device=dev) if want_frame_weight else None
+    masks = None if marker_masks is None else f32(marker_masks)
+    lens = None if seq_lengths is None else seq_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    idx = (C.c_int * 12)(*marker_idxs)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().empose_pack_inputs(B, F, len(marker_idxs), idx, _lib.dptr(marker_pos),
+                                                 _lib.dptr(marker_oris), _lib.dptr(masks), _lib.dptr(lens),
+                                                 _lib.dptr(x), ldx, _lib.dptr(weight), _lib.current_stream()))
+    return (x, weight) if want_frame_weight else x
+
+
 class BaseModel(nn.Module):
+    """What the three model families share (contract of reference models.py:36-163: attribute names, `prepare_inputs`,
+    `window_generator`, the `model_name` suffix).  Sizes come from SENSOR_FEATURES; on GPU tensors `prepare_inputs` is
+    one pack launch."""
+
     def __init__(self, config, smpl_model=None):
         super(BaseModel, self).__init__()
-        self.n_markers = config.n_markers if getattr(config, 'n_markers', -1) > -1 else CONST.N_TRACKERS_WO_ROOT
-        self.config = config
+        self.config, self.smpl = config, smpl_model
+        configured = getattr(config, 'n_markers', -1)
+        self.n_markers = configured if configured > -1 else CONST.N_TRACKERS_WO_ROOT
         self.n_frames = config.window_size
-        self.smpl = smpl_model
-        self.estimate_shape = config.m_estimate_shape
-        self.shape_avg = config.m_average_shape
+        self.estimate_shape, self.shape_avg = config.m_estimate_shape, config.m_average_shape
         self.fk_loss_weight = config.m_fk_loss
         self.do_fk = self.fk_loss_weight > 0.0
-        if self.do_fk:
-            assert self.smpl is not None
-            assert self.estimate_shape or isinstance(self, IterativeErrorFeedback)
-        self.shape_weight = getattr(config, 'm_shape_loss_weight', 1.0)
         self.pose_weight = getattr(config, 'm_pose_loss_weight', 1.0)
+        self.shape_weight = getattr(config, 'm_shape_loss_weight', 1.0)
+        if self.do_fk and (self.smpl is None or not (self.estimate_shape or isinstance(self, IterativeErrorFeedback))):
+            raise AssertionError('an FK loss needs a body model and an estimated shape')
         self.set_input_output_size()
         self.create_model()
 
+    def active_features(self):
+        """Rows of SENSOR_FEATURES the configuration enables; orientations and normals exclude each other."""
+        on = [row for row in SENSOR_FEATURES if getattr(self.config, row[0])]
+        assert not (self.config.use_marker_ori and self.config.use_marker_nor)
+        return on
+
     def set_input_output_size(self):
-        input_size = 0
-        if self.config.use_marker_pos:
-            input_size += self.n_markers * 3
-        if self.config.use_marker_ori:
-            input_size += self.n_markers * 9
-            assert not self.config.use_marker_nor
-        if self.config.use_marker_nor:
-            input_size += self.n_markers * 3
-            assert not self.config.use_marker_ori
-        setattr(self.config, 'input_size', input_size)
-        setattr(self.config, 'output_size', (CONST.N_JOINTS + 1) * 3)
-        self.input_size = input_size
-        self.output_size = self.config.output_size
+        self.input_size = self.n_markers * sum(width for _, _, width in self.active_features())
+        self.output_size = (CONST.N_JOINTS + 1) * 3
+        self.config.input_size, self.config.output_size = self.input_size, self.output_size
 
     def create_model(self):
         raise NotImplementedError('Must be implemented by subclass.')
 
+    def sensor_subset(self):
+        """Indices (into the 12 sensors of a batch) of the sensors this model reads."""
+        if self.n_markers not in (6, 12):
+            raise AssertionError('6 or 12 sensors')
+        return list(range(12)) if self.n_markers == 12 else list(CONST.S_CONFIG_6)
+
     def prepare_inputs(self, batch_inputs):
-        """(N,F,12*3) + (N,F,12*9) -> (N,F,D_in), 6-sensor subset if configured (reference models.py:106-125)."""
-        n, f = batch_inputs['marker_pos'].shape[0], batch_inputs['marker_pos'].shape[1]
-        m_pos = batch_inputs['marker_pos'].reshape((n, f, -1, 3))
-        m_ori = batch_inputs['marker_oris'].reshape((n, f, -1, 3, 3))
-        assert self.n_markers in [6, 12]
-        if self.n_markers == 6:
-            idx = getattr(self, '_s6_idx_dev', None)   # device-side index: no host copy per call (graph capture)
-            if idx is None or idx.device != m_pos.device:
-                idx = torch.tensor(list(CONST.S_CONFIG_6), dtype=torch.long, device=m_pos.device)
-                self._s6_idx_dev = idx
-            m_pos, m_ori = m_pos.index_select(2, idx), m_ori.index_select(2, idx)
-        model_in = []
-        if self.config.use_marker_pos:
-            model_in.append(m_pos.reshape((n, f, -1)))
-        if self.config.use_marker_ori:
-            model_in.append(m_ori.reshape((n, f, -1)))
-        if self.config.use_marker_nor:
+        """Input dict of a batch -> (N, F, input_size) rows: per enabled feature, the model's sensors flattened."""
+        feats = self.active_features()
+        if any(flag == 'use_marker_nor' for flag, _, _ in feats):
             raise ValueError('Normals currently not supported.')
-        return torch.cat(model_in, dim=-1)
+        pos, ori = batch_inputs['marker_pos'], batch_inputs['marker_oris']
+        subset = self.sensor_subset()
+        if pos.is_cuda and [flag for flag, _, _ in feats] == ['use_marker_pos', 'use_marker_ori']:
+            return pack_sensor_inputs(pos, ori, subset)
+        # CPU tensors (the ResNet plumbing configuration) or a single feature: plain indexing
+        n, f = pos.shape[0], pos.shape[1]
+        pick = torch.as_tensor(subset, dtype=torch.long, device=pos.device)
+        cols = [batch_inputs[key].reshape(n, f, 12, width).index_select(2, pick).reshape(n, f, -1)
+                for _, key, width in feats]
+        return cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1)
 
     def window_generator(self, batch, window_size):
-        """reference models.py:146-163 (the sliced branch is only valid for batch size 1, as in the reference)."""
-        if window_size is not None:
-            seq_len = batch.seq_length
-            n_windows = seq_len // window_size + int(seq_len % window_size > 0)
-            for i in range(n_windows):
-                sf, ef = i * window_size, min((i + 1) * window_size, seq_len)
-                batch_inputs = batch.get_inputs(sf=sf, ef=ef)
-                batch_inputs['seq_lengths'] = torch.tensor([ef - sf], dtype=batch.seq_lengths.dtype,
-                                                           device=batch.seq_lengths.device)
-                yield batch_inputs
+        """The batch as one piece (window_size None: every caller in the tree), or cut along time into pieces of
+        `window_size` frames with a fresh one-entry `seq_lengths` -- valid for batch size 1 only, like the reference's
+        (models.py:146-163)."""
+        if window_size is None:
+            pieces = [(None, None, batch.seq_lengths)]
         else:
-            batch_inputs = batch.get_inputs()
-            batch_inputs['seq_lengths'] = batch.seq_lengths
+            total = batch.seq_length
+            one = lambda n: torch.tensor([n], dtype=batch.seq_lengths.dtype, device=batch.seq_lengths.device)
+            pieces = [(sf, min(sf + window_size, total), one(min(sf + window_size, total) - sf))
+                      for sf in range(0, total, window_size)]
+        for sf, ef, lengths in pieces:
+            batch_inputs = batch.get_inputs() if sf is None else batch.get_inputs(sf=sf, ef=ef)
+            batch_inputs['seq_lengths'] = lengths
             yield batch_inputs
 
     def model_name(self):
-        """Suffix shared by the baselines (reference models.py:86-96)."""
-        base_name = ''
+        """`-shape<h>[-avg][-fk<w>]-n<sensors>-lr<lr>`: the suffix of the baselines' names."""
+        parts = []
         if self.estimate_shape is not None:
-            base_name += '-shape{}{}'.format(self.config.m_shape_hidden_size, '-avg' if self.shape_avg else '')
+            parts.append('shape{}{}'.format(self.config.m_shape_hidden_size, '-avg' if self.shape_avg else ''))
         if self.do_fk:
-            base_name += '-fk{}'.format(self.fk_loss_weight)
-        base_name += '-n{}'.format(self.n_markers)
-        base_name += '-lr{}'.format(self.config.lr)
-        return base_name
+            parts.append('fk{}'.format(self.fk_loss_weight))
+        parts += ['n{}'.format(self.n_markers), 'lr{}'.format(self.config.lr)]
+        return ''.join('-' + part for part in parts)
 
     def maybe_do_fk(self, pose_hat, shape_hat):
         """Joints of the predicted pose if an FK loss is configured (reference models.py:134-144)."""
@@ -350,8 +383,7 @@ class IterativeErrorFeedback(BaseModel):
         super(IterativeErrorFeedback, self).__init__(config, smpl_model)
         self.vertex_ids = list(CONST.VERTEX_IDS)
         self.helper_ids = None  # optional explicit helper-vertex table (data of a trained model), else derived
-        assert self.n_markers in [6, 12]
-        self.marker_idxs = list(range(12)) if self.n_markers == 12 else list(CONST.S_CONFIG_6)
+        self.marker_idxs = self.sensor_subset()
         self.keep_history = True
         # False: per-window shape mean over all F frames incl. padding, as the reference; True: over valid frames only
         self.shape_avg_valid_only = False

@@ -183,34 +183,80 @@ class LgdTrainEngine(object):
     def ws(self, nbytes):
         return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=self.dev)
 
+    # ---- where gradients go -------------------------------------------------------------------------------------
+    @staticmethod
+    def gradient_order(net):
+        """The parameters in the order in which the reverse sweep finishes their gradients: update networks, then what
+        produced the initial estimate (heads, LSTM last).  `helpers.distributed.GradientBuckets` lays its flat buckets
+        out in this order so that the first buckets can be all-reduced while the rest is still being computed."""
+        order = []
+        for mlp in (net.pose_net_iter, net.shape_net_iter):
+            order += _MlpView(mlp).parameter_list()
+        if net.rnn_init:
+            order += [net.pose_net_init.weight, net.pose_net_init.bias, net.shape_net_init.weight,
+                      net.shape_net_init.bias]
+            order += [w for unit in net.rnn._unit_params() for w in unit]
+        else:
+            for mlp in (net.pose_net_init, net.shape_net_init):
+                order += _MlpView(mlp).parameter_list()
+        seen, out = set(), []
+        for p in order:
+            if id(p) not in seen and p.requires_grad:
+                seen.add(id(p))
+                out.append(p)
+        return out
+
+    def _grad_like(self, p):
+        """Where the kernels write p's gradient: p's slice of a persistent flat bucket when a gradient sink is attached
+        and nothing has been accumulated into p.grad yet (then the slice simply BECOMES p.grad), else a fresh tensor."""
+        sink = getattr(self.net, '_grad_sink', None)
+        if sink is not None and p.grad is None and p.requires_grad:
+            view = sink.view_of(p)
+            if view is not None:
+                return view
+        return torch.empty_like(p)
+
+    def _deposit(self, named):
+        """autograd's AccumulateGrad for a finished group of parameters, then tell the sink that they are final."""
+        sink = getattr(self.net, '_grad_sink', None)
+        for p_, g_ in named:
+            if not p_.requires_grad:
+                continue
+            if p_.grad is None:
+                p_.grad = g_
+            elif p_.grad.data_ptr() != g_.data_ptr():
+                self._axpby(1, g_.numel(), 1.0, g_.data_ptr(), g_.numel(), 1.0, p_.grad.data_ptr(), g_.numel(),
+                            p_.grad.data_ptr(), g_.numel())
+            if sink is not None:
+                sink.stage(p_)
+
     def new(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
 
     # ---- forward ------------------------------------------------------------------------------------------------
     def forward(self, batch_inputs):
         net = self.net
-        inputs_ = net.prepare_inputs(batch_inputs)
-        if not inputs_.is_cuda:
+        if not batch_inputs['marker_pos'].is_cuda:
             raise _lib.EmposeError('IterativeErrorFeedback needs GPU tensors; there is no CPU fallback')
-        dev = self.dev = inputs_.device
+        dev = self.dev = batch_inputs['marker_pos'].device
         lib = self.lib = _lib.lib()
         self.stream = _lib.current_stream()
-        B, F = inputs_.shape[0], inputs_.shape[1]
-        T, N, s = B * F, net.N, float(net.step_size)
-        d_in, d_x = net.input_size, net.input_iter_size
-        x0 = inputs_.reshape(T, d_in).contiguous().float()
         seq_lengths = batch_inputs['seq_lengths'].to(dev)
         lens32 = seq_lengths.to(torch.int32).contiguous()
         masks = batch_inputs['marker_masks']
-        masks = None if masks is None else masks.to(dev, torch.float32).reshape(T, 12).contiguous()
+        masks = None if masks is None else masks.to(dev, torch.float32).contiguous()
+        # network input rows + the per-frame weight of the in-loop residual (reference loss.py:36-39 times the B * F
+        # rescale of models.py:578-579) in one launch
+        from em_pose_amd.nn.models import pack_sensor_inputs
+        inputs_, scale = pack_sensor_inputs(batch_inputs['marker_pos'], batch_inputs['marker_oris'], net.marker_idxs,
+                                            masks, lens32, want_frame_weight=True)
+        B, F = inputs_.shape[0], inputs_.shape[1]
+        T, N, s = B * F, net.N, float(net.step_size)
+        d_in, d_x = net.input_size, net.input_iter_size
+        x0 = inputs_.reshape(T, d_in)
+        masks = None if masks is None else masks.reshape(T, 12)
         offset_r = batch_inputs['offset_r'].to(dev, torch.float32).contiguous()
         offset_t = batch_inputs['offset_t'].to(dev, torch.float32).contiguous()
-        # per-frame weight of the in-loop residual (reference loss.py:36-39 times the B * F rescale of models.py:578-579)
-        live = (torch.arange(F, device=dev)[None, :] < seq_lengths[:, None]).float()
-        scale = live * (float(F) / seq_lengths.float())[:, None]
-        if masks is not None:
-            scale = scale * masks.reshape(B, F, 12).ne(0).all(dim=-1).float()
-        scale = scale.reshape(T).contiguous()
 
         ctx = self.ctx = {'B': B, 'F': F, 'x0': x0, 'lens32': lens32, 'masks': masks, 'offset_r': offset_r,
                           'offset_t': offset_t}
@@ -335,7 +381,7 @@ class LgdTrainEngine(object):
             dspad = torch.zeros(T, 12, dtype=torch.float32, device=dev)
             tmp10 = self.new(T, 10)
             views = ctx['views']
-            grads = [[torch.empty_like(p) for p in v.parameter_list()] for v in views]
+            grads = [[self._grad_like(p) for p in v.parameter_list()] for v in views]
             X = ctx['X']
             deferred = self.batched_wgrad and 1 <= N <= 8   # (row counts off the 32-row grid: per application inside)
             for v in views:
@@ -379,6 +425,8 @@ class LgdTrainEngine(object):
                 if pend[k]:
                     self._mlp_wgrad(views[k], [q[0] for q in pend[k]], d_x, [q[1] for q in pend[k]],
                                     [q[2] for q in pend[k]], grads[k], T)
+                if N > 0:   # final: a gradient sink may start averaging them while the rest of the sweep runs
+                    self._deposit(list(zip(views[k].parameter_list(), grads[k])))
             # ---- initial estimate
             self._axpby(T, 66, 1.0, Dp.data_ptr(), 66, 0.0, None, 0, dpad.data_ptr(), 68)
             if net.shape_avg:
@@ -387,16 +435,13 @@ class LgdTrainEngine(object):
             else:
                 self._axpby(T, 10, 1.0, Ds.data_ptr(), 10, 0.0, None, 0, dspad.data_ptr(), 12)
             named = []
-            if N > 0:
-                for v, g in zip(views, grads):
-                    named += list(zip(v.parameter_list(), g))
             if net.rnn_init:
                 rnn, y = net.rnn, ctx['y']
                 H, L = rnn.hidden_size, rnn.num_layers
                 dy = self.new(T, H)
                 first = True
                 for lin, dpd, ld, n_out in ((net.pose_net_init, dpad, 68, 66), (net.shape_net_init, dspad, 12, 10)):
-                    gw, gb = torch.empty_like(lin.weight), torch.empty_like(lin.bias)
+                    gw, gb = self._grad_like(lin.weight), self._grad_like(lin.bias)
                     nb = lib.empose_gemm_atb_workspace_bytes(T, n_out, H)
                     wsa = self.ws(nb)
                     _lib.check(lib.empose_gemm_atb_f32(T, n_out, H, dpd.data_ptr(), ld, y.data_ptr(), H, gw.data_ptr(), H,
@@ -411,7 +456,9 @@ class LgdTrainEngine(object):
                 weights = [w for unit in rnn._unit_params() for w in unit]
                 p, g = _lib.LstmParams(), _lib.LstmGrads()
                 p.num_layers, p.input_size, p.hidden_size = L, d_in, H
-                lg = [torch.empty_like(w) for w in weights]
+                self._deposit(named)
+                named = []
+                lg = [self._grad_like(w) for w in weights]
                 for l in range(L):
                     p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [weights[4 * l + k].data_ptr() for k in range(4)]
                     g.w_ih[l], g.w_hh[l], g.b_ih[l], g.b_hh[l] = [lg[4 * l + k].data_ptr() for k in range(4)]
@@ -423,17 +470,10 @@ class LgdTrainEngine(object):
                 named += list(zip(weights, lg))
             else:
                 for v, sv, dpd, ld in zip(ctx['init_views'], ctx['init_saves'], (dpad, dspad), (68, 12)):
-                    gi = [torch.empty_like(p_) for p_ in v.parameter_list()]
+                    gi = [self._grad_like(p_) for p_ in v.parameter_list()]
                     self._mlp_bwd(v, ctx['x0'].data_ptr(), d_in, dpd.data_ptr(), ld, sv, gi, False, T)
                     named += list(zip(v.parameter_list(), gi))
-            for p_, g_ in named:   # autograd's AccumulateGrad
-                if not p_.requires_grad:
-                    continue
-                if p_.grad is None:
-                    p_.grad = g_
-                else:
-                    self._axpby(1, g_.numel(), 1.0, g_.data_ptr(), g_.numel(), 1.0, p_.grad.data_ptr(), g_.numel(),
-                                p_.grad.data_ptr(), g_.numel())
+            self._deposit(named)
         self.ctx = None
         total = loss_vals[4]
         keys = ('pose', 'shape', 'reconstruction', 'fk', 'total_loss')

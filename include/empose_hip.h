@@ -338,6 +338,18 @@ int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const f
                            const float* const* save, const float* const* dz_stash, const empose_mlp_grads* grads,
                            int accumulate, void* workspace, size_t workspace_bytes, empose_stream_t stream);
 
+/* Network input rows and the per-frame residual weight as one launch.
+ * Replaces `BaseModel.prepare_inputs` (reference models.py:106-125: reshape, 6-sensor subset S_CONFIG_6, concat
+ * positions | row-major orientations) and the frame weighting of `reconstruction_loss` as the loop applies it
+ * (reference loss.py:31-39 with the B * F rescale of models.py:578-579): weight[t] = [f < len_b] * F / len_b *
+ * [all 12 sensors present].
+ *   marker_pos [B*F][36], marker_oris [B*F][108]; marker_idx: the n_markers (<= 12) sensors taken, in order;
+ *   marker_masks [B*F][12] or NULL; seq_lengths [B] (int32) or NULL (= F everywhere);
+ *   x [B*F][ldx]: columns [0, 12 * n_markers) are written; frame_weight [B*F] or NULL (not wanted). */
+int empose_pack_inputs(int B, int F, int n_markers, const int* marker_idx, const float* marker_pos,
+                       const float* marker_oris, const float* marker_masks, const int* seq_lengths, float* x, int ldx,
+                       float* frame_weight, empose_stream_t stream);
+
 /* out[t][c] = mean of in[.][c] over the window of frame t (F consecutive rows); the operator is its own adjoint, so
  * the same call back-propagates (`_to_single_shape`, reference models.py:529-535,588-589). */
 int empose_window_mean(int T, int F, int C, const float* in, int ld_in, float* out, int ld_out, empose_stream_t stream);

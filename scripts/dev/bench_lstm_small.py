@@ -2,6 +2,7 @@
 import os, sys, time
 sys.path.insert(0, '.')
 import torch
+from em_pose_amd import _lib
 from em_pose_amd.nn.layers import RNNLayer
 dev = 'cuda:0'
 layer = RNNLayer(60, 512, 2).eval().to(dev)
@@ -11,10 +12,11 @@ for B in (1, 2, 3, 4, 6, 8, 12, 16):
         lens = torch.full((B,), F, device=dev)
         res = []
         for mode in ('1', '0'):
-            os.environ['EMPOSE_LSTM_PERSIST'] = mode
+            _lib.check(_lib.lib().empose_set_option(b'lstm_persist', int(mode)))   # the library reads no environment
             for _ in range(3): layer(x, lens)
             torch.cuda.synchronize(); t0 = time.time()
             for _ in range(10): layer(x, lens)
             torch.cuda.synchronize(); res.append((time.time() - t0) / 10 * 1e3)
         print('B=%2d F=%3d: whole-sequence %.3f ms (%.2f us/step)   step launches %.3f ms (%.2f us/step)' % (
             B, F, res[0], res[0] * 1e3 / (F + 1), res[1], res[1] * 1e3 / (F + 1)))
+_lib.check(_lib.lib().empose_set_option(b'lstm_persist', 1))

@@ -144,6 +144,8 @@ def main():
     p.add_argument('--repeat', type=int, default=1,
                    help='Evaluate the set this many times and report every pass; the first pass still pays one-time '
                         'costs (kernels and allocations of every batch shape that occurs), later ones do not.')
+    p.add_argument('--force_dist', action='store_true',
+                   help='Initialise the process group (RCCL) and run the metric gather even with one rank (self-test).')
     p.add_argument('--no_warmup', action='store_true',
                    help='Do not run the first chunk of the first recording once before the timed evaluation '
                         '(code-object loading, workspace allocation).')
@@ -165,9 +167,12 @@ def main():
         torch.cuda.set_device(device)
     sync = (lambda: None) if on_cpu else torch.cuda.synchronize
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and not on_cpu):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29534')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', device_id=device)
 
     net, smpl, lengths, load, name = (synthetic_setup if args.synthetic else real_setup)(args, device)
@@ -200,7 +205,7 @@ def main():
     elapsed = passes[-1]
     rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]
     if dist is not None:
-        me_all.gather(device=device)
+        me_all.gather(device=device, force=args.force_dist)
         gathered = [None] * world
         dist.all_gather_object(gathered, (rows, frames, elapsed, passes))
         rows = sorted(r for g in gathered for r in g[0])

@@ -30,7 +30,8 @@ from em_pose_amd import synthetic  # noqa: E402
 from em_pose_amd.bodymodels.smpl import SMPLLayer  # noqa: E402
 from em_pose_amd.data.data import SyntheticBatch  # noqa: E402
 from em_pose_amd.helpers.configuration import lgd_config  # noqa: E402
-from em_pose_amd.helpers.distributed import allreduce_gradients, init_from_env  # noqa: E402
+from em_pose_amd.helpers.distributed import (GradientBuckets, allreduce_gradients, attach_gradient_buckets,  # noqa: E402
+                                             init_from_env)
 from em_pose_amd.nn.models import create_model  # noqa: E402
 
 
@@ -39,6 +40,25 @@ def _body_columns(sample):
     from em_pose_amd.helpers.configuration import CONSTANTS as C
     sample.poses, sample.shape = sample.poses[:, :C.MAX_INDEX_ROOT_AND_BODY], sample.shape[:C.N_SHAPE_PARAMS]
     return sample
+
+
+def make_buckets(net, params, world, args):
+    """Persistent flat gradient buckets in the order the reverse sweep finishes them (helpers/distributed.py); with more
+    than one rank -- or `--force_dist`, the single-rank self-test of the RCCL path -- the engine writes gradients straight
+    into them and each bucket's all-reduce overlaps the rest of the sweep."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or not (world > 1 or args.force_dist):
+        return None
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    order = LgdTrainEngine.gradient_order(net) if LgdTrainEngine.supported(net) else []
+    rest = [p for p in params if id(p) not in {id(q) for q in order}]
+    buckets = GradientBuckets(order + rest, bucket_bytes=args.bucket_mb << 20, force=args.force_dist)
+    attach_gradient_buckets(net, buckets)
+    return buckets
+
+
+def average_gradients(buckets, params):
+    return buckets.finish() if buckets is not None else allreduce_gradients(params)
 
 
 def train_on_amass(args, dev, rank, world):
@@ -65,6 +85,7 @@ def train_on_amass(args, dev, rank, world):
     offsets = args.offset_files or sorted(glob.glob(os.path.join(C.DATA_DIR_TEST or '.', '*_offsets.npz')))
     if not offsets:
         raise SystemExit('no *_offsets.npz files: pass --offset_files or set EM_DATA_REAL')
+    buckets = make_buckets(net, params, world, args)
     fn_train = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=True)
     fn_valid = get_end_to_end_preprocess_fn(cfg, smpl, offsets, randomize_if_configured=False)
 
@@ -131,7 +152,7 @@ def train_on_amass(args, dev, rank, world):
             opt.zero_grad()
             batch = fn_train(abatch.to_gpu(dev))
             loss, vals = net.backward(batch, net(batch))
-            allreduce_gradients(params)
+            average_gradients(buckets, params)
             opt.step()
             if rank == 0:
                 print('[TRAIN {:0>5d} | {:0>3d}] '.format(i + 1, epoch + 1) +
@@ -180,6 +201,9 @@ def main():
     # training on AMASS sequences (the loop of reference scripts/train.py:125-230 with checkpoints and validation)
     p.add_argument('--amass_dir', default=None, help='directory tree of AMASS *.npz sequences; switches from the '
                                                      'synthetic step benchmark to real training')
+    p.add_argument('--force_dist', action='store_true', help='initialise the process group (RCCL) and run the gradient '
+                                                           'collectives even with one rank (self-test)')
+    p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
     p.add_argument('--amass_lmdb', default=None, help='LMDB database in the reference key schema (needs `lmdb`)')
     p.add_argument('--valid_lmdb', default=None, help='validation LMDB (e.g. 3DPW); default: held-out training sequences')
     p.add_argument('--offset_files', nargs='*', default=None, help='*_offsets.npz files (default: $EM_DATA_REAL/*_offsets.npz)')
@@ -232,6 +256,7 @@ def main():
         return b
     batches = [make_batch(s) for s in range(4)]  # data preparation is not part of the measured step
     net.train()
+    buckets = make_buckets(net, params, world, args)
     graphed = None
     if args.graph:
         from em_pose_amd.helpers.graphed import GraphedTrainStep
@@ -243,15 +268,15 @@ def main():
         batch = batches[step % len(batches)]
         if graphed is not None:
             vals = graphed(batch)            # forward + backward replayed; gradients in the static .grad tensors
-            allreduce_gradients(params)
+            average_gradients(buckets, params)
             opt.step()
             torch.cuda.synchronize()
             vals = {k: float(v) for k, v in vals.items()}
         else:
             opt.zero_grad()
             out = net(batch)
-            loss, vals = net.backward(batch, out)
-            allreduce_gradients(params)
+            loss, vals = net.backward(batch, out)     # finished buckets are already being averaged on a side stream
+            average_gradients(buckets, params)
             opt.step()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0

@@ -161,7 +161,28 @@ def _grad_worker(rank, world, port, q):
         net(x).sum().backward()
         net[1].bias.grad = None if rank == 1 else net[1].bias.grad  # a parameter without gradient on one rank
         n_buckets = allreduce_gradients(list(net.parameters()) + [frozen], bucket_bytes=16 << 10)
-        q.put((rank, n_buckets, [p.grad.numpy().copy() for p in net.parameters()]))  # plain arrays: no fd passing
+        first = [p.grad.numpy().copy() for p in net.parameters()]
+        # the persistent form: buckets kept across steps, parameters staged one by one as a reverse sweep would finish
+        # them (last layer first), `.grad` is the bucket slice afterwards and stays at the same address
+        from em_pose_amd.helpers.distributed import GradientBuckets
+        order = list(net.parameters())[::-1]
+        buckets = GradientBuckets(order, bucket_bytes=4 << 10)
+        ptrs, second = None, None
+        for step in range(2):
+            for p in net.parameters():
+                p.grad = None
+            net(x).sum().backward()
+            if rank == 1:
+                net[1].bias.grad = None
+            for p in order:
+                buckets.stage(p)
+            assert buckets.finish() == buckets.n_buckets >= 2
+            now = [p.grad.data_ptr() for p in net.parameters()]
+            assert all(p.grad.data_ptr() == buckets.view_of(p).data_ptr() for p in net.parameters())
+            assert ptrs is None or ptrs == now
+            ptrs, second = now, [p.grad.numpy().copy() for p in net.parameters()]
+        assert all(np.array_equal(a, b) for a, b in zip(first, second))
+        q.put((rank, n_buckets, first))  # plain arrays: no fd passing
     finally:
         dist.destroy_process_group()
 
