@@ -145,7 +145,7 @@ def test_training_gradients_when_hidden_is_narrower_than_the_input(rnn):
     assert gmax > 0 and set(grads[True]) == set(grads[False]) and len(grads[True]) >= 14
     for k, want in grads[False].items():
         assert np.isfinite(grads[True][k]).all(), k
-        np.testing.assert_allclose(grads[True][k], want, atol=1e-3 * max(np.abs(want).max(), 1e-3 * gmax), rtol=1e-3,
+        np.testing.assert_allclose(grads[True][k], want, atol=3e-3 * max(np.abs(want).max(), 1e-3 * gmax), rtol=3e-3,
                                    err_msg=k)
 
 
