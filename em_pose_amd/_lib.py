@@ -178,6 +178,7 @@ SIGNATURES = {
     'empose_mlp_train_wgrad': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_int,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(MlpGrads), C.c_int,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_smpl_tile_supported': (C.c_int, [C.c_void_p]),
     'empose_pack_inputs': (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'empose_window_mean': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

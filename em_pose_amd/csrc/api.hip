@@ -109,6 +109,11 @@ struct empose_model {
   int any_skip = 0;
   int smpl_only = 0;
   int rod_conv = 0;            // EMPOSE_RODRIGUES_*
+  // frame-per-lane path (smpl_tile.hip): tables, the blend matrix with per-patch vertex copies in fragment order
+  int tile_ok = 0, ncp2 = 0, tile_nloc = 0, tile_nbl = 0;
+  TileTables* tile_tab = nullptr;
+  float* wc2_frag = nullptr;   // [ncp2][200]
+  float* wc2t_frag = nullptr;  // [200][ncp2]
 };
 
 struct empose_rnn {
@@ -331,16 +336,31 @@ struct Carver {
 // ---- workspace layouts ------------------------------------------------------------------------------------------
 struct SmplWs {
   float *rot, *feat, *out, *d_out, *d_feat, *d_rot;
+  float* theta_t;   // theta in tile layout for the frame-per-lane kernel
+  float* tgt_t;     // targets in tile layout (stand-alone entry points; the LGD loop has its own copy)
 };
+constexpr int D_FEAT_T_COLS = 224;   // the 200 feature cotangents in tile layout, whole 32-column tiles
 SmplWs carve_smpl(Carver& c, const empose_model* m, int T) {
+  // Either path fits: row-major [T][cols] for chain_sensors_kernel, tile layout [ceil(T / 64)][cols][64] for
+  // smpl_tile_kernel (which does not use `rot`: it evaluates Rodrigues itself).
   SmplWs w;
+  const size_t Tp = (size_t)(T + TL_FR - 1) / TL_FR * TL_FR;
+  const size_t ncp = m->tab.ncp > m->ncp2 ? m->tab.ncp : m->ncp2;
   w.rot = c.f((size_t)T * 198);
   w.feat = c.f((size_t)T * 200);
-  w.out = c.f((size_t)T * m->tab.ncp);
-  w.d_out = c.f((size_t)T * m->tab.ncp);
-  w.d_feat = c.f((size_t)T * 200);
-  w.d_rot = c.f((size_t)T * 198);
+  w.out = c.f(Tp * ncp);
+  w.d_out = c.f(Tp * ncp);
+  w.d_feat = c.f(Tp * D_FEAT_T_COLS);
+  w.d_rot = c.f(Tp * 198);
+  w.theta_t = c.f(Tp * 66);
+  w.tgt_t = c.f(Tp * 144);
   return w;
+}
+// The frame-per-lane path pays from a few thousand frames on (a workgroup is 64 frames: 4096 frames are 64 workgroups);
+// option "smpl_tile": 0 never, 1 by size, 2 always (tests).
+bool use_tile_path(const empose_model* m, int T, const float* cot_joints = nullptr) {
+  const int opt = options().smpl_tile;
+  return m->tile_ok && opt != 0 && !cot_joints && (opt == 2 || T >= 4096);
 }
 
 struct UpdWs {
@@ -581,7 +601,33 @@ int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, c
 int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const float* offset_r, const float* offset_t,
                   const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori, float* joints,
                   float* pos2, float* ori2, float* joints2, hipStream_t stream, const float* cot_pos = nullptr,
-                  const float* cot_ori = nullptr, const float* cot_joints = nullptr) {
+                  const float* cot_ori = nullptr, const float* cot_joints = nullptr, const float* theta = nullptr,
+                  int ld_theta = 0, const float* tgt_t = nullptr) {
+  if (theta && use_tile_path(m, T, cot_joints)) {
+    // frame-per-lane path: blend GEMM -> tile layout -> smpl_tile_kernel -> tile layout -> transposed GEMM
+    prof_mark(P_BLEND_GEMM, stream);
+    hipError_t e = launch_gemm_rows_t(ws.feat, 200, false, m->wc2_frag, ws.out, m->ncp2, T, m->ncp2, 200, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm (tile): %s", hipGetErrorString(e));
+    const bool bwd = tgt || cot_pos;
+    TileArgs a;
+    a.tab = m->tile_tab; a.theta = theta; a.ld_theta = ld_theta; a.out_t = ws.out;
+    a.theta_t = ws.theta_t; a.tgt_t = tgt ? tgt_t : nullptr;
+    a.offset_r = offset_r; a.offset_t = offset_t; a.tgt = tgt; a.ld_tgt = ld_tgt; a.frame_scale = frame_scale;
+    a.n_markers = m->n_markers;
+    for (int i = 0; i < 12; ++i) a.used_slot[i] = m->used_slot[i];
+    a.pos = pos; a.ori = ori; a.joints = joints; a.pos2 = pos2; a.ori2 = ori2; a.joints2 = joints2;
+    a.d_out_t = ws.d_out; a.d_rot_t = ws.d_rot; a.T = T; a.F = F; a.rod_conv = m->rod_conv;
+    a.cot_pos = cot_pos; a.cot_ori = cot_ori;
+    prof_mark(P_CHAIN, stream);
+    e = launch_smpl_tile(a, bwd, m->tile_nloc, m->tile_nbl, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "smpl tile kernel: %s", hipGetErrorString(e));
+    if (bwd) {
+      prof_mark(P_BLEND_T_GEMM, stream);
+      e = launch_gemm_rows_t(ws.d_out, m->ncp2, true, m->wc2t_frag, ws.d_feat, D_FEAT_T_COLS, T, 200, m->ncp2, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm (tile): %s", hipGetErrorString(e));
+    }
+    return EMPOSE_OK;
+  }
   GemmBatch b;
   b.count = 1;
   GemmProb& p = b.p[0];
@@ -635,6 +681,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
+      {"smpl_tile", &o.smpl_tile},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -648,6 +695,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
+      {"smpl_tile", o.smpl_tile},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};
@@ -757,6 +805,23 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
     MTRY(upload(m->allocs, blob.data(), blob.size(), &bp));
     t.blob = bp;
   }
+  {
+    // frame-per-lane path: only for patches that are closed fans of at most TL_NR faces over at most TL_NBL bones
+    // (closed manifold meshes; anything else keeps chain_sensors_kernel)
+    TileTables tt;
+    std::vector<float> wc2;
+    if (s.n_sensors == 12 && build_tile_tables(s.nv, s.kb, s.max_deg, s.j_off, s.wc, s.parents, s.skin_idx, s.skin_w,
+                                               s.s_center, s.s_helper, s.s_deg, s.s_faces, &tt, &wc2)) {
+      std::vector<float> wc2t((size_t)200 * tt.ncp2);
+      for (int r = 0; r < tt.ncp2; ++r)
+        for (int k = 0; k < 200; ++k) wc2t[(size_t)k * tt.ncp2 + r] = wc2[(size_t)r * 200 + k];
+      MTRY(upload(m->allocs, &tt, 1, &m->tile_tab));
+      MTRY(pack_fragments_raw(m->allocs, wc2.data(), tt.ncp2, 200, &m->wc2_frag));
+      MTRY(pack_fragments_raw(m->allocs, wc2t.data(), 200, tt.ncp2, &m->wc2t_frag));
+      m->ncp2 = tt.ncp2; m->tile_nloc = tt.nloc; m->tile_nbl = tt.nbl;
+      m->tile_ok = tt.ncp2 <= 320;   // the widest tile gemm_rows_t_kernel covers
+    }
+  }
 
   m->n_markers = d->n_markers;
   for (int i = 0; i < 12; ++i) { m->marker_idx[i] = 0; m->used_slot[i] = -1; }
@@ -802,6 +867,8 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
   return EMPOSE_OK;
 }
 
+int empose_smpl_tile_supported(const empose_model_t* m) { return m && m->tile_ok ? 1 : 0; }
+
 size_t empose_smpl_workspace_bytes(const empose_model_t* m, int T) {
   Carver c(nullptr);
   carve_smpl(c, m, T);
@@ -822,6 +889,7 @@ size_t empose_lstm_workspace_bytes(const empose_model_t* m, int B, int F) {
 
 struct LgdWs {
   float *x, *scale, *d_pose, *d_shape, *pos, *ori, *joints;
+  float* x_t;   // the sensor columns of x in tile layout (targets of the frame-per-lane kernel)
   SmplWs smpl;
   UpdWs upd;
   LstmWs lstm;
@@ -837,6 +905,7 @@ static LgdWs carve_lgd(Carver& c, const empose_model* m, int B, int F) {
   w.pos = c.f(T * 36);
   w.ori = c.f(T * 108);
   w.joints = c.f(T * 66);
+  w.x_t = c.f((T + TL_FR - 1) / TL_FR * TL_FR * m->d_in);
   w.smpl = carve_smpl(c, m, (int)T);
   w.upd = carve_upd(c, m, (int)T);
   if (m->rnn_init) {
@@ -884,6 +953,10 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
   prof_mark(P_PACK, stream);
   hipError_t e = launch_pack_inputs(pa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "pack kernel: %s", hipGetErrorString(e));
+  if (m->use_gradient && m->N > 0 && use_tile_path(m, T)) {   // the targets of the frame-per-lane kernel, once per forward
+    e = launch_rows_to_tile(w.x, dx, m->d_in, w.x_t, T, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "tile transpose: %s", hipGetErrorString(e));
+  }
 
   // ---- initial estimate (reference models.py:511-526)
   if (m->rnn_init) {
@@ -916,7 +989,8 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
       fa.d_theta = w.d_pose; fa.theta_step = m->step;
       fa.d_beta = w.d_shape; fa.beta_keep = 1.f; fa.beta_step = m->step;
     }
-    fa.rot = w.smpl.rot; fa.feat = w.smpl.feat;
+    const bool tile = use_tile_path(m, T);
+    fa.rot = tile ? nullptr : w.smpl.rot; fa.feat = w.smpl.feat; fa.theta_t = tile ? w.smpl.theta_t : nullptr;
     fa.out_theta = hist(io->hist_pose, i, 66); fa.out_beta = hist(io->hist_shape, i, 10);
     fa.out_theta2 = (i == N) ? io->pose_hat : nullptr;
     fa.out_beta2 = (i == N) ? io->shape_hat : nullptr;
@@ -930,11 +1004,23 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     float* ho = hist(io->hist_markers_ori, i, 108);
     float* hj = hist(io->hist_joints, i, 66);
     if ((hm == nullptr) != (ho == nullptr)) return fail(EMPOSE_EINVAL, "hist_markers and hist_markers_ori go together");
+    // (the frame-per-lane kernel skips outputs nobody asked for; the general kernel always writes its scratch copies)
     TRY(run_smpl_eval(m, T, F, w.smpl, io->offset_r, io->offset_t, need_grad ? w.x : nullptr, dx, w.scale,
-                      hm ? hm : w.pos, ho ? ho : w.ori, (i == N) ? io->joints_hat : (hj ? hj : w.joints),
-                      nullptr, nullptr, (i == N) ? hj : nullptr, stream));
+                      hm ? hm : (tile ? nullptr : w.pos), ho ? ho : (tile ? nullptr : w.ori),
+                      (i == N) ? io->joints_hat : (hj ? hj : (tile ? nullptr : w.joints)),
+                      nullptr, nullptr, (i == N) ? hj : nullptr, stream, nullptr, nullptr, nullptr, x_theta, dx, w.x_t));
     if (i == N) break;
-    if (m->use_gradient) {
+    if (m->use_gradient && tile) {
+      RodBwdTArgs ra;
+      ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot_t = w.smpl.d_rot; ra.d_feat_t = w.smpl.d_feat;
+      ra.ld_feat_t = D_FEAT_T_COLS;
+      ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
+      ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
+      ra.T = T; ra.rod_conv = m->rod_conv;
+      prof_mark(P_ROD_BWD, stream);
+      e = launch_rodrigues_bwd_t(ra, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
+    } else if (m->use_gradient) {
       RodBwdArgs ra;
       ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot = w.smpl.d_rot; ra.d_feat = w.smpl.d_feat;
       ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
@@ -973,14 +1059,26 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
   FeatArgs fa;   // the caller's rows are read in place (no update: the kernel does not write them back)
   fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
-  fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
+  const bool tile = use_tile_path(m, T);
+  fa.shape_avg = 0; fa.rot = tile ? nullptr : ws.rot; fa.feat = ws.feat; fa.theta_t = tile ? ws.theta_t : nullptr;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
   fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
   hipError_t e = launch_update_feat(fa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+  if (tgt && tile) {
+    e = launch_rows_to_tile(tgt, ld_tgt, 12 * m->n_markers, ws.tgt_t, T, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "tile transpose: %s", hipGetErrorString(e));
+  }
   TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, tgt, ld_tgt, frame_scale, pos, ori, joints, nullptr, nullptr,
-                    nullptr, stream));
-  if (tgt) {
+                    nullptr, stream, nullptr, nullptr, nullptr, theta, ld_theta, tile ? ws.tgt_t : nullptr));
+  if (tgt && tile) {
+    RodBwdTArgs ra;
+    ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot_t = ws.d_rot; ra.d_feat_t = ws.d_feat; ra.ld_feat_t = D_FEAT_T_COLS;
+    ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
+    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
+    e = launch_rodrigues_bwd_t(ra, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
+  } else if (tgt) {
     RodBwdArgs ra;
     ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
     ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
@@ -1009,13 +1107,23 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   FeatArgs fa;   // the caller's rows are read in place (no update: the kernel does not write them back)
   fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
-  fa.shape_avg = 0; fa.rot = ws.rot; fa.feat = ws.feat;
+  const bool tile = use_tile_path(m, T, d_joints);
+  fa.shape_avg = 0; fa.rot = tile ? nullptr : ws.rot; fa.feat = ws.feat; fa.theta_t = tile ? ws.theta_t : nullptr;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
   fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
   hipError_t e = launch_update_feat(fa, stream);
   if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
-  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, pos, ori, joints, nullptr, nullptr, nullptr,
-                    stream, d_pos, d_ori, d_joints));
+  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, tile ? nullptr : pos, tile ? nullptr : ori,
+                    tile ? nullptr : joints, nullptr, nullptr, nullptr, stream, d_pos, d_ori, d_joints, theta, ld_theta));
+  if (tile) {
+    RodBwdTArgs rt;
+    rt.theta = theta; rt.ld_theta = ld_theta; rt.d_rot_t = ws.d_rot; rt.d_feat_t = ws.d_feat; rt.ld_feat_t = D_FEAT_T_COLS;
+    rt.g_theta = g_theta; rt.ld_g = 66; rt.g_beta = g_beta; rt.ld_gb = 10;
+    rt.trace_g_theta = nullptr; rt.trace_g_beta = nullptr; rt.T = T; rt.rod_conv = m->rod_conv;
+    e = launch_rodrigues_bwd_t(rt, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
+    return EMPOSE_OK;
+  }
   RodBwdArgs ra;
   ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
   ra.g_theta = g_theta; ra.ld_g = 66; ra.g_beta = g_beta; ra.ld_gb = 10;

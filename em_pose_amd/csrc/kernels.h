@@ -6,6 +6,7 @@
 
 #include <initializer_list>
 #include <utility>
+#include <vector>
 
 namespace empose {
 
@@ -16,6 +17,7 @@ struct Options {
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
+  int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 4096 frames on, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
 };
@@ -322,6 +324,7 @@ struct FeatArgs {
   float* feat;                         // [T][200]
   float* out_theta; float* out_beta;   // optional dense copies [T][66], [T][10]
   float* out_theta2; float* out_beta2; // optional second copy (history)
+  float* theta_t = nullptr;            // optional: the updated theta in tile layout [tiles][66][64] (smpl_tile.hip)
   int T, F;
   int rod_conv = 0;                    // EMPOSE_RODRIGUES_SMPLX (0) or EMPOSE_RODRIGUES_SO3 (1)
 };
@@ -360,6 +363,67 @@ struct RodBwdArgs {
   int rod_conv = 0;
 };
 hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// SMPL sub-mesh with one frame per lane (smpl_tile.hip): tables, arguments, launchers.
+// "Tile layout" of a per-frame matrix X[T][C]: X_t[tile = t / 64][c][t % 64] -- a column of 64 frames is contiguous.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TL_FR = 64;             // frames per tile = lanes of a wave
+constexpr int TL_NR = 8;              // largest ring (= sensor vertex degree) the kernel takes
+constexpr int TL_NLOC = TL_NR + 1;    // local vertices of a sensor patch: centre + ring
+constexpr int TL_NBL = 8;              // distinct bones under one patch
+struct TileSensor {
+  int deg, helper, col, nb;           // ring size, ring index of the helper vertex, first column of the patch, bones
+  int bone[TL_NBL];                   // the patch's bones (unused slots: bone 0 with zero weights)
+  int bones, pad[3];                  // bit mask of the bones (host: scheduling)
+  float w[TL_NLOC][TL_NBL];           // dense skin weights of local vertex i over the patch's bones
+};
+struct TileTables {                   // one per model, in device memory, read with scalar loads
+  int ncp2, j_off2, nloc, nbl;        // columns of the tile (multiple of 32), first rest-joint column, most local
+                                      // vertices / bones of a patch
+  int n_rounds;
+  TileSensor s[12];
+  int parent[22];
+};
+bool build_tile_tables(int nv, int kb, int max_deg, int j_off, const float* wc, const int* parents, const int* skin_idx,
+                       const float* skin_w, const int* s_center, const int* s_helper, const int* s_deg,
+                       const int* s_faces, TileTables* out, std::vector<float>* wc2);
+struct TileArgs {
+  const TileTables* tab;
+  const float* theta; int ld_theta;   // [T][ld] axis-angles (66 used)
+  const float* theta_t = nullptr;     // the same in tile layout [tiles][66][64], or nullptr (strided loads: 64 cache
+                                      // lines per load instruction)
+  const float* tgt_t = nullptr;       // tgt in tile layout [tiles][12 * n_markers][64], or nullptr
+  const float* out_t;                 // tile layout [tiles][ncp2][64]: v_posed of the patches | rest joints
+  const float* offset_r;              // [T/F][12][9]
+  const float* offset_t;              // [T/F][12][3]
+  const float* tgt; int ld_tgt;       // network-input layout; nullptr with backward => external cotangents
+  const float* frame_scale;           // [T]
+  int n_markers; int used_slot[12];
+  float* pos; float* ori; float* joints;       // [T][36], [T][108], [T][66] or nullptr (not wanted)
+  float* pos2; float* ori2; float* joints2;    // optional second copies
+  float* d_out_t;                     // tile layout [tiles][ncp2][64]
+  float* d_rot_t;                     // tile layout [tiles][198][64]
+  int T, F;
+  int rod_conv;
+  const float* cot_pos = nullptr;     // [T][36], [T][108]: external cotangents instead of the residual
+  const float* cot_ori = nullptr;
+};
+hipError_t launch_smpl_tile(const TileArgs& a, bool backward, int nloc, int nbl, hipStream_t stream);
+struct RodBwdTArgs {
+  const float* theta; int ld_theta;
+  const float* d_rot_t;               // tile layout [tiles][198][64]
+  const float* d_feat_t; int ld_feat_t;   // tile layout [tiles][ld_feat_t][64] (columns 0..198 used)
+  float* g_theta; int ld_g; float* g_beta; int ld_gb;
+  float* trace_g_theta; float* trace_g_beta;
+  int T; int rod_conv;
+};
+hipError_t launch_rodrigues_bwd_t(const RodBwdTArgs& a, hipStream_t stream);
+hipError_t launch_rows_to_tile(const float* src, int ld, int cols, float* dst_t, int T, hipStream_t stream);
+// C = A . Wp^T with tile-layout operands (mlp_fused.hip): A row-major [M][lda] or tile layout (a_tile), C in tile layout
+// [tiles][ldc_t][64] (ldc_t >= N rounded up to 32; the padding columns are written as zeros).
+hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float* Wp, float* C_t, int ldc_t, int M, int N,
+                              int K, hipStream_t stream);
 
 // Full-mesh: chain only (joints + relative transforms) and dense skinning.
 constexpr int MESH_MAX_JOINTS = 52;   // SMPL-H: 22 body + 2 x 15 hand joints

@@ -42,7 +42,7 @@ typedef const __attribute__((address_space(1))) char* fm_gbyte_t;
 
 // One layer for the workgroup's rows; the input activations are in `act` (row stride lda, columns [0, 8 * KG4) valid or
 // zero).  The wave computes WM x WN tiles of 32 x 32 starting at (row_tile0, col_tile0).
-template <int WM, int WN>
+template <int WM, int WN, bool OUT_T = false>   // OUT_T: the last layer's result goes to LDS, transposed (gemm_rows_t_kernel)
 __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act,
                                               int lda, int row_tile0, int col_tile0, int layer_index, bool last) {
   using namespace fm;
@@ -159,7 +159,22 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   FM_STAMP(4 * layer_index + 2)
 
   __syncthreads();   // every wave has read its last A fragment: the buffer may be overwritten
-  if (last) {
+  if (last && OUT_T) {
+    // C^T into the (now free) activation buffer as [column][64 rows], rows rotated by the column so that the 32 lanes of
+    // a store (32 columns, one row) hit 32 banks; gemm_rows_t_kernel copies it out as whole 256-byte columns.
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      if (col_tile0 + j >= NT32) continue;
+      const int n = (col_tile0 + j) * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          act[n * 64 + ((row + n) & 63)] = acc[i][j][r];
+        }
+    }
+  } else if (last) {
     // last layer: to the net's output
     GemmProb p;
     p.C = net.out; p.ldc = net.ld_out;
@@ -308,6 +323,108 @@ hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, 
   L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
   if (N > 256) return launch_gemm_rows_cfg<128, 2, 5, 2>(a, stream);
   return launch_gemm_rows_cfg<64, 1, 4, 2>(a, stream);
+}
+
+// The row-block GEMM with tile-layout operands (kernels.h "tile layout"; the frame-per-lane SMPL kernel, smpl_tile.hip,
+// reads and writes columns of 64 frames): 64 rows (= one tile) per workgroup, 2 x 2 waves of 32 x (32 WN).  A comes
+// row-major or in tile layout (A_T); C leaves through LDS as whole columns.
+template <int WN, bool A_T>
+__global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
+  const int tid = threadIdx.x;
+  const int K0 = L.K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
+  const int lda = kpad + 4;
+  if (A_T) {
+    // A_t[tile][k][64]: a thread takes four frames of one column (16 bytes, coalesced) and scatters them over four rows
+    const f32x4* src = reinterpret_cast<const f32x4*>(net.x + (size_t)tile * net.ldx * 64);
+    for (int i0 = tid; i0 < kpad * 16; i0 += 4 * fm::NT) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < kpad * 16 && (i >> 4) < K0) v[u] = src[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        if (i < kpad * 16) {
+          const int k = i >> 4, f = (i & 15) * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) act[(f + e) * lda + k] = v[u][e];
+        }
+      }
+    }
+  } else {
+    const int c4n = kpad / 4;
+    for (int i0 = tid; i0 < 64 * c4n; i0 += 4 * fm::NT) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < 64 * c4n) {
+          const int r = i / c4n, c = (i % c4n) * 4;
+          const int row = m0 + r < M ? m0 + r : M - 1;
+          if (c < K0) v[u] = *reinterpret_cast<const f32x4*>(net.x + (size_t)row * net.ldx + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * fm::NT;
+        if (i < 64 * c4n) *reinterpret_cast<f32x4*>(act + (i / c4n) * lda + (i % c4n) * 4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  fused_layer_t<1, WN, true>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
+  // C^T is in LDS ([column][64], rows rotated by the column): out as 16-byte pieces of whole columns
+  const int NT32 = (L.N + 31) / 32;
+  float* dst = net.out + (size_t)tile * net.ld_out * 64;
+  for (int i = tid; i < net.ld_out * 16; i += fm::NT) {
+    const int n = i >> 4, f = (i & 15) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < NT32 * 32) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act[n * 64 + ((f + e + n) & 63)];
+    }
+    *reinterpret_cast<f32x4*>(dst + (size_t)n * 64 + f) = v;
+  }
+}
+
+template <int WN, bool A_T>
+static hipError_t launch_gemm_rows_t_cfg(const FusedMlpArgs& args, hipStream_t stream) {
+  const FusedLayer& L = args.net[0].layer[0];
+  const int kpad = (((L.K + 7) / 8 + 3) & ~3) * 8;
+  const size_t a_bytes = (size_t)64 * (kpad + 4) * sizeof(float), c_bytes = (size_t)((L.N + 31) / 32) * 32 * 64 * sizeof(float);
+  const size_t lds = (a_bytes > c_bytes ? a_bytes : c_bytes);
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_t_kernel<WN, A_T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  hipLaunchKernelGGL((gemm_rows_t_kernel<WN, A_T>), dim3((args.M + 63) / 64), dim3(fm::NT), lds, stream, args);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float* Wp, float* C_t, int ldc_t, int M, int N,
+                              int K, hipStream_t stream) {
+  if (K % 4 != 0 || N > 320 || ldc_t < ((N + 31) / 32) * 32) return hipErrorInvalidValue;
+  FusedMlpArgs a;
+  a.count = 1; a.M = M;
+  FusedNet& fn = a.net[0];
+  fn.x = A; fn.ldx = lda; fn.out = C_t; fn.ld_out = ldc_t; fn.n_layers = 1;
+  FusedLayer& L = fn.layer[0];
+  L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
+  if (N > 256) return a_tile ? launch_gemm_rows_t_cfg<5, true>(a, stream) : launch_gemm_rows_t_cfg<5, false>(a, stream);
+  return a_tile ? launch_gemm_rows_t_cfg<4, true>(a, stream) : launch_gemm_rows_t_cfg<4, false>(a, stream);
 }
 
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream) {

@@ -14,6 +14,7 @@
 // chain is a per-(joint,row) walk down the root path, the reverse chain uses the world-space form
 // dR_j = G_p^T (sum_subtree M_b - F_b (x) t_j) G_j, which needs subtree sums instead of a level-by-level sweep.
 #include "kernels.h"
+#include "smpl_math.h"
 
 #include <cstdlib>
 
@@ -58,40 +59,6 @@ hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream) {
   const long n = (long)a.B * a.F * (a.n_markers * 12 + 1);
   hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-struct Rod {
-  float ux, uy, uz, ang, dx, dy, dz, s, c;   // (ux, uy, uz) = ang * d(ang)/d(r)
-};
-
-// Axis-angle -> rotation, R = I + sin(a) K + (1 - cos a) K^2 with K = hat(r / a).  The un-vendored BodyModel's guard of
-// the angle at r = 0 is not pinned, so both published conventions are kept (EMPOSE_RODRIGUES_*):
-//   smplx  a = ||r + 1e-8||                 (smplx lbs.batch_rodrigues)
-//   so3    a = sqrt(max(||r||^2, 1e-4))     (reference helpers/so3.py:116-121; below the clamp a is constant)
-__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, int conv, Rod& q, float (&R)[9]) {
-  if (conv == 0) {
-    q.ux = rx + 1e-8f; q.uy = ry + 1e-8f; q.uz = rz + 1e-8f;
-    q.ang = sqrtf(q.ux * q.ux + q.uy * q.uy + q.uz * q.uz);
-  } else {
-    const float n2 = rx * rx + ry * ry + rz * rz;
-    const bool clamped = n2 < 1e-4f;
-    q.ux = clamped ? 0.f : rx; q.uy = clamped ? 0.f : ry; q.uz = clamped ? 0.f : rz;
-    q.ang = sqrtf(fmaxf(n2, 1e-4f));
-  }
-  q.dx = rx / q.ang; q.dy = ry / q.ang; q.dz = rz / q.ang;
-  sincosf(q.ang, &q.s, &q.c);
-  const float oc = 1.f - q.c;
-  // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  R = I + s K + (1-c) K K
-  R[0] = 1.f + oc * (-q.dz * q.dz - q.dy * q.dy);
-  R[1] = -q.s * q.dz + oc * (q.dx * q.dy);
-  R[2] = q.s * q.dy + oc * (q.dx * q.dz);
-  R[3] = q.s * q.dz + oc * (q.dx * q.dy);
-  R[4] = 1.f + oc * (-q.dz * q.dz - q.dx * q.dx);
-  R[5] = -q.s * q.dx + oc * (q.dy * q.dz);
-  R[6] = -q.s * q.dy + oc * (q.dx * q.dz);
-  R[7] = q.s * q.dx + oc * (q.dy * q.dz);
-  R[8] = 1.f + oc * (-q.dy * q.dy - q.dx * q.dx);
 }
 
 // One thread per (frame, slot): slots 0..21 are joints, 22..31 the ten shape coefficients.  The two wide outputs (rot:
@@ -144,6 +111,10 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
       }
       if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
       if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
+      if (a.theta_t) {
+        float* o = a.theta_t + ((size_t)(t >> 6) * 66 + slot * 3) * 64 + (t & 63);
+        o[0] = r0; o[64] = r1; o[128] = r2;
+      }
       Rod q; float R[9];
       rodrigues(r0, r1, r2, a.rod_conv, q, R);
       float* ro = s_rot + (fl * NB + slot) * 9;
@@ -174,7 +145,7 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
   __syncthreads();
   // the block's frames are contiguous in both outputs
   const int nf = min(UF_FRAMES, a.T - t0);
-  {
+  if (a.rot) {   // (the frame-per-lane kernel evaluates the rotations itself)
     const float2* src = reinterpret_cast<const float2*>(s_rot);
     float2* dst = reinterpret_cast<float2*>(a.rot + (size_t)t0 * NB * 9);   // 198 floats per frame: 8-byte pieces
     for (int i = threadIdx.x; i < nf * (NB * 9 / 2); i += 256) dst[i] = src[i];
@@ -288,20 +259,6 @@ constexpr int CHUNK = CHAIN_CHUNK;  // (vertex, weight) pairs per partial-sum ch
 size_t chain_lds_bytes(const SmplTables& tab, int frames_per_block) {
   const ChainLds l = chain_layout(tab.nv, tab.ncp, tab.max_deg, tab.n_chunks);
   return ((size_t)l.total * frames_per_block + ((tab.off.total + 3) & ~3)) * sizeof(float);
-}
-
-__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
-  o[0] = a[1] * b[2] - a[2] * b[1];
-  o[1] = a[2] * b[0] - a[0] * b[2];
-  o[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ float norm3(const float* a) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
-// y = x/|x|  ->  dx = (dy - y (y.dy)) / |x|
-__device__ __forceinline__ void unit_bwd(const float* dy, const float* y, float inv_n, float* dx) {
-  const float d = dy[0] * y[0] + dy[1] * y[1] + dy[2] * y[2];
-  dx[0] = (dy[0] - y[0] * d) * inv_n;
-  dx[1] = (dy[1] - y[1] * d) * inv_n;
-  dx[2] = (dy[2] - y[2] * d) * inv_n;
 }
 
 #ifdef EMPOSE_CHAIN_TRACE   // dev build only (scripts/dev/chain_trace.sh): shader-clock stamps of two blocks per phase

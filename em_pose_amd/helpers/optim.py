@@ -3,10 +3,11 @@ Adam as one kernel launch per step (`empose_adam_step`): torch.optim.Adam semant
 what reference scripts/train.py:125-130 constructs.  torch's own Adam is a dozen multi-tensor kernels per step; on the
 training path every other kernel is hand-written, so is this one.
 
-* Parameters whose `.grad` is None are skipped, moments untouched, like torch does (the chunk tables are built over the
-  parameters that have a gradient and rebuilt when that set changes).
+* Parameters whose `.grad` is None are skipped, moments AND step count untouched, like torch does (torch keeps a step
+  count per parameter: the bias correction of a parameter that sat out a step lags behind).  The chunk tables are
+  built per group of parameters with the same step count -- one group, one launch, unless gradients were ever missing.
 * `param_groups[0]['lr']` is read at every step, so a schedule can be driven by assigning to it; `state_dict()` /
-  `load_state_dict()` use torch.optim.Adam's layout (a checkpoint written by either restores into the other).
+  `load_state_dict()` use torch.optim.Adam's layout (a checkpoint written by either restores into a HipAdam).
 * The kernel updates parameters through raw device pointers: `tensor._version` does not move.  Everything that caches
   something derived from the weights (the folded inference handle of nn/models.py) is invalidated through
   `layers.BN_STATS_GENERATION`, bumped here.
@@ -27,20 +28,21 @@ class HipAdam(object):
                               'eps': float(eps), 'weight_decay': 0, 'amsgrad': False}]
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self.steps = 0
+        self.step_of = [0] * len(self.params)     # per parameter, as torch.optim.Adam keeps it
         self.dev = self.params[0].device
-        self._active, self._tables = None, None
-        n = len(self.params)
-        # gradient pointer table: pinned staging + a persistent device table (no pageable copy on the hot path)
-        self._g_host = torch.zeros(n, dtype=torch.int64).pin_memory()
-        self._g = torch.zeros(n, dtype=torch.int64, device=self.dev)
-        self._g_seen, self._g_copied = None, None
+        self._groups = {}                         # tuple of parameter indices -> device tables
+        self._stage = {}                          # tuple of parameter indices -> (pinned host table, event)
 
     # torch.optim.Optimizer vocabulary
     lr = property(lambda self: self.param_groups[0]['lr'],
                   lambda self, v: self.param_groups[0].__setitem__('lr', float(v)))
     betas = property(lambda self: self.param_groups[0]['betas'])
     eps = property(lambda self: self.param_groups[0]['eps'])
+
+    @property
+    def steps(self):
+        """The step count when all parameters share one (the usual case)."""
+        return max(self.step_of) if self.step_of else 0
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -49,50 +51,57 @@ class HipAdam(object):
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def _tables_for(self, active):
-        if active != self._active:
+    def _tables_for(self, idx):
+        t = self._groups.get(idx)
+        if t is None:
             i64 = lambda v: torch.tensor(v, dtype=torch.int64, device=self.dev)
-            ps = [self.params[i] for i in active]
+            ps = [self.params[i] for i in idx]
             ct, co = [], []
             for k, p in enumerate(ps):
                 for off in range(0, p.numel(), _CHUNK):
                     ct.append(k)
                     co.append(off)
-            self._tables = {'p': i64([p.data_ptr() for p in ps]), 'm': i64([self.exp_avg[i].data_ptr() for i in active]),
-                            'v': i64([self.exp_avg_sq[i].data_ptr() for i in active]),
-                            'sizes': i64([p.numel() for p in ps]),
-                            'chunk_tensor': torch.tensor(ct, dtype=torch.int32, device=self.dev), 'chunk_offset': i64(co)}
-            self._active, self._g_seen = active, None
-        return self._tables
+            t = {'p': i64([p.data_ptr() for p in ps]), 'm': i64([self.exp_avg[i].data_ptr() for i in idx]),
+                 'v': i64([self.exp_avg_sq[i].data_ptr() for i in idx]), 'sizes': i64([p.numel() for p in ps]),
+                 'chunk_tensor': torch.tensor(ct, dtype=torch.int32, device=self.dev), 'chunk_offset': i64(co),
+                 # gradient pointer table: pinned staging + a persistent device table (no pageable copy per step)
+                 'g': torch.zeros(len(idx), dtype=torch.int64, device=self.dev),
+                 'g_host': torch.zeros(len(idx), dtype=torch.int64).pin_memory(), 'g_seen': None, 'g_copied': None}
+            self._groups[idx] = t
+        return t
 
     def step(self):
-        active = tuple(i for i, p in enumerate(self.params) if p.grad is not None)
-        self.steps += 1
         _bump_weights_generation()
-        if not active:
-            return
-        t = self._tables_for(active)
-        ptrs = [self.params[i].grad.data_ptr() for i in active]
-        if ptrs != self._g_seen:   # gradient tensors are re-allocated every eager step, static inside a HIP graph
-            if self._g_copied is not None:
-                self._g_copied.synchronize()   # the previous upload has left the staging buffer (host ran ahead)
-            self._g_host[:len(ptrs)] = torch.tensor(ptrs, dtype=torch.int64)
-            self._g[:len(ptrs)].copy_(self._g_host[:len(ptrs)], non_blocking=True)
-            self._g_copied = torch.cuda.Event()
-            self._g_copied.record()
-            self._g_seen = ptrs
+        by_step = {}
+        for i, p in enumerate(self.params):
+            if p.grad is not None:
+                by_step.setdefault(self.step_of[i] + 1, []).append(i)
         g = self.param_groups[0]
-        with torch.cuda.device(self.dev):
-            _lib.check(_lib.lib().empose_adam_step(
-                t['chunk_tensor'].numel(), t['p'].data_ptr(), self._g.data_ptr(), t['m'].data_ptr(), t['v'].data_ptr(),
-                t['sizes'].data_ptr(), t['chunk_tensor'].data_ptr(), t['chunk_offset'].data_ptr(), g['lr'],
-                g['betas'][0], g['betas'][1], g['eps'], self.steps, _lib.current_stream()))
+        for step, members in sorted(by_step.items()):
+            idx = tuple(members)
+            t = self._tables_for(idx)
+            ptrs = [self.params[i].grad.data_ptr() for i in idx]
+            if ptrs != t['g_seen']:   # gradient tensors are re-allocated every eager step, static inside a HIP graph
+                if t['g_copied'] is not None:
+                    t['g_copied'].synchronize()   # the previous upload has left the staging buffer (host ran ahead)
+                t['g_host'].copy_(torch.tensor(ptrs, dtype=torch.int64))
+                t['g'].copy_(t['g_host'], non_blocking=True)
+                t['g_copied'] = torch.cuda.Event()
+                t['g_copied'].record()
+                t['g_seen'] = ptrs
+            with torch.cuda.device(self.dev):
+                _lib.check(_lib.lib().empose_adam_step(
+                    t['chunk_tensor'].numel(), t['p'].data_ptr(), t['g'].data_ptr(), t['m'].data_ptr(),
+                    t['v'].data_ptr(), t['sizes'].data_ptr(), t['chunk_tensor'].data_ptr(), t['chunk_offset'].data_ptr(),
+                    g['lr'], g['betas'][0], g['betas'][1], g['eps'], step, _lib.current_stream()))
+            for i in idx:
+                self.step_of[i] = step
 
     def state_dict(self):
         grp = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         grp['params'] = list(range(len(self.params)))
-        return {'state': {i: {'step': torch.tensor(float(self.steps)), 'exp_avg': m, 'exp_avg_sq': v}
-                          for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq))},
+        return {'state': {i: {'step': torch.tensor(float(self.step_of[i])), 'exp_avg': m, 'exp_avg_sq': v}
+                          for i, (m, v) in enumerate(zip(self.exp_avg, self.exp_avg_sq)) if self.step_of[i] > 0},
                 'param_groups': [grp]}
 
     def load_state_dict(self, sd):
@@ -103,22 +112,19 @@ class HipAdam(object):
         if len(grp['params']) != len(self.params):
             raise ValueError('optimizer state for {} parameters, this optimizer has {}'.format(
                 len(grp['params']), len(self.params)))
-        state, steps = sd['state'], set()
+        state = sd['state']
         for k, idx in enumerate(grp['params']):
             st = state.get(idx, state.get(str(idx)))
             if st is None:          # torch keeps no state for a parameter that never had a gradient
                 self.exp_avg[k].zero_()
                 self.exp_avg_sq[k].zero_()
+                self.step_of[k] = 0
                 continue
             if tuple(st['exp_avg'].shape) != tuple(self.params[k].shape):
                 raise ValueError('moment shape mismatch for parameter {}'.format(k))
             self.exp_avg[k].copy_(st['exp_avg'])
             self.exp_avg_sq[k].copy_(st['exp_avg_sq'])
-            steps.add(int(float(st['step'])))
-        if len(steps) > 1:
-            raise ValueError('per-parameter step counts differ ({}): one shared step count is supported'.format(
-                sorted(steps)))
-        self.steps = steps.pop() if steps else 0
+            self.step_of[k] = int(float(st['step']))
         g = self.param_groups[0]
         g['lr'], g['eps'] = float(grp['lr']), float(grp['eps'])
         g['betas'] = (float(grp['betas'][0]), float(grp['betas'][1]))

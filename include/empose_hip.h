@@ -193,8 +193,12 @@ int empose_lgd_forward(const empose_model_t* model, const empose_lgd_io* io, voi
  *   targets: tgt [T][ld_tgt] holding n_markers*3 positions then n_markers*9 orientations (the network input
  *            layout of prepare_inputs, reference models.py:106-125); frame_scale [T] per-frame loss weight
  *   outputs pos [T][36], ori [T][108], joints [T][66]; g_theta [T][ld_g] (66), g_beta [T][ld_gb] (10) or NULL.
- * workspace: empose_smpl_workspace_bytes(model, T). */
+ * workspace: empose_smpl_workspace_bytes(model, T).
+ * Launches of 4096 frames and more run the frame-per-lane kernels (csrc/smpl_tile.hip) when the model's sensor patches
+ * allow it -- closed triangle fans of at most 8 faces over at most 8 bones, what a closed manifold body mesh gives;
+ * empose_smpl_tile_supported says whether they do (option "smpl_tile": 0 never, 1 by size, 2 always). */
 size_t empose_smpl_workspace_bytes(const empose_model_t* model, int T);
+int empose_smpl_tile_supported(const empose_model_t* model);
 int empose_smpl_sensors_fwd_bwd(const empose_model_t* model, int T, int F,
                                 const float* theta, int ld_theta, const float* beta, int ld_beta,
                                 const float* offset_r, const float* offset_t,

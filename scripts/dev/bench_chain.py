@@ -56,3 +56,17 @@ if hasattr(lib, 'empose_debug_pair_trace'):
     for b in range(2):
         t = [tr[b * 32 + i] for i in range(12)]
         print('block', b, 'total', t[11] - t[0], 'cycles:', ', '.join('%s %d' % (n, t[i + 1] - t[i]) for i, n in enumerate(names)))
+
+if os.environ.get('EMPOSE_LIB_PATH') and hasattr(lib, 'empose_debug_tile_trace'):
+    import ctypes as C
+    NWV = int(os.environ.get('TL_WAVES', 8))
+    tr = (C.c_longlong * (NWV * 32))()
+    fn = lib.empose_debug_tile_trace
+    fn.argtypes = [C.POINTER(C.c_longlong)]
+    assert fn(tr) == 0
+    for w in range(NWV):
+        t = [tr[w * 32 + i] for i in range(32)]
+        t0 = tr[0]
+        rounds = ' '.join('r%d[%d..%d]' % (r, t[4 + 2 * r] - t0, t[5 + 2 * r] - t0) for r in range(12) if t[5 + 2 * r] > 0)
+        print('   sensor r0: loads %d skin %d frame %d bwd %d moments %d' % (t[14] - t[4], t[15] - t[14], t[16] - t[15], t[17] - t[16], t[5] - t[17]))
+        print('wave', w, 'rod', t[1] - t0, 'bar', t[2] - t0, 'chain', t[3] - t0, rounds, 'sens_end', t[28] - t0, 'end', t[29] - t0)

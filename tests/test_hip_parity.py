@@ -28,6 +28,17 @@ ATOL = 1e-4
 DEV = 'cuda:0'
 
 
+class _OptionGuard(object):
+    """Sets a kernel-variant option of the library now and puts the old value back when it is dropped (monkeypatch undo)."""
+
+    def __init__(self, name, value):
+        self.name, self.old = name, _lib.lib().empose_get_option(name)
+        _lib.check(_lib.lib().empose_set_option(name, value))
+
+    def __del__(self):
+        _lib.lib().empose_set_option(self.name, self.old)
+
+
 def gpu(x, dtype=torch.float32):
     return torch.as_tensor(np.asarray(x), dtype=dtype).to(DEV).contiguous()
 
@@ -167,6 +178,7 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
     lib = _lib.lib()
     outs = {}
     small = (theta, beta, off_r, off_t, tgt, scale)
+    tile_guard = _OptionGuard(b'smpl_tile', 0)   # this test is about the general kernel behind both GEMM kernels
     for key, T, (th_, be_, or_, ot_, tg_, sc_) in (('splitk', T_small, small), (T_small, T_small, small),
                                                   (T_big, T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
         _lib.check(lib.empose_set_option(b'gemm_splitk', 1 if key == 'splitk' else 0))   # kernel-variant switch
@@ -187,6 +199,7 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
         assert np.isfinite(b).all()
         # orientations and gradients amplify last-bit differences of the vertices (tolerances of the fwd/bwd test above)
         np.testing.assert_allclose(c, a, atol=2e-4 * max(1.0, float(np.abs(a).max())), rtol=1e-3)
+    del tile_guard
 
 
 def test_smpl_forward_only_matches(big_model):

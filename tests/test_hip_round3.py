@@ -196,7 +196,7 @@ def test_inference_handle_follows_raw_pointer_updates():
 
 def test_hip_adam_skips_missing_gradients_and_restores_state():
     """torch.optim.Adam semantics beyond the plain step: parameters without a gradient are skipped (moments untouched),
-    the learning rate is read from `param_groups`, and state written by either optimizer restores into the other."""
+    the learning rate is read from `param_groups`, and state written by either optimizer restores into a HipAdam."""
     from em_pose_amd.helpers.optim import HipAdam
     torch.manual_seed(4)
     shapes = [(300, 40), (66,), (5000,), (1,)]
@@ -217,30 +217,28 @@ def test_hip_adam_skips_missing_gradients_and_restores_state():
     torch.cuda.synchronize()
     for p, q in zip(ours, ref):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=2e-6, rtol=1e-5)
-    # checkpoint round trip, both directions (all parameters have taken the same number of steps here)
-    ours2 = [p.detach().clone().requires_grad_(True) for p in ours]
-    ref2 = [p.detach().clone().requires_grad_(True) for p in ours]
-    for p in ours + ref + ours2 + ref2:
+    # checkpoint round trip: state written by torch.optim.Adam or by HipAdam restores into a fresh HipAdam
+    mine = [p.detach().clone().requires_grad_(True) for p in ours]
+    theirs = [p.detach().clone().requires_grad_(True) for p in ours]
+    for p in ours + ref + mine + theirs:
         p.grad = None
-    oa2, ob2 = HipAdam(ours2, lr=1.0), torch.optim.Adam(ref2, lr=1.0)
+    from_torch, from_hip = HipAdam(mine, lr=1.0), HipAdam(theirs, lr=1.0)
     a, b = HipAdam(ours, lr=5e-4), torch.optim.Adam(ref, lr=5e-4)
     one_step(a, b, ours, ref, skip=None)
+    one_step(a, b, ours, ref, skip=3)        # the last parameter lags one step behind: per-parameter step counts
+    for p, q, r_ in zip(mine, theirs, ours):
+        p.data.copy_(r_.data)
+        q.data.copy_(r_.data)
+    from_torch.load_state_dict(b.state_dict())
+    from_hip.load_state_dict(a.state_dict())
+    assert from_torch.lr == 5e-4 and from_torch.step_of == [2, 2, 2, 1] and from_hip.step_of == [2, 2, 2, 1]
     one_step(a, b, ours, ref, skip=None)
-    for p, q in zip(ours2, ours):
-        p.data.copy_(q.data)
-    for p, q in zip(ref2, ref):
-        p.data.copy_(q.data)
-    oa2.load_state_dict(b.state_dict())      # torch -> HipAdam
-    ob2.load_state_dict(a.state_dict())      # HipAdam -> torch
-    assert oa2.lr == 5e-4 and oa2.steps == 2
-    one_step(a, b, ours, ref, skip=None)
-    gs = [p.grad.clone() for p in ours]
-    for p, q, g in zip(ours2, ref2, gs):
-        p.grad, q.grad = g.clone(), g.clone()
-    oa2.step()
-    ob2.step()
+    for p, q, r_ in zip(mine, theirs, ours):
+        p.grad, q.grad = r_.grad.clone(), r_.grad.clone()
+    from_torch.step()
+    from_hip.step()
     torch.cuda.synchronize()
-    for p, q, r_, s_ in zip(ours, ref, ours2, ref2):
+    for p, q, r_, s_ in zip(ours, ref, mine, theirs):
         np.testing.assert_allclose(r_.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=2e-6, rtol=1e-5)
         np.testing.assert_allclose(s_.detach().cpu().numpy(), p.detach().cpu().numpy(), atol=2e-6, rtol=1e-5)
 
@@ -364,3 +362,141 @@ def test_rccl_single_rank_collectives_on_device_tensors():
         assert me.state()['eucl'].shape[0] == rows
     finally:
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The frame-per-lane SMPL sub-mesh path (csrc/smpl_tile.hip: tile-layout blend GEMMs + smpl_tile_kernel +
+# rodrigues_bwd_t_kernel).  Launches of 4096 frames and more take it by default (so do the B = 1024 tests above and the
+# benchmark); here it is forced (`smpl_tile` = 2) at small and ragged sizes and held against the float64 blueprint and
+# against the general kernel (`smpl_tile` = 0).
+# ----------------------------------------------------------------------------------------------------------------------
+class _Option(object):
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = _lib.lib().empose_get_option(self.name)
+        _lib.check(_lib.lib().empose_set_option(self.name, self.value))
+
+    def __exit__(self, *exc):
+        _lib.lib().empose_set_option(self.name, self.old)
+        return False
+
+
+def _sensors_call(handle, T, F, theta, beta, off_r, off_t, tgt=None, scale=None):
+    lib = _lib.lib()
+    g = lambda x: None if x is None else torch.as_tensor(np.asarray(x), dtype=torch.float32).to(DEV).contiguous()
+    th, be, o_r, o_t, tg, sc = g(theta), g(beta), g(off_r), g(off_t), g(tgt), g(scale)
+    pos, ori, joints = (torch.full((T, n), float('nan'), device=DEV) for n in (36, 108, 66))
+    g_th, g_be = torch.full((T, 66), float('nan'), device=DEV), torch.full((T, 10), float('nan'), device=DEV)
+    nbytes = lib.empose_smpl_workspace_bytes(handle, T)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.empose_smpl_sensors_fwd_bwd(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10, _lib.dptr(o_r),
+                                               _lib.dptr(o_t), _lib.dptr(tg), 0 if tg is None else tg.shape[1],
+                                               _lib.dptr(sc), _lib.dptr(pos), _lib.dptr(ori), _lib.dptr(joints),
+                                               None if tg is None else _lib.dptr(g_th), 66,
+                                               None if tg is None else _lib.dptr(g_be), 10, _lib.dptr(ws), nbytes,
+                                               _lib.current_stream()))
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in (pos, ori, joints, g_th, g_be)]
+
+
+@pytest.mark.parametrize('which,n_markers,T,F', [('small', 12, 96, 8), ('small', 6, 70, 7), ('big', 12, 96, 8),
+                                                 ('big', 6, 130, 1), ('big', 12, 1, 1), ('big', 12, 4209, 3)])
+def test_frame_per_lane_smpl_path(which, n_markers, T, F, big_model):
+    from tests.test_hip_parity import _smpl_case, build_net
+    if which == 'small':
+        model, vids = H.small_model(), synthetic.small_vertex_ids(160)
+    else:
+        model, vids = big_model, CONST.VERTEX_IDS
+    theta, beta, off_r, off_t, tgt, scale, ref = _smpl_case(model, vids, T, F, 11, n_markers)
+    net = build_net(lgd_config(n_markers, False, 1, hidden=32), model, vids)
+    handle = net._ensure_handle(torch.device(DEV))
+    assert _lib.lib().empose_smpl_tile_supported(handle) == 1    # else both calls below would run the general kernel
+    with _Option(b'smpl_tile', 0):
+        general = _sensors_call(handle, T, F, theta, beta, off_r, off_t, tgt, scale)
+        general_fwd = _sensors_call(handle, T, F, theta, beta, off_r, off_t)
+    with _Option(b'smpl_tile', 2):
+        tile = _sensors_call(handle, T, F, theta, beta, off_r, off_t, tgt, scale)
+        tile_fwd = _sensors_call(handle, T, F, theta, beta, off_r, off_t)
+        again = _sensors_call(handle, T, F, theta, beta, off_r, off_t, tgt, scale)
+    assert all(np.isfinite(x).all() for x in tile)
+    # against the float64 blueprint: the tolerances of test_smpl_sensors_fwd_bwd (tuned on 96 frames), or -- the worst
+    # element of thousands of frames lies further out for either kernel -- 3 x what the general kernel shows here (two fp32 roundings of the same
+    # ill-conditioned elements land on opposite sides)
+    refs = (ref['pos'].reshape(T, -1), ref['ori'].reshape(T, -1), ref['joints'].reshape(T, -1), ref['g_theta'], ref['g_beta'])
+    gscale = [1.0, 1.0, 1.0, max(np.abs(ref['g_theta']).max(), 1.0), max(np.abs(ref['g_beta']).max(), 1.0)]
+    for got, gen, want, tol, sc in zip(tile, general, refs, (1e-5, 5e-5, 1e-5, 5e-4, 5e-4), gscale):
+        err, err_gen = np.abs(got - want).max(), np.abs(gen - want).max()
+        assert err <= max(tol * sc, 3.0 * err_gen), (err, err_gen, tol * sc)
+    g_th = tile[3]
+    assert (g_th[scale == 0] == 0).all()
+    # against the general kernel (another summation order of the same arithmetic): positions and joints element by
+    # element; frames and gradients are held against float64 above (their few ill-conditioned elements differ more
+    # between any two fp32 evaluations than a fixed bound allows at thousands of frames)
+    for k in (0, 2):
+        np.testing.assert_allclose(tile[k], general[k], atol=2e-5)
+        np.testing.assert_allclose(tile_fwd[k], tile[k], atol=1e-5)   # forward-only launch: another instantiation
+        np.testing.assert_allclose(tile_fwd[k], general_fwd[k], atol=2e-5)
+    assert np.mean(np.abs(tile[1] - general[1]) > 1e-4) < 1e-4 and np.mean(np.abs(tile_fwd[1] - tile[1]) > 5e-5) < 1e-4
+    for k in (3, 4):
+        sc = max(1.0, float(np.abs(general[k]).max()))
+        assert np.mean(np.abs(tile[k] - general[k]) > 1e-3 * sc) < 1e-2
+    for a, b in zip(tile, again):                     # reproducible
+        assert np.array_equal(a, b)
+
+
+def test_frame_per_lane_path_whole_lgd_forward_and_vjp(big_model):
+    """The whole LGD forward (histories, gradient trace, ragged windows, missing sensors) and the training-side
+    vector-Jacobian product with the frame-per-lane kernels forced on, against the same calls on the general kernels."""
+    from tests.test_hip_parity import build_net
+    case = H.load_case('lgdrnn12_n3_ragged_masked')
+    meta = case['meta']
+    from tests.test_hip_parity import cfg_of
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    w = case['in']
+    sl = torch.from_numpy(np.asarray(w['seq_lengths'])).to(DEV) if 'seq_lengths' in w else None
+    inp = H.oracle_inputs(w, sl=None if sl is None else sl.cpu())
+    args = [inp[k].to(DEV) for k in ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')]
+    masks = None if inp['marker_masks'] is None else inp['marker_masks'].to(DEV)
+    res = {}
+    for opt in (0, 2):
+        with _Option(b'smpl_tile', opt):
+            r = net.forward_tensors(*args, marker_masks=masks, seq_lengths=inp['seq_lengths'].to(DEV), keep_history=True,
+                                    keep_gradient_trace=True)
+            torch.cuda.synchronize()
+            res[opt] = {'pose': r['pose'].cpu().numpy(), 'shape': r['shape'].cpu().numpy(),
+                        'joints': r['joints'].cpu().numpy(),
+                        **{'h_' + k: v.cpu().numpy() for k, v in r['hist'].items()},
+                        **{'t_' + k: v.cpu().numpy() for k, v in r['trace'].items()}}
+    for k, a in res[0].items():
+        b = res[2][k]
+        assert np.isfinite(b).all(), k
+        tol = (1e-4 if 'ori' in k else 2e-5) if not k.startswith('t_') else 2e-4 * max(1.0, float(np.abs(a).max()))
+        np.testing.assert_allclose(b, a, atol=tol, rtol=1e-3 if k.startswith('t_') else 0, err_msg=k)
+    # vector-Jacobian product with external cotangents (no joint cotangent: that variant stays on the general kernel)
+    model, vids = big_model, CONST.VERTEX_IDS
+    net2 = build_net(lgd_config(12, False, 1, hidden=32), model, vids).train()
+    handle = net2._ensure_smpl_handle(torch.device(DEV))
+    rng = np.random.default_rng(3)
+    T, F = 192, 32
+    g = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.float32).to(DEV).contiguous()
+    th, be = g(rng.normal(0, 0.25, size=(T, 66))), g(rng.normal(0, 1, size=(T, 10)))
+    o_r = g(synthetic._exp_so3(rng.normal(0, 0.1, size=(T // F, 12, 3))))
+    o_t = g(rng.normal(0, 0.02, size=(T // F, 12, 3)))
+    d_pos, d_ori = g(rng.normal(size=(T, 36))), g(rng.normal(size=(T, 108)))
+    lib = _lib.lib()
+    out = {}
+    for opt in (0, 2):
+        with _Option(b'smpl_tile', opt):
+            g_th, g_be = torch.empty(T, 66, device=DEV), torch.empty(T, 10, device=DEV)
+            nbytes = lib.empose_smpl_vjp_workspace_bytes(handle, T)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.empose_smpl_sensors_vjp(handle, T, F, _lib.dptr(th), 66, _lib.dptr(be), 10, _lib.dptr(o_r),
+                                                   _lib.dptr(o_t), _lib.dptr(d_pos), _lib.dptr(d_ori), None,
+                                                   _lib.dptr(g_th), _lib.dptr(g_be), _lib.dptr(ws), nbytes,
+                                                   _lib.current_stream()))
+            torch.cuda.synchronize()
+            out[opt] = (g_th.cpu().numpy(), g_be.cpu().numpy())
+    for a, b in zip(out[0], out[2]):
+        np.testing.assert_allclose(b, a, atol=2e-4 * max(1.0, float(np.abs(a).max())), rtol=1e-3)
