@@ -356,11 +356,12 @@ SmplWs carve_smpl(Carver& c, const empose_model* m, int T) {
   w.tgt_t = c.f(Tp * 144);
   return w;
 }
-// The frame-per-lane path pays from a few thousand frames on (a workgroup is 64 frames: 4096 frames are 64 workgroups);
-// option "smpl_tile": 0 never, 1 by size, 2 always (tests).
+// The frame-per-lane path pays once its 64-frame workgroups fill the 256 CUs (one per CU, 152 KB of LDS each): from
+// 16384 frames on.  Measured at 8192 frames (the training step at 256 windows): 2 % slower than the general kernel.
+// Option "smpl_tile": 0 never, 1 by size, 2 always (tests).
 bool use_tile_path(const empose_model* m, int T, const float* cot_joints = nullptr) {
   const int opt = options().smpl_tile;
-  return m->tile_ok && opt != 0 && !cot_joints && (opt == 2 || T >= 4096);
+  return m->tile_ok && opt != 0 && !cot_joints && (opt == 2 || T >= 16384);
 }
 
 struct UpdWs {
@@ -681,7 +682,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"smpl_tile", &o.smpl_tile},
+      {"smpl_tile", &o.smpl_tile}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -695,7 +696,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"smpl_tile", o.smpl_tile},
+      {"smpl_tile", o.smpl_tile}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};
@@ -1444,6 +1445,7 @@ struct MlpTrainWs {
   float* d[2];       // [M][hidden] cotangent ping-pong
   float* wt;         // transposed weight [hidden][max(hidden, out_pad)]
   float* atb; size_t atb_floats; float* bn; float* slope_partial; int* counter;
+  float* part; float* coef;   // fused path: per-row-block partial sums, BatchNorm-reverse coefficients [3][H]
 };
 // every A^T B product of one MLP over M rows: (H, in_dim), (H, H), (out_dim, H)
 size_t mlp_atb_floats(const empose_mlp_params* p, int M) {
@@ -1459,9 +1461,23 @@ MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
   w.bn = c.f(bn_prelu_workspace_floats(M, H) + 64);
   w.slope_partial = c.f((size_t)(H + 31) / 32 + 8);
   w.counter = reinterpret_cast<int*>(c.f(64));
+  w.part = c.f(bn_fused_partial_floats(M, H) + 64);
+  w.coef = c.f((size_t)3 * H + 64);
   return w;
 }
-size_t mlp_layer_save(const empose_mlp_params* p, int M) { return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden; }
+// The BatchNorm / PReLU passes folded into the GEMMs (train_fused.hip).  Opt-in: gradient parity with the reference is
+// tested, but at 256 windows the step is no faster (the operand transform and the statistics epilogue cost the GEMMs
+// about what the removed passes cost: 701-711 k against 705-720 k frames/s).  Option "train_fused": 0 never (default),
+// 1 from BN_SINGLE_PASS_ROWS rows on, 2 always (tests).
+bool mlp_train_fused(const empose_mlp_params* p, int M) {
+  const int opt = options().train_fused;
+  return opt != 0 && (opt == 2 || M > BN_SINGLE_PASS_ROWS) && p->hidden % 4 == 0 && p->in_dim % 4 == 0;
+}
+// per hidden layer: unfused  z [M][H] | a [M][H] | mean [H] | rstd [H];  fused  y [M][H] | mean | rstd | s | t
+size_t mlp_layer_save(const empose_mlp_params* p, int M) {
+  if (mlp_train_fused(p, M)) return (size_t)M * p->hidden + 4 * (size_t)p->hidden;
+  return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden;
+}
 }  // namespace
 
 size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M) {
@@ -1486,6 +1502,33 @@ int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int 
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
   const int H = p->hidden, L = p->n_layers;
+  if (mlp_train_fused(p, M)) {
+    // y_l = a_{l-1} W_l^T + b_l with a_{l-1} = PReLU(s y_{l-1} + t) formed while the GEMM stages its A operand; the
+    // epilogue leaves the column statistics of y_l per row block, a small kernel turns them into (mean, rstd, s, t)
+    const size_t lsz = mlp_layer_save(p, M);
+    for (int l = 0; l < L; ++l) {
+      const bool last = l == L - 1;
+      float* sv = save + (size_t)l * lsz;                      // this layer's y | mean | rstd | s | t
+      const float* pv = l > 0 ? save + (size_t)(l - 1) * lsz : nullptr;
+      TrainGemmArgs g{};
+      g.A = l == 0 ? x : pv; g.lda = l == 0 ? ldx : H; g.W = p->weight[l]; g.ldw = l == 0 ? p->in_dim : H;
+      g.C = last ? out : sv; g.ldc = last ? ld_out : H;
+      g.M = M; g.N = last ? p->out_dim : H; g.K = l == 0 ? p->in_dim : H; g.bias = p->bias[l];
+      if (l > 0) { g.a_s = pv + (size_t)M * H + 2 * H; g.a_t = g.a_s + H; g.a_slope = p->prelu[l - 1]; }
+      g.part = w.part;
+      hipError_t e = launch_gemm_train(g, l > 0 ? 1 : 0, last ? 0 : 1, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mlp forward gemm: %s", hipGetErrorString(e));
+      if (last) break;
+      BnFusedFwdArgs c{};
+      c.M = M; c.C = H; c.part = w.part; c.gamma = p->bn_weight[l]; c.beta = p->bn_bias[l];
+      c.eps = p->bn_eps; c.momentum = p->bn_momentum; c.running_mean = p->bn_running_mean[l];
+      c.running_var = p->bn_running_var[l]; c.num_batches_tracked = p->bn_num_batches[l];
+      c.mean = sv + (size_t)M * H; c.rstd = c.mean + H; c.s = c.rstd + H; c.t = c.s + H;
+      e = launch_bn_fused_combine_fwd(c, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused bn combine: %s", hipGetErrorString(e));
+    }
+    return EMPOSE_OK;
+  }
   const float* in = x;
   int ld_in = ldx, k_in = p->in_dim;
   for (int l = 0; l < L; ++l) {
@@ -1546,6 +1589,63 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
     return launch_gemm(b, stream);
   };
   auto layer_save = [&](int l) { return save + (size_t)l * mlp_layer_save(p, M); };
+  if (mlp_train_fused(p, M)) {
+    // The dX GEMM's epilogue writes dyh_l = dA_l * PReLU'(yhat_l) and the column sums BatchNorm's reverse needs; a
+    // small kernel turns the sums into dgamma / dbeta / dslope and three per-column coefficients, one pass forms
+    // dY_l = c1 dyh_l + c3 y_l + c0 in place.  The layer inputs a_{l-1} are not stored: the A^T B product re-forms them
+    // from y_{l-1} while it stages its B operand.
+    auto stats_of = [&](int l) { return layer_save(l) + (size_t)M * H; };   // mean | rstd | s | t
+    auto dz_of = [&](int l) -> float* { return stash ? stash + (size_t)M * l * H : w.d[l & 1]; };
+    auto atb = [&](int l) -> int {   // dW_l, db_l (not deferred)
+      const bool last = l == L - 1;
+      AtbArgs ab{};
+      ab.A = last ? d_out : dz_of(l); ab.lda = last ? ld_dout : H;
+      ab.B = l == 0 ? x : layer_save(l - 1); ab.ldb = l == 0 ? ldx : H;
+      ab.C = gr->weight[l]; ab.ldc = l == 0 ? p->in_dim : H; ab.bias = gr->bias[l];
+      ab.M = M; ab.N = last ? p->out_dim : H; ab.K = l == 0 ? p->in_dim : H; ab.accumulate = accumulate;
+      if (l > 0) { ab.b_mode = 1; ab.Bs_seg[0] = stats_of(l - 1) + 2 * H; ab.b_slope = p->prelu[l - 1]; }
+      hipError_t e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dW: %s", hipGetErrorString(e));
+      return EMPOSE_OK;
+    };
+    for (int l = L - 1; l >= 0; --l) {
+      const bool last = l == L - 1;
+      if (last && stash) {   // keep d_out for empose_mlp_train_wgrad (no copy when the caller produced it in its slot)
+        float* slot = stash + (size_t)M * (L - 1) * H;
+        if (d_out != slot || ld_dout != op) {
+          hipError_t e = launch_axpby2d(M, op, 1.f, d_out, ld_dout, 0.f, nullptr, 0, slot, op, stream);
+          if (e != hipSuccess) return fail(EMPOSE_EHIP, "stash: %s", hipGetErrorString(e));
+        }
+      }
+      if (!stash) TRY(atb(l));
+      if (l == 0) break;
+      // dA_{l-1} = dY_l W_l on the forward tile against W_l^T, its epilogue already in terms of layer l - 1
+      const float* wt = p->weight_t[l];
+      const int kdim = last ? op : H;
+      if (!wt) {
+        if (last) HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
+        hipError_t e = launch_transpose(p->weight[l], H, w.wt, kdim, last ? p->out_dim : H, H, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+        wt = w.wt;
+      }
+      TrainGemmArgs g{};
+      g.A = last ? d_out : dz_of(l); g.lda = last ? ld_dout : H; g.W = wt; g.ldw = kdim;
+      g.C = dz_of(l - 1); g.ldc = H; g.M = M; g.N = H; g.K = kdim; g.bias = nullptr;
+      g.part = w.part; g.e_y = layer_save(l - 1); g.ld_ey = H;
+      g.e_mean = stats_of(l - 1); g.e_rstd = g.e_mean + H; g.e_s = g.e_rstd + H; g.e_t = g.e_s + H; g.e_slope = p->prelu[l - 1];
+      hipError_t e = launch_gemm_train(g, 0, 2, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dX gemm: %s", hipGetErrorString(e));
+      BnFusedBwdArgs c{};
+      c.M = M; c.C = H; c.part = w.part; c.gamma = p->bn_weight[l - 1]; c.mean = stats_of(l - 1); c.rstd = stats_of(l - 1) + H;
+      c.dgamma = gr->bn_weight[l - 1]; c.dbeta = gr->bn_bias[l - 1]; c.dslope = gr->prelu[l - 1];
+      c.dslope_partial = w.slope_partial; c.coef = w.coef; c.accumulate = accumulate;
+      e = launch_bn_fused_combine_bwd(c, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused bn reverse combine: %s", hipGetErrorString(e));
+      e = launch_bn_fused_apply_bwd(dz_of(l - 1), layer_save(l - 1), w.coef, M, H, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused bn reverse apply: %s", hipGetErrorString(e));
+    }
+    return EMPOSE_OK;
+  }
   // output layer: dW = d_out^T a_{L-2}, db, dA = d_out . W
   {
     const int l = L - 1;
@@ -1652,11 +1752,39 @@ int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const f
               ((uintptr_t)dz_stash[s] & 15) == 0;
   for (int s = 0; s < n_app; ++s)
     if (!x[s] || !save[s] || !dz_stash[s]) return fail(EMPOSE_EINVAL, "null argument");
+  const bool fused = mlp_train_fused(p, M);
   for (int l = 0; l < L; ++l) {
     if (!gr->weight[l] || !gr->bias[l]) return fail(EMPOSE_EINVAL, "null gradient output");
     const bool last = l == L - 1;
     const int ld_a = last ? op : H, n_out = last ? p->out_dim : H;
     const int ld_b = l == 0 ? ldx : H, k_in = l == 0 ? p->in_dim : H;
+    if (fused) {
+      // operands as the fused sweeps left them: dY_l (stash), y_{l-1} and its (s, t) (save)
+      const size_t lsz = mlp_layer_save(p, M);
+      AtbArgs ab{};
+      ab.lda = ld_a; ab.ldb = ld_b; ab.C = gr->weight[l]; ab.ldc = k_in; ab.bias = gr->bias[l]; ab.N = n_out; ab.K = k_in;
+      ab.b_mode = l > 0 ? 1 : 0; ab.b_slope = l > 0 ? p->prelu[l - 1] : nullptr;
+      auto fill = [&](int slot, int s) {
+        ab.A_seg[slot] = dz_stash[s] + (size_t)M * l * H;
+        ab.B_seg[slot] = l == 0 ? x[s] : save[s] + (size_t)(l - 1) * lsz;
+        ab.Bs_seg[slot] = l > 0 ? save[s] + (size_t)(l - 1) * lsz + (size_t)M * H + 2 * H : nullptr;
+      };
+      if (batched) {
+        for (int s = 0; s < n_app; ++s) fill(s, s);
+        ab.A = ab.A_seg[0]; ab.B = ab.B_seg[0]; ab.M = n_app * M; ab.accumulate = accumulate;
+        ab.n_seg = n_app; ab.seg_rows = M;
+        hipError_t e = launch_gemm_atb(ab, ws, ws_floats, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dW: %s", hipGetErrorString(e));
+      } else {
+        for (int s = 0; s < n_app; ++s) {
+          fill(0, s);
+          ab.A = ab.A_seg[0]; ab.B = ab.B_seg[0]; ab.M = M; ab.accumulate = accumulate || s > 0;
+          hipError_t e = launch_gemm_atb(ab, ws, ws_floats, stream);
+          if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dW: %s", hipGetErrorString(e));
+        }
+      }
+      continue;
+    }
     auto a_of = [&](int s) { return dz_stash[s] + (size_t)M * l * H; };
     auto b_of = [&](int s) { return l == 0 ? x[s] : save[s] + (size_t)(l - 1) * mlp_layer_save(p, M) + (size_t)M * H; };
     AtbArgs ab{};

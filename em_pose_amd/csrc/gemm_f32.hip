@@ -64,8 +64,140 @@ __device__ __forceinline__ void store_tile(float* lds, int tid, const float4 (&r
   }
 }
 
+// Train-mode fusion (ROLE 2, train_fused.hip): the staged A tile becomes PReLU(s[k] A + t[k]); padding stays zero.
+// The coefficients of a K tile are fetched together with the tile (coef_tile), not between the barrier and the LDS store.
+template <typename C>
+__device__ __forceinline__ void coef_tile(const float* __restrict__ a_s, const float* __restrict__ a_t, int k0, int K, int tid,
+                                          float4& s, float4& t) {
+  const int gk = k0 + (tid % C::C4) * 4;   // NT % C4 == 0: the same k columns for every slot of a thread
+  if (gk < K) { s = *reinterpret_cast<const float4*>(a_s + gk); t = *reinterpret_cast<const float4*>(a_t + gk); }
+}
+template <typename C, int N>
+__device__ __forceinline__ void transform_tile(const float4 s, const float4 t, float slope, int row0, int nrows, int k0, int K,
+                                               int tid, float4 (&regs)[N]) {
+  if (k0 + (tid % C::C4) * 4 >= K) return;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int r = (tid + i * C::NT) / C::C4;
+    if (row0 + r >= nrows) continue;
+    float y;
+    y = s.x * regs[i].x + t.x; regs[i].x = y > 0.f ? y : slope * y;
+    y = s.y * regs[i].y + t.y; regs[i].y = y > 0.f ? y : slope * y;
+    y = s.z * regs[i].z + t.z; regs[i].z = y > 0.f ? y : slope * y;
+    y = s.w * regs[i].w + t.w; regs[i].w = y > 0.f ? y : slope * y;
+  }
+}
+
+// Train-mode epilogues of a wave's WM x WN grid of 32 x 32 tiles (C/D layout: col = lane & 31, row = (r & 3) +
+// 8 (r >> 2) + 4 (lane >> 5)).  Forward: C = acc + shift, and per 32-row block and column the sum and the centred sum of
+// squares -> stat_part [M / 32][2][N].  Backward (e_y set): the product is dA; C = dyh = dA * PReLU'(e_s y + e_t) and
+// stat_part [M / 32][3][N] = sums of dyh, dyh (y - mean) rstd, (yhat <= 0) dA yhat.
+// Addressing as in gemm_epilogue.h: a wave-uniform base plus a 32-bit per-lane byte offset, row bounds resolved outside
+// the loops (FULL) -- the straightforward form of this epilogue cost 15-20 us per 8192 x 512 launch.
+template <int WM, int WN, bool FULL, bool BWD>
+__device__ __forceinline__ void train_epilogue_mode(float* __restrict__ C, float* __restrict__ part,
+                                                    const float* __restrict__ shift, const float* __restrict__ ey,
+                                                    const float* __restrict__ e_s, const float* __restrict__ e_t,
+                                                    const float* __restrict__ e_mean, const float* __restrict__ e_rstd,
+                                                    float slope, int M, int N, long ldc, long ldy,
+                                                    const f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31, int lh) {
+  epi_gbyte_t cb = (epi_gbyte_t)(C + (long)mw0 * ldc);
+  epi_cgbyte_t yb = BWD ? (epi_cgbyte_t)(ey + (long)mw0 * ldy) : nullptr;
+  const unsigned ldc4 = (unsigned)ldc * 4u, ldy4 = (unsigned)ldy * 4u;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = nw0 + j * 32 + l31;
+    if (n >= N) continue;
+    const unsigned c_lane = (unsigned)(4 * lh) * ldc4 + (unsigned)n * 4u;
+    const unsigned y_lane = (unsigned)(4 * lh) * ldy4 + (unsigned)n * 4u;
+    const float sh = (!BWD && shift) ? shift[n] : 0.f;
+    const float es = BWD ? e_s[n] : 0.f, et = BWD ? e_t[n] : 0.f, mu = BWD ? e_mean[n] : 0.f, rs = BWD ? e_rstd[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int mb = mw0 + i * 32;
+      const int rows_valid = FULL ? 32 : min(32, M - mb);
+      if (!FULL && rows_valid <= 0) continue;
+      if (!BWD) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (!FULL && mw0 + 4 * lh + dm >= M) continue;
+          const float y = acc[i][j][r] + sh;
+          *(epi_gfloat_t)(cb + (c_lane + (unsigned)dm * ldc4)) = y;
+          s1 += y;
+        }
+        // the block's sum and centred sum of squares (the two halves of the wave hold 16 rows each)
+        s1 += __shfl_xor(s1, 32, 64);
+        const float shift_mean = sh - s1 * (1.f / (float)rows_valid);   // y - mean = acc + (sh - mean)
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          const float d = acc[i][j][r] + shift_mean;
+          if (FULL || mw0 + 4 * lh + dm < M) s2 += d * d;
+        }
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lh == 0 && part) {
+          float* pp = part + (size_t)(mb >> 5) * 2 * N;
+          pp[n] = s1;
+          pp[N + n] = s2;
+        }
+      } else {
+        float yv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {   // all loads of the tile column first
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          yv[r] = (FULL || mw0 + 4 * lh + dm < M) ? *(epi_cgfloat_t)(yb + (y_lane + (unsigned)dm * ldy4)) : 0.f;
+        }
+        float sb = 0.f, sg = 0.f, sa = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (!FULL && mw0 + 4 * lh + dm >= M) continue;
+          const float yh = es * yv[r] + et;
+          const float dA = acc[i][j][r];
+          const float dyh = yh > 0.f ? dA : slope * dA;
+          *(epi_gfloat_t)(cb + (c_lane + (unsigned)dm * ldc4)) = dyh;
+          sb += dyh;
+          sg += dyh * ((yv[r] - mu) * rs);
+          sa += yh > 0.f ? 0.f : dA * yh;
+        }
+        sb += __shfl_xor(sb, 32, 64);
+        sg += __shfl_xor(sg, 32, 64);
+        sa += __shfl_xor(sa, 32, 64);
+        if (lh == 0) {
+          float* pp = part + (size_t)(mb >> 5) * 3 * N;
+          pp[n] = sb;
+          pp[N + n] = sg;
+          pp[2 * N + n] = sa;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, bool BWD>   // BWD: the reverse epilogue (ROLE 3), else the forward one (ROLE 2)
+__device__ __forceinline__ void train_epilogue(const GemmProb& p, const f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31,
+                                               int lh) {
+  float* C = p.C; float* part = p.stat_part;
+  const float* shift = p.shift; const float* ey = p.e_y;
+  const float* e_s = p.e_s; const float* e_t = p.e_t; const float* e_mean = p.e_mean; const float* e_rstd = p.e_rstd;
+  const long ldc = p.ldc, ldy = p.ld_ey;
+  const int M = p.M, N = p.N;
+  const float slope = BWD ? p.e_slope[0] : 0.f;
+  mw0 = __builtin_amdgcn_readfirstlane(mw0);
+  nw0 = __builtin_amdgcn_readfirstlane(nw0);
+  const bool full = mw0 + 32 * WM <= M;
+#define EMPOSE_TEPI(FULL, BWD) \
+  train_epilogue_mode<WM, WN, FULL, BWD>(C, part, shift, ey, e_s, e_t, e_mean, e_rstd, slope, M, N, ldc, ldy, acc, mw0, nw0, l31, lh)
+  if (full) EMPOSE_TEPI(true, BWD); else EMPOSE_TEPI(false, BWD);
+#undef EMPOSE_TEPI
+}
+
 // ROLE only separates instantiations by name so that profilers report the update-net hidden layers (ROLE 1) apart
-// from the other users of the same tile configuration.
+// from the other users of the same tile configuration; ROLE 2 / 3 add the train-mode fusion above (forward: optional
+// A-operand transform + statistics epilogue; reverse: the dyh epilogue).
 template <typename C, int ROLE>
 __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDT = C::LDT, WM = C::WM, WN = C::WN;
@@ -101,8 +233,17 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
 
   float4 ra[C::NA], rb[C::NB_];
   const int nk = (p.K + BK - 1) / BK;
+  const bool a_tr = ROLE == 2 && p.a_s != nullptr;
+  const float a_slope = a_tr ? p.a_slope[0] : 0.f;
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), ct = cs;
   load_tile<C>(p.A, p.lda, m0, p.M, 0, p.K, tid, ra);
   load_tile<C>(p.W, p.ldw, n0, p.N, 0, p.K, tid, rb);
+  if (ROLE == 2) {
+    if (a_tr) {
+      coef_tile<C>(p.a_s, p.a_t, 0, p.K, tid, cs, ct);
+      transform_tile<C>(cs, ct, a_slope, m0, p.M, 0, p.K, tid, ra);
+    }
+  }
   store_tile<C>(lds, tid, ra);
   store_tile<C>(lds + BM * LDT, tid, rb);
   __syncthreads();
@@ -113,6 +254,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
     if (kt + 1 < nk) {
       load_tile<C>(p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid, ra);
       load_tile<C>(p.W, p.ldw, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+      if (ROLE == 2) { if (a_tr) coef_tile<C>(p.a_s, p.a_t, (kt + 1) * BK, p.K, tid, cs, ct); }
     }
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
@@ -133,6 +275,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (ROLE == 2) { if (a_tr && kt + 1 < nk) transform_tile<C>(cs, ct, a_slope, m0, p.M, (kt + 1) * BK, p.K, tid, ra); }
     if (C::DB) {
       // The other stage was last read in iteration kt-1, and every wave has passed that iteration's barrier.
       if (kt + 1 < nk) {
@@ -151,7 +294,11 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
     }
   }
 
-  epilogue<WM, WN>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
+  if (ROLE >= 2) {
+    train_epilogue<WM, WN, ROLE == 3>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
+  } else {
+    epilogue<WM, WN>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
+  }
 }
 
 template <typename C, int ROLE = 0>
@@ -870,6 +1017,23 @@ static GemmPick pick_gemm(const GemmBatch& batch) {
   if (nblocks(128, 128) >= 512) return PICK_LARGE;
   if (nblocks(64, 128) >= 256) return PICK_S12;
   return PICK_S11;
+}
+
+// The train-mode fused layer GEMM (train_fused.hip) on the training step's 64 x 128 tile.
+hipError_t launch_gemm_train(const TrainGemmArgs& t, int amode, int emode, hipStream_t stream) {
+  if (amode > 1 || emode > 2) return hipErrorInvalidValue;
+  GemmBatch b;
+  b.count = 1; b.xcd_swizzle = 1; b.role = 2;
+  GemmProb& g = b.p[0];
+  g.A = t.A; g.lda = t.lda; g.W = t.W; g.ldw = t.ldw; g.C = t.C; g.ldc = t.ldc; g.M = t.M; g.N = t.N; g.K = t.K;
+  g.scale = nullptr; g.shift = t.bias; g.resid = nullptr; g.ldr = 0; g.act = 0; g.slope = 0.f;
+  if (amode == 1) { g.a_s = t.a_s; g.a_t = t.a_t; g.a_slope = t.a_slope; }
+  if (emode >= 1) g.stat_part = t.part;
+  if (emode == 2) {
+    g.e_y = t.e_y; g.ld_ey = t.ld_ey; g.e_s = t.e_s; g.e_t = t.e_t; g.e_mean = t.e_mean; g.e_rstd = t.e_rstd;
+    g.e_slope = t.e_slope;
+  }
+  return emode == 2 ? launch_cfg<CfgS12, 3>(b, stream) : launch_cfg<CfgS12, 2>(b, stream);
 }
 
 // Name (as a profiler prints it) of the kernel `launch_gemm` runs for `count` problems of this shape.

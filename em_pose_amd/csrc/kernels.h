@@ -17,7 +17,9 @@ struct Options {
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
-  int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 4096 frames on, 2 always
+  int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 16384 frames on, 2 always
+  int train_fused = 0;    // train-mode BatchNorm / PReLU folded into the GEMMs: 0 never (default: measured no faster,
+                          // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
 };
@@ -36,6 +38,12 @@ struct GemmProb {
   const float* resid; int ldr;  // added after the activation (skip connections) or nullptr
   int act;                  // 0 none, 1 PReLU(slope) then + resid, 2 + resid then ReLU
   float slope;
+  // Train-mode layer fusion (gemm_tn_f32_kernel<Cfg, 2> only; see TrainGemmArgs / train_fused.hip):
+  const float* a_s = nullptr; const float* a_t = nullptr; const float* a_slope = nullptr;   // A' = PReLU(s[k] A + t[k])
+  float* stat_part = nullptr;                                                               // column statistics of C
+  const float* e_y = nullptr; int ld_ey = 0;                                                // product is dA: C = dyh, sums
+  const float* e_s = nullptr; const float* e_t = nullptr; const float* e_mean = nullptr; const float* e_rstd = nullptr;
+  const float* e_slope = nullptr;
 };
 struct GemmBatch { GemmProb p[2]; int count; int role = 0; int xcd_swizzle = 1; };  // role 1 = update-net hidden layer (profiling name only)
 
@@ -82,6 +90,44 @@ struct BnPreluArgs {
 constexpr int BN_SINGLE_PASS_ROWS = 1024;   // up to here one workgroup per 32 columns walks all rows
 size_t bn_prelu_workspace_floats(int M, int C);
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Train-mode MLP layer with the BatchNorm / PReLU passes folded into the GEMMs (train_fused.hip)
+// ---------------------------------------------------------------------------------------------------------------
+struct TrainGemmArgs {       // C[M][N] = A'[M][K] . W[N][K]^T (+ bias), 64 x 128 tile
+  const float* A; int lda;
+  const float* W; int ldw;
+  float* C; int ldc;
+  int M, N, K;               // K % 4 == 0, lda / ldw / ld_ay % 4 == 0, 16-byte aligned operands
+  const float* bias;         // [N] or nullptr
+  // A operand as it is staged.  amode 1: A' = PReLU(s[k] A + t[k]) (a_slope: one device float)
+  const float* a_s; const float* a_t; const float* a_slope;
+  const float* a_y; int ld_ay; const float* a_c;   // (amode 2, dev: A' = c[k] A + c[K + k] Y[m][k] + c[2K + k])
+  // epilogue.  emode 1: also per 32-row block and column the sum and centred sum of squares of C -> part [M/32][2][N];
+  // emode 2: the product is dA: C = dyh = dA * PReLU'(e_s y + e_t) and part [M/32][3][N] = sums of dyh,
+  // dyh * (y - mean) rstd, (yhat <= 0) dA yhat
+  float* part;
+  const float* e_y; int ld_ey; const float* e_s; const float* e_t; const float* e_mean; const float* e_rstd;
+  const float* e_slope;
+};
+hipError_t launch_gemm_train(const TrainGemmArgs& p, int amode, int emode, hipStream_t stream);
+struct BnFusedFwdArgs {
+  int M, C; const float* part;                        // [ceil(M / 32)][2][C]
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; long long* num_batches_tracked;   // may be null
+  float* mean; float* rstd; float* s; float* t;       // [C] each: statistics and the fused transform a = PReLU(s y + t)
+};
+hipError_t launch_bn_fused_combine_fwd(const BnFusedFwdArgs& a, hipStream_t stream);
+struct BnFusedBwdArgs {
+  int M, C; const float* part;                        // [ceil(M / 32)][3][C]
+  const float* gamma; const float* mean; const float* rstd;
+  float* dgamma; float* dbeta; float* dslope; float* dslope_partial;   // [C], [C], [1], [ceil(C / 64)] scratch
+  float* coef;                                        // [3][C]: dY = coef0 dyh + coef1 y + coef2
+  int accumulate;
+};
+hipError_t launch_bn_fused_combine_bwd(const BnFusedBwdArgs& a, hipStream_t stream);
+size_t bn_fused_partial_floats(int M, int C);
+hipError_t launch_bn_fused_apply_bwd(float* dyh, const float* y, const float* coef, int M, int C, hipStream_t stream);
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).
 hipError_t launch_gemm(const GemmBatch& batch, hipStream_t stream);
@@ -172,6 +218,11 @@ struct AtbArgs {             // C[N][ldc] = A[M][lda]^T . B[M][ldb]  (+ bias[n] 
   int n_seg = 0, seg_rows = 0;
   const float* A_seg[ATB_MAX_SEG] = {};
   const float* B_seg[ATB_MAX_SEG] = {};
+  // Operand transform of the fused train-mode layer (train_fused.hip), per segment (index 0 without segments):
+  //   b_mode 1: B' = PReLU(Bs[k] B + Bs[K + k])   (the layer input a_{l-1} re-formed from y_{l-1}; b_slope: device float)
+  int b_mode = 0;
+  const float* Bs_seg[ATB_MAX_SEG] = {};
+  const float* b_slope = nullptr;
   // set by launch_gemm_atb
   int S; float* partial; float* bias_partial;
 };

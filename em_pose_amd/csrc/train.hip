@@ -152,11 +152,25 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   // row segments (the applications of one network): a chunk never straddles two (seg_rows is a multiple of 32), and
   // the segment is looked up again only when the walk leaves it
   const float* A0 = a.A; const float* B0 = a.B;
+  // Operand transform of the fused train-mode layer (kernels.h AtbArgs): a thread stages the same four columns of every
+  // row, so its coefficients are registers, re-read only when the walk enters another segment (= application).
+  f4 cbs = {1.f, 1.f, 1.f, 1.f}, cbt = {0.f, 0.f, 0.f, 0.f};
+  const float b_slope = a.b_mode ? a.b_slope[0] : 0.f;
+  const int b_cols = min(4, max(0, a.K - (k_base + c4)));
+  auto load_coefs = [&](int sg) {
+    if (a.b_mode && b_cols > 0) {
+      const float* c = a.Bs_seg[sg] + k_base + c4;
+      for (int e = 0; e < b_cols; ++e) { cbs[e] = c[e]; cbt[e] = c[a.K + e]; }
+    }
+  };
+  if (a.n_seg == 0) load_coefs(0);
+  bool rv[P];
   int mrel = 0, seg_end = a.n_seg > 0 ? 0 : 0x7fffffff;
   auto gload = [&](int m0) {
     if (m0 >= seg_end) {
       const int sg = min(m0 / a.seg_rows, a.n_seg - 1);
       A0 = a.A_seg[sg]; B0 = a.B_seg[sg]; mrel = sg * a.seg_rows;
+      load_coefs(sg);
       seg_end = sg + 1 < a.n_seg ? mrel + a.seg_rows : 0x7fffffff;
     }
     if (tile_full && m0 + MC <= me) {   // interior chunk (all but the edges): straight loads, no per-lane branches
@@ -166,6 +180,7 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
       for (int p = 0; p < P; ++p) {
         ga[p] = *reinterpret_cast<const f4*>(pa + (size_t)(8 * p) * a.lda);
         gb[p] = *reinterpret_cast<const f4*>(pb + (size_t)(8 * p) * a.ldb);
+        rv[p] = true;
       }
       return;
     }
@@ -184,12 +199,20 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
         else
           for (int e = 0; e < 4; ++e) if (k_base + c4 + e < a.K) vb[e] = pb[e];
       }
-      ga[p] = va; gb[p] = vb;
+      ga[p] = va; gb[p] = vb; rv[p] = row_ok;
     }
   };
   auto lwrite = [&](float* st) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
+      if (a.b_mode && rv[p]) {   // a_{l-1} = PReLU(s y + t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < b_cols) {
+            const float y = cbs[e] * gb[p][e] + cbt[e];
+            gb[p][e] = y > 0.f ? y : b_slope * y;
+          }
+      }
       *reinterpret_cast<f4*>(st + (r8 + 8 * p) * BN + c4) = ga[p];
       *reinterpret_cast<f4*>(st + MC * BN + (r8 + 8 * p) * BK + c4) = gb[p];
       if (do_bias) bs += ga[p];   // here, not at the load: the loads have landed by now
@@ -335,6 +358,7 @@ hipError_t launch_gemm_atb(AtbArgs a, float* workspace, size_t workspace_floats,
   } else {
     aligned = aligned && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
   }
+  if (a.b_mode && !aligned) return hipErrorInvalidValue;   // callers keep these operands aligned
   if (aligned && atb_chunk_rows(a.M, a.N, a.K) == 16)
     hipLaunchKernelGGL(gemm_atb_lds_kernel<16>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
   else if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel<32>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);

@@ -194,7 +194,7 @@ int empose_lgd_forward(const empose_model_t* model, const empose_lgd_io* io, voi
  *            layout of prepare_inputs, reference models.py:106-125); frame_scale [T] per-frame loss weight
  *   outputs pos [T][36], ori [T][108], joints [T][66]; g_theta [T][ld_g] (66), g_beta [T][ld_gb] (10) or NULL.
  * workspace: empose_smpl_workspace_bytes(model, T).
- * Launches of 4096 frames and more run the frame-per-lane kernels (csrc/smpl_tile.hip) when the model's sensor patches
+ * Launches of 16384 frames and more run the frame-per-lane kernels (csrc/smpl_tile.hip) when the model's sensor patches
  * allow it -- closed triangle fans of at most 8 faces over at most 8 bones, what a closed manifold body mesh gives;
  * empose_smpl_tile_supported says whether they do (option "smpl_tile": 0 never, 1 by size, 2 always). */
 size_t empose_smpl_workspace_bytes(const empose_model_t* model, int T);

@@ -204,6 +204,8 @@ def main():
     p.add_argument('--force_dist', action='store_true', help='initialise the process group (RCCL) and run the gradient '
                                                            'collectives even with one rank (self-test)')
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
+    p.add_argument('--option', action='append', default=[], metavar='NAME=INT',
+                   help='kernel-variant switch of the library (empose_set_option), e.g. train_fused=0; repeatable')
     p.add_argument('--amass_lmdb', default=None, help='LMDB database in the reference key schema (needs `lmdb`)')
     p.add_argument('--valid_lmdb', default=None, help='validation LMDB (e.g. 3DPW); default: held-out training sequences')
     p.add_argument('--offset_files', nargs='*', default=None, help='*_offsets.npz files (default: $EM_DATA_REAL/*_offsets.npz)')
@@ -222,6 +224,10 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     rank, world = init_from_env(dev)
+    for kv in args.option:
+        from em_pose_amd import _lib
+        name, value = kv.split('=')
+        _lib.check(_lib.lib().empose_set_option(name.encode(), int(value)))
 
     if args.amass_dir or args.amass_lmdb:
         return train_on_amass(args, dev, rank, world)

@@ -768,11 +768,15 @@ def test_linear_train_function_vs_torch_autograd(M, K, N):
                                        None) != 0
 
 
+@pytest.mark.parametrize('fused', [False, True], ids=['bn_kernels', 'bn_in_gemms'])
 @pytest.mark.parametrize('name', ['train_lgdrnn12_n2', 'train_lgd6_n2'])
-def test_training_step_matches_reference_gradients(name):
+def test_training_step_matches_reference_gradients(name, fused):
     """forward (train mode) + backward: losses and EVERY parameter gradient against the reference's own training
-    step recorded in tests/golden (incl. the in-forward E.backward() deposits, ragged lengths, train-mode BatchNorm)."""
+    step recorded in tests/golden (incl. the in-forward E.backward() deposits, ragged lengths, train-mode BatchNorm).
+    `fused`: the BatchNorm / PReLU passes folded into the GEMMs (csrc/train_fused.hip; by default from 1024 rows on,
+    forced here onto the recorded 48-frame batch)."""
     from em_pose_amd.data.data import SyntheticBatch
+    guard = _OptionGuard(b'train_fused', 2 if fused else 0)
     case = H.load_case(name)
     meta, w, rec = case['meta'], case['in'], case['run']
     net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
@@ -824,6 +828,7 @@ def test_training_step_matches_reference_gradients(name):
     net.zero_grad()
     net.backward(batch, net(batch))
     assert net._smpl_handle.value == h1
+    del guard
 
 
 def test_training_weight_gradients_once_over_all_iterations_equal_per_iteration_sums():
