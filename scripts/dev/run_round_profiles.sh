@@ -5,7 +5,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.log
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/${TAG}_gpu_tests.log
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
 python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
