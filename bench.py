@@ -245,6 +245,8 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
     ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=INT',
+                    help='kernel-variant switch of the library (empose_set_option), for A/B runs; repeatable')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -259,6 +261,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
+    for kv in args.option:
+        from em_pose_amd import _lib
+        name, _, value = kv.partition('=')
+        _lib.check(_lib.lib().empose_set_option(name.encode(), int(value)))
     if args.workload == 'vertices':
         if world > 1:
             raise SystemExit('the vertices workload is a single-GPU micro-benchmark')

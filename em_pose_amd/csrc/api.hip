@@ -598,20 +598,38 @@ int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, c
   return EMPOSE_OK;
 }
 
-// One SMPL evaluation given rot/feat already produced by update_feat.
-int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const float* offset_r, const float* offset_t,
-                  const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori, float* joints,
-                  float* pos2, float* ori2, float* joints2, hipStream_t stream, const float* cot_pos = nullptr,
-                  const float* cot_ori = nullptr, const float* cot_joints = nullptr, const float* theta = nullptr,
-                  int ld_theta = 0, const float* tgt_t = nullptr) {
-  if (theta && use_tile_path(m, T, cot_joints)) {
+// Where the residual gradient of one SMPL evaluation goes (null: no gradient wanted).
+struct GradOut {
+  float* g_theta; int ld_g; float* g_beta; int ld_gb;
+  float* trace_g_theta; float* trace_g_beta;
+};
+// One SMPL evaluation: pose / shape update + feature row (fa: what to update and where the copies go; rot / feat /
+// theta_t are filled in here), blend GEMM, chain + skinning + sensors (+ reverse), transposed GEMM, Rodrigues reverse.
+// On the frame-per-lane path the first and the last step ride on the GEMMs (option "smpl_fuse", default on).
+int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, FeatArgs fa, const float* offset_r,
+                  const float* offset_t, const float* tgt, int ld_tgt, const float* frame_scale, float* pos, float* ori,
+                  float* joints, float* pos2, float* ori2, float* joints2, hipStream_t stream,
+                  const float* cot_pos = nullptr, const float* cot_ori = nullptr, const float* cot_joints = nullptr,
+                  const float* tgt_t = nullptr, const GradOut* go = nullptr) {
+  const bool bwd = tgt || cot_pos;
+  const bool tile = use_tile_path(m, T, cot_joints);
+  const bool fuse = tile && options().smpl_fuse != 0;
+  fa.rot = tile ? nullptr : ws.rot; fa.feat = ws.feat; fa.theta_t = tile ? ws.theta_t : nullptr;
+  fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
+  if (bwd && !go) return fail(EMPOSE_EINVAL, "gradient outputs missing");
+  if (!fuse) {
+    prof_mark(P_UPDATE_FEAT, stream);
+    hipError_t e = launch_update_feat(fa, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
+  }
+  if (tile) {
     // frame-per-lane path: blend GEMM -> tile layout -> smpl_tile_kernel -> tile layout -> transposed GEMM
     prof_mark(P_BLEND_GEMM, stream);
-    hipError_t e = launch_gemm_rows_t(ws.feat, 200, false, m->wc2_frag, ws.out, m->ncp2, T, m->ncp2, 200, stream);
+    hipError_t e = fuse ? launch_blend_feat_gemm(fa, m->wc2_frag, ws.out, m->ncp2, m->ncp2, stream)
+                        : launch_gemm_rows_t(ws.feat, 200, false, m->wc2_frag, ws.out, m->ncp2, T, m->ncp2, 200, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm (tile): %s", hipGetErrorString(e));
-    const bool bwd = tgt || cot_pos;
     TileArgs a;
-    a.tab = m->tile_tab; a.theta = theta; a.ld_theta = ld_theta; a.out_t = ws.out;
+    a.tab = m->tile_tab; a.theta = fa.theta; a.ld_theta = fa.ld_theta; a.out_t = ws.out;
     a.theta_t = ws.theta_t; a.tgt_t = tgt ? tgt_t : nullptr;
     a.offset_r = offset_r; a.offset_t = offset_t; a.tgt = tgt; a.ld_tgt = ld_tgt; a.frame_scale = frame_scale;
     a.n_markers = m->n_markers;
@@ -623,9 +641,23 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
     e = launch_smpl_tile(a, bwd, m->tile_nloc, m->tile_nbl, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "smpl tile kernel: %s", hipGetErrorString(e));
     if (bwd) {
+      RodBwdTArgs ra;
+      ra.theta = fa.theta; ra.ld_theta = fa.ld_theta; ra.theta_t = ws.theta_t; ra.d_rot_t = ws.d_rot;
+      ra.d_feat_t = ws.d_feat; ra.ld_feat_t = D_FEAT_T_COLS;
+      ra.g_theta = go->g_theta; ra.ld_g = go->ld_g; ra.g_beta = go->g_beta; ra.ld_gb = go->ld_gb;
+      ra.trace_g_theta = go->trace_g_theta; ra.trace_g_beta = go->trace_g_beta;
+      ra.T = T; ra.rod_conv = m->rod_conv;
       prof_mark(P_BLEND_T_GEMM, stream);
+      if (fuse) {
+        e = launch_blend_t_gemm_rod(ws.d_out, m->ncp2, m->wc2t_frag, m->ncp2, ra, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm + rodrigues_bwd (tile): %s", hipGetErrorString(e));
+        return EMPOSE_OK;
+      }
       e = launch_gemm_rows_t(ws.d_out, m->ncp2, true, m->wc2t_frag, ws.d_feat, D_FEAT_T_COLS, T, 200, m->ncp2, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm (tile): %s", hipGetErrorString(e));
+      prof_mark(P_ROD_BWD, stream);
+      e = launch_rodrigues_bwd_t(ra, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
     }
     return EMPOSE_OK;
   }
@@ -660,6 +692,13 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, const f
             ? launch_gemm_rows(ws.d_out, m->tab.ncp, m->wct_frag, ws.d_feat, 200, T, 200, m->tab.ncp, stream)
             : launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm: %s", hipGetErrorString(e));
+    RodBwdArgs ra;
+    ra.theta = fa.theta; ra.ld_theta = fa.ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
+    ra.g_theta = go->g_theta; ra.ld_g = go->ld_g; ra.g_beta = go->g_beta; ra.ld_gb = go->ld_gb;
+    ra.trace_g_theta = go->trace_g_theta; ra.trace_g_beta = go->trace_g_beta; ra.T = T; ra.rod_conv = m->rod_conv;
+    prof_mark(P_ROD_BWD, stream);
+    e = launch_rodrigues_bwd(ra, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;
 }
@@ -682,7 +721,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"smpl_tile", &o.smpl_tile}, {"train_fused", &o.train_fused},
+      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -696,7 +735,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"smpl_tile", o.smpl_tile}, {"train_fused", o.train_fused},
+      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};
@@ -991,46 +1030,23 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
       fa.d_beta = w.d_shape; fa.beta_keep = 1.f; fa.beta_step = m->step;
     }
     const bool tile = use_tile_path(m, T);
-    fa.rot = tile ? nullptr : w.smpl.rot; fa.feat = w.smpl.feat; fa.theta_t = tile ? w.smpl.theta_t : nullptr;
     fa.out_theta = hist(io->hist_pose, i, 66); fa.out_beta = hist(io->hist_shape, i, 10);
     fa.out_theta2 = (i == N) ? io->pose_hat : nullptr;
     fa.out_beta2 = (i == N) ? io->shape_hat : nullptr;
-    fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
-    prof_mark(P_UPDATE_FEAT, stream);
-    e = launch_update_feat(fa, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
 
     const bool need_grad = (i < N) && m->use_gradient;
     float* hm = hist(io->hist_markers, i, 36);
     float* ho = hist(io->hist_markers_ori, i, 108);
     float* hj = hist(io->hist_joints, i, 66);
     if ((hm == nullptr) != (ho == nullptr)) return fail(EMPOSE_EINVAL, "hist_markers and hist_markers_ori go together");
+    GradOut go{x_gtheta, dx, x_gbeta, dx, hist(io->trace_g_pose, i, 66), hist(io->trace_g_shape, i, 10)};
     // (the frame-per-lane kernel skips outputs nobody asked for; the general kernel always writes its scratch copies)
-    TRY(run_smpl_eval(m, T, F, w.smpl, io->offset_r, io->offset_t, need_grad ? w.x : nullptr, dx, w.scale,
+    TRY(run_smpl_eval(m, T, F, w.smpl, fa, io->offset_r, io->offset_t, need_grad ? w.x : nullptr, dx, w.scale,
                       hm ? hm : (tile ? nullptr : w.pos), ho ? ho : (tile ? nullptr : w.ori),
                       (i == N) ? io->joints_hat : (hj ? hj : (tile ? nullptr : w.joints)),
-                      nullptr, nullptr, (i == N) ? hj : nullptr, stream, nullptr, nullptr, nullptr, x_theta, dx, w.x_t));
+                      nullptr, nullptr, (i == N) ? hj : nullptr, stream, nullptr, nullptr, nullptr, w.x_t,
+                      need_grad ? &go : nullptr));
     if (i == N) break;
-    if (m->use_gradient && tile) {
-      RodBwdTArgs ra;
-      ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot_t = w.smpl.d_rot; ra.d_feat_t = w.smpl.d_feat;
-      ra.ld_feat_t = D_FEAT_T_COLS;
-      ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
-      ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
-      ra.T = T; ra.rod_conv = m->rod_conv;
-      prof_mark(P_ROD_BWD, stream);
-      e = launch_rodrigues_bwd_t(ra, stream);
-      if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
-    } else if (m->use_gradient) {
-      RodBwdArgs ra;
-      ra.theta = x_theta; ra.ld_theta = dx; ra.d_rot = w.smpl.d_rot; ra.d_feat = w.smpl.d_feat;
-      ra.g_theta = x_gtheta; ra.ld_g = dx; ra.g_beta = x_gbeta; ra.ld_gb = dx;
-      ra.trace_g_theta = hist(io->trace_g_pose, i, 66); ra.trace_g_beta = hist(io->trace_g_shape, i, 10);
-      ra.T = T; ra.rod_conv = m->rod_conv;
-      prof_mark(P_ROD_BWD, stream);
-      e = launch_rodrigues_bwd(ra, stream);
-      if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
-    }
     const Mlp* nets[2] = {&m->pose_iter, &m->shape_iter};
     float* outs[2] = {w.d_pose, w.d_shape};
     const int lds[2] = {66, 10};
@@ -1061,32 +1077,15 @@ int empose_smpl_sensors_fwd_bwd(const empose_model_t* m, int T, int F, const flo
   fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   const bool tile = use_tile_path(m, T);
-  fa.shape_avg = 0; fa.rot = tile ? nullptr : ws.rot; fa.feat = ws.feat; fa.theta_t = tile ? ws.theta_t : nullptr;
+  fa.shape_avg = 0;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-  fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
-  hipError_t e = launch_update_feat(fa, stream);
-  if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
   if (tgt && tile) {
-    e = launch_rows_to_tile(tgt, ld_tgt, 12 * m->n_markers, ws.tgt_t, T, stream);
+    hipError_t e = launch_rows_to_tile(tgt, ld_tgt, 12 * m->n_markers, ws.tgt_t, T, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "tile transpose: %s", hipGetErrorString(e));
   }
-  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, tgt, ld_tgt, frame_scale, pos, ori, joints, nullptr, nullptr,
-                    nullptr, stream, nullptr, nullptr, nullptr, theta, ld_theta, tile ? ws.tgt_t : nullptr));
-  if (tgt && tile) {
-    RodBwdTArgs ra;
-    ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot_t = ws.d_rot; ra.d_feat_t = ws.d_feat; ra.ld_feat_t = D_FEAT_T_COLS;
-    ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
-    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
-    e = launch_rodrigues_bwd_t(ra, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
-  } else if (tgt) {
-    RodBwdArgs ra;
-    ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
-    ra.g_theta = g_theta; ra.ld_g = ld_g; ra.g_beta = g_beta; ra.ld_gb = ld_gb;
-    ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
-    e = launch_rodrigues_bwd(ra, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
-  }
+  GradOut go{g_theta, ld_g, g_beta, ld_gb, nullptr, nullptr};
+  TRY(run_smpl_eval(m, T, F, ws, fa, offset_r, offset_t, tgt, ld_tgt, frame_scale, pos, ori, joints, nullptr, nullptr,
+                    nullptr, stream, nullptr, nullptr, nullptr, tile ? ws.tgt_t : nullptr, tgt ? &go : nullptr));
   return EMPOSE_OK;
 }
 
@@ -1109,28 +1108,11 @@ int empose_smpl_sensors_vjp(const empose_model_t* m, int T, int F, const float* 
   fa.theta = const_cast<float*>(theta); fa.ld_theta = ld_theta; fa.beta = const_cast<float*>(beta); fa.ld_beta = ld_beta;
   fa.d_theta = nullptr; fa.d_beta = nullptr; fa.theta_step = 0.f; fa.beta_keep = 1.f; fa.beta_step = 0.f;
   const bool tile = use_tile_path(m, T, d_joints);
-  fa.shape_avg = 0; fa.rot = tile ? nullptr : ws.rot; fa.feat = ws.feat; fa.theta_t = tile ? ws.theta_t : nullptr;
+  fa.shape_avg = 0;
   fa.out_theta = fa.out_beta = fa.out_theta2 = fa.out_beta2 = nullptr;
-  fa.T = T; fa.F = F; fa.rod_conv = m->rod_conv;
-  hipError_t e = launch_update_feat(fa, stream);
-  if (e != hipSuccess) return fail(EMPOSE_EHIP, "update_feat kernel: %s", hipGetErrorString(e));
-  TRY(run_smpl_eval(m, T, F, ws, offset_r, offset_t, nullptr, 0, nullptr, tile ? nullptr : pos, tile ? nullptr : ori,
-                    tile ? nullptr : joints, nullptr, nullptr, nullptr, stream, d_pos, d_ori, d_joints, theta, ld_theta));
-  if (tile) {
-    RodBwdTArgs rt;
-    rt.theta = theta; rt.ld_theta = ld_theta; rt.d_rot_t = ws.d_rot; rt.d_feat_t = ws.d_feat; rt.ld_feat_t = D_FEAT_T_COLS;
-    rt.g_theta = g_theta; rt.ld_g = 66; rt.g_beta = g_beta; rt.ld_gb = 10;
-    rt.trace_g_theta = nullptr; rt.trace_g_beta = nullptr; rt.T = T; rt.rod_conv = m->rod_conv;
-    e = launch_rodrigues_bwd_t(rt, stream);
-    if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd (tile) kernel: %s", hipGetErrorString(e));
-    return EMPOSE_OK;
-  }
-  RodBwdArgs ra;
-  ra.theta = theta; ra.ld_theta = ld_theta; ra.d_rot = ws.d_rot; ra.d_feat = ws.d_feat;
-  ra.g_theta = g_theta; ra.ld_g = 66; ra.g_beta = g_beta; ra.ld_gb = 10;
-  ra.trace_g_theta = nullptr; ra.trace_g_beta = nullptr; ra.T = T; ra.rod_conv = m->rod_conv;
-  e = launch_rodrigues_bwd(ra, stream);
-  if (e != hipSuccess) return fail(EMPOSE_EHIP, "rodrigues_bwd kernel: %s", hipGetErrorString(e));
+  GradOut go{g_theta, 66, g_beta, 10, nullptr, nullptr};
+  TRY(run_smpl_eval(m, T, F, ws, fa, offset_r, offset_t, nullptr, 0, nullptr, tile ? nullptr : pos, tile ? nullptr : ori,
+                    tile ? nullptr : joints, nullptr, nullptr, nullptr, stream, d_pos, d_ori, d_joints, nullptr, &go));
   return EMPOSE_OK;
 }
 

@@ -18,6 +18,7 @@ struct Options {
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
   int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 16384 frames on, 2 always
+  int smpl_fuse = 1;      // on that path: update + feature row / Rodrigues reverse inside the blend GEMMs (0: own kernels)
   int train_fused = 0;    // train-mode BatchNorm / PReLU folded into the GEMMs: 0 never (default: measured no faster,
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
@@ -463,6 +464,7 @@ struct TileArgs {
 hipError_t launch_smpl_tile(const TileArgs& a, bool backward, int nloc, int nbl, hipStream_t stream);
 struct RodBwdTArgs {
   const float* theta; int ld_theta;
+  const float* theta_t = nullptr;     // optional: the same values in tile layout [tiles][66][64] (coalesced loads)
   const float* d_rot_t;               // tile layout [tiles][198][64]
   const float* d_feat_t; int ld_feat_t;   // tile layout [tiles][ld_feat_t][64] (columns 0..198 used)
   float* g_theta; int ld_g; float* g_beta; int ld_gb;
@@ -472,9 +474,16 @@ struct RodBwdTArgs {
 hipError_t launch_rodrigues_bwd_t(const RodBwdTArgs& a, hipStream_t stream);
 hipError_t launch_rows_to_tile(const float* src, int ld, int cols, float* dst_t, int T, hipStream_t stream);
 // C = A . Wp^T with tile-layout operands (mlp_fused.hip): A row-major [M][lda] or tile layout (a_tile), C in tile layout
-// [tiles][ldc_t][64] (ldc_t >= N rounded up to 32; the padding columns are written as zeros).
+// [tiles][ldc_t][64] (ldc_t == N rounded up to 32; the padding columns are written as zeros).
 hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float* Wp, float* C_t, int ldc_t, int M, int N,
                               int K, hipStream_t stream);
+
+// The same two products with the small kernels around them folded in (mlp_fused.hip): the pose / shape update +
+// feature row as the prologue of the first (the [T][200] feature matrix never reaches HBM), the Rodrigues reverse as
+// the epilogue of the second (neither do the feature cotangents).
+hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream);
+hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
+                                   hipStream_t stream);
 
 // Full-mesh: chain only (joints + relative transforms) and dense skinning.
 constexpr int MESH_MAX_JOINTS = 52;   // SMPL-H: 22 body + 2 x 15 hand joints

@@ -18,6 +18,7 @@
 // 10-column layer does not cost a 512-column one, and write to the net's output instead of the LDS buffer.
 // Skip connections would need the block input kept besides the activations: such nets take the layer-by-layer path.
 #include "gemm_epilogue.h"
+#include "feat_rows.h"
 
 namespace empose {
 
@@ -42,7 +43,12 @@ typedef const __attribute__((address_space(1))) char* fm_gbyte_t;
 
 // One layer for the workgroup's rows; the input activations are in `act` (row stride lda, columns [0, 8 * KG4) valid or
 // zero).  The wave computes WM x WN tiles of 32 x 32 starting at (row_tile0, col_tile0).
-template <int WM, int WN, bool OUT_T = false>   // OUT_T: the last layer's result goes to LDS, transposed (gemm_rows_t_kernel)
+// OUT_T (last layer only): 0 the net's output rows | 1 C^T to LDS as [column][64], rotated (callers that go on
+// working on it) | 2 straight to the tile-layout output [tile][column][64] as 16-byte pieces of four consecutive rows
+// (the C/D layout has rows 4q .. 4q+3 of a column in one lane), no LDS and no barrier after the K loop.
+// A_KMAJOR: the A operand lies in LDS as [k][64 rows] (a tile-layout block copied as it is: no transposition on the way
+// in, conflict-free 4-byte reads) instead of [64 rows][lda].
+template <int WM, int WN, int OUT_T = 0, bool A_KMAJOR = false>
 __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act,
                                               int lda, int row_tile0, int col_tile0, int layer_index, bool last) {
   using namespace fm;
@@ -54,8 +60,10 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   const int NT32 = (N + 31) / 32;             // column tiles of the packed weights
   const int KG4 = ((K + 7) / 8 + 3) & ~3;     // k-groups of the packed weights (padded with zeros to a multiple of 4)
   if (col_tile0 >= NT32) {   // wave-uniform: nothing of this layer falls to this wave; keep the two barriers
-    __syncthreads();
-    __syncthreads();
+    if (OUT_T != 2) {
+      __syncthreads();
+      __syncthreads();
+    }
     return;
   }
   // Column tiles past the layer's width are clamped to the last one: fetched and multiplied like the others (no
@@ -67,7 +75,8 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   for (int j = 0; j < WN; ++j)
     b_voff[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 1024 + lane * 16);
   fm_gbyte_t wb = (fm_gbyte_t)L.W;
-  const float* a_rd = act + (row_tile0 * 32 + l31) * lda + lh * 4;   // A fragments: row tile i adds 32 rows, group g adds 8
+  // A fragments: row tile i adds 32 rows, group g adds 8 columns (K-major: 8 rows of 64)
+  const float* a_rd = A_KMAJOR ? act + (lh * 4) * 64 + row_tile0 * 32 + l31 : act + (row_tile0 * 32 + l31) * lda + lh * 4;
 
   // epilogue constants of this lane's columns, fetched now so that their latency hides under the K loop.  Columns past
   // N (zero padding of the next layer's K) get scale = shift = 0, so the hidden epilogue needs no select for them.
@@ -90,8 +99,16 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   f32x4 fb[4][WN];              // B fragment ring: slot s holds k-group 4 t + s
 
   auto fread = [&](int g, f32x4 (&a)[WM]) {
+    if (A_KMAJOR) {
+      const int gc = g < KG4 ? g : KG4 - 1;   // (the look-ahead past the last group stays inside the block)
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * lda + g * 8);
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[i][e] = a_rd[(gc * 8 + e) * 64 + i * 32];
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * lda + g * 8);
+    }
   };
   auto bload = [&](f32x4 (&b)[WN], int kg) {   // k-group kg of the packed weights (clamped: fetched, never used)
     const int kc = kg < KG4 ? kg : KG4 - 1;
@@ -109,13 +126,14 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
   auto pattern = [&]() {   // one k-group: WM fragment reads and WN weight loads spread over the NMMA MFMAs
-    constexpr int step = NMMA >= 2 * (WM + WN) + 2 ? 2 : 1;
-    static_assert(NMMA >= step * (WM + WN), "k-group too small for its memory operations");
+    constexpr int NDS = A_KMAJOR ? 4 * WM : WM;   // LDS reads per k-group
+    constexpr int step = NMMA >= 2 * (NDS + WN) + 2 ? 2 : 1;
+    static_assert(NMMA >= step * (NDS + WN), "k-group too small for its memory operations");
 #pragma unroll
-    for (int q = 0; q < WM; ++q) { FM_SGB(SG_MFMA, step); FM_SGB(SG_DS_RD, 1); }
+    for (int q = 0; q < NDS; ++q) { FM_SGB(SG_MFMA, step); FM_SGB(SG_DS_RD, 1); }
 #pragma unroll
     for (int q = 0; q < WN; ++q) { FM_SGB(SG_MFMA, step); FM_SGB(SG_VMEM_RD, 1); }
-    FM_SGB(SG_MFMA, NMMA - step * (WM + WN));
+    FM_SGB(SG_MFMA, NMMA - step * (NDS + WN));
   };
 
 #pragma unroll
@@ -158,8 +176,25 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   for (int g = 4; g < KG4; g += 4) quad(g);
   FM_STAMP(4 * layer_index + 2)
 
+  if (last && OUT_T == 2) {
+    float* dst = net.out + (size_t)(m0 >> 6) * net.ld_out * 64;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (col_tile0 + j) * 32 + l31;
+      if (col_tile0 + j >= NT32 || n >= net.ld_out) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (row_tile0 + i) * 32 + 8 * q + 4 * lh;
+          *reinterpret_cast<f32x4*>(dst + (size_t)n * 64 + row) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+    }
+    return;
+  }
   __syncthreads();   // every wave has read its last A fragment: the buffer may be overwritten
-  if (last && OUT_T) {
+  if (last && OUT_T == 1) {
     // C^T into the (now free) activation buffer as [column][64 rows], rows rotated by the column so that the 32 lanes of
     // a store (32 columns, one row) hit 32 banks; gemm_rows_t_kernel copies it out as whole 256-byte columns.
 #pragma unroll
@@ -327,66 +362,58 @@ hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, 
 
 // The row-block GEMM with tile-layout operands (kernels.h "tile layout"; the frame-per-lane SMPL kernel, smpl_tile.hip,
 // reads and writes columns of 64 frames): 64 rows (= one tile) per workgroup, 2 x 2 waves of 32 x (32 WN).  A comes
-// row-major or in tile layout (A_T); C leaves through LDS as whole columns.
-template <int WN, bool A_T>
-__global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) {
-  extern __shared__ __attribute__((aligned(16))) float act[];
-  const FusedNet& net = args.net[0];
-  const FusedLayer& L = net.layer[0];
-  const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
+// row-major or in tile layout (A_T: copied to LDS as it lies, K-major); C leaves straight from the accumulators as
+// 16-byte pieces of the tile-layout columns.  No LDS beyond the A block: two workgroups per CU, so that one's staging
+// and stores run beside the other's K loop (with C^T staged in LDS, 82 KB, it was one).
+namespace rt {
+// A_t[tile][k][64] -> act[k][64] as it lies (fused_layer_t's K-major operand): 16-byte pieces, no transposition; the
+// columns [K0, kpad) are zero
+__device__ __forceinline__ void stage_a_tile(const float* x_t, int ldx, int tile, int K0, int kpad, float* act) {
   const int tid = threadIdx.x;
-  const int K0 = L.K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
-  const int lda = kpad + 4;
-  if (A_T) {
-    // A_t[tile][k][64]: a thread takes four frames of one column (16 bytes, coalesced) and scatters them over four rows
-    const f32x4* src = reinterpret_cast<const f32x4*>(net.x + (size_t)tile * net.ldx * 64);
-    for (int i0 = tid; i0 < kpad * 16; i0 += 4 * fm::NT) {
-      f32x4 v[4];
+  const f32x4* src = reinterpret_cast<const f32x4*>(x_t + (size_t)tile * ldx * 64);
+  for (int i0 = tid; i0 < kpad * 16; i0 += 4 * fm::NT) {
+    f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * fm::NT;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < kpad * 16 && (i >> 4) < K0) v[u] = src[i];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * fm::NT;
-        if (i < kpad * 16) {
-          const int k = i >> 4, f = (i & 15) * 4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) act[(f + e) * lda + k] = v[u][e];
-        }
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * fm::NT;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < kpad * 16 && (i >> 4) < K0) v[u] = src[i];
     }
-  } else {
-    const int c4n = kpad / 4;
-    for (int i0 = tid; i0 < 64 * c4n; i0 += 4 * fm::NT) {
-      f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * fm::NT;
-        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < 64 * c4n) {
-          const int r = i / c4n, c = (i % c4n) * 4;
-          const int row = m0 + r < M ? m0 + r : M - 1;
-          if (c < K0) v[u] = *reinterpret_cast<const f32x4*>(net.x + (size_t)row * net.ldx + c);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = i0 + u * fm::NT;
-        if (i < 64 * c4n) *reinterpret_cast<f32x4*>(act + (i / c4n) * lda + (i % c4n) * 4) = v[u];
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * fm::NT;
+      if (i < kpad * 16) reinterpret_cast<f32x4*>(act)[i] = v[u];
     }
   }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  fused_layer_t<1, WN, true>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
-  // C^T is in LDS ([column][64], rows rotated by the column): out as 16-byte pieces of whole columns
-  const int NT32 = (L.N + 31) / 32;
-  float* dst = net.out + (size_t)tile * net.ld_out * 64;
-  for (int i = tid; i < net.ld_out * 16; i += fm::NT) {
+}
+// row-major A[M][ldx] -> act[64][lda] (rows past the end repeat the last one; never stored)
+__device__ __forceinline__ void stage_a_rows(const float* x, int ldx, int m0, int M, int K0, int kpad, int lda, float* act) {
+  const int tid = threadIdx.x;
+  const int c4n = kpad / 4;
+  for (int i0 = tid; i0 < 64 * c4n; i0 += 4 * fm::NT) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * fm::NT;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 64 * c4n) {
+        const int r = i / c4n, c = (i % c4n) * 4;
+        const int row = m0 + r < M ? m0 + r : M - 1;
+        if (c < K0) v[u] = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * fm::NT;
+      if (i < 64 * c4n) *reinterpret_cast<f32x4*>(act + (i / c4n) * lda + (i % c4n) * 4) = v[u];
+    }
+  }
+}
+// C^T in LDS ([column][64], rows rotated by the column; fused_layer_t<.., OUT_T>) out as 16-byte pieces of whole columns
+__device__ __forceinline__ void store_ct(const float* act, int N, float* out_t, int ld_out, int tile) {
+  const int NT32 = (N + 31) / 32;
+  float* dst = out_t + (size_t)tile * ld_out * 64;
+  for (int i = threadIdx.x; i < ld_out * 16; i += fm::NT) {
     const int n = i >> 4, f = (i & 15) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (n < NT32 * 32) {
@@ -396,13 +423,96 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) 
     *reinterpret_cast<f32x4*>(dst + (size_t)n * 64 + f) = v;
   }
 }
+}  // namespace rt
+
+template <int WN, bool A_T>
+__global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
+  const int K0 = L.K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
+  const int lda = kpad + 4;
+  if (A_T) rt::stage_a_tile(net.x, net.ldx, tile, K0, kpad, act);
+  else rt::stage_a_rows(net.x, net.ldx, m0, M, K0, kpad, lda, act);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  fused_layer_t<1, WN, 2, A_T>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
+}
+
+// The blend-shape GEMM of the frame-per-lane path with the iteration's pose / shape update, Rodrigues and the feature
+// row as its PROLOGUE (feat_rows.h: the body of update_feat_kernel): the 64 x 200 feature block is built in LDS from
+// 76 floats per frame and never exists in HBM.  out_t = feat . Wc2^T in tile layout.
+template <int WN>
+__global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs args, FeatArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
+  const int tid = threadIdx.x;
+  constexpr int K0 = 200, kpad = 224, lda = kpad + 4;
+  for (int i = tid; i < 64 * (lda - K0); i += fm::NT) act[(i / (lda - K0)) * lda + K0 + i % (lda - K0)] = 0.f;
+  const int fl = tid >> 5, slot = tid & 31;
+  // window means of the shape update, once per window of the tile (32 lanes per window), through the pad columns'
+  // neighbours in LDS: s_mean[window in tile][10] behind the A block
+  float* s_mean = act + 64 * lda;
+  const bool avg = fa.d_beta && fa.shape_avg;
+  const int t_last = min(m0 + 63, M - 1);
+  const int w_first = m0 / fa.F, n_win = avg ? t_last / fa.F - w_first + 1 : 0;   // <= 64
+  for (int w = fl; w < n_win; w += 8) {
+    const float d = shape_window_mean(fa, w_first + w, slot);
+    if (slot >= NB) s_mean[w * 10 + slot - NB] = d;
+  }
+  if (avg) __syncthreads();
+  // 32 lanes per frame, eight frames per pass: the loads of all eight passes first, then Rodrigues and the rows
+  FeatLane v[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int t = m0 + p * 8 + fl;
+    const float d = (avg && slot >= NB && t < M) ? s_mean[(t / fa.F - w_first) * 10 + slot - NB] : 0.f;
+    v[p] = feat_lane_load(fa, t, slot, d);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = p * 8 + fl;
+    if (m0 + r >= M) {
+      for (int c = slot; c < K0; c += 32) act[r * lda + c] = 0.f;
+    }
+    feat_lane_finish(fa, m0 + r, slot, v[p], act + r * lda, nullptr);
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  fused_layer_t<1, WN, 2>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
+}
+
+// The transposed blend-shape GEMM of the frame-per-lane path (d_feat = d_out . Wc2, both in tile layout) with the
+// Rodrigues reverse as its EPILOGUE (feat_rows.h: the body of rodrigues_bwd_t_kernel): the feature cotangents stay in
+// LDS, what leaves is g_theta / g_beta in the caller's rows.
+template <int WN>
+__global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs args, RodBwdTArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
+  const int K0 = L.K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
+  const int lda = kpad + 4;
+  rt::stage_a_tile(net.x, net.ldx, tile, K0, kpad, act);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  fused_layer_t<1, WN, 1, true>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
+  const int NT32 = (L.N + 31) / 32;
+  float* sg = act + NT32 * 32 * 64;
+  const int lane = threadIdx.x & 63;
+  rodrigues_bwd_tile(ra, tile, sg, [&](int col) { return act[col * 64 + ((lane + col) & 63)]; });
+}
 
 template <int WN, bool A_T>
 static hipError_t launch_gemm_rows_t_cfg(const FusedMlpArgs& args, hipStream_t stream) {
   const FusedLayer& L = args.net[0].layer[0];
   const int kpad = (((L.K + 7) / 8 + 3) & ~3) * 8;
-  const size_t a_bytes = (size_t)64 * (kpad + 4) * sizeof(float), c_bytes = (size_t)((L.N + 31) / 32) * 32 * 64 * sizeof(float);
-  const size_t lds = (a_bytes > c_bytes ? a_bytes : c_bytes);
+  const size_t lds = (size_t)64 * (A_T ? kpad : kpad + 4) * sizeof(float);
   static size_t attr = 0;
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_t_kernel<WN, A_T>),
@@ -416,7 +526,7 @@ static hipError_t launch_gemm_rows_t_cfg(const FusedMlpArgs& args, hipStream_t s
 
 hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float* Wp, float* C_t, int ldc_t, int M, int N,
                               int K, hipStream_t stream) {
-  if (K % 4 != 0 || N > 320 || ldc_t < ((N + 31) / 32) * 32) return hipErrorInvalidValue;
+  if (K % 4 != 0 || N > 320 || ldc_t != ((N + 31) / 32) * 32) return hipErrorInvalidValue;
   FusedMlpArgs a;
   a.count = 1; a.M = M;
   FusedNet& fn = a.net[0];
@@ -425,6 +535,51 @@ hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float*
   L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
   if (N > 256) return a_tile ? launch_gemm_rows_t_cfg<5, true>(a, stream) : launch_gemm_rows_t_cfg<5, false>(a, stream);
   return a_tile ? launch_gemm_rows_t_cfg<4, true>(a, stream) : launch_gemm_rows_t_cfg<4, false>(a, stream);
+}
+
+static FusedMlpArgs rows_t_args(const float* A, int lda, const float* Wp, float* C_t, int ldc_t, int M, int N, int K) {
+  FusedMlpArgs a;
+  a.count = 1; a.M = M;
+  FusedNet& fn = a.net[0];
+  fn.x = A; fn.ldx = lda; fn.out = C_t; fn.ld_out = ldc_t; fn.n_layers = 1;
+  FusedLayer& L = fn.layer[0];
+  L.W = Wp; L.K = K; L.N = N; L.scale = nullptr; L.shift = nullptr; L.slope = 0.f; L.act = 0;
+  return a;
+}
+
+template <class Kern, class Extra>
+static hipError_t launch_rows_t_fused(Kern kern, size_t lds, size_t* attr, const FusedMlpArgs& a, const Extra& x,
+                                      hipStream_t stream) {
+  if (lds > *attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    *attr = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.M + 63) / 64), dim3(fm::NT), lds, stream, a, x);
+  return hipGetLastError();
+}
+
+hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream) {
+  if (N > 320 || ldc_t != ((N + 31) / 32) * 32) return hipErrorInvalidValue;
+  const FusedMlpArgs a = rows_t_args(nullptr, 0, Wp, C_t, ldc_t, fa.T, N, 200);
+  const size_t lds = (size_t)(64 * 228 + 64 * 10) * sizeof(float);   // the A block + the tile's window means
+  static size_t attr5 = 0, attr4 = 0;
+  if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5>, lds, &attr5, a, fa, stream);
+  return launch_rows_t_fused(blend_feat_gemm_kernel<4>, lds, &attr4, a, fa, stream);
+}
+
+hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
+                                   hipStream_t stream) {
+  constexpr int N = 200;
+  if (K % 4 != 0) return hipErrorInvalidValue;
+  const FusedMlpArgs a = rows_t_args(A_t, lda_t, Wp, nullptr, 0, ra.T, N, K);
+  const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;
+  const size_t a_bytes = (size_t)64 * kpad * sizeof(float);
+  const size_t c_bytes = ((size_t)((N + 31) / 32) * 32 * 64 + (size_t)TL_FR * 77) * sizeof(float);
+  const size_t lds = a_bytes > c_bytes ? a_bytes : c_bytes;
+  static size_t attr = 0;
+  return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, lds, &attr, a, ra, stream);
 }
 
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream) {

@@ -15,6 +15,7 @@
 // dR_j = G_p^T (sum_subtree M_b - F_b (x) t_j) G_j, which needs subtree sums instead of a level-by-level sweep.
 #include "kernels.h"
 #include "smpl_math.h"
+#include "feat_rows.h"
 
 #include <cstdlib>
 
@@ -70,78 +71,7 @@ __global__ __launch_bounds__(256) void update_feat_kernel(FeatArgs a) {
   __shared__ __attribute__((aligned(16))) float s_feat[UF_FRAMES * 200];
   const int t0 = blockIdx.x * UF_FRAMES;
   const int fl = threadIdx.x >> 5, slot = threadIdx.x & 31;
-  const int t = t0 + fl;
-  // Window mean of the shape update (shape_avg): the 32 lanes of a frame each fetch the frames slot, slot + 32, ... of
-  // the frame's window and the sums meet by shuffles -- independent loads instead of a serial walk over the window by
-  // the ten shape lanes.
-  //   shape_avg == 1: mean over ALL frames of the window incl. padded ones (reference models.py:529-532);
-  //   shape_avg == 2: mean over the valid frames only (what an unpadded window of that length would give; used by the
-  //   batched streaming driver so that ragged batches reproduce one-recording-at-a-time results)
-  float d_mean = 0.f;   // for lane slot >= NB: the mean of coefficient slot - NB
-  if (a.d_beta && a.shape_avg) {
-    const int tc = t < a.T ? t : a.T - 1;
-    const int w0 = (tc / a.F) * a.F;
-    const int n = (a.shape_avg == 2 && a.seq_lengths) ? max(1, min(a.F, a.seq_lengths[tc / a.F])) : a.F;
-    float part[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) part[k] = 0.f;
-    for (int f = slot; f < n; f += 32) {   // ten independent loads per trip (long windows: F = 256 is eight trips)
-      const float* row = a.d_beta + (size_t)(w0 + f) * 10;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) part[k] += row[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      float v = part[k];
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 32);
-      if (slot == NB + k) d_mean = v / (float)n;
-    }
-  }
-  if (t < a.T) {
-    if (slot < NB) {
-      float* th = a.theta + (size_t)t * a.ld_theta + slot * 3;
-      float r0 = th[0], r1 = th[1], r2 = th[2];
-      if (a.d_theta) {
-        const float* d = a.d_theta + (size_t)t * 66 + slot * 3;
-        r0 = r0 + d[0] * a.theta_step;
-        r1 = r1 + d[1] * a.theta_step;
-        r2 = r2 + d[2] * a.theta_step;
-        th[0] = r0; th[1] = r1; th[2] = r2;
-      }
-      if (a.out_theta) { float* o = a.out_theta + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
-      if (a.out_theta2) { float* o = a.out_theta2 + (size_t)t * 66 + slot * 3; o[0] = r0; o[1] = r1; o[2] = r2; }
-      if (a.theta_t) {
-        float* o = a.theta_t + ((size_t)(t >> 6) * 66 + slot * 3) * 64 + (t & 63);
-        o[0] = r0; o[64] = r1; o[128] = r2;
-      }
-      Rod q; float R[9];
-      rodrigues(r0, r1, r2, a.rod_conv, q, R);
-      float* ro = s_rot + (fl * NB + slot) * 9;
-#pragma unroll
-      for (int e = 0; e < 9; ++e) ro[e] = R[e];
-      if (slot >= 1) {
-        float* f = s_feat + fl * 200 + (slot - 1) * 9;
-        f[0] = R[0] - 1.f; f[1] = R[1]; f[2] = R[2];
-        f[3] = R[3]; f[4] = R[4] - 1.f; f[5] = R[5];
-        f[6] = R[6]; f[7] = R[7]; f[8] = R[8] - 1.f;
-      }
-    } else {
-      const int k = slot - NB;
-      float* be = a.beta + (size_t)t * a.ld_beta + k;
-      float v = a.beta_keep != 0.f ? *be * a.beta_keep : 0.f;
-      if (a.d_beta) {
-        const float d = a.shape_avg ? d_mean : a.d_beta[(size_t)t * 10 + k];
-        v = v + d * a.beta_step;
-      }
-      // The lanes of a window read d_beta of all its frames but write only beta[t][k]: no hazard.
-      if (a.d_beta || a.beta_keep != 1.f) *be = v;   // plain evaluation: the caller's rows are left alone
-      if (a.out_beta) a.out_beta[(size_t)t * 10 + k] = v;
-      if (a.out_beta2) a.out_beta2[(size_t)t * 10 + k] = v;
-      s_feat[fl * 200 + 189 + k] = v;
-      if (k == 0) s_feat[fl * 200 + 199] = 1.f;
-    }
-  }
+  feat_frame(a, t0 + fl, slot, s_feat + fl * 200, s_rot + fl * NB * 9);   // feat_rows.h
   __syncthreads();
   // the block's frames are contiguous in both outputs
   const int nf = min(UF_FRAMES, a.T - t0);

@@ -23,6 +23,7 @@
 // loss.py:23-41; reverse pass as in oracle/analytic_np.py (same formulas as chain_sensors_kernel).
 #include "kernels.h"
 #include "smpl_math.h"
+#include "feat_rows.h"
 
 #include <algorithm>
 #include <cstring>
@@ -759,67 +760,10 @@ __global__ __launch_bounds__(64 * NW) void smpl_tile_kernel(TileArgs a) {
 // of a frame leave through LDS as contiguous row pieces (the caller's rows have a stride of ~300 floats).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rodrigues_bwd_t_kernel(RodBwdTArgs a) {
-  constexpr int FR = TL_FR, LD = 77;
-  __shared__ float sg[FR * LD];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __shared__ float sg[TL_FR * 77];
   const int tile = blockIdx.x;
-  const int t = tile * FR + lane;
-  const int tc = t < a.T ? t : a.T - 1;
-  const float* dr_t = a.d_rot_t + (size_t)tile * (NB * 9) * FR + lane;
-  const float* df_t = a.d_feat_t + (size_t)tile * a.ld_feat_t * FR + lane;
-  for (int j = wave; j < NB; j += 4) {
-    const float* th = a.theta + (size_t)tc * a.ld_theta + j * 3;
-    Rod q; float R[9];
-    rodrigues(th[0], th[1], th[2], a.rod_conv, q, R);
-    float dR[9];
-#pragma unroll
-    for (int e = 0; e < 9; ++e) dR[e] = dr_t[(size_t)(j * 9 + e) * FR];
-    if (j >= 1) {
-#pragma unroll
-      for (int e = 0; e < 9; ++e) dR[e] += df_t[(size_t)((j - 1) * 9 + e) * FR];
-    }
-    const float K[9] = {0.f, -q.dz, q.dy, q.dz, 0.f, -q.dx, -q.dy, q.dx, 0.f};
-    const float KK[9] = {-q.dz * q.dz - q.dy * q.dy, q.dx * q.dy, q.dx * q.dz,
-                         q.dx * q.dy, -q.dz * q.dz - q.dx * q.dx, q.dy * q.dz,
-                         q.dx * q.dz, q.dy * q.dz, -q.dy * q.dy - q.dx * q.dx};
-    float ds = 0.f, dc1 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { ds += dR[e] * K[e]; dc1 += dR[e] * KK[e]; }
-    const float oc = 1.f - q.c;
-    float dK[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float mm = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) mm += dR[r * 3 + k] * K[c * 3 + k] + K[k * 3 + r] * dR[k * 3 + c];
-        dK[r * 3 + c] = q.s * dR[r * 3 + c] + oc * mm;
-      }
-    const float ddx = dK[7] - dK[5], ddy = dK[2] - dK[6], ddz = dK[3] - dK[1];
-    float da = ds * q.c + dc1 * q.s;
-    da -= (ddx * q.dx + ddy * q.dy + ddz * q.dz) / q.ang;
-    sg[lane * LD + j * 3 + 0] = ddx / q.ang + da * q.ux / q.ang;
-    sg[lane * LD + j * 3 + 1] = ddy / q.ang + da * q.uy / q.ang;
-    sg[lane * LD + j * 3 + 2] = ddz / q.ang + da * q.uz / q.ang;
-  }
-  for (int k = wave; k < 10; k += 4) sg[lane * LD + 66 + k] = df_t[(size_t)(189 + k) * FR];
-  __syncthreads();
-  // rows out: thread -> (frame, column), consecutive threads consecutive columns of one frame
-  for (int i = threadIdx.x; i < FR * 76; i += 256) {
-    const int f = i / 76, c = i - f * 76;
-    const int tt = tile * FR + f;
-    if (tt >= a.T) continue;
-    const float val = sg[f * LD + c];
-    if (c < 66) {
-      a.g_theta[(size_t)tt * a.ld_g + c] = val;
-      if (a.trace_g_theta) a.trace_g_theta[(size_t)tt * 66 + c] = val;
-    } else {
-      a.g_beta[(size_t)tt * a.ld_gb + (c - 66)] = val;
-      if (a.trace_g_beta) a.trace_g_beta[(size_t)tt * 10 + (c - 66)] = val;
-    }
-  }
+  const float* df_t = a.d_feat_t + (size_t)tile * a.ld_feat_t * TL_FR + (threadIdx.x & 63);
+  rodrigues_bwd_tile(a, tile, sg, [&](int col) { return df_t[(size_t)col * TL_FR]; });   // feat_rows.h
 }
 
 template <bool BWD, int NLOC, int NBL>

@@ -478,6 +478,18 @@ def test_frame_per_lane_path_whole_lgd_forward_and_vjp(big_model):
                         'joints': r['joints'].cpu().numpy(),
                         **{'h_' + k: v.cpu().numpy() for k, v in r['hist'].items()},
                         **{'t_' + k: v.cpu().numpy() for k, v in r['trace'].items()}}
+    # the update / feature row and the Rodrigues reverse folded into the blend GEMMs (option smpl_fuse, the default) are
+    # the same code as the stand-alone kernels (same values up to the compiler's contraction choices in the inlined context)
+    with _Option(b'smpl_tile', 2), _Option(b'smpl_fuse', 0):
+        r = net.forward_tensors(*args, marker_masks=masks, seq_lengths=inp['seq_lengths'].to(DEV), keep_history=True,
+                                keep_gradient_trace=True)
+        torch.cuda.synchronize()
+        unfused = {'pose': r['pose'].cpu().numpy(), 'shape': r['shape'].cpu().numpy(), 'joints': r['joints'].cpu().numpy(),
+                   **{'h_' + k: v.cpu().numpy() for k, v in r['hist'].items()},
+                   **{'t_' + k: v.cpu().numpy() for k, v in r['trace'].items()}}
+    for k, a in unfused.items():
+        np.testing.assert_allclose(res[2][k], a, atol=3e-6 * max(1.0, float(np.abs(a).max())), rtol=1e-5,
+                                   err_msg="fused vs separate kernels: " + k)
     for k, a in res[0].items():
         b = res[2][k]
         assert np.isfinite(b).all(), k
