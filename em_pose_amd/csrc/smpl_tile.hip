@@ -16,10 +16,10 @@
 //     fan order (face k = (centre, ring k, ring k+1)) and its vertices' (bone, weight) lists, so no register array is
 //     ever indexed by a run-time value;
 //   * only what crosses sensors lives in LDS: the 22 joint transforms (written by the chain phase) and the per-bone
-//     force / rest-space moment sums (added by the sensors; sensors that run concurrently touch disjoint bones --
-//     host-made schedule -- so the sums are ordered and reproducible).
-// Phases of a workgroup (4 waves, 64 frames): Rodrigues | chain, level by level | sensors, round by round | reverse
-// chain, deepest level first.  Maths: reference models.py:471-483, 560-579, virtual_sensors.py:16-38, utils.py:126-146,
+//     force / rest-space moment sums (added by the sensors with plain read-add-write IN SENSOR ORDER -- a turn counter
+//     in LDS serialises just that short update -- so the sums are ordered and reproducible).
+// Phases of a workgroup (4 waves with the reverse pass, 8 without; 64 frames): Rodrigues + chain, a wave per limb path |
+// sensors, wave w takes w, w + NW, ... | reverse chain, a wave per limb, then the spine.  Maths: reference models.py:471-483, 560-579, virtual_sensors.py:16-38, utils.py:126-146,
 // loss.py:23-41; reverse pass as in oracle/analytic_np.py (same formulas as chain_sensors_kernel).
 #include "kernels.h"
 #include "smpl_math.h"

@@ -54,7 +54,11 @@ const char* empose_arch(void);
 /* Kernel-variant selection for A/B measurements and bit-identity tests: several paths have two implementations (the
  * one-launch fused update MLPs vs layer-by-layer GEMMs, whole-sequence LSTM kernels vs step launches, ...) that must
  * give the same results.  Options are process-wide ints, default 1 = the faster variant; the library never reads the
- * environment.  Names: "mlp_fused", "lstm_persist", "gemm_splitk", "gemm_wide", "atb_target", "atb_chunk".
+ * environment.  Names: "mlp_fused", "lstm_persist", "gemm_splitk", "gemm_wide", "atb_target", "atb_chunk",
+ * "smpl_tile" (frame-per-lane SMPL sub-mesh kernels: 0 never, 1 from 16384 frames on [default], 2 always),
+ * "smpl_fuse" (on that path: pose / shape update and Rodrigues reverse inside the blend GEMMs; 0 = own kernels),
+ * "train_fused" (train-mode MLP layer with BatchNorm / PReLU folded into the GEMMs: 0 never [default], 1 above 1024
+ * rows, 2 always).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
 int empose_set_option(const char* name, int value);
 int empose_get_option(const char* name);
