@@ -721,7 +721,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"train_fused", &o.train_fused},
+      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -735,7 +735,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"train_fused", o.train_fused},
+      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};
@@ -1804,6 +1804,12 @@ struct TrainLstmWs {
   size_t atb_floats;
   float* ksplit;           // partial tiles of the K-split recurrent product, or nullptr
   size_t ksplit_floats;
+  // the reverse recurrences of two layers as a wavefront (bptt_wave): the upper layer's pre-activation gradients, cell
+  // state cotangent and carry next to the lower layer's, three transposed weight matrices at once
+  int wave = 0;            // 0 no, 1 matrix-vector kernel, 2 K-split tiles
+  float* dgates_up; float* carry_up; float* dc_up;
+  float* wt_hh_up; float* wt_ih_up;
+  float* rec;              // partial tiles of both problems of a wavefront step (K-split form)
 };
 int check_lstm_params(const empose_lstm_params* p) {
   if (!p) return fail(EMPOSE_EINVAL, "null argument");
@@ -1834,6 +1840,18 @@ TrainLstmWs carve_train_lstm(Carver& c, const empose_lstm_params* p, int B, int 
   w.atb = c.f(w.atb_floats + 64);
   w.ksplit_floats = gemm_ksplit_applicable(B, H, 4 * H) ? gemm_ksplit_workspace_floats(B, H, 4 * H) : 0;
   w.ksplit = w.ksplit_floats ? c.f(w.ksplit_floats) : nullptr;
+  w.wave = 0;
+  w.dgates_up = w.carry_up = w.dc_up = w.wt_hh_up = w.wt_ih_up = w.rec = nullptr;
+  if (L == 2 && options().bptt_wave != 0 && (4 * H) % 256 == 0) {
+    if (gemm_fewrows_applicable(B, H, 4 * H) && 4 * H <= 2048) w.wave = 1;
+    else if (w.ksplit_floats && 8 * H / 256 <= 16) w.wave = 2;   // (not the pointer: null while sizes are counted)
+  }
+  if (w.wave) {
+    w.dgates_up = c.f((size_t)B * F * 4 * H);
+    w.carry_up = c.f((size_t)B * H); w.dc_up = c.f((size_t)B * H);
+    w.wt_hh_up = c.f((size_t)H * 4 * H); w.wt_ih_up = c.f((size_t)H * 4 * H);
+    if (w.wave == 2) w.rec = c.f(rec_ksplit_workspace_floats(B, H, 8 * H, 2));
+  }
   return w;
 }
 }  // namespace
@@ -1929,6 +1947,77 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
     g.scale = nullptr; g.shift = nullptr; g.resid = resid; g.ldr = ldr; g.act = 0; g.slope = 0.f;
     return launch_gemm(b, stream);
   };
+  if (w.wave) {
+    // ---- two layers as a wavefront: stage s runs the cell of (layer 1, step s) and of (layer 0, step s + 1).  Both
+    // need only what stage s + 1 left: dh1_s = dG1_{s+1} . W_hh1, and dh0_{s+1} = dG0_{s+2} . W_hh0 + dG1_{s+1} . W_ih1
+    // -- the cotangent of layer 0's output, which the layer-after-layer form gets from one batched product over all
+    // steps afterwards, is the second K segment of layer 0's recurrent product here.  F + 1 stages of one launch (or
+    // one launch pair) instead of 2 F; the batched dX product of layer 1 disappears.
+    hipError_t e = launch_transpose(p->w_hh[1], H, w.wt_hh_up, 4 * H, 4 * H, H, stream);
+    if (e == hipSuccess) e = launch_transpose(p->w_ih[1], H, w.wt_ih_up, 4 * H, 4 * H, H, stream);
+    if (e == hipSuccess) e = launch_transpose(p->w_hh[0], H, w.wt, 4 * H, 4 * H, H, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(w.dc, 0, bh * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(w.dc_up, 0, bh * sizeof(float), stream));
+    auto cell_of = [&](int l, int t) {
+      const float* sv = save + (size_t)l * 7 * bfh;
+      LstmCellBwdArgs ca;
+      ca.gates = sv; ca.c_all = sv + 4 * bfh; ca.c0 = c0 ? c0 + l * bh : nullptr;
+      ca.dy = l == 1 ? dy : nullptr; ca.ld_dy = H; ca.dh_in = nullptr;
+      ca.dc = l == 1 ? w.dc_up : w.dc; ca.dgates = l == 1 ? w.dgates_up : w.dgates;
+      ca.dh_carry = l == 1 ? w.carry_up : w.carry;
+      ca.seq_lengths = seq_lengths; ca.B = B; ca.F = F; ca.H = H; ca.t = t;
+      return ca;
+    };
+    e = launch_lstm_cell_bwd(cell_of(1, F - 1), stream);   // stage F - 1: nothing flows into the last step of the top layer
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm cell backward: %s", hipGetErrorString(e));
+    for (int s = F - 2; s >= -1; --s) {
+      RecBatch rb;
+      LstmCellBwdArgs cells[2];
+      rb.count = 0;
+      if (s >= 0) {   // (layer 1, step s)
+        RecProb& q = rb.p[rb.count];
+        q.nseg = 1; q.seg[0] = RecSeg{w.dgates_up + (size_t)(s + 1) * 4 * H, F * 4 * H, w.wt_hh_up, 4 * H, 4 * H};
+        q.M = B; q.N = H; q.resid = w.carry_up; q.ldr = H;
+        cells[rb.count++] = cell_of(1, s);
+      }
+      {               // (layer 0, step s + 1)
+        const int t0 = s + 1;
+        RecProb& q = rb.p[rb.count];
+        q.nseg = 0;
+        if (t0 + 1 <= F - 1) q.seg[q.nseg++] = RecSeg{w.dgates + (size_t)(t0 + 1) * 4 * H, F * 4 * H, w.wt, 4 * H, 4 * H};
+        q.seg[q.nseg++] = RecSeg{w.dgates_up + (size_t)t0 * 4 * H, F * 4 * H, w.wt_ih_up, 4 * H, 4 * H};
+        q.M = B; q.N = H; q.resid = t0 + 1 <= F - 1 ? w.carry : nullptr; q.ldr = H;
+        cells[rb.count++] = cell_of(0, t0);
+      }
+      e = w.wave == 2 ? launch_rec_ksplit(rb, cells, w.rec, stream) : launch_rec_fewrows(rb, cells, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward (wavefront): %s", hipGetErrorString(e));
+    }
+    // ---- the batched products: weight gradients of both layers, the input cotangent of layer 0
+    for (int l = 1; l >= 0; --l) {
+      const float* sv = save + (size_t)l * 7 * bfh;
+      const int in_l = l == 0 ? p->input_size : H;
+      const float* x_l = l == 0 ? x : save + 6 * bfh;
+      const int ldx_l = l == 0 ? ldx : H;
+      float* dg = l == 1 ? w.dgates_up : w.dgates;
+      AtbArgs ab{};
+      ab.A = dg; ab.lda = 4 * H; ab.B = x_l; ab.ldb = ldx_l; ab.C = grads->w_ih[l]; ab.ldc = in_l;
+      ab.bias = grads->b_ih[l]; ab.M = B * F; ab.N = 4 * H; ab.K = in_l;
+      e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_ih: %s", hipGetErrorString(e));
+      HIP_TRY(hipMemcpyAsync(grads->b_hh[l], grads->b_ih[l], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      ab.B = sv + 5 * bfh; ab.ldb = H; ab.C = grads->w_hh[l]; ab.ldc = H; ab.bias = nullptr; ab.K = H;
+      e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW_hh: %s", hipGetErrorString(e));
+    }
+    if (dx) {
+      e = launch_transpose(p->w_ih[0], p->input_size, w.wt, 4 * H, 4 * H, p->input_size, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+      e = gemm(w.dgates, 4 * H, w.wt, 4 * H, dx, p->input_size, B * F, p->input_size, 4 * H, nullptr, 0);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "dX gemm: %s", hipGetErrorString(e));
+    }
+    return EMPOSE_OK;
+  }
   for (int l = L - 1; l >= 0; --l) {
     const float* sv = save + (size_t)l * 7 * bfh;
     const int in_l = l == 0 ? p->input_size : H;

@@ -971,6 +971,236 @@ hipError_t launch_gemm_fewrows_cell(const GemmProb& p, const LstmCellBwdArgs& ce
   return launch_fewrows(b, stream, &cell);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two recurrent-product kernels above for a wavefront step of back-propagation through time (kernels.h RecBatch):
+// up to two problems per launch, each a sum over up to two K segments, each followed by its own LSTM cell.  The
+// arithmetic of a problem with ONE segment is that of the single-problem kernels (same slices, same order).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rec_ksplit_kernel(RecBatch b, float* partial, int tiles, int s_max) {
+  using namespace ks;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sA = sm;
+  float* sW = sm + BT * LDK;
+  const RecProb& p = b.p[blockIdx.z];
+  const int M = p.M, N = p.N;
+  const int nt_n = (N + BT - 1) / BT;
+  const int tile = blockIdx.x, m0 = (tile / nt_n) * BT, n0 = (tile % nt_n) * BT;
+  // slice -> (segment, k0): the slices of segment 0 first
+  const int s0 = (p.seg[0].K + KS - 1) / KS;
+  const int s_tot = s0 + (p.nseg > 1 ? (p.seg[1].K + KS - 1) / KS : 0);
+  if ((int)blockIdx.y >= s_tot) return;
+  const bool second = (int)blockIdx.y >= s0;
+  const RecSeg& sg = p.seg[second ? 1 : 0];
+  const int k0 = ((int)blockIdx.y - (second ? s0 : 0)) * KS, K = sg.K;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {
+    f32x4 va[16], vw[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = tid + u * 256, r = i >> 6, c = (i & 63) * 4;
+      const bool kin = k0 + c < K;   // K % 4 == 0
+      va[u] = kin ? *reinterpret_cast<const f32x4*>(sg.A + (size_t)min(m0 + r, M - 1) * sg.lda + k0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      vw[u] = kin ? *reinterpret_cast<const f32x4*>(sg.W + (size_t)min(n0 + r, N - 1) * sg.ldw + k0 + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = tid + u * 256, r = i >> 6, c = (i & 63) * 4;
+      *reinterpret_cast<f32x4*>(sA + r * LDK + c) = va[u];
+      *reinterpret_cast<f32x4*>(sW + r * LDK + c) = vw[u];
+    }
+  }
+  __syncthreads();
+  const int mq = (wave >> 1) * 32, nq = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ar = sA + (mq + l31) * LDK + lh * 4;
+  const float* wr = sW + (nq + l31) * LDK + lh * 4;
+#pragma unroll 8
+  for (int g = 0; g < KS / 8; ++g) {
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(ar + g * 8);
+    const f32x4 fb = *reinterpret_cast<const f32x4*>(wr + g * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+  }
+  // [problem][slice][tile][wave][reg][lane]
+  float* pt = partial + ((((size_t)blockIdx.z * s_max + blockIdx.y) * tiles + tile) * 4 + wave) * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pt[r * 64 + lane] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void rec_ksplit_reduce_kernel(RecBatch b, const float* partial, int tiles, int s_max,
+                                                                LstmCellBwdArgs cell0, LstmCellBwdArgs cell1) {
+  using namespace ks;
+  const RecProb& p = b.p[blockIdx.y];
+  const LstmCellBwdArgs& cell = blockIdx.y == 0 ? cell0 : cell1;
+  const int M = p.M, N = p.N;
+  const int nt_n = (N + BT - 1) / BT;
+  const int S = (p.seg[0].K + KS - 1) / KS + (p.nseg > 1 ? (p.seg[1].K + KS - 1) / KS : 0);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)tiles * 4096) return;
+  const float* base = partial + (size_t)blockIdx.y * s_max * tiles * 4096 + idx;
+  float ps[KSPLIT_MAX_S];
+#pragma unroll
+  for (int s2 = 0; s2 < KSPLIT_MAX_S; ++s2) ps[s2] = s2 < S ? base[(size_t)s2 * tiles * 4096] : 0.f;
+  float v = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < KSPLIT_MAX_S; ++s2) v += ps[s2];
+  const int tile = (int)(idx >> 12), wave = (int)(idx >> 10) & 3, r = (int)(idx >> 6) & 15, lane = (int)idx & 63;
+  const int m0 = (tile / nt_n) * BT, n0 = (tile % nt_n) * BT;
+  const int mq = (wave >> 1) * 32, nq = (wave & 1) * 32, l31 = lane & 31, lh = lane >> 5;
+  const int row = m0 + mq + (r & 3) + 8 * (r >> 2) + 4 * lh, n = n0 + nq + l31;
+  if (row >= M || n >= N) return;
+  float y = v;
+  if (p.resid) y += p.resid[(size_t)row * p.ldr + n];
+  lstm_cell_bwd_elem(cell, row * cell.H + n, y);
+}
+
+size_t rec_ksplit_workspace_floats(int M, int N, int K_total_max, int count) {
+  const size_t tiles = (size_t)((M + ks::BT - 1) / ks::BT) * ((N + ks::BT - 1) / ks::BT);
+  const size_t S = (K_total_max + ks::KS - 1) / ks::KS;
+  return (size_t)count * tiles * S * 4096 + 64;
+}
+
+hipError_t launch_rec_ksplit(const RecBatch& b, const LstmCellBwdArgs* cells, float* workspace, hipStream_t stream) {
+  int tiles = 0, s_max = 0;
+  for (int i = 0; i < b.count; ++i) {
+    const RecProb& p = b.p[i];
+    int s = 0;
+    for (int g = 0; g < p.nseg; ++g) {
+      if (p.seg[g].K % ks::KS != 0) return hipErrorInvalidValue;
+      s += p.seg[g].K / ks::KS;
+    }
+    if (s > KSPLIT_MAX_S || p.nseg < 1 || p.nseg > 2) return hipErrorInvalidValue;
+    s_max = s > s_max ? s : s_max;
+    const int t = ((p.M + ks::BT - 1) / ks::BT) * ((p.N + ks::BT - 1) / ks::BT);
+    if (i > 0 && t != tiles) return hipErrorInvalidValue;   // the problems of a wavefront step share M and N
+    tiles = t;
+  }
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec_ksplit_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(rec_ksplit_kernel, dim3(tiles, s_max, b.count), dim3(256), ks::LDS_BYTES, stream, b, workspace, tiles,
+                     s_max);
+  hipLaunchKernelGGL(rec_ksplit_reduce_kernel, dim3(tiles * 16, b.count), dim3(256), 0, stream, b, (const float*)workspace,
+                     tiles, s_max, cells[0], cells[b.count > 1 ? 1 : 0]);
+  return hipGetLastError();
+}
+
+template <int MB>
+__global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBwdArgs cell0, LstmCellBwdArgs cell1) {
+  extern __shared__ __attribute__((aligned(16))) float arow[];   // [MB][K of the segment]
+  const RecProb& p = b.p[blockIdx.y];
+  const LstmCellBwdArgs& cell = blockIdx.y == 0 ? cell0 : cell1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.x * 4 + wave;
+  const int M = p.M, N = p.N;
+  constexpr int WMAX = 8;   // a segment's K <= 64 lanes x 4 x 8 = 2048
+  float acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = 0.f;
+  for (int g = 0; g < p.nseg; ++g) {
+    const RecSeg& sg = p.seg[g];
+    const int K = sg.K, k4n = K >> 2;
+    if (g > 0) __syncthreads();   // every wave is done with the previous segment's rows
+    // this wave's weight row first: its 16-byte pieces are in flight while the rows of A are staged
+    const float* __restrict__ wrow = sg.W + (size_t)(n < N ? n : N - 1) * sg.ldw;
+    f32x4 w[WMAX];
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) {
+      const int k4 = j * 256 + lane * 4;
+      w[j] = k4 < K ? *reinterpret_cast<const f32x4*>(wrow + k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const float* __restrict__ A = sg.A;
+      constexpr int SB = 8;
+      int m = (int)threadIdx.x / k4n, c = (int)threadIdx.x - m * k4n;   // k4n >= 256: a step of 256 wraps at most once
+      for (int i0 = threadIdx.x; i0 < MB * k4n; i0 += 256 * SB) {
+        f32x4 v[SB];
+        int mu[SB], cu[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          mu[u] = m; cu[u] = c;
+          const int mr = m < M ? m : M - 1;
+          v[u] = *reinterpret_cast<const f32x4*>(A + (size_t)mr * sg.lda + (c < k4n ? c : 0) * 4);
+          if (m >= M) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          c += 256;
+          if (c >= k4n) { c -= k4n; ++m; }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+          if (mu[u] < MB) *reinterpret_cast<f32x4*>(arow + (size_t)mu[u] * K + cu[u] * 4) = v[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WMAX; ++j) {
+      const int k4 = j * 256 + lane * 4;
+      const int kk = k4 < K ? k4 : 0;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (size_t)m * K + kk);
+        acc[m] = __builtin_fmaf(a[3], w[j][3], __builtin_fmaf(a[2], w[j][2], __builtin_fmaf(a[1], w[j][1], __builtin_fmaf(a[0], w[j][0], acc[m]))));
+      }
+    }
+  }
+  if (n >= N) return;
+  float out = 0.f;   // lane m ends up with row m
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == m) out = v;
+  }
+  if (lane < M) {
+    float y = out;
+    if (p.resid) y += p.resid[(size_t)lane * p.ldr + n];
+    lstm_cell_bwd_elem(cell, lane * cell.H + n, y);
+  }
+}
+
+template <int MB>
+static hipError_t launch_rec_fewrows_cfg(const RecBatch& b, const LstmCellBwdArgs* cells, int maxN, int maxK,
+                                         hipStream_t stream) {
+  const size_t lds = (size_t)MB * maxK * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec_fewrows_kernel<MB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FEWROWS_MAX_LDS);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(rec_fewrows_kernel<MB>, dim3((maxN + 3) / 4, b.count), dim3(256), lds, stream, b, cells[0],
+                     cells[b.count > 1 ? 1 : 0]);
+  return hipGetLastError();
+}
+
+hipError_t launch_rec_fewrows(const RecBatch& b, const LstmCellBwdArgs* cells, hipStream_t stream) {
+  int maxN = 0, maxM = 0, maxK = 0;
+  for (int i = 0; i < b.count; ++i) {
+    const RecProb& p = b.p[i];
+    if (p.nseg < 1 || p.nseg > 2) return hipErrorInvalidValue;
+    for (int g = 0; g < p.nseg; ++g) {
+      if (p.seg[g].K < 1024 || p.seg[g].K > 2048 || p.seg[g].K % 4 != 0) return hipErrorInvalidValue;
+      maxK = p.seg[g].K > maxK ? p.seg[g].K : maxK;
+    }
+    maxN = p.N > maxN ? p.N : maxN;
+    maxM = p.M > maxM ? p.M : maxM;
+  }
+  if (maxM > FEWROWS_MAX_M) return hipErrorInvalidValue;
+  if (maxM <= 4) return launch_rec_fewrows_cfg<4>(b, cells, maxN, maxK, stream);
+  if (maxM <= 8) return launch_rec_fewrows_cfg<8>(b, cells, maxN, maxK, stream);
+  if (maxM <= 12) return launch_rec_fewrows_cfg<12>(b, cells, maxN, maxK, stream);
+  return launch_rec_fewrows_cfg<16>(b, cells, maxN, maxK, stream);
+}
+
 enum GemmPick { PICK_S11, PICK_S12, PICK_S21, PICK_WIDE, PICK_LARGE, PICK_SPLITK, PICK_FEWROWS };
 
 static GemmPick pick_gemm(const GemmBatch& batch) {

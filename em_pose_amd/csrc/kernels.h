@@ -16,6 +16,7 @@ struct Options {
   int mlp_fused = 1;      // one-launch LDS-resident update MLPs (0: layer by layer)
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
+  int bptt_wave = 1;      // training: the reverse recurrences of a 2-layer LSTM as a wavefront (0: layer after layer)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
   int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 16384 frames on, 2 always
   int smpl_fuse = 1;      // on that path: update + feature row / Rodrigues reverse inside the blend GEMMs (0: own kernels)
@@ -60,6 +61,19 @@ hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t s
 // At most 16 rows: the matrix-vector kernel, same epilogue.
 bool gemm_fewrows_applicable(int M, int N, int K);
 hipError_t launch_gemm_fewrows_cell(const GemmProb& p, const LstmCellBwdArgs& cell, hipStream_t stream);
+
+// Back-propagation through time as a wavefront over the layers: one launch forms the incoming hidden-state cotangent
+// of up to two (layer, step) units and runs their cells.  A unit's product may have two K segments with their own
+// operands -- dh0_t = dG0_{t+1} . W_hh0 + dG1_t . W_ih1 is one K = 8H product over the rows [dG0_{t+1} | dG1_t] that
+// are never concatenated in memory.  C = sum_seg A_seg . W_seg^T (+ resid); the unit's cell consumes it.
+struct RecSeg { const float* A; int lda; const float* W; int ldw; int K; };   // A [M][lda], W [N][ldw], K % 4 == 0
+struct RecProb { RecSeg seg[2]; int nseg; int M, N; const float* resid; int ldr; };
+struct RecBatch { RecProb p[2]; int count; };
+size_t rec_ksplit_workspace_floats(int M, int N, int K_total_max, int count);
+// K-split tiles (a few hundred rows; every segment's K a multiple of 256) / matrix-vector kernel (<= 16 rows, every
+// segment's K in [1024, 2048]); cells[i] is the cell of problem i.
+hipError_t launch_rec_ksplit(const RecBatch& b, const LstmCellBwdArgs* cells, float* workspace, hipStream_t stream);
+hipError_t launch_rec_fewrows(const RecBatch& b, const LstmCellBwdArgs* cells, hipStream_t stream);
 
 // C[M][N] = A . W^T (+ bias) with strided operands: A(m, k) = A[m * a_rs + k * a_ks], W(n, k) = W[n * w_rs + k * w_ks]
 // (small problems only, split-K tile; `strided_gemm_applicable`).

@@ -1408,7 +1408,9 @@ def test_linear_train_large_batch_vs_torch_autograd(M, K, N):
 @pytest.mark.parametrize('B,F,K,H,L,ragged,carry', [(12, 32, 144, 512, 2, False, False), (5, 9, 72, 64, 2, True, True),
                                                     (40, 16, 144, 128, 1, True, False), (300, 8, 144, 256, 2, False, True),
                                                     (3, 4, 8, 16, 3, True, False),
-                                                    (256, 5, 144, 512, 2, True, True)])   # K-split recurrent products
+                                                    (256, 5, 144, 512, 2, True, True),    # K-split recurrent products
+                                                    (12, 6, 144, 256, 2, True, True),     # wavefront, matrix-vector form
+                                                    (130, 3, 16, 128, 2, True, False)])   # wavefront, K-split form
 def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
     """empose_lstm_train_fwd/bwd (all three step kernels: B <= 16, <= 256, larger) against torch.nn.LSTM over packed
     sequences with autograd, in float64 on the CPU: outputs, final state, dx and every parameter gradient."""

@@ -521,3 +521,33 @@ def test_frame_per_lane_path_whole_lgd_forward_and_vjp(big_model):
             out[opt] = (g_th.cpu().numpy(), g_be.cpu().numpy())
     for a, b in zip(out[0], out[2]):
         np.testing.assert_allclose(b, a, atol=2e-4 * max(1.0, float(np.abs(a).max())), rtol=1e-3)
+
+
+@pytest.mark.parametrize('B,F,H', [(12, 32, 512), (256, 7, 512), (9, 5, 256)])
+def test_reverse_lstm_wavefront_equals_layer_after_layer(B, F, H):
+    """Back-propagation through time of the 2-layer LSTM as a wavefront over the layers (option bptt_wave, default) against
+    the layer-after-layer form: same gradients up to summation order (layer 0's output cotangent is a second K segment
+    of its recurrent product instead of a batched product afterwards)."""
+    from em_pose_amd.nn.layers import _LstmTrainFn
+    torch.manual_seed(B + F)
+    K, L = 144, 2
+    ref = torch.nn.LSTM(K, H, L)
+    weights = [getattr(ref, '%s_l%d' % (n, l)).detach() for l in range(L)
+               for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    x = torch.randn(B, F, K)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0] = F
+    h0, c0 = 0.5 * torch.randn(L, B, H), 0.5 * torch.randn(L, B, H)
+    dy = torch.randn(B, F, H)
+    out = {}
+    for opt in (0, 1):
+        with _Option(b'bptt_wave', opt):
+            wg = [w.clone().to(DEV).requires_grad_(True) for w in weights]
+            xg = x.clone().to(DEV).requires_grad_(True)
+            y, h_n, c_n = _LstmTrainFn.apply(xg, lens.to(DEV, torch.int32), h0.to(DEV), c0.to(DEV), L, *wg)
+            (y * dy.to(DEV)).sum().backward()
+            torch.cuda.synchronize()
+            out[opt] = [xg.grad.cpu().numpy()] + [g.grad.cpu().numpy() for g in wg]
+    for a, b in zip(out[0], out[1]):
+        assert np.isfinite(b).all()
+        np.testing.assert_allclose(b, a, atol=2e-5 * max(1.0, float(np.abs(a).max())), rtol=1e-4)
