@@ -65,7 +65,8 @@ class LgdIO(C.Structure):
                 ('pose_hat', C.c_void_p), ('shape_hat', C.c_void_p), ('joints_hat', C.c_void_p),
                 ('hist_pose', C.c_void_p), ('hist_shape', C.c_void_p), ('hist_joints', C.c_void_p),
                 ('hist_markers', C.c_void_p), ('hist_markers_ori', C.c_void_p),
-                ('trace_g_pose', C.c_void_p), ('trace_g_shape', C.c_void_p)]
+                ('trace_g_pose', C.c_void_p), ('trace_g_shape', C.c_void_p),
+                ('suppress_missing', C.c_int), ('mask_value', C.c_float)]
 
 
 class LstmParams(C.Structure):   # empose_lstm_params: DEVICE pointers
@@ -121,6 +122,7 @@ SIGNATURES = {
     'empose_model_destroy': (None, [C.c_void_p]),
     'empose_lgd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     'empose_lgd_forward': (C.c_int, [C.c_void_p, C.POINTER(LgdIO), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'empose_lgd_forward_phase': (C.c_int, [C.c_void_p, C.POINTER(LgdIO), C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]),
     'empose_smpl_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'empose_smpl_sensors_fwd_bwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -743,7 +743,7 @@ int empose_get_option(const char* name) {
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;
 }
-int empose_version(void) { return 1; }
+int empose_version(void) { return 2; }   // 2: empose_lgd_io gained suppress_missing / mask_value
 const char* empose_arch(void) { return "gfx950"; }
 
 int empose_profile_enable(int on) {
@@ -966,7 +966,13 @@ size_t empose_lgd_workspace_bytes(const empose_model_t* m, int B, int F) {
 
 int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
                        empose_stream_t stream_) {
+  return empose_lgd_forward_phase(m, io, workspace, workspace_bytes, stream_, EMPOSE_LGD_PHASE_INIT | EMPOSE_LGD_PHASE_ITER);
+}
+
+int empose_lgd_forward_phase(const empose_model_t* m, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
+                             empose_stream_t stream_, int phases) {
   if (!m || !io || !workspace) return fail(EMPOSE_EINVAL, "null argument");
+  if (phases < 1 || phases > 3) return fail(EMPOSE_EINVAL, "phases: EMPOSE_LGD_PHASE_INIT, _ITER or both");
   if (m->smpl_only) return fail(EMPOSE_EINVAL, "this handle holds the body model only (no networks)");
   const int B = io->B, F = io->F;
   if (B <= 0 || F <= 0) return fail(EMPOSE_EINVAL, "B and F must be positive");
@@ -984,11 +990,13 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
   float* x_gtheta = w.x + din + 76;
   float* x_gbeta = w.x + din + 142;
 
+  if (phases & EMPOSE_LGD_PHASE_INIT) {
   PackArgs pa;
   pa.marker_pos = io->marker_pos; pa.marker_oris = io->marker_oris; pa.marker_masks = io->marker_masks;
   pa.seq_lengths = io->seq_lengths; pa.x = w.x; pa.ldx = dx; pa.frame_scale = w.scale;
   pa.B = B; pa.F = F; pa.n_markers = m->n_markers;
   pa.rows_as_unpadded = (m->shape_avg == 2) ? 1 : 0;
+  pa.suppress_missing = io->suppress_missing; pa.mask_value = io->mask_value;
   for (int i = 0; i < 12; ++i) pa.marker_idx[i] = m->marker_idx[i];
   prof_mark(P_PACK, stream);
   hipError_t e = launch_pack_inputs(pa, stream);
@@ -1014,7 +1022,10 @@ int empose_lgd_forward(const empose_model_t* m, const empose_lgd_io* io, void* w
     const int lds[2] = {dx, 10};
     TRY(run_mlps(nets, 2, outs, lds, w.x, dx, T, w.upd, m->hidden_max, stream, true));
   }
+  }   // EMPOSE_LGD_PHASE_INIT
+  if (!(phases & EMPOSE_LGD_PHASE_ITER)) return EMPOSE_OK;
 
+  hipError_t e = hipSuccess;
   const int N = m->N;
   auto hist = [&](float* base, int i, size_t width) -> float* { return base ? base + (size_t)i * T * width : nullptr; };
   for (int i = 0; i <= N; ++i) {

@@ -373,6 +373,8 @@ struct PackArgs {
   int B, F, n_markers;
   int marker_idx[12];
   int rows_as_unpadded = 0;   // 1: a ragged row counts as an unpadded window of its own length
+  int suppress_missing = 0;   // 1: readings of sensors whose mask is not 1 are replaced by mask_value (the
+  float mask_value = 0.f;     //    arithmetic of reference data/data.py:284-302: x * valid + mask_value * !valid)
 };
 hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream);
 

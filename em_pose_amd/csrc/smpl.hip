@@ -45,13 +45,20 @@ __global__ void pack_inputs_kernel(PackArgs a) {
     return;
   }
   float v;
+  int marker;
   if (c < a.n_markers * 3) {
     const int mi = c / 3, k = c % 3;
-    v = a.marker_pos[(size_t)t * 36 + a.marker_idx[mi] * 3 + k];
+    marker = a.marker_idx[mi];
+    v = a.marker_pos[(size_t)t * 36 + marker * 3 + k];
   } else {
     const int cc = c - a.n_markers * 3;
     const int mi = cc / 9, k = cc % 9;
-    v = a.marker_oris[(size_t)t * 108 + a.marker_idx[mi] * 9 + k];
+    marker = a.marker_idx[mi];
+    v = a.marker_oris[(size_t)t * 108 + marker * 9 + k];
+  }
+  if (a.suppress_missing && a.marker_masks) {   // the reference's arithmetic, so that a NaN reading stays a NaN
+    const bool valid = a.marker_masks[(size_t)t * 12 + marker] == 1.f;
+    v = v * (valid ? 1.f : 0.f) + (0.f + a.mask_value) * (valid ? 0.f : 1.f);
   }
   a.x[(size_t)t * a.ldx + c] = v;
 }

@@ -123,9 +123,19 @@ class RealBatch(ABatch):
     def to_gpu(self, device=None):
         device = C.DEVICE if device is None else device
         self.seq_lengths = self.seq_lengths.to(dtype=torch.int, device=device)
-        for name in ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes',
-                     'trans', 'offset_t', 'offset_r'):
-            setattr(self, name, getattr(self, name).to(dtype=C.DTYPE, device=device))
+        names = ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes',
+                 'trans', 'offset_t', 'offset_r')
+        fields = [getattr(self, name) for name in names]
+        if torch.device(device).type == 'cuda' and all(not f.is_cuda for f in fields):
+            # host fields: ONE staged copy (nine separate blocking copies of a 256-frame chunk cost more than its forward)
+            flat = torch.cat([f.reshape(-1).to(C.DTYPE) for f in fields]).to(device)
+            at = 0
+            for name, f in zip(names, fields):
+                setattr(self, name, flat[at:at + f.numel()].view(f.shape))
+                at += f.numel()
+            return self
+        for name, f in zip(names, fields):
+            setattr(self, name, f.to(dtype=C.DTYPE, device=device))
         return self
 
     def _suppress_missing_markers(self, mask_value):
@@ -142,11 +152,20 @@ class RealBatch(ABatch):
         self.marker_normal_real = _mask(self.marker_normal_real)
 
     def get_inputs(self, sf=None, ef=None, **kwargs):
-        self._suppress_missing_markers(kwargs.get('mask_value', 0.0))
+        """`suppress_on_device=True` (the LGD model on the GPU asks for it): the readings are handed over as they are
+        together with `mask_value`, and the model's input packing kernel replaces the missing ones -- the same values
+        without the dozen small device kernels of `_suppress_missing_markers` per chunk."""
+        mask_value = kwargs.get('mask_value', 0.0)
+        on_device = bool(kwargs.get('suppress_on_device', False))
+        if not on_device:
+            self._suppress_missing_markers(mask_value)
         joints = self.joints_hat[:, sf:ef] if self.joints_hat is not None else None
-        return {'marker_pos': self.marker_pos_real[:, sf:ef], 'marker_oris': self.marker_ori_real[:, sf:ef],
-                'marker_normals': self.marker_normal_real[:, sf:ef], 'joints': joints,
-                'offset_t': self.offset_t, 'offset_r': self.offset_r, 'marker_masks': self.marker_masks[:, sf:ef]}
+        out = {'marker_pos': self.marker_pos_real[:, sf:ef], 'marker_oris': self.marker_ori_real[:, sf:ef],
+               'marker_normals': self.marker_normal_real[:, sf:ef], 'joints': joints,
+               'offset_t': self.offset_t, 'offset_r': self.offset_r, 'marker_masks': self.marker_masks[:, sf:ef]}
+        if on_device:
+            out['suppress_mask_value'] = float(mask_value)
+        return out
 
 
 class SyntheticBatch(ABatch):

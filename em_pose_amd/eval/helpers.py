@@ -139,6 +139,14 @@ def partition_sequences(lengths, world_size):
     return [sorted(p) for p in parts]
 
 
+class _nothing(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=None):
     """
     :param batches: iterable of single-recording `RealBatch`es (root already normalised), on the CPU.
@@ -149,26 +157,52 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
     per_sequence, frames = [], 0
     is_lgd = isinstance(net, IterativeErrorFeedback)
     ws = window_size if is_lgd else None
-    for batch in batches:
-        if log:
-            log('Evaluate {} ({} frames)'.format(batch.ids[0], int(batch.seq_lengths[0])))
-        first_shape_hat = None
-        me_ind.reset()
-        # (Staging the whole recording on the device once and slicing views was measured slower: recordings have 36
-        # different lengths, and every new size costs the caching allocator a ~50 ms hipMalloc/hipFree round.)
-        for c, chunk in enumerate(window_generator(batch, ws)):
-            n_frames = int(chunk.seq_lengths.sum())   # read while the lengths are still on the host
-            chunk = chunk.to_gpu(device)
-            out = net(chunk, is_new_sequence=(c == 0))
-            if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
-                first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
-            # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once per chunk into
-            # the recording's engine (its rows stay on the device until the recording is done), merge once per recording
-            me_ind.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
-                           chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
-            frames += n_frames
-        me_all.merge(me_ind.state())
-        per_sequence.append((batch.ids[0], me_ind.get_metrics()))
+    # Chunks of a recording depend on each other only through the LSTM state, so chunk c + 1's packing + LSTM (current
+    # stream) runs beside chunk c's refinement iterations and metrics (a side stream, IterativeErrorFeedback.iter_stream).
+    # Same results as one chunk after the other.
+    dev = torch.device(device)
+    pipelined = is_lgd and dev.type == 'cuda' and not net.training
+    side = None
+    if pipelined:
+        # one side stream per network, kept: a fresh stream per call may land on the hardware queue of the current
+        # stream (measured: the first pass pipelined, later passes with their new streams did not)
+        side = getattr(net, '_side_stream', None)
+        if side is None or side.device != dev:
+            side = net._side_stream = torch.cuda.Stream(device=dev)
+        net.iter_stream = side
+    try:
+        for batch in batches:
+            if log:
+                log('Evaluate {} ({} frames)'.format(batch.ids[0], int(batch.seq_lengths[0])))
+            first_shape_hat = None
+            me_ind.reset()
+            # (Staging the whole recording on the device once and slicing views was measured slower: recordings have 36
+            # different lengths, and every new size costs the caching allocator a ~50 ms hipMalloc/hipFree round.)
+            for c, chunk in enumerate(window_generator(batch, ws)):
+                frames += int(chunk.seq_lengths.sum())   # read while the lengths are still on the host
+                # the frames that count, while lengths and masks are still on the host (no device kernels for it)
+                valid = MetricsEngine.valid_frames(chunk.seq_lengths, chunk.batch_size, chunk.seq_length,
+                                                   chunk.marker_masks)
+                chunk = chunk.to_gpu(device)
+                out = net(chunk, is_new_sequence=(c == 0))
+                with torch.cuda.stream(side) if side is not None else _nothing():
+                    if side is not None:   # the chunk lives in memory of the current stream's pool
+                        for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
+                            t.record_stream(side)
+                    if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
+                        first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
+                    # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once per chunk
+                    # into the recording's engine (its rows stay on the device until the recording is done), merge once
+                    # per recording
+                    me_ind.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
+                                   chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks, valid=valid)
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)   # the recording's rows are complete
+            me_all.merge(me_ind.state())
+            per_sequence.append((batch.ids[0], me_ind.get_metrics()))
+    finally:
+        if pipelined:
+            net.iter_stream = None
     return me_all, per_sequence, frames
 
 

@@ -109,6 +109,12 @@ class MetricsEngine(object):
 
     # ---- accumulation -------------------------------------------------------------------------------------------
     @staticmethod
+    def valid_frames(seq_lengths, n, f, frame_mask=None):
+        """The frames `compute` counts -- inside the sequence and with every sensor present -- from host tensors."""
+        return MetricsEngine._mask(seq_lengths.cpu() if seq_lengths is not None else None, n, f,
+                                   frame_mask.cpu() if frame_mask is not None else None, 'cpu')
+
+    @staticmethod
     def _mask(seq_lengths, n, f, frame_mask, device):
         if seq_lengths is not None:
             mask = torch.arange(f, device=seq_lengths.device)[None, :] < seq_lengths.reshape(-1, 1)
@@ -172,11 +178,13 @@ class MetricsEngine(object):
             self._add_eucl(js, js_hat)
 
     def compute(self, pose, shape, pose_hat, shape_hat=None, seq_lengths=None, pose_root=None, pose_root_hat=None,
-                frame_mask=None):
-        """Same arguments as the reference (metrics.py:183-241)."""
+                frame_mask=None, valid=None):
+        """Same arguments as the reference (metrics.py:183-241).  `valid` (optional, bool (n, f), any device): the
+        frames that count, for a caller that already has `seq_lengths` / `frame_mask` on the host (`valid_frames`) --
+        the device path then launches nothing for the mask."""
         n, f = pose.shape[0], pose.shape[1]
         shape_hat = shape if shape_hat is None else shape_hat
-        mask = self._mask(seq_lengths, n, f, frame_mask, pose.device)
+        mask = valid if valid is not None else self._mask(seq_lengths, n, f, frame_mask, pose.device)
         if pose.is_cuda and self.angle_glob and hasattr(self.smpl_model, 'fk_joints'):
             # device path (SURVEY.md 8f-1): joints-only forward kinematics + one metrics kernel over ALL n * f frames;
             # the valid rows are picked when the accumulators are read (`_flush`), so nothing here waits for the
@@ -186,10 +194,14 @@ class MetricsEngine(object):
             zeros = torch.zeros(n * f, 3, dtype=pose.dtype, device=pose.device)
             root_f = zeros if pose_root is None else flat(pose_root)
             root_hat_f = zeros if pose_root is None else flat(pose_root_hat)
-            kp3d = self.smpl_model.fk_joints(flat(pose), per_frame(shape), poses_root=root_f)
-            kp3d_hat = self.smpl_model.fk_joints(flat(pose_hat), per_frame(shape_hat), poses_root=root_hat_f)
-            self._add_device_rows(kp3d, kp3d_hat, flat(pose), flat(pose_hat), valid=mask.reshape(n * f))
+            # ground truth and estimate through ONE forward-kinematics launch
+            both = self.smpl_model.fk_joints(torch.cat([flat(pose), flat(pose_hat)]),
+                                             torch.cat([per_frame(shape), per_frame(shape_hat)]),
+                                             poses_root=torch.cat([root_f, root_hat_f]))
+            self._add_device_rows(both[:n * f], both[n * f:], flat(pose), flat(pose_hat), valid=mask.reshape(n * f))
             return
+        if valid is not None:
+            mask = mask.to(pose.device)
         if mask.sum() == 0:
             return
 

@@ -220,7 +220,7 @@ class BaseModel(nn.Module):
                 for _, key, width in feats]
         return cols[0] if len(cols) == 1 else torch.cat(cols, dim=-1)
 
-    def window_generator(self, batch, window_size):
+    def window_generator(self, batch, window_size, **input_options):
         """The batch as one piece (window_size None: every caller in the tree), or cut along time into pieces of
         `window_size` frames with a fresh one-entry `seq_lengths` -- valid for batch size 1 only, like the reference's
         (models.py:146-163)."""
@@ -232,7 +232,8 @@ class BaseModel(nn.Module):
             pieces = [(sf, min(sf + window_size, total), one(min(sf + window_size, total) - sf))
                       for sf in range(0, total, window_size)]
         for sf, ef, lengths in pieces:
-            batch_inputs = batch.get_inputs() if sf is None else batch.get_inputs(sf=sf, ef=ef)
+            batch_inputs = batch.get_inputs(**input_options) if sf is None else \
+                batch.get_inputs(sf=sf, ef=ef, **input_options)
             batch_inputs['seq_lengths'] = lengths
             yield batch_inputs
 
@@ -399,6 +400,14 @@ class IterativeErrorFeedback(BaseModel):
         self._smpl_handle = None      # body-model-only handle used by the training path
         self._smpl_handle_key = None
         self._workspace = None
+        # Streaming (eval/helpers.py::evaluate_sequences): a side stream for the refinement iterations.  When set, a
+        # forward runs input packing + initial estimate (the LSTM with its state carry) on the current stream and the N
+        # iterations on this one, so that the NEXT chunk's LSTM -- which needs only this chunk's final LSTM state --
+        # runs beside this chunk's iterations.  The outputs are then complete only when `self.outputs_ready` (an event
+        # on the side stream, renewed by every forward) has passed: the caller waits for it before it reads them.
+        self.iter_stream = None
+        self.outputs_ready = None
+        self._pipe = None   # two workspaces in turn + the event after which each may be reused
 
     def set_input_output_size(self):
         if self.config.use_marker_nor:
@@ -449,8 +458,22 @@ class IterativeErrorFeedback(BaseModel):
 
     # ---- HIP model handle ------------------------------------------------------------------------------------
     def _own_parameters(self):
-        return [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
-               [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
+        # (walking the module tree costs ~0.5 ms: more than the host side of a whole streaming chunk; the list only
+        # changes when tensors are replaced, which goes through _apply / load_state_dict)
+        cached = self.__dict__.get('_own_cache')
+        if cached is None:
+            cached = [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
+                     [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
+            self.__dict__['_own_cache'] = cached
+        return cached
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_own_cache'] = None
+        return super(IterativeErrorFeedback, self)._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__['_own_cache'] = None
+        return super(IterativeErrorFeedback, self).load_state_dict(*args, **kwargs)
 
     def _rodrigues(self):
         return getattr(self.smpl, 'rodrigues_convention', 'smplx')
@@ -593,9 +616,11 @@ class IterativeErrorFeedback(BaseModel):
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward_tensors(self, marker_pos, marker_oris, offset_t, offset_r, marker_masks=None, seq_lengths=None,
-                        state=None, keep_history=False, keep_gradient_trace=False):
+                        state=None, keep_history=False, keep_gradient_trace=False, suppress_mask_value=None):
         """
         One window batch through `empose_lgd_forward`. All tensors on the GPU, fp32.
+        `suppress_mask_value` (a float): the readings are raw and the packing kernel replaces those of sensors whose
+        mask is not 1 by that value (what `RealBatch.get_inputs` otherwise does before the model sees them).
         :return: dict(pose (B,F,66), shape (B,F,10), joints (B,F,66), state (h_n,c_n) or None, hist {...} or None)
         """
         if self.training:
@@ -624,6 +649,8 @@ class IterativeErrorFeedback(BaseModel):
             io.marker_pos, io.marker_oris = _lib.dptr(marker_pos), _lib.dptr(marker_oris)
             io.offset_t, io.offset_r = _lib.dptr(offset_t), _lib.dptr(offset_r)
             io.marker_masks, io.seq_lengths = _lib.dptr(marker_masks), _lib.dptr(seq_lengths)
+            if suppress_mask_value is not None and marker_masks is not None:
+                io.suppress_missing, io.mask_value = 1, float(suppress_mask_value)
             out = {'pose': new(B, F, 66), 'shape': new(B, F, 10), 'joints': new(B, F, 66), 'state': None,
                    'hist': None, 'trace': None}
             io.pose_hat, io.shape_hat, io.joints_hat = [_lib.dptr(out[k]) for k in ('pose', 'shape', 'joints')]
@@ -648,10 +675,42 @@ class IterativeErrorFeedback(BaseModel):
                 io.trace_g_pose, io.trace_g_shape = _lib.dptr(trace['g_pose']), _lib.dptr(trace['g_shape'])
                 out['trace'] = trace
             need = lib.empose_lgd_workspace_bytes(handle, B, F)
-            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-            _lib.check(lib.empose_lgd_forward(handle, C.byref(io), _lib.dptr(self._workspace),
-                                              self._workspace.numel(), _lib.current_stream()))
+            if self.iter_stream is None:
+                if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                _lib.check(lib.empose_lgd_forward(handle, C.byref(io), _lib.dptr(self._workspace),
+                                                  self._workspace.numel(), _lib.current_stream()))
+                self.outputs_ready = None
+            else:
+                side, cur = self.iter_stream, torch.cuda.current_stream(dev)
+                if self._pipe is None or self._pipe['dev'] != dev:
+                    self._pipe = {'dev': dev, 'turn': 0, 'ws': [None, None], 'free': [None, None]}
+                k = self._pipe['turn'] = 1 - self._pipe['turn']
+                ws = self._pipe['ws'][k]
+                if ws is None or ws.numel() < need:
+                    ws = self._pipe['ws'][k] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    ws.record_stream(side)
+                if self._pipe['free'][k] is not None:
+                    cur.wait_event(self._pipe['free'][k])     # the iterations of two chunks ago are done with it
+                _lib.check(lib.empose_lgd_forward_phase(handle, C.byref(io), _lib.dptr(ws), ws.numel(),
+                                                        C.c_void_p(cur.cuda_stream), 1))
+                started = torch.cuda.Event()
+                started.record(cur)
+                side.wait_event(started)
+                # what the side stream reads or writes was allocated for the current stream: keep it from being
+                # handed out again before the side stream is done with it
+                touched = [offset_t, offset_r, seq_lengths, out['pose'], out['shape'], out['joints']]
+                touched += list(out['hist'].values()) if out['hist'] else []
+                touched += list(out['trace'].values()) if out['trace'] else []
+                for t in touched:
+                    if t is not None:
+                        t.record_stream(side)
+                _lib.check(lib.empose_lgd_forward_phase(handle, C.byref(io), _lib.dptr(ws), ws.numel(),
+                                                        C.c_void_p(side.cuda_stream), 2))
+                done = torch.cuda.Event()
+                done.record(side)
+                self._pipe['free'][k] = done
+                self.outputs_ready = done
         return out
 
     # ---- training path (BASELINE configs[4]) -------------------------------------------------------------------
@@ -751,7 +810,9 @@ class IterativeErrorFeedback(BaseModel):
                 getattr(self, 'differentiable', False):
             return self._forward_with_graph(batch, window_size)
         outs, hists, traces = [], [], []
-        for batch_inputs in self.window_generator(batch, window_size=window_size):
+        # (on the GPU the packing kernel replaces the readings of missing sensors; see RealBatch.get_inputs)
+        on_device = bool(batch.seq_lengths.is_cuda)
+        for batch_inputs in self.window_generator(batch, window_size=window_size, suppress_on_device=on_device):
             state = None
             if self.rnn_init:
                 self.rnn.init_state = self.rnn.final_state
@@ -760,7 +821,8 @@ class IterativeErrorFeedback(BaseModel):
                                        batch_inputs['offset_t'], batch_inputs['offset_r'],
                                        batch_inputs['marker_masks'], batch_inputs['seq_lengths'], state=state,
                                        keep_history=self.keep_history,
-                                       keep_gradient_trace=self.keep_gradient_trace)
+                                       keep_gradient_trace=self.keep_gradient_trace,
+                                       suppress_mask_value=batch_inputs.get('suppress_mask_value'))
             if self.rnn_init:
                 self.rnn.final_state = res['state']
             outs.append(res)

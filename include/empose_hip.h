@@ -179,6 +179,11 @@ typedef struct {
   /* optional trace of the gradient features fed to the update nets (reference models.py:578-582); NULL to skip */
   float* trace_g_pose;           /* [N][T][66] */
   float* trace_g_shape;          /* [N][T][10] */
+  /* RealBatch.get_inputs replaces the readings of missing sensors by a constant before the model sees them
+   * (reference data/data.py:284-302,304-309).  suppress_missing != 0: marker_pos / marker_oris are the RAW readings
+   * and the packing kernel does that replacement (x * valid + mask_value * !valid with valid = mask == 1). */
+  int suppress_missing;
+  float mask_value;
 } empose_lgd_io;
 
 size_t empose_lgd_workspace_bytes(const empose_model_t* model, int B, int F);
@@ -186,6 +191,17 @@ size_t empose_lgd_workspace_bytes(const empose_model_t* model, int B, int F);
 /* Replaces IterativeErrorFeedback.forward for one window batch (reference models.py:485-632). */
 int empose_lgd_forward(const empose_model_t* model, const empose_lgd_io* io, void* workspace, size_t workspace_bytes,
                        empose_stream_t stream);
+
+/* The same forward in two parts that may be issued on different streams: EMPOSE_LGD_PHASE_INIT = input packing + the
+ * initial estimate (LSTM with state carry + heads, or the init MLPs; reads io->h0/c0, writes io->h_n/c_n),
+ * EMPOSE_LGD_PHASE_ITER = the N refinement iterations and the outputs.  The second part reads what the first left in
+ * `workspace` (same io, same workspace; order them with an event).  A streaming caller runs chunk c + 1's INIT -- which
+ * depends only on chunk c's final LSTM state -- beside chunk c's ITER, with two workspaces.  New in this library; the
+ * reference runs the chunks of a recording strictly one after the other (scripts/evaluate_real.py:39-61). */
+#define EMPOSE_LGD_PHASE_INIT 1
+#define EMPOSE_LGD_PHASE_ITER 2
+int empose_lgd_forward_phase(const empose_model_t* model, const empose_lgd_io* io, void* workspace,
+                             size_t workspace_bytes, empose_stream_t stream, int phases);
 
 /* ---- building blocks (also what the unit tests drive) --------------------------------------------------------- */
 

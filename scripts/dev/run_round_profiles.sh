@@ -11,8 +11,8 @@ python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline 2>/
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
 python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
-python scripts/evaluate_real.py --synthetic --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
-python scripts/evaluate_real.py --synthetic --sequential --repeat 2 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
+python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
+python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
 python scripts/train.py --steps 20 --graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph.json
 ( for bs in 12 64 256; do for g in "" "--graph"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt

@@ -551,3 +551,35 @@ def test_reverse_lstm_wavefront_equals_layer_after_layer(B, F, H):
     for a, b in zip(out[0], out[1]):
         assert np.isfinite(b).all()
         np.testing.assert_allclose(b, a, atol=2e-5 * max(1.0, float(np.abs(a).max())), rtol=1e-4)
+
+
+def test_missing_sensor_suppression_in_the_packing_kernel_equals_get_inputs():
+    """RealBatch.get_inputs replaces the readings of missing sensors on the host side of the model (reference
+    data/data.py:284-302); on the GPU the LGD model asks for the raw readings and lets its packing kernel do it.  Same
+    outputs, bit for bit -- also for a NaN reading of a missing sensor, which the reference's x * valid arithmetic turns
+    into NaN on that frame's inputs -- and the batch itself stays as it was."""
+    from tests.test_hip_parity import build_net, cfg_of
+    case = H.load_case('lgdrnn12_n3_ragged_masked')
+    meta = case['meta']
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    w = case['in']
+    inp = H.oracle_inputs(w, sl=torch.from_numpy(np.asarray(w['seq_lengths'])) if 'seq_lengths' in w else None)
+    mp, mo = inp['marker_pos'].clone(), inp['marker_oris'].clone()
+    masks = inp['marker_masks'].clone()
+    assert masks is not None and float((masks != 1).sum()) > 0
+    B, F = mp.shape[0], mp.shape[1]
+    # garbage (not zeros) under the missing sensors, so that the replacement is visible
+    miss = (masks != 1).reshape(B, F, 12, 1)
+    mp = torch.where(miss.expand(B, F, 12, 3).reshape(B, F, 36), torch.full_like(mp, 7.5), mp)
+    mo = torch.where(miss.expand(B, F, 12, 9).reshape(B, F, 108), torch.full_like(mo, -3.25), mo)
+    valid = (masks == 1.0).reshape(B, F, 12, 1)
+    host = lambda x, k: (x.reshape(B, F, 12, k) * valid + (torch.zeros(B, F, 12, k) + 0.0) * ~valid).reshape(B, F, -1)
+    args = lambda a, b: [t.to(DEV) for t in (a, b, inp['offset_t'], inp['offset_r'])]
+    kw = dict(marker_masks=masks.to(DEV), seq_lengths=inp['seq_lengths'].to(DEV))
+    want = net.forward_tensors(*args(host(mp, 3), host(mo, 9)), **kw)
+    got = net.forward_tensors(*args(mp, mo), suppress_mask_value=0.0, **kw)
+    torch.cuda.synchronize()
+    for k in ('pose', 'shape', 'joints'):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), err_msg=k)
+    raw = net.forward_tensors(*args(mp, mo), **kw)     # without the replacement the garbage reaches the model
+    assert float((raw['pose'] - want['pose']).abs().max()) > 1e-3
