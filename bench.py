@@ -152,6 +152,51 @@ def cpu_baseline(net, model, w, hip_out=None, seconds_target=20.0):
             'threads_sweep_frames_per_sec_8_windows': {str(k): v for k, v in sweep.items()}}
 
 
+def pmc_traffic_live(argv_tail, kernel_name, timeout_s=240):
+    """HBM bytes per launch of the dominant kernel measured NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
+    separate runs, kernel trace only, as MI355X_MICROARCH.md's HBM section prescribes) of this same command with two
+    timed steps, as child processes.  The counter unit is KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
+    coalesced streaming read, so bytes = (2 FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes, description) or
+    (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    norm = lambda k: k.replace('empose::', '').replace('void ', '').replace(' ', '')
+    means = {}
+    env = dict(os.environ, TMPDIR='/tmp')
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix='empose_pmc_', dir='/tmp')
+        try:
+            cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'pmc', '--',
+                   sys.executable, os.path.abspath(__file__)] + argv_tail + \
+                  ['--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--no_profile']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get('Counter_Name') == counter and norm(row['Kernel_Name']).startswith(kernel_name):
+                            vals.append(float(row['Counter_Value']))
+            if not vals:
+                return None, 'rocprofv3 --pmc %s pass gave no rows for %s (exit code %d)' % (counter, kernel_name,
+                                                                                          r.returncode)
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except (subprocess.TimeoutExpired, OSError) as e:
+            return None, 'rocprofv3 --pmc %s pass failed: %s' % (counter, type(e).__name__)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    nbytes = (2.0 * means['FETCH_SIZE'][0] + means['WRITE_SIZE'][0]) * 1024.0
+    return nbytes, ('measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command '
+                    '(2 timed steps each; %d / %d dispatches of the kernel), bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB'
+                    % (means['FETCH_SIZE'][1], means['WRITE_SIZE'][1]))
+
+
 def pmc_traffic(T, hidden, kernel_name):
     """HBM bytes per launch of the dominant kernel, NOT measured in this run: hardware counters need rocprofv3 around the
     process (`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, scripts/dev/run_pmc.sh,
@@ -244,6 +289,8 @@ def main():
                          "contraction (not the reference's arithmetic; the headline never uses it)")
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
+    ap.add_argument('--no_traffic', action='store_true',
+                    help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic (~25 s each)')
     ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=INT',
                     help='kernel-variant switch of the library (empose_set_option), for A/B runs; repeatable')
@@ -373,11 +420,21 @@ def main():
             avg_ms = raw - pair
             timing.update({'avg_launch_ms_bracketed_alone': raw, 'empty_event_pair_ms': pair})
         ach = flops / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(B * F, h, kname)
+        traffic, traffic_src = (None, 'skipped (--no_traffic)')
+        if world == 1 and not args.no_traffic:   # hardware counters: two child passes of this command under rocprofv3
+            tail = ['--batch', str(B), '--frames', str(F), '--n_markers', str(args.n_markers),
+                    '--iterations', str(args.iterations)] + (['--no_rnn'] if args.no_rnn else []) + \
+                   [a for kv in args.option for a in ('--option', kv)]
+            traffic, traffic_src = pmc_traffic_live(tail, kname)
+        if traffic is None:
+            why = traffic_src
+            traffic, traffic_src = pmc_traffic(B * F, h, kname)
+            if traffic_src:
+                traffic_src += (' (rocprofv3 --pmc passes of this command in an EARLIER run, not measured by this '
+                                'process: %s)' % why)
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                              'traffic_source': (traffic_src + ' (rocprofv3 --pmc passes of this command in a separate '
-                                                 'run; not measured by this process)') if traffic_src else None,
+                              'traffic_source': traffic_src,
                               'kernel': kname + what,
                               'avg_launch_ms': avg_ms, 'timing': timing, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,

@@ -7,8 +7,8 @@ R=$PWD
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/${TAG}_gpu_tests.log
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
-python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
-python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
+python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
+python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
 python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
 python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
