@@ -29,6 +29,10 @@ __device__ __forceinline__ float bp_reduce_rows(float v, float* red, int rg, int
   return s;
 }
 
+// R = rows per thread (M <= 32 R): a thread's rows stay in registers from the first pass to the last, so every operand
+// is read from memory ONCE (three dependent trips to L2 per call before: 7.5 / 11.3 us per 384 x 512 layer, forty layer
+// applications per training step at the reference's batch).  Same sums in the same order as before.
+template <int R>
 __global__ __launch_bounds__(bp::NT) void bn_prelu_fwd_kernel(BnPreluArgs a) {
   using namespace bp;
   __shared__ float red[RG * COLS];
@@ -37,21 +41,33 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_fwd_kernel(BnPreluArgs a) {
   const bool ok = col < a.C;
   const int cc = ok ? col : a.C - 1;
   const float inv_m = 1.f / (float)a.M;
+  const float g = a.gamma[cc], b = a.beta[cc], slope = a.slope[0];
+  float xv[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = rg + i * RG;
+    xv[i] = m < a.M ? a.x[(size_t)m * a.ldx + cc] : 0.f;
+  }
   float s = 0.f;
-#pragma unroll 4
-  for (int m = rg; m < a.M; m += RG) s += a.x[(size_t)m * a.ldx + cc];
+#pragma unroll
+  for (int i = 0; i < R; ++i) s += xv[i];          // (rows past M add 0: the same bits as stopping at M)
   const float mean = bp_reduce_rows(s, red, rg, c) * inv_m;
   float q = 0.f;
-#pragma unroll 4
-  for (int m = rg; m < a.M; m += RG) { const float d = a.x[(size_t)m * a.ldx + cc] - mean; q += d * d; }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const float d = xv[i] - mean;
+    q += (rg + i * RG < a.M) ? d * d : 0.f;
+  }
   const float var = bp_reduce_rows(q, red, rg, c) * inv_m;      // biased: what normalises the batch
   const float rstd = 1.f / sqrtf(var + a.eps);
-  const float g = a.gamma[cc], b = a.beta[cc], slope = a.slope[0];
   if (ok) {
-#pragma unroll 4
-    for (int m = rg; m < a.M; m += RG) {
-      const float y = g * ((a.x[(size_t)m * a.ldx + col] - mean) * rstd) + b;
-      a.z[(size_t)m * a.ldz + col] = y > 0.f ? y : slope * y;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int m = rg + i * RG;
+      if (m < a.M) {
+        const float y = g * ((xv[i] - mean) * rstd) + b;
+        a.z[(size_t)m * a.ldz + col] = y > 0.f ? y : slope * y;
+      }
     }
     if (rg == 0) {
       a.save_mean[col] = mean;
@@ -66,6 +82,7 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_fwd_kernel(BnPreluArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
 }
 
+template <int R>
 __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
   using namespace bp;
   __shared__ float red[RG * COLS];
@@ -75,15 +92,19 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
   const int cc = ok ? col : a.C - 1;
   const float mean = a.save_mean[cc], rstd = a.save_rstd[cc];
   const float g = a.gamma[cc], b = a.beta[cc], slope = a.slope[0];
+  float xh[R], dy[R];
   float s_b = 0.f, s_g = 0.f, s_a = 0.f;
-#pragma unroll 4
-  for (int m = rg; m < a.M; m += RG) {
-    const float xh = (a.x[(size_t)m * a.ldx + cc] - mean) * rstd;
-    const float y = g * xh + b;
-    const float dz = a.dz[(size_t)m * a.lddz + cc];
-    const float dy = y > 0.f ? dz : slope * dz;
-    s_b += dy;
-    s_g += dy * xh;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = rg + i * RG;
+    const bool in = m < a.M;
+    const float x = in ? a.x[(size_t)m * a.ldx + cc] : mean;
+    const float dz = in ? a.dz[(size_t)m * a.lddz + cc] : 0.f;
+    xh[i] = (x - mean) * rstd;
+    const float y = g * xh[i] + b;
+    dy[i] = y > 0.f ? dz : slope * dz;
+    s_b += dy[i];
+    s_g += dy[i] * xh[i];
     s_a += y > 0.f ? 0.f : dz * y;
   }
   const float dbeta = bp_reduce_rows(s_b, red, rg, c);
@@ -110,13 +131,10 @@ __global__ __launch_bounds__(bp::NT) void bn_prelu_bwd_kernel(BnPreluArgs a) {
   }
   if (!ok) return;
   const float k = g * rstd / (float)a.M;
-#pragma unroll 4
-  for (int m = rg; m < a.M; m += RG) {
-    const float xh = (a.x[(size_t)m * a.ldx + col] - mean) * rstd;
-    const float y = g * xh + b;
-    const float dz = a.dz[(size_t)m * a.lddz + col];
-    const float dy = y > 0.f ? dz : slope * dz;
-    a.dx[(size_t)m * a.lddx + col] = k * ((float)a.M * dy - dbeta - xh * dgamma);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int m = rg + i * RG;
+    if (m < a.M) a.dx[(size_t)m * a.lddx + col] = k * ((float)a.M * dy[i] - dbeta - xh[i] * dgamma);
   }
   if (rg == 0) {
     a.dgamma[col] = dgamma + (a.accumulate ? a.dgamma[col] : 0.f);
@@ -321,8 +339,19 @@ hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stre
     return hipGetLastError();
   }
   const int blocks = (a.C + bp::COLS - 1) / bp::COLS;
-  if (backward) hipLaunchKernelGGL(bn_prelu_bwd_kernel, dim3(blocks), dim3(bp::NT), 0, stream, a);
-  else hipLaunchKernelGGL(bn_prelu_fwd_kernel, dim3(blocks), dim3(bp::NT), 0, stream, a);
+  const int r = (a.M + bp::RG - 1) / bp::RG;   // rows per thread, <= 32
+#define BP_LAUNCH(R)                                                                                         \
+  do {                                                                                                       \
+    if (backward) hipLaunchKernelGGL(bn_prelu_bwd_kernel<R>, dim3(blocks), dim3(bp::NT), 0, stream, a);      \
+    else hipLaunchKernelGGL(bn_prelu_fwd_kernel<R>, dim3(blocks), dim3(bp::NT), 0, stream, a);               \
+  } while (0)
+  if (r <= 4) BP_LAUNCH(4);
+  else if (r <= 8) BP_LAUNCH(8);
+  else if (r <= 12) BP_LAUNCH(12);
+  else if (r <= 16) BP_LAUNCH(16);
+  else if (r <= 24) BP_LAUNCH(24);
+  else BP_LAUNCH(32);
+#undef BP_LAUNCH
   return hipGetLastError();
 }
 

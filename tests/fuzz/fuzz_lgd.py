@@ -22,6 +22,7 @@ for name in ('lgdrnn12_n4_carry', 'lgdrnn6_n2', 'lgd12_n4'):
     net.load_state_dict(H.sd_to_torch(case['sd']), strict=False); net.vertex_ids = vids
     nets[name] = (net.to(DEV).eval(), H.sd_to_torch(case['sd']), meta, vids, R.sensor_tables(model['f'], vids))
 t_end, n, worst = time.time() + budget, 0, 0.0
+side, variants = torch.cuda.Stream(), {}
 while time.time() < t_end:
     name = list(nets)[int(rng.integers(0, len(nets)))]
     net, sd, meta, vids, tables = nets[name]
@@ -42,9 +43,28 @@ while time.time() < t_end:
     want, tr = R.ief_forward(sd, bm, tables, vids, inp, n_markers=int(meta['n_markers']), N=int(meta['N']), rnn_init=rnn,
                              rnn_state=state)
     g = lambda t: None if t is None else t.to(DEV)
-    res = net.forward_tensors(g(inp['marker_pos']), g(inp['marker_oris']), g(inp['offset_t']), g(inp['offset_r']),
+    # round 3: the kernel variants behind the same call -- frame-per-lane SMPL kernels forced on / off, the small kernels
+    # inside the blend GEMMs or on their own, missing-sensor replacement in the packing kernel (raw readings with garbage
+    # under the missing sensors), the forward in two parts on two streams
+    from em_pose_amd import _lib
+    tile, fuse = int(rng.choice([0, 2])), int(rng.integers(0, 2))
+    _lib.check(_lib.lib().empose_set_option(b'smpl_tile', tile))
+    _lib.check(_lib.lib().empose_set_option(b'smpl_fuse', fuse))
+    mp, mo, kw = inp['marker_pos'], inp['marker_oris'], {}
+    if inp['marker_masks'] is not None and rng.integers(0, 2):
+        miss = (inp['marker_masks'] != 1).reshape(B, F, 12, 1)
+        mp = torch.where(miss.expand(B, F, 12, 3).reshape(B, F, 36), torch.full_like(mp, 9.0), mp)
+        mo = torch.where(miss.expand(B, F, 12, 9).reshape(B, F, 108), torch.full_like(mo, -2.0), mo)
+        kw['suppress_mask_value'] = 0.0
+    two_parts = bool(rng.integers(0, 2))
+    net.iter_stream = side if two_parts else None
+    res = net.forward_tensors(g(mp), g(mo), g(inp['offset_t']), g(inp['offset_r']),
                               marker_masks=g(inp['marker_masks']), seq_lengths=g(inp['seq_lengths']),
-                              state=None if state is None else tuple(g(t) for t in state))
+                              state=None if state is None else tuple(g(t) for t in state), **kw)
+    if two_parts:
+        torch.cuda.current_stream().wait_event(net.outputs_ready)
+    net.iter_stream = None
+    variants[(tile, fuse, 'suppress_mask_value' in kw, two_parts)] = variants.get((tile, fuse, 'suppress_mask_value' in kw, two_parts), 0) + 1
     valid = (torch.arange(F)[None, :] < torch.as_tensor(lens)[:, None]).numpy()
     err = 0.0
     for got, ref in ((res['pose'].cpu().numpy()[:, :, 3:], want['pose_hat'].numpy()),
@@ -57,3 +77,4 @@ while time.time() < t_end:
     if not err < 1e-4:
         print('MISMATCH', name, dict(B=B, F=F, masks='marker_masks' in w, state=state is not None), err); sys.exit(1)
 print('lgd: %d random cases, worst abs error %.2e' % (n, worst))
+print('     (smpl_tile, smpl_fuse, on-device suppression, two-part forward) -> cases:', sorted(variants.items()))
