@@ -128,11 +128,17 @@ class RealBatch(ABatch):
         fields = [getattr(self, name) for name in names]
         if torch.device(device).type == 'cuda' and all(not f.is_cuda for f in fields):
             # host fields: ONE staged copy (nine separate blocking copies of a 256-frame chunk cost more than its forward)
-            flat = torch.cat([f.reshape(-1).to(C.DTYPE) for f in fields]).to(device)
-            at = 0
-            for name, f in zip(names, fields):
-                setattr(self, name, flat[at:at + f.numel()].view(f.shape))
-                at += f.numel()
+            # every field starts on a 256-byte boundary of the staging buffer (kernels read 16-byte pieces)
+            starts, at = [], 0
+            for f in fields:
+                starts.append(at)
+                at += (f.numel() + 63) // 64 * 64
+            host = torch.zeros(at, dtype=C.DTYPE)
+            for f, st in zip(fields, starts):
+                host[st:st + f.numel()] = f.reshape(-1)
+            flat = host.to(device)
+            for name, f, st in zip(names, fields, starts):
+                setattr(self, name, flat[st:st + f.numel()].view(f.shape))
             return self
         for name, f in zip(names, fields):
             setattr(self, name, f.to(dtype=C.DTYPE, device=device))

@@ -3,11 +3,13 @@ import os, sys, time
 sys.path.insert(0, '.')
 import torch
 from em_pose_amd import _lib
+if os.environ.get('EMPOSE_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['EMPOSE_LIB_PATH']   # dev: a lab build of the library (scripts/dev/persist_lab.sh)
 from em_pose_amd.nn.layers import RNNLayer
 dev = 'cuda:0'
 layer = RNNLayer(60, 512, 2).eval().to(dev)
 for B in (1, 2, 3, 4, 6, 8, 12, 16):
-    for F in (64,):
+    for F in (int(os.environ.get('F', 64)),):
         x = torch.randn(B, F, 60, device=dev)
         lens = torch.full((B,), F, device=dev)
         res = []
