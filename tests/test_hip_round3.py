@@ -583,3 +583,41 @@ def test_missing_sensor_suppression_in_the_packing_kernel_equals_get_inputs():
         np.testing.assert_array_equal(got[k].cpu().numpy(), want[k].cpu().numpy(), err_msg=k)
     raw = net.forward_tensors(*args(mp, mo), **kw)     # without the replacement the garbage reaches the model
     assert float((raw['pose'] - want['pose']).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize('B,F,valid_only', [(3, 100, False), (2, 256, False), (5, 37, True), (1, 300, True)])
+def test_frame_per_lane_path_long_and_odd_windows(B, F, valid_only):
+    """The frame-per-lane kernels work on tiles of 64 frames whatever the window length: windows longer than a tile
+    (the per-window shape mean then spans tiles), lengths that do not divide 64, ragged rows, and the shape mean over
+    the valid frames only (the batched streaming driver's mode) -- against the general kernels on the same call."""
+    from tests.test_hip_parity import build_net, cfg_of
+    case = H.load_case('lgdrnn12_n4_carry')
+    meta = case['meta']
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    net.shape_avg_valid_only = valid_only
+    rng = np.random.default_rng(B * 1000 + F)
+    g = lambda *shape, s=1.0: torch.as_tensor(rng.normal(0, s, size=shape), dtype=torch.float32).to(DEV)
+    mp, mo = g(B, F, 36, s=0.3), g(B, F, 108, s=0.5)
+    o_t = g(B, 12, 3, s=0.02)
+    o_r = torch.as_tensor(synthetic._exp_so3(rng.normal(0, 0.1, size=(B, 12, 3))), dtype=torch.float32).to(DEV)
+    lens = torch.as_tensor(rng.integers(1, F + 1, size=B), dtype=torch.int32)
+    lens[0] = F
+    masks = torch.as_tensor((rng.uniform(size=(B, F, 12)) > 0.03).astype(np.float32)).to(DEV)
+    state = (g(2, B, 32, s=0.3), g(2, B, 32, s=0.3))
+    res = {}
+    for opt in (0, 2):
+        with _Option(b'smpl_tile', opt):
+            r = net.forward_tensors(mp, mo, o_t, o_r, marker_masks=masks, seq_lengths=lens.to(DEV), state=state,
+                                    keep_history=True)
+            torch.cuda.synchronize()
+            res[opt] = {'pose': r['pose'].cpu().numpy(), 'shape': r['shape'].cpu().numpy(),
+                        'joints': r['joints'].cpu().numpy(), **{'h_' + k: v.cpu().numpy() for k, v in r['hist'].items()}}
+    valid = (np.arange(F)[None, :] < lens.numpy()[:, None])
+    for k, a in res[0].items():
+        b = res[2][k]
+        if k.startswith('h_'):
+            a, b = a.reshape(a.shape[0], B, F, -1)[:, valid], b.reshape(b.shape[0], B, F, -1)[:, valid]
+        else:
+            a, b = a[valid], b[valid]
+        assert np.isfinite(b).all(), k
+        np.testing.assert_allclose(b, a, atol=1e-4 if 'ori' in k else 3e-5, rtol=0, err_msg=k)
