@@ -239,6 +239,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise EmposeError('HIP extension not built: {} is missing. Run `python em_pose_amd/build.py` '
                               '(or __graft_entry__.build()). There is no CPU fallback.'.format(LIB_PATH))
+        # PyTorch first: the library links libamdhip64.so.7 by name, and the process must end up with ONE HIP runtime --
+        # the one torch ships and allocates device memory with.  Loaded the other way round, the library binds the
+        # system copy under /opt/rocm and torch brings its own: two runtimes, and this one then sees no device
+        # ("no ROCm-capable device is detected" from the first hipMalloc; seen with build() + smoke() in one process).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
