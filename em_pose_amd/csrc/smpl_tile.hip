@@ -768,7 +768,10 @@ __global__ __launch_bounds__(256) void rodrigues_bwd_t_kernel(RodBwdTArgs a) {
 
 template <bool BWD, int NLOC, int NBL>
 static hipError_t launch_tile_cfg(const TileArgs& a, hipStream_t stream) {
-  constexpr int NWAVES = BWD ? 4 : 8;
+#ifndef TL_BWD_WAVES
+#define TL_BWD_WAVES 4
+#endif
+  constexpr int NWAVES = BWD ? TL_BWD_WAVES : 8;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smpl_tile_kernel<BWD, NLOC, NBL, NWAVES>),
