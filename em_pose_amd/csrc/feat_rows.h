@@ -68,6 +68,10 @@ __device__ __forceinline__ FeatLane feat_lane_load(const FeatArgs& a, int t, int
 // The stores of frame t (the caller's rows and the optional copies), Rodrigues and the 200-float feature row
 // [vec(R_j - I), j = 1..21 | beta | 1] to feat_row; when rot_row is given, the 22 rotations (198 floats) too.  Frames
 // past the end (t >= a.T) leave everything untouched.
+// FAST: Rodrigues with the short sine / cosine of smpl_math.h (what the frame-per-lane kernel uses for the chain's
+// rotations of the same frames; ~1 ulp from the library's) -- the GEMM prologue has nothing to hide ~150 dependent
+// instructions behind.
+template <bool FAST = false>
 __device__ __forceinline__ void feat_lane_finish(const FeatArgs& a, int t, int slot, const FeatLane& v, float* feat_row,
                                                  float* rot_row) {
   if (t >= a.T) return;
@@ -84,7 +88,8 @@ __device__ __forceinline__ void feat_lane_finish(const FeatArgs& a, int t, int s
       o[0] = r0; o[64] = r1; o[128] = r2;
     }
     Rod q; float R[9];
-    rodrigues(r0, r1, r2, a.rod_conv, q, R);
+    if (FAST) rodrigues_fast(r0, r1, r2, a.rod_conv, q, R);
+    else rodrigues(r0, r1, r2, a.rod_conv, q, R);
     if (rot_row) {
       float* ro = rot_row + slot * 9;
 #pragma unroll
@@ -116,9 +121,11 @@ __device__ __forceinline__ void feat_frame(const FeatArgs& a, int t, int slot, f
 }
 
 // d R_j -> d theta_j for one (frame, joint): dR = the chain's cotangent + the feature cotangent (joints >= 1).
+template <bool FAST = false>
 __device__ __forceinline__ void rodrigues_bwd_joint(const float (&th)[3], int rod_conv, const float (&dR)[9], float (&g)[3]) {
   Rod q; float R[9];
-  rodrigues(th[0], th[1], th[2], rod_conv, q, R);
+  if (FAST) rodrigues_fast(th[0], th[1], th[2], rod_conv, q, R);
+  else rodrigues(th[0], th[1], th[2], rod_conv, q, R);
   const float K[9] = {0.f, -q.dz, q.dy, q.dz, 0.f, -q.dx, -q.dy, q.dx, 0.f};
   const float KK[9] = {-q.dz * q.dz - q.dy * q.dy, q.dx * q.dy, q.dx * q.dz,
                        q.dx * q.dy, -q.dz * q.dz - q.dx * q.dx, q.dy * q.dz,
@@ -149,7 +156,7 @@ __device__ __forceinline__ void rodrigues_bwd_joint(const float (&th)[3], int ro
 // d_rot in tile layout from global memory, the feature cotangents through `df(column)` (global tile layout or LDS), the 76
 // outputs of a frame through `sg` (LDS, 64 x 77 floats) as contiguous row pieces (the caller's rows have a stride of
 // ~300 floats).  Ends with the rows written; contains one __syncthreads.
-template <class DF>
+template <bool FAST = false, class DF>
 __device__ __forceinline__ void rodrigues_bwd_tile(const RodBwdTArgs& a, int tile, float* sg, DF df) {
   constexpr int FR = TL_FR, LD = 77;
   const int lane = threadIdx.x & 63;
@@ -180,7 +187,7 @@ __device__ __forceinline__ void rodrigues_bwd_tile(const RodBwdTArgs& a, int til
       for (int e = 0; e < 9; ++e) dR[u][e] += df((j - 1) * 9 + e);
     }
     float g[3];
-    rodrigues_bwd_joint(th[u], a.rod_conv, dR[u], g);
+    rodrigues_bwd_joint<FAST>(th[u], a.rod_conv, dR[u], g);
     sg[lane * LD + j * 3 + 0] = g[0];
     sg[lane * LD + j * 3 + 1] = g[1];
     sg[lane * LD + j * 3 + 2] = g[2];

@@ -172,8 +172,22 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   // compiler's wait-count insertion keeps the ring's prefetch distance (vmcnt(10)) instead of draining every load at
   // the top of each iteration (vmcnt(0)).  Measured floor of this loop: 8272 cycles per four k-groups with no memory
   // operations (8192 ideal), 8700 with the sixteen 1 KB weight-fragment loads, i.e. ~23 cycles per load.
+  // Whole quads of real k-groups, then the 1..3 groups that are left (K = 200: 25 groups, K = 296: 37) from what the last
+  // quad has already fetched -- its look-ahead holds the A fragment of group KGQ and the weights of KGQ .. KGQ + 2 -- instead
+  // of a fourth quad that multiplies the zero padding (3 of 28 / 40 groups).  Same products in the same k order.
+  const int KG = (K + 7) / 8;
+  const int KGQ = KG >= 4 ? (KG & ~3) : KG4, tail = KG >= 4 ? KG - KGQ : 0;   // (fewer than four groups: one padded quad)
   quad(0);
-  for (int g = 4; g < KG4; g += 4) quad(g);
+  for (int g = 4; g < KGQ; g += 4) quad(g);
+  if (tail >= 1) mma(fa[0], fb[0]);
+  if (tail >= 2) {
+    fread(KGQ + 1, fa[1]);
+    mma(fa[1], fb[1]);
+  }
+  if (tail >= 3) {
+    fread(KGQ + 2, fa[0]);
+    mma(fa[0], fb[2]);
+  }
   FM_STAMP(4 * layer_index + 2)
 
   if (last && OUT_T == 2) {
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs ar
     if (m0 + r >= M) {
       for (int c = slot; c < K0; c += 32) act[r * lda + c] = 0.f;
     }
-    feat_lane_finish(fa, m0 + r, slot, v[p], act + r * lda, nullptr);
+    feat_lane_finish<true>(fa, m0 + r, slot, v[p], act + r * lda, nullptr);
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs a
   const int NT32 = (L.N + 31) / 32;
   float* sg = act + NT32 * 32 * 64;
   const int lane = threadIdx.x & 63;
-  rodrigues_bwd_tile(ra, tile, sg, [&](int col) { return act[col * 64 + ((lane + col) & 63)]; });
+  rodrigues_bwd_tile<true>(ra, tile, sg, [&](int col) { return act[col * 64 + ((lane + col) & 63)]; });
 }
 
 template <int WN, bool A_T>
