@@ -133,7 +133,7 @@ class RealBatch(ABatch):
             for f in fields:
                 starts.append(at)
                 at += (f.numel() + 63) // 64 * 64
-            host = torch.zeros(at, dtype=C.DTYPE)
+            host = torch.empty(at, dtype=C.DTYPE)   # (not zeros: a fill of this size wakes the whole CPU thread pool, 2 ms)
             for f, st in zip(fields, starts):
                 host[st:st + f.numel()] = f.reshape(-1)
             flat = host.to(device)
