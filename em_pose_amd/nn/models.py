@@ -67,6 +67,21 @@ def normal_mse(x_gt, x_hat, seq_lengths=None, marker_mask=None):
     return per.mean()
 
 
+# Counts registrations of parameters / buffers / submodules anywhere in the process: what invalidates the per-network
+# tensor lists cached by IterativeErrorFeedback._own_parameters (a Parameter assigned to a module attribute goes through
+# register_parameter, so a replaced weight is seen; in-place changes are seen through _version / data_ptr in the key).
+_REGISTRATIONS = [0]
+
+
+def _count_registration(*_args):
+    _REGISTRATIONS[0] += 1
+
+
+for _register in ('register_module_parameter_registration_hook', 'register_module_buffer_registration_hook',
+                  'register_module_module_registration_hook'):
+    getattr(torch.nn.modules.module, _register)(_count_registration)
+
+
 def _cat_windows(parts):
     """Per-window results along the frame axis; a single window is returned as it is (a view, no device copy)."""
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
@@ -458,14 +473,17 @@ class IterativeErrorFeedback(BaseModel):
 
     # ---- HIP model handle ------------------------------------------------------------------------------------
     def _own_parameters(self):
-        # (walking the module tree costs ~0.5 ms: more than the host side of a whole streaming chunk; the list only
-        # changes when tensors are replaced, which goes through _apply / load_state_dict)
+        # `named_parameters()` over the module tree costs ~0.5 ms per call (prefix strings, memo sets): more than the
+        # host side of a whole streaming chunk.  The list is cached and thrown away whenever ANY module registers a
+        # parameter, a buffer or a submodule (global registration hooks below: such events are construction-time only),
+        # or tensors are replaced wholesale (_apply / load_state_dict).
         cached = self.__dict__.get('_own_cache')
-        if cached is None:
-            cached = [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
-                     [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
+        if cached is None or cached[0] != _REGISTRATIONS[0]:
+            tensors = [p for n, p in self.named_parameters() if not n.startswith('smpl.')] + \
+                      [b for n, b in self.named_buffers() if not n.startswith('smpl.')]
+            cached = (_REGISTRATIONS[0], tensors)
             self.__dict__['_own_cache'] = cached
-        return cached
+        return cached[1]
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__['_own_cache'] = None

@@ -201,6 +201,18 @@ def test_inference_handle_follows_raw_pointer_updates():
     torch.cuda.synchronize()
     assert float((fresh - before).abs().max()) > 1e-4             # three steps at lr 1e-2 moved the outputs
     assert torch.equal(cached, fresh)
+    # a REPLACED parameter (new tensor object under the same name) is seen too: the network keeps a cached list of its
+    # tensors for the handle's key, which any parameter / buffer / submodule registration in the process invalidates
+    lin = net.pose_net_iter.hidden_to_output
+    with torch.no_grad():
+        lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight))
+        lin.bias = torch.nn.Parameter(torch.zeros_like(lin.bias))
+    replaced = net.forward_tensors(*args(probe))['pose'].clone()
+    net.release()
+    replaced_fresh = net.forward_tensors(*args(probe))['pose'].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(replaced, replaced_fresh)
+    assert float((replaced - fresh).abs().max()) > 1e-6           # a pose update of zero is not what the trained head gave
 
 
 def test_hip_adam_skips_missing_gradients_and_restores_state():
