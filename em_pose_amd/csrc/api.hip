@@ -380,6 +380,8 @@ struct LstmWs {
   float* c[8];
   float* yb[2];   // [B][F][2H] ping-pong between the layers of a bidirectional stack
   float* xch;     // exchange words of the whole-sequence small-batch kernel (lstm_persist_kernel), or nullptr
+  float* h3[8];   // third hidden-state buffer per unit + counters of the whole-sequence large-batch kernel, or nullptr
+  unsigned* seq_cnt;
 };
 LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
@@ -394,6 +396,9 @@ LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   w.yb[0] = need_y ? c.f((size_t)B * F * 2 * H) : nullptr;
   w.yb[1] = (need_y && r.num_layers > 2) ? c.f((size_t)B * F * 2 * H) : nullptr;
   w.xch = (r.dirs == 1 && B <= LSTM_PERSIST_B) ? c.f(lstm_persist_xch_floats(r.num_layers, B, H)) : nullptr;
+  const bool seq = r.dirs == 1 && B >= LSTM_SEQ_MIN_B && r.num_layers <= 4;
+  for (int u = 0; u < 8; ++u) w.h3[u] = (seq && u < U) ? c.f((size_t)B * H) : nullptr;
+  w.seq_cnt = seq ? reinterpret_cast<unsigned*>(c.f(lstm_seq_counter_uints(B))) : nullptr;
   return w;
 }
 LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) { return carve_lstm_of(c, m->rnn, B, F); }
@@ -520,6 +525,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   }
   LstmWaveArgs a;
   a.seq_lengths = seq_lengths; a.B = B; a.F = F; a.H = H;
+  bool seq_done = false;
   if (D == 1) {
     // Stacked uni-directional layers: wavefront over (layer, time), launch s advances layer l by its step s - l.
     if (L > 4) return fail(EMPOSE_EINVAL, "at most 4 stacked layers per wavefront");
@@ -540,6 +546,15 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
       a.s = 0;
       hipError_t e = launch_lstm_persist(a, ws.xch, stream, &done);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel: %s", hipGetErrorString(e));
+    }
+    // Large batches: the whole sequence in one cooperative launch too (lstm_seq_kernel; the workgroups of a row group
+    // synchronise through counters); falls back to the step launches when its workgroups cannot all be resident.
+    if (!done && ws.seq_cnt && F >= 4 && options().lstm_seq != 0 && !a.unit[0].sv_gates) {
+      prof_mark(P_LSTM_STEP, stream);
+      a.s = 0;
+      hipError_t e = launch_lstm_seq(a, ws.h3, ws.seq_cnt, stream, &done);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel (large batch): %s", hipGetErrorString(e));
+      seq_done = done;
     }
     for (int s = 0; !done && s < F + L - 1; ++s) {
       a.s = s;
@@ -573,7 +588,9 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   }
   prof_mark(P_COPY, stream);
   for (int u = 0; u < U; ++u) {
-    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + u * bh, ws.h[u][F & 1], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    // the final hidden state: buffer F & 1 after step launches, F % 3 of (h[0], h[1], h3) after the large-batch sequence kernel
+    const float* h_last = seq_done ? (F % 3 == 2 ? ws.h3[u] : ws.h[u][F % 3]) : ws.h[u][F & 1];
+    if (h_n) HIP_TRY(hipMemcpyAsync(h_n + u * bh, h_last, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
     if (c_n) HIP_TRY(hipMemcpyAsync(c_n + u * bh, ws.c[u], bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
   }
   return EMPOSE_OK;
@@ -721,7 +738,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
+      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"lstm_seq", &o.lstm_seq}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -735,7 +752,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
+      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"lstm_seq", o.lstm_seq}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};

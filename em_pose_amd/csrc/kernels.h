@@ -16,6 +16,7 @@ struct Options {
   int mlp_fused = 1;      // one-launch LDS-resident update MLPs (0: layer by layer)
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
+  int lstm_seq = 0;       // large batches: the whole sequence in one cooperative launch (measured slower: 0 = a launch per wavefront step)
   int bptt_wave = 1;      // training: the reverse recurrences of a 2-layer LSTM as a wavefront (0: layer after layer)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
   int smpl_tile = 1;      // frame-per-lane SMPL sub-mesh kernel: 0 never, 1 from 16384 frames on, 2 always
@@ -212,6 +213,21 @@ struct LstmWaveArgs {
   int z_beg[4], z_cnt[4];
 };
 hipError_t launch_lstm_wave(const LstmWaveArgs& a, hipStream_t stream);
+// Whole sequence of a stacked uni-directional LSTM on a LARGE batch (B > 256) in one cooperative launch (lstm.hip,
+// lstm_seq_kernel): the units' hidden states rotate through three buffers (h[0], h[1] of the unit + a third one), the
+// workgroups of a 64-row group synchronise through `counters` (lstm_seq_counter_uints(B) unsigned, zeroed by the launcher).
+struct LstmSeqArgs {
+  LstmUnitArgs unit[4];
+  float* hs[4][3];
+  int n_units;
+  const int* seq_lengths;
+  int B, F, H;
+  unsigned* counters;
+  int spin_limit;
+};
+constexpr int LSTM_SEQ_MIN_B = 257;   // below: lstm_mid_kernel / the small-batch kernels
+size_t lstm_seq_counter_uints(int B);
+hipError_t launch_lstm_seq(const LstmWaveArgs& a, float* const* h_third, unsigned* counters, hipStream_t stream, bool* done);
 // Whole sequence of a stacked uni-directional LSTM in one cooperative launch (B <= 16); *done = false: not covered.
 constexpr int LSTM_PERSIST_B = 16;   // largest batch of the whole-sequence kernel
 size_t lstm_persist_xch_floats(int n_units, int B, int H);   // its exchange buffer (8-byte aligned)

@@ -300,6 +300,346 @@ __global__ __launch_bounds__(256) void lstm_chain_kernel(LstmWaveArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same tile stream over the WHOLE sequence in one cooperative launch (large batches: B > 256; round 3).  A step
+// launch of lstm_chain_kernel is the serial path of one workgroup (27 K tiles) plus ~2 us of set-up and the gap to the
+// next launch; here a workgroup keeps walking: the stream simply continues with the next wavefront step, its loads two
+// tiles ahead as before -- the first tiles of a step are the stored input, which depends on nothing.  What a step needs
+// from the other workgroups of its 64-row group (their 32-unit slices of h) is guarded by one counter per (row group,
+// unit): each wave adds 1 after its hidden-state stores of a unit have left (two tiles after the unit's finish, when
+// the wait for them is free), and a consumer enters a segment that reads such rows once the counter has reached
+// workgroups x 4 waves x steps -- its value is fetched a segment ahead, so in the steady state nobody waits.  Hidden states go
+// through agent-scope stores / loads (the row group's workgroups sit on different XCDs: plain accesses would see
+// their own L2) and through THREE buffers in turn: a workgroup one step ahead then never overwrites rows a slower one
+// is still reading (the final state is therefore in buffer F % 3, not F & 1 as after step launches).  Polls are bounded: a counter that never arrives poisons the outputs with NaN instead of hanging
+// the GPU.  Same arithmetic in the same order as the step launches: bit-identical results.
+// MEASURED (B = 1024, F = 32, 2 x 512): 2.35 ms against 2.07 ms for the 33 step launches (2.24 with plain, L2-cached loads of
+// the hidden-state tiles, which would be wrong): the launches follow each other without a gap (kernel time 62.5 us of 62.7
+// launch to launch), so there is nothing to win back, and the agent-scope loads / the bookkeeping in the loop cost 4-8 us a
+// step.  Opt-in (option lstm_seq, default 0); kept for what it shows.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_seq_kernel(LstmSeqArgs a) {
+  using namespace lc;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  LSTM_STAMP(0)
+  const int H = a.H, B = a.B, F = a.F;
+  const int j0 = blockIdx.x * BU, m0 = blockIdx.y * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wrow = wave >> 1, wcol = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int NU = a.n_units, S = F + NU - 1;
+  unsigned* __restrict__ cnt = a.counters + (size_t)blockIdx.y * 4;   // this row group's counters, one per unit
+  const unsigned n_peers = gridDim.x;                                  // workgroups of a row group
+  bool failed = false;
+
+  // ---- per-thread constants
+  const int lr = tid >> 4, c16 = tid & 15;                 // global side: row lr + 16 i, 16-byte chunk c16 of the K tile
+  int a_row[4], a_len[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = m0 + lr + 16 * i;
+    a_row[i] = r < B ? r : B - 1;
+    a_len[i] = a.seq_lengths ? a.seq_lengths[a_row[i]] : F;
+  }
+  int w_row[8];                                            // gate * H + unit of the thread's 8 weight rows
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int wr = lr + 16 * i, un = j0 + (wr & 31);
+    w_row[i] = (wr >> 5) * H + (un < H ? un : H - 1);
+  }
+  const int wr_ofs = lr * BK + ((c16 ^ (lr & 15)) << 2);   // LDS write offset of piece 0 (floats); piece i: + 16 i rows
+  const int a_rd = (wrow * 32 + l15) * BK;                 // fragment rows (floats); row tile i: + 16 rows
+  const int b_rd = (BM + wcol * 16 + l15) * BK;            // gate g: + 32 rows
+  int sw[4];                                               // swizzled chunk offset of k-chunk ch for this lane
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) sw[ch] = ((((ch << 2) ^ (l15 & 12)) | (lq ^ (l15 & 3))) << 2);
+
+  f32x4 g[12];
+  bool g_ok = true;
+  f32x4 fa[2][2], fb[2][4];
+  f32x4 acc[2][4];
+
+  // ---- the load side of the tile stream: current segment (scalar registers), the thread's byte offsets into its two
+  // operands (recomputed when the stream enters a segment) and the k tile within the segment
+  // segment (s, u, part) of the whole-sequence stream, built here (the step launches get theirs from the host)
+  auto make_seg = [&](int s, int u, int part) -> LstmSeg {
+    const LstmUnitArgs& L = a.unit[u];
+    const int t = s - L.t_offset;
+    LstmSeg d;
+    d.k = t; d.tstride = 0; d.unit = u; d.pad = 0;
+    if (part == 0) {
+      if (L.in_from < 0) { d.a = L.in_seq + (size_t)t * L.in_ld; d.lda = F * L.in_ld; }
+      else { d.a = a.hs[L.in_from][(t + 1) % 3]; d.lda = H; d.pad = 1 + L.in_from + 8 * (t + 1); }
+      d.w = L.w_ih; d.ldw = L.in_k; d.K = L.in_k;
+    } else {
+      d.a = a.hs[u][t % 3]; d.lda = H; d.w = L.w_hh; d.ldw = H; d.K = H;
+      if (t > 0) d.pad = 1 + u + 8 * t;     // (t == 0: the caller's initial state)
+    }
+    d.ntiles = (d.K + BK - 1) / BK;
+    return d;
+  };
+  // `pad` of a segment whose A rows are hidden states produced inside this launch: 1 + producing unit + 8 * (steps that
+  // unit must have published).  The counter is fetched when the stream enters the segment BEFORE (its value is there
+  // when it is needed) and only polled if that value was short.
+  auto active = [&](int s, int u) -> bool { const int t = s - a.unit[u].t_offset; return t >= 0 && t < F; };
+  int ld_s = 0, ld_u = 0, ld_part = 0, ld_kt = 0;
+  while (!active(ld_s, ld_u)) { if (++ld_u == NU) { ld_u = 0; ++ld_s; } }
+  LstmSeg ld = make_seg(ld_s, ld_u, 0);
+  bool ld_end = false, ld_wait = false;
+  unsigned dep_seen = 0;     // counter value fetched ahead for the NEXT segment's dependency
+  LstmSeg nx = ld;           // the segment after `ld`
+  auto peek_next = [&]() {   // nx <- successor of ld (or ld itself at the end of the stream); prefetch its counter
+    int s2 = ld_s, u2 = ld_u, p2 = ld_part;
+    if (p2 == 0) p2 = 1;
+    else {
+      p2 = 0;
+      do { if (++u2 == NU) { u2 = 0; ++s2; } } while (s2 < S && !active(s2, u2));
+    }
+    if (s2 >= S) { nx = ld; nx.pad = 0; nx.unit = -1; return; }
+    nx = make_seg(s2, u2, p2);
+    nx.unit = u2 | (s2 << 8) | (p2 << 30);
+  };
+  // the counter the NEXT segment depends on, fetched a segment ahead (0 when it depends on nothing: never compared)
+  auto prefetch_dep = [&]() {
+    dep_seen = nx.pad ? __hip_atomic_load(cnt + ((nx.pad - 1) & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  };
+  bool ld_prefetch = false;
+  unsigned a_off[4], w_off[8];
+  auto seg_offsets = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tr = a_len[i] - 1 - ld.k;
+      a_off[i] = (unsigned)(((long)a_row[i] * ld.lda + (long)(tr > 0 ? tr : 0) * ld.tstride + c16 * 4) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w_off[i] = (unsigned)(((long)w_row[i] * ld.ldw + c16 * 4) * 4);
+  };
+  seg_offsets();
+  peek_next();
+  prefetch_dep();
+  auto gload = [&]() -> bool {   // fetch the tile under the load cursor; returns whether it is ragged
+    g_ok = ld_kt * BK + c16 * 4 < ld.K;
+    const unsigned back = g_ok ? 0u : (unsigned)(c16 * 16);   // lanes past K re-read chunk 0 of the tile; zeroed later
+    gbyte_t pa = (gbyte_t)(ld.a + ld_kt * BK);
+    gbyte_t pw = (gbyte_t)(ld.w + ld_kt * BK);
+    if (ld.pad) {   // rows other workgroups (other XCDs, other L2s) wrote in this launch: agent-scope loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>((const char*)pa + (a_off[i] - back));
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g[i] = f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                     __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = *(gvec_t)(pa + (a_off[i] - back));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[4 + i] = *(gvec_t)(pw + (w_off[i] - back));
+    return (ld_kt + 1) * BK > ld.K;
+  };
+  auto ld_advance = [&]() {      // uniform; past the end of the stream it parks on a valid tile that is never used
+    if (++ld_kt == ld.ntiles) {
+      ld_kt = 0;
+      if (nx.unit >= 0) {
+        ld_s = (nx.unit >> 8) & 0x3fffff; ld_u = nx.unit & 0xff; ld_part = (nx.unit >> 30) & 1;
+        ld = nx; ld.unit = ld_u;
+        ld_wait = ld.pad != 0;   // hidden states of other workgroups: checked right before the segment's first load
+        seg_offsets();
+        peek_next();
+        ld_prefetch = true;
+      } else {
+        ld_end = true;
+      }
+    }
+  };
+  auto gzero = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[i][e] = g_ok ? g[i][e] : 0.f;
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(st + wr_ofs + i * 16 * BK) = g[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(st + BM * BK + wr_ofs + i * 16 * BK) = g[4 + i];
+  };
+  auto fread = [&](const float* st, int ch, f32x4 (&fa_)[2], f32x4 (&fb_)[4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa_[i] = *reinterpret_cast<const f32x4*>(st + a_rd + i * 16 * BK + sw[ch]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb_[q] = *reinterpret_cast<const f32x4*>(st + b_rd + q * 32 * BK + sw[ch]);
+  };
+  auto mma = [&](const f32x4 (&fa_)[2], const f32x4 (&fb_)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa_[i][e], fb_[q][e], acc[i][q], 0, 0, 0);
+  };
+  // Cell non-linearities of a finished unit; C/D layout: col = lane & 15, row = 4 * (lane >> 4) + r.  What they read
+  // besides the accumulators (bias, old cell state, lengths, old hidden state of rows past their length) is fetched
+  // when the stream ENTERS the unit, so the finish itself is arithmetic and stores only.  Nobody else touches these
+  // (row, unit) elements during the launch.
+  const int e_unit = j0 + wcol * 16 + l15;
+  const int e_unit_c = e_unit < H ? e_unit : H - 1;
+  float e_bias[4], e_c[8], e_hp[8];
+  int e_len[8];
+  auto enter_unit = [&](int u, int t) {
+    const LstmUnitArgs& L = a.unit[u];
+    const float* __restrict__ bias = L.bias;
+    const float* h_prev = a.hs[u][t % 3];
+    const float* __restrict__ cst = L.c;
+    const int* __restrict__ lens = a.seq_lengths;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_bias[q] = bias[q * H + e_unit_c];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = m0 + wrow * 32 + (e >> 2) * 16 + lq * 4 + (e & 3);
+      const int rc = row < B ? row : B - 1;
+      const size_t hc = (size_t)rc * H + e_unit_c;
+      e_c[e] = cst[hc];
+      e_len[e] = lens ? lens[rc] : F;
+      // only rows past their length carry the old state over (this workgroup's own element, written with an agent-scope
+      // store a step ago: read it the same way)
+      e_hp[e] = lens ? __hip_atomic_load(h_prev + hc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    }
+  };
+  auto finish_unit = [&](int u, int t) {
+    const LstmUnitArgs& L = a.unit[u];
+    const bool rev = false;
+    if (e_unit >= H) return;
+    float* h_next = a.hs[u][(t + 1) % 3];
+    const float poison = __builtin_nanf("");
+    float* __restrict__ cst = L.c;
+    float* __restrict__ yout = L.y;
+    const long y_ld = L.y_ld, y_col = L.y_col;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = e >> 2, r = e & 3;
+      const int row = m0 + wrow * 32 + i * 16 + lq * 4 + r;
+      if (row >= B) continue;
+      const size_t hc = (size_t)row * H + e_unit;
+      const bool live = t < e_len[e];
+      const int t_out = (rev && live) ? e_len[e] - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
+      const float g_i = fsigmoid(acc[i][0][r] + e_bias[0]), g_f = fsigmoid(acc[i][1][r] + e_bias[1]);
+      const float g_g = ftanh(acc[i][2][r] + e_bias[2]), g_o = fsigmoid(acc[i][3][r] + e_bias[3]);
+      const float c_new = g_f * e_c[e] + g_i * g_g;
+      const float h_new = g_o * ftanh(c_new);
+      if (live) cst[hc] = failed ? poison : c_new;
+      const float h_out = failed ? poison : (live ? h_new : e_hp[e]);
+      // other workgroups (on other XCDs) read this row in the next step: a store that reaches the memory side
+      __hip_atomic_store(h_next + hc, h_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (yout) yout[((size_t)row * F + t_out) * y_ld + y_col + e_unit] = failed ? poison : (live ? h_new : 0.f);
+      if (L.sv_gates) {   // training forward: what back-propagation through time reads
+        const size_t rt = (size_t)row * F + t;
+        float* sg = L.sv_gates + rt * 4 * H + e_unit;
+        sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
+        L.sv_c[rt * H + e_unit] = live ? c_new : e_c[e];
+        if (t + 1 < F) L.sv_hprev[(rt + 1) * H + e_unit] = live ? h_new : e_hp[e];
+      }
+    }
+  };
+
+  LSTM_STAMP(1)
+  // ---- prologue: tile 0 -> stage 0, tile 1 in flight
+  bool ragged = gload();
+  if (ragged) gzero();
+  lwrite(lds);
+  ld_advance();
+  ragged = gload();
+  ld_advance();
+  __syncthreads();
+  fread(lds, 0, fa[0], fb[0]);
+  LSTM_STAMP(2)
+  int stamp = 3;
+  (void)stamp;
+
+  int parity = 0;
+  // A unit's new hidden states are PUBLISHED (the row group's counter of that unit goes up by one per workgroup) two
+  // tile iterations after its finish: by then every wave's stores have long left (they were issued a whole tile before
+  // the loads the first of those iterations waited for), so the wait below costs nothing, and the consumers need them a
+  // dozen tiles later at the earliest.
+  int pub_unit = -1, pub_wait = 0;
+  for (int s = 0; s < S; ++s)
+  for (int u = 0; u < NU; ++u) {
+    const int t = s - a.unit[u].t_offset;
+    if (t < 0 || t >= F) continue;   // idle while the wavefront ramps up or down
+    const int unit_tiles = (a.unit[u].in_k + BK - 1) / BK + (H + BK - 1) / BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    enter_unit(u, t);
+    for (int j = 0; j < unit_tiles; ++j) {
+      const float* cur = lds + parity * STAGE;
+      float* nxt = lds + (parity ^ 1) * STAGE;
+      parity ^= 1;
+      if (ragged) gzero();     // uniform branch; the registers hold the next tile of the stream
+      // ---- chunk 0
+      fread(cur, 1, fa[1], fb[1]);
+      lwrite(nxt);
+      mma(fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 1); LSTM_SGB(SG_DS_RD, 1); }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_WR, 1); }
+      LSTM_SGB(SG_MFMA, 2);
+      // ---- chunk 1
+      fread(cur, 2, fa[0], fb[0]);
+      if (pub_unit >= 0 && --pub_wait == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's hidden-state stores have completed
+        if (lane == 0) __hip_atomic_fetch_add(cnt + pub_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pub_unit = -1;
+      }
+      if (ld_wait) {   // (after this wave's own publication: the waves of a row group wait for each other here)
+        const unsigned need = n_peers * 4u * (unsigned)(ld.pad >> 3);
+        int spins = 0;
+        while (dep_seen < need) {
+          if (++spins > a.spin_limit) {
+            failed = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+          dep_seen = __hip_atomic_load(cnt + ((ld.pad - 1) & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ld_wait = false;
+      }
+      if (ld_prefetch) { prefetch_dep(); ld_prefetch = false; }   // (after the poll above: one value, one owner)
+      ragged = gload();
+      mma(fa[1], fb[1]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 1); LSTM_SGB(SG_DS_RD, 1); }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_VMEM_RD, 1); }
+      LSTM_SGB(SG_MFMA, 2);
+      // ---- chunk 2
+      fread(cur, 3, fa[1], fb[1]);
+      mma(fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_RD, 1); }
+      LSTM_SGB(SG_MFMA, 20);
+      __syncthreads();
+      // ---- chunk 3
+      fread(nxt, 0, fa[0], fb[0]);
+      mma(fa[1], fb[1]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { LSTM_SGB(SG_MFMA, 2); LSTM_SGB(SG_DS_RD, 1); }
+      LSTM_SGB(SG_MFMA, 20);
+      ld_advance();
+      LSTM_STAMP(stamp++)
+    }
+    finish_unit(u, t);
+    pub_unit = u; pub_wait = 2;
+    LSTM_STAMP(stamp++)
+  }
+}
+
+
 // Segment table of one launch: two segments per active unit, grouped by blockIdx.z.
 static void lstm_build_chain(LstmWaveArgs& a, int units_per_block) {
   int n = 0, z = 0;
@@ -946,6 +1286,51 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
             (a.n_units + units_per_block - 1) / units_per_block);
   hipLaunchKernelGGL(lstm_chain_kernel, grid, dim3(256), lc::LDS_BYTES, stream, a);
   return hipGetLastError();
+}
+
+size_t lstm_seq_counter_uints(int B) { return (size_t)((B + lc::BM - 1) / lc::BM) * 4; }
+
+// Whole sequence for a stacked uni-directional LSTM on a large batch; *done = false when the configuration is outside
+// what the kernel covers or its workgroups cannot all be resident (the caller then steps launch by launch).
+hipError_t launch_lstm_seq(const LstmWaveArgs& w, float* const* h_third, unsigned* counters, hipStream_t stream, bool* done) {
+  *done = false;
+  if (w.B <= LSTM_MID_B || w.n_units < 1 || w.n_units > 4 || !counters) return hipSuccess;
+  for (int u = 0; u < w.n_units; ++u) {
+    const LstmUnitArgs& U = w.unit[u];
+    if (U.reverse || U.t_offset != u || (u == 0 ? U.in_from >= 0 : U.in_from != u - 1) || !h_third[u]) return hipSuccess;
+  }
+  LstmSeqArgs a;
+  for (int u = 0; u < 4; ++u) {
+    a.unit[u] = w.unit[u < w.n_units ? u : 0];
+    const int uu = u < w.n_units ? u : 0;
+    a.hs[u][0] = w.unit[uu].h[0]; a.hs[u][1] = w.unit[uu].h[1]; a.hs[u][2] = h_third[uu];
+  }
+  a.n_units = w.n_units; a.seq_lengths = w.seq_lengths; a.B = w.B; a.F = w.F; a.H = w.H;
+  a.counters = counters; a.spin_limit = 1 << 16;   // ~0.1 s per poll at most: a lost counter poisons, it does not hang
+  const dim3 grid((w.H + lc::BU - 1) / lc::BU, (w.B + lc::BM - 1) / lc::BM);
+  static int capacity = -1;
+  const void* fn = reinterpret_cast<const void*>(lstm_seq_kernel);
+  if (capacity < 0) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lc::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    capacity = per_cu * prop.multiProcessorCount;
+  }
+  if ((int)(grid.x * grid.y) > capacity) return hipSuccess;
+  hipError_t e = hipMemsetAsync(counters, 0, lstm_seq_counter_uints(w.B) * sizeof(unsigned), stream);
+  if (e != hipSuccess) return e;
+  void* params[] = {&a};
+  if (hipLaunchCooperativeKernel(fn, grid, dim3(256), params, (unsigned)lc::LDS_BYTES, stream) != hipSuccess) {
+    (void)hipGetLastError();   // no cooperative launch in this context: the caller steps launch by launch
+    return hipSuccess;
+  }
+  *done = true;
+  return hipSuccess;
 }
 
 }  // namespace empose

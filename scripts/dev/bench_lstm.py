@@ -1,7 +1,9 @@
 """Dev: time the LSTM alone (B=1024, F=32, 2x512) through empose_lstm_fwd."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, '.')
 import torch
 from em_pose_amd import _lib, synthetic
+if os.environ.get('EMPOSE_LIB_PATH'):
+    _lib.LIB_PATH = os.environ['EMPOSE_LIB_PATH']   # dev: a lab build of the library
 from em_pose_amd.bodymodels.smpl import SMPLLayer
 from em_pose_amd.helpers.configuration import lgd_config
 from em_pose_amd.nn.models import create_model
@@ -9,6 +11,8 @@ dev = torch.device('cuda:0')
 net = create_model(lgd_config(12, True, 4), SMPLLayer(synthetic.make_model(nu=8, nv=20, seed=160))).to(dev).eval()
 net.vertex_ids = synthetic.small_vertex_ids(160)
 h = net._ensure_handle(dev); lib = _lib.lib()
+if len(sys.argv) > 1:
+    _lib.check(lib.empose_set_option(b'lstm_seq', int(sys.argv[1])))
 B, F = 1024, 32
 x = torch.randn(B, F, 144, device=dev); y = torch.empty(B, F, 512, device=dev)
 nb = lib.empose_lstm_workspace_bytes(h, B, F); ws = torch.empty(nb, dtype=torch.uint8, device=dev)

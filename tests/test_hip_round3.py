@@ -633,3 +633,33 @@ def test_frame_per_lane_path_long_and_odd_windows(B, F, valid_only):
             a, b = a[valid], b[valid]
         assert np.isfinite(b).all(), k
         np.testing.assert_allclose(b, a, atol=1e-4 if 'ori' in k else 3e-5, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize('B,F', [(257, 9), (1024, 32), (640, 5)])
+def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F):
+    """Large batches can run the 2 x 512 LSTM as ONE cooperative launch (lstm_seq_kernel, option lstm_seq; opt-in: it
+    measured slower than the step launches): the same tile stream, synchronised through per-row-group counters.  Same bits: outputs and final state,
+    ragged rows and carried state included; repeated launches agree with each other."""
+    In, Hd, L = 144, 512, 2
+    torch.manual_seed(B + F)
+    layer = RNNLayer(In, Hd, L).eval().to(DEV)
+    x = torch.randn(B, F, In, device=DEV)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0], lens[-1] = F, 1
+    state = (0.5 * torch.randn(L, B, Hd, device=DEV), 0.5 * torch.randn(L, B, Hd, device=DEV))
+    res = {}
+    for opt in (0, 1, 1):
+        with _Option(b'lstm_seq', opt):
+            outs = []
+            for st in (None, state):
+                layer.init_state = st
+                y = layer(x, lens.to(DEV))
+                torch.cuda.synchronize()
+                outs += [y.cpu().numpy(), layer.final_state[0].cpu().numpy(), layer.final_state[1].cpu().numpy()]
+            res.setdefault(opt, []).append(outs)
+    for k, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        assert np.isfinite(b).all(), k
+        np.testing.assert_array_equal(b, a, err_msg='output %d' % k)
+    for a, b in zip(res[1][0], res[1][1]):
+        np.testing.assert_array_equal(b, a)
+    layer.release()
