@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void lstm_seq_kernel(LstmSeqArgs a) {
       LSTM_SGB(SG_MFMA, 2);
       // ---- chunk 1
       fread(cur, 2, fa[0], fb[0]);
-      if (pub_unit >= 0 && --pub_wait == 0) {
+      if (pub_unit >= 0 && (--pub_wait == 0 || ld_wait)) {   // (early when this wave is about to wait for the others)
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's hidden-state stores have completed
         if (lane == 0) __hip_atomic_fetch_add(cnt + pub_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pub_unit = -1;
@@ -1298,6 +1298,9 @@ hipError_t launch_lstm_seq(const LstmWaveArgs& w, float* const* h_third, unsigne
   for (int u = 0; u < w.n_units; ++u) {
     const LstmUnitArgs& U = w.unit[u];
     if (U.reverse || U.t_offset != u || (u == 0 ? U.in_from >= 0 : U.in_from != u - 1) || !h_third[u]) return hipSuccess;
+    // a unit's hidden states are published at most two tile iterations after its finish, inside the NEXT unit's stream:
+    // every unit needs a few tiles for that to precede the next finish (the released sizes have 11 and 16)
+    if ((U.in_k + lc::BK - 1) / lc::BK + (w.H + lc::BK - 1) / lc::BK < 4) return hipSuccess;
   }
   LstmSeqArgs a;
   for (int u = 0; u < 4; ++u) {

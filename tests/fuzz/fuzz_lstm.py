@@ -11,7 +11,10 @@ t_end, n, worst = time.time() + budget, 0, 0.0
 while time.time() < t_end:
     bi = bool(rng.integers(0, 2)); L = int(rng.integers(1, 5 if not bi else 3))
     H = int(rng.integers(1, 17)) * 4; In = int(rng.integers(1, 40)) * 4
-    B = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 256, 257, 300])); F = int(rng.integers(1, 24))
+    B = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700])); F = int(rng.integers(1, 24))
+    # round 3: above 256 rows the whole-sequence cooperative kernel (opt-in) in half of the cases, small shapes included
+    from em_pose_amd import _lib
+    _lib.check(_lib.lib().empose_set_option(b'lstm_seq', int(rng.integers(0, 2))))
     torch.manual_seed(n)
     layer = RNNLayer(In, H, L, bidirectional=bi).eval()
     with torch.no_grad():

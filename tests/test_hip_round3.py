@@ -635,12 +635,12 @@ def test_frame_per_lane_path_long_and_odd_windows(B, F, valid_only):
         np.testing.assert_allclose(b, a, atol=1e-4 if 'ori' in k else 3e-5, rtol=0, err_msg=k)
 
 
-@pytest.mark.parametrize('B,F', [(257, 9), (1024, 32), (640, 5)])
-def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F):
+@pytest.mark.parametrize('B,F,In,Hd,L', [(257, 9, 144, 512, 2), (1024, 32, 144, 512, 2), (640, 5, 144, 512, 2),
+                                         (300, 11, 200, 192, 3), (513, 6, 72, 256, 4)])
+def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F, In, Hd, L):
     """Large batches can run the 2 x 512 LSTM as ONE cooperative launch (lstm_seq_kernel, option lstm_seq; opt-in: it
     measured slower than the step launches): the same tile stream, synchronised through per-row-group counters.  Same bits: outputs and final state,
     ragged rows and carried state included; repeated launches agree with each other."""
-    In, Hd, L = 144, 512, 2
     torch.manual_seed(B + F)
     layer = RNNLayer(In, Hd, L).eval().to(DEV)
     x = torch.randn(B, F, In, device=DEV)
