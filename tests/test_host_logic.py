@@ -336,3 +336,48 @@ def test_lmdb_reader_errors_and_transform():
     assert LMDBDataset(records, transform=lambda s: s.n_frames)[2] == 33
     with pytest.raises(ImportError, match='lmdb'):   # a path needs the real package, which this image lacks
         LMDBDataset('/nonexistent/amass_lmdb')
+
+
+def test_handle_key_tensor_list_is_cached_and_follows_registrations():
+    """The LGD model keys its packed device handle on its parameter / buffer tensors; the list is cached (walking the
+    module tree per forward cost more than a streaming chunk's host side) and must be rebuilt when a tensor object is
+    replaced -- seen through the process-wide registration hooks -- or tensors move (`_apply`, `load_state_dict`)."""
+    net = create_model(lgd_config(12, True, 2, hidden=32, rnn_hidden=32), SMPLLayer(H.small_model()))
+    first = net._own_parameters()
+    assert net._own_parameters() is first                       # cached
+    assert not any(t is p for p in net.smpl.parameters() for t in first)
+    assert len(first) == len([n for n, _ in net.named_parameters() if not n.startswith('smpl.')]) + \
+        len([n for n, _ in net.named_buffers() if not n.startswith('smpl.')])
+    lin = net.pose_net_iter.hidden_to_output
+    new_w = torch.nn.Parameter(torch.zeros_like(lin.weight))
+    lin.weight = new_w                                           # a replaced Parameter: new object, same name
+    second = net._own_parameters()
+    assert second is not first and any(t is new_w for t in second)
+    net.load_state_dict(net.state_dict())
+    assert net._own_parameters() is not second
+    third = net._own_parameters()
+    net.double()
+    assert net._own_parameters() is not third
+
+
+def test_metrics_engine_accepts_a_precomputed_valid_mask():
+    """`MetricsEngine.compute(..., valid=...)`: a caller that has lengths and masks on the host (the streaming driver)
+    hands over the frames that count; same accumulators as letting the engine derive them."""
+    from em_pose_amd.eval.metrics import MetricsEngine
+    rng = np.random.default_rng(3)
+    n, f = 3, 7
+    t = lambda *s: torch.as_tensor(rng.normal(0, 0.3, size=s), dtype=torch.float32)
+    pose, pose_hat, shape = t(n, f, 63), t(n, f, 63), t(n, 10)
+    root, root_hat = t(n, f, 3), t(n, f, 3)
+    lens = torch.tensor([7, 3, 5])
+    masks = torch.ones(n, f, 12)
+    masks[0, 2, 4] = 0.0
+    a, b = MetricsEngine(None), MetricsEngine(None)
+    a.compute(pose, shape, pose_hat, None, lens, root, root_hat, frame_mask=masks)
+    valid = MetricsEngine.valid_frames(lens, n, f, masks)
+    assert int(valid.sum()) == 7 + 3 + 5 - 1
+    b.compute(pose, shape, pose_hat, None, lens, root, root_hat, frame_mask=masks, valid=valid)
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k])
+    assert sa['angle'].shape[0] == 14
