@@ -232,6 +232,20 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
         # the recordings go to the device once; chunks are cut and padded there
         fields = ('poses', 'shapes', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks', 'offset_t', 'offset_r')
         on_dev = [{k: getattr(b, k).to(device=device, dtype=C.DTYPE) for k in fields} for b in batches]
+        # As in `evaluate_sequences`: chunk c + 1's cutting, packing and LSTM (current stream) beside chunk c's refinement
+        # iterations and metrics (side stream); nothing in the loop reads device results back -- the valid frames come
+        # from the host copies of lengths and masks, the metric rows are merged after the last chunk.
+        dev = torch.device(device)
+        side = None
+        if dev.type == 'cuda' and not net.training:
+            side = getattr(net, '_side_stream', None)
+            if side is None or side.device != dev:
+                side = net._side_stream = torch.cuda.Stream(device=dev)
+            net.iter_stream = side
+        import numpy as np
+        masks_host = [b.marker_masks.cpu().numpy() for b in batches]   # numpy: a torch CPU op on a 36 x 256 x 12 block
+        # wakes the whole intra-op thread pool (milliseconds per chunk on a 128-core host)
+        deferred = []      # (engine of the chunk, rows, valid frames per row)
         for c in range(n_chunks):
             sf = c * window_size
             rows = [i for i in range(n) if lengths[i] > sf]
@@ -242,6 +256,10 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             chunk = RealBatch([batches[i].ids[0] for i in rows], torch.tensor(lens), cut('poses'), whole('shapes'),
                               cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'), cut('marker_masks'),
                               whole('offset_t'), whole('offset_r')).to_gpu(device)
+            valid_np = np.zeros((len(rows), f), dtype=bool)   # inside the row's length and every sensor present
+            for k, i in enumerate(rows):
+                valid_np[k, :lens[k]] = (masks_host[i][0, sf:sf + lens[k]] != 0).all(axis=-1)
+            valid = torch.from_numpy(valid_np)
             if net.rnn_init and c > 0:
                 keep = torch.tensor([rows_prev.index(i) for i in rows], device=device)
                 net.rnn.final_state = (state[0].index_select(1, keep).contiguous(),
@@ -249,23 +267,32 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             out = net(chunk, is_new_sequence=(c == 0))
             if net.rnn_init:
                 state, rows_prev = net.rnn.final_state, rows
-            if c == 0:
-                for k, i in enumerate(rows):
-                    first_shape[i] = out['shape_hat'][k:k + 1, 0]
-            # one metrics pass over the whole chunk; its per-frame rows come back in (row, frame) order, so each recording's
-            # rows are a contiguous slice
-            me_tmp = MetricsEngine(smpl_model)
-            me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], torch.cat([first_shape[i] for i in rows]),
-                           chunk.seq_lengths, chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks)
+            with torch.cuda.stream(side) if side is not None else _nothing():
+                if side is not None:   # the chunk lives in memory of the current stream's pool
+                    for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
+                        t.record_stream(side)
+                if c == 0:
+                    for k, i in enumerate(rows):
+                        first_shape[i] = out['shape_hat'][k:k + 1, 0]
+                # one metrics pass over the whole chunk; its per-frame rows come back in (row, frame) order, so each
+                # recording's rows are a contiguous slice
+                me_tmp = MetricsEngine(smpl_model)
+                me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], torch.cat([first_shape[i] for i in rows]),
+                               chunk.seq_lengths, chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks,
+                               valid=valid)
+            deferred.append((me_tmp, rows, valid_np.sum(axis=1).tolist()))
+            frames += sum(lens)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        for me_tmp, rows, counts in deferred:
             st = me_tmp.state()
-            counts = MetricsEngine._mask(chunk.seq_lengths, len(rows), f, chunk.marker_masks, device).sum(dim=1).tolist()
             at = 0
             for k, i in enumerate(rows):
                 engines[i].merge({key: v[at:at + counts[k]] for key, v in st.items()})
                 at += counts[k]
-            frames += sum(lens)
     finally:
         net.shape_avg_valid_only = was_valid_only
+        net.iter_stream = None
     me_all = MetricsEngine(smpl_model)
     per_sequence = []
     for i in range(n):  # recording order, exactly as the sequential driver accumulates
