@@ -104,6 +104,8 @@ struct empose_model {
   int d_in = 144, d_x = 296;
   Lstm rnn;
   Dense pose_head, shape_head;
+  float* heads_frag = nullptr;   // both heads stacked ([66 + 10][H]) in fragment order, and their stacked bias
+  float* heads_bias = nullptr;
   Mlp pose_init, shape_init, pose_iter, shape_iter;
   int hidden_max = 0;
   int any_skip = 0;
@@ -738,7 +740,7 @@ int empose_set_option(const char* name, int value) {
   Options& o = options();
   const struct { const char* n; int* v; } tab[] = {
       {"mlp_fused", &o.mlp_fused}, {"lstm_persist", &o.lstm_persist}, {"gemm_splitk", &o.gemm_splitk},
-      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"lstm_seq", &o.lstm_seq}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
+      {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"heads_rows", &o.heads_rows}, {"lstm_seq", &o.lstm_seq}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk}};
@@ -752,7 +754,7 @@ int empose_get_option(const char* name) {
   const Options& o = options();
   const struct { const char* n; int v; } tab[] = {
       {"mlp_fused", o.mlp_fused}, {"lstm_persist", o.lstm_persist}, {"gemm_splitk", o.gemm_splitk},
-      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"lstm_seq", o.lstm_seq}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
+      {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"heads_rows", o.heads_rows}, {"lstm_seq", o.lstm_seq}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk}};
@@ -899,6 +901,17 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
     MTRY(pack_lstm(m->allocs, r, 1, r.w_ih, r.w_hh, r.b_ih, r.b_hh, &m->rnn));
     MTRY(pack_dense(m->allocs, d->pose_head, &m->pose_head));
     MTRY(pack_dense(m->allocs, d->shape_head, &m->shape_head));
+    if (d->pose_head.out_dim == 66 && d->shape_head.out_dim == 10 && d->pose_head.in_dim == d->shape_head.in_dim &&
+        !d->pose_head.bn_weight && !d->shape_head.bn_weight && !d->pose_head.has_prelu && !d->shape_head.has_prelu) {
+      const int K = d->pose_head.in_dim;
+      std::vector<float> wst((size_t)76 * K), bst(76, 0.f);
+      std::memcpy(wst.data(), d->pose_head.weight, (size_t)66 * K * sizeof(float));
+      std::memcpy(wst.data() + (size_t)66 * K, d->shape_head.weight, (size_t)10 * K * sizeof(float));
+      for (int n = 0; n < 66; ++n) bst[n] = d->pose_head.bias ? d->pose_head.bias[n] : 0.f;
+      for (int n = 0; n < 10; ++n) bst[66 + n] = d->shape_head.bias ? d->shape_head.bias[n] : 0.f;
+      MTRY(pack_fragments_raw(m->allocs, wst.data(), 76, K, &m->heads_frag));
+      MTRY(upload(m->allocs, bst.data(), bst.size(), &m->heads_bias));
+    }
     if (m->pose_head.out_dim != 66 || m->shape_head.out_dim != 10 || m->pose_head.in_dim != r.hidden_size)
       return bail(fail(EMPOSE_EINVAL, "init head dims"));
   } else if (d->pose_init.n_layers == 0 && d->n_iterations == 0) {
@@ -1031,6 +1044,10 @@ int empose_lgd_forward_phase(const empose_model_t* m, const empose_lgd_io* io, v
     b.p[0] = linear_prob(w.y, m->rnn.H, m->pose_head, x_theta, dx, T);
     b.p[1] = linear_prob(w.y, m->rnn.H, m->shape_head, w.d_shape, 10, T);
     prof_mark(P_HEADS, stream);
+    if (m->heads_frag && options().heads_rows != 0 && heads_rows_applicable(T, m->rnn.H))
+      e = launch_heads_rows(w.y, m->rnn.H, m->heads_frag, m->heads_bias, x_theta, dx, w.d_shape, 10, T, m->rnn.H, 66, 10,
+                            stream);
+    else
     e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "head gemm: %s", hipGetErrorString(e));
   } else {

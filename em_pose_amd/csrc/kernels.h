@@ -16,6 +16,7 @@ struct Options {
   int mlp_fused = 1;      // one-launch LDS-resident update MLPs (0: layer by layer)
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
   int gemm_splitk = 1;    // split-K tile for problems of few output tiles (0: generic tiles)
+  int heads_rows = 1;     // large batches: both init heads as one row-block product (0: two problems on the generic tile)
   int lstm_seq = 0;       // large batches: the whole sequence in one cooperative launch (measured slower: 0 = a launch per wavefront step)
   int bptt_wave = 1;      // training: the reverse recurrences of a 2-layer LSTM as a wavefront (0: layer after layer)
   int gemm_wide = 1;      // 256 x 256 four-wave tile (0: generic tiles)
@@ -516,6 +517,12 @@ hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float*
 hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream);
 hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
                                    hipStream_t stream);
+
+// The two init heads on the LSTM output as one product over their stacked columns (mlp_fused.hip): Wp = the stacked weight
+// [n_pose + n_shape][K] in fragment order, bias stacked likewise.
+bool heads_rows_applicable(int M, int K);
+hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const float* bias, float* theta, int ld_theta,
+                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, hipStream_t stream);
 
 // Full-mesh: chain only (joints + relative transforms) and dense skinning.
 constexpr int MESH_MAX_JOINTS = 52;   // SMPL-H: 22 body + 2 x 15 hand joints

@@ -551,6 +551,38 @@ hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float*
   return a_tile ? launch_gemm_rows_t_cfg<4, true>(a, stream) : launch_gemm_rows_t_cfg<4, false>(a, stream);
 }
 
+// The two initial-estimate heads (reference models.py:511-526: pose 66 + shape 10 columns on the LSTM output) as ONE
+// product over the 76 stacked columns: the 64 x K block of y is staged once (the two-problem launch on the 256 x 128 tile
+// read y twice and multiplied 256 padded columns), the result leaves through LDS to its two destinations -- the pose
+// columns of the network input rows and the shape buffer -- with the bias added on the way.
+struct HeadsArgs {
+  const float* bias;        // [76]
+  float* theta; int ld_theta;
+  float* shape; int ld_shape;
+  int n_pose, n_all;        // 66, 76
+};
+__global__ __launch_bounds__(fm::NT) void heads_rows_kernel(FusedMlpArgs args, HeadsArgs h) {
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[0];
+  const FusedLayer& L = net.layer[0];
+  const int M = args.M, m0 = blockIdx.x * 64;
+  const int K0 = L.K;
+  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
+  const int lda = kpad + 4;
+  rt::stage_a_rows(net.x, net.ldx, m0, M, K0, kpad, lda, act);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  fused_layer_t<1, 2, 1>(net, L, M, m0, act, lda, wave & 1, (wave >> 1) * 2, 0, true);
+  // C^T in LDS ([column][64], rows rotated by the column)
+  for (int i = threadIdx.x; i < 64 * h.n_all; i += fm::NT) {
+    const int row = i / h.n_all, n = i - row * h.n_all;
+    if (m0 + row >= M) continue;
+    const float v = act[n * 64 + ((row + n) & 63)] + h.bias[n];
+    if (n < h.n_pose) h.theta[(size_t)(m0 + row) * h.ld_theta + n] = v;
+    else h.shape[(size_t)(m0 + row) * h.ld_shape + (n - h.n_pose)] = v;
+  }
+}
+
 static FusedMlpArgs rows_t_args(const float* A, int lda, const float* Wp, float* C_t, int ldc_t, int M, int N, int K) {
   FusedMlpArgs a;
   a.count = 1; a.M = M;
@@ -594,6 +626,26 @@ hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp,
   const size_t lds = a_bytes > c_bytes ? a_bytes : c_bytes;
   static size_t attr = 0;
   return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, lds, &attr, a, ra, stream);
+}
+
+bool heads_rows_applicable(int M, int K) { return M >= 4096 && K % 4 == 0 && K <= FUSED_MAX_WIDTH; }
+
+hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const float* bias, float* theta, int ld_theta,
+                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, hipStream_t stream) {
+  if (n_pose + n_shape > 128) return hipErrorInvalidValue;
+  const FusedMlpArgs a = rows_t_args(y, ldy, Wp, nullptr, 0, M, n_pose + n_shape, K);
+  HeadsArgs h{bias, theta, ld_theta, shape, ld_shape, n_pose, n_pose + n_shape};
+  const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;
+  const size_t lds = (size_t)64 * (kpad + 4) * sizeof(float) + 64;
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = lds;
+  }
+  hipLaunchKernelGGL(heads_rows_kernel, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
+  return hipGetLastError();
 }
 
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream) {

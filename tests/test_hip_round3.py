@@ -663,3 +663,26 @@ def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F, In, Hd,
     for a, b in zip(res[1][0], res[1][1]):
         np.testing.assert_array_equal(b, a)
     layer.release()
+
+
+def test_init_heads_as_one_row_block_product_equal_the_two_problem_launch(big_model):
+    """From 4096 frames on the pose (66) and shape (10) heads on the LSTM output run as ONE product over their stacked
+    columns (heads_rows_kernel, option heads_rows) instead of two problems on the generic tile: same k order, same bias
+    add -- the whole forward is bit-identical."""
+    torch.manual_seed(11)
+    net = create_model(lgd_config(12, True, 2), SMPLLayer(big_model))
+    _randomize_bn(net, 12)
+    net = net.eval().to(DEV)
+    B, F = 130, 32     # 4160 frames: not a multiple of the 64-row blocks
+    g = torch.Generator().manual_seed(13)
+    args = [torch.randn(B, F, 36, generator=g).to(DEV), torch.randn(B, F, 108, generator=g).to(DEV),
+            (0.02 * torch.randn(B, 12, 3, generator=g)).to(DEV), torch.eye(3).expand(B, 12, 3, 3).contiguous().to(DEV)]
+    res = {}
+    for opt in (0, 1):
+        with _Option(b'heads_rows', opt):
+            r = net.forward_tensors(*args, keep_history=True)
+            torch.cuda.synchronize()
+            res[opt] = [r['hist']['pose'][0].cpu(), r['hist']['shape'][0].cpu(), r['pose'].cpu(), r['joints'].cpu()]
+    for a, b in zip(res[0], res[1]):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)
