@@ -57,6 +57,7 @@ const char* empose_arch(void);
  * environment.  Names: "mlp_fused", "lstm_persist", "gemm_splitk", "gemm_wide", "atb_target", "atb_chunk",
  * "smpl_tile" (frame-per-lane SMPL sub-mesh kernels: 0 never, 1 from 16384 frames on [default], 2 always),
  * "smpl_fuse" (on that path: pose / shape update and Rodrigues reverse inside the blend GEMMs; 0 = own kernels),
+ * "heads_rows" (both init heads as one row-block product from 4096 frames on; 0 = two problems on the generic tile),
  * "lstm_seq" (batches above 256 rows: the LSTM's whole sequence in one cooperative launch; 0 [default] = one launch per
  * wavefront step, which measured faster), "bptt_wave" (training: reverse LSTM recurrences of two layers as a wavefront),
  * "train_fused" (train-mode MLP layer with BatchNorm / PReLU folded into the GEMMs: 0 never [default], 1 above 1024
