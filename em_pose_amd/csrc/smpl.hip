@@ -17,6 +17,7 @@
 #include "smpl_math.h"
 #include "feat_rows.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace empose {
@@ -63,7 +64,42 @@ __global__ void pack_inputs_kernel(PackArgs a) {
   a.x[(size_t)t * a.ldx + c] = v;
 }
 
+// All twelve sensors in their own order and nothing to replace (the headline configuration): the input columns of a frame
+// are its 36 position and 108 orientation values as they lie -- 36 pieces of 16 bytes per frame, no index arithmetic per
+// element; thread 36 of a frame's group writes the frame weight.  (25.6 -> 13 us at 32768 frames.)
+__global__ __launch_bounds__(256) void pack_inputs_all_kernel(PackArgs a) {
+  const int T = a.B * a.F;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(idx / 37), q = (int)(idx - (long)t * 37);
+  if (t >= T) return;
+  if (q == 36) {
+    if (!a.frame_scale) return;
+    const int b = t / a.F, f = t - b * a.F;
+    const int len = a.seq_lengths ? a.seq_lengths[b] : a.F;
+    float s = (f < len) ? (a.rows_as_unpadded ? 1.f : (float)a.F / (float)len) : 0.f;
+    if (a.marker_masks) {
+      bool all = true;
+      for (int m = 0; m < 12; ++m) all = all && (a.marker_masks[(size_t)t * 12 + m] != 0.f);
+      if (!all) s = 0.f;
+    }
+    a.frame_scale[t] = s;
+    return;
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = q < 9 ? reinterpret_cast<const f4*>(a.marker_pos + (size_t)t * 36)[q]
+                     : reinterpret_cast<const f4*>(a.marker_oris + (size_t)t * 108)[q - 9];
+  reinterpret_cast<f4*>(a.x + (size_t)t * a.ldx)[q] = v;
+}
+
 hipError_t launch_pack_inputs(const PackArgs& a, hipStream_t stream) {
+  bool plain = a.n_markers == 12 && !(a.suppress_missing && a.marker_masks) && a.ldx % 4 == 0 &&
+               (((uintptr_t)a.marker_pos | (uintptr_t)a.marker_oris | (uintptr_t)a.x) & 15) == 0;
+  for (int i = 0; i < 12; ++i) plain = plain && a.marker_idx[i] == i;
+  if (plain) {
+    const long n37 = (long)a.B * a.F * 37;
+    hipLaunchKernelGGL(pack_inputs_all_kernel, dim3((unsigned)((n37 + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   const long n = (long)a.B * a.F * (a.n_markers * 12 + 1);
   hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
