@@ -636,7 +636,11 @@ hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const flo
   const FusedMlpArgs a = rows_t_args(y, ldy, Wp, nullptr, 0, M, n_pose + n_shape, K);
   HeadsArgs h{bias, theta, ld_theta, shape, ld_shape, n_pose, n_pose + n_shape};
   const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;
-  const size_t lds = (size_t)64 * (kpad + 4) * sizeof(float) + 64;
+  // the staged rows of y, later the transposed result (whole 32-column tiles): whichever is larger (a narrow LSTM's
+  // row block is smaller than the 96 x 64 result)
+  const size_t a_bytes = (size_t)64 * (kpad + 4) * sizeof(float) + 64;
+  const size_t c_bytes = (size_t)((n_pose + n_shape + 31) / 32) * 32 * 64 * sizeof(float);
+  const size_t lds = a_bytes > c_bytes ? a_bytes : c_bytes;
   static size_t attr = 0;
   if (lds > attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_rows_kernel),

@@ -10,7 +10,8 @@ from em_pose_amd.helpers.configuration import lgd_config
 from em_pose_amd.nn.models import create_model
 from oracle import torch_ref as R
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
+n_cases = int(sys.argv[2][2:]) if len(sys.argv) > 2 and sys.argv[2].startswith('n=') else None
+budget = 1e9 if n_cases else (float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
 DEV = 'cuda:0'
 model = H.small_model(); bm = R.BodyModelTensors(model)
 nets = {}
@@ -23,7 +24,8 @@ for name in ('lgdrnn12_n4_carry', 'lgdrnn6_n2', 'lgd12_n4'):
     nets[name] = (net.to(DEV).eval(), H.sd_to_torch(case['sd']), meta, vids, R.sensor_tables(model['f'], vids))
 t_end, n, worst = time.time() + budget, 0, 0.0
 side, variants = torch.cuda.Stream(), {}
-while time.time() < t_end:
+worst_case = None
+while time.time() < t_end and (n_cases is None or n < n_cases):
     name = list(nets)[int(rng.integers(0, len(nets)))]
     net, sd, meta, vids, tables = nets[name]
     B = int(rng.choice([1, 2, 4, 7, 16, 17, 33, 64, 130, 257])); F = int(rng.integers(1, 20))
@@ -73,8 +75,12 @@ while time.time() < t_end:
         err = max(err, float(np.abs(got - ref)[valid].max()))
     if rnn:
         err = max(err, float((res['state'][0].cpu() - tr['rnn_state'][0]).abs().max()))
+    if err > 1e-5:
+        print('case %d above 1e-5: %.3e' % (n, err), name, dict(B=B, F=F, masks='marker_masks' in w, state=state is not None), (tile, fuse, 'suppress_mask_value' in kw, two_parts), flush=True)
+    if err > worst:
+        worst_case = (name, dict(B=B, F=F, masks='marker_masks' in w, state=state is not None), (tile, fuse, 'suppress_mask_value' in kw, two_parts))
     worst = max(worst, err); n += 1
     if not err < 1e-4:
         print('MISMATCH', name, dict(B=B, F=F, masks='marker_masks' in w, state=state is not None), err); sys.exit(1)
-print('lgd: %d random cases, worst abs error %.2e' % (n, worst))
+print('lgd: %d random cases, worst abs error %.2e' % (n, worst), 'at', worst_case)
 print('     (smpl_tile, smpl_fuse, on-device suppression, two-part forward) -> cases:', sorted(variants.items()))

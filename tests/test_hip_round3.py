@@ -665,12 +665,16 @@ def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F, In, Hd,
     layer.release()
 
 
-def test_init_heads_as_one_row_block_product_equal_the_two_problem_launch(big_model):
+@pytest.mark.parametrize('width', [512, 32])
+def test_init_heads_as_one_row_block_product_equal_the_two_problem_launch(big_model, width):
     """From 4096 frames on the pose (66) and shape (10) heads on the LSTM output run as ONE product over their stacked
     columns (heads_rows_kernel, option heads_rows) instead of two problems on the generic tile: same k order, same bias
     add -- the whole forward is bit-identical."""
     torch.manual_seed(11)
-    net = create_model(lgd_config(12, True, 2), SMPLLayer(big_model))
+    # (width 32: a narrow LSTM, whose staged 64-row block is smaller than the kernel's transposed 96 x 64 result -- the
+    # shared-memory size has to cover both; found by tests/fuzz/fuzz_lgd.py)
+    cfg = lgd_config(12, True, 2) if width == 512 else lgd_config(12, True, 2, hidden=32, rnn_hidden=32)
+    net = create_model(cfg, SMPLLayer(big_model))
     _randomize_bn(net, 12)
     net = net.eval().to(DEV)
     B, F = 130, 32     # 4160 frames: not a multiple of the 64-row blocks
