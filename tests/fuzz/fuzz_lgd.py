@@ -10,6 +10,7 @@ from em_pose_amd.helpers.configuration import lgd_config
 from em_pose_amd.nn.models import create_model
 from oracle import torch_ref as R
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+torch.manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)   # the carried LSTM states come from torch's generator: same seed, same cases
 n_cases = int(sys.argv[2][2:]) if len(sys.argv) > 2 and sys.argv[2].startswith('n=') else None
 budget = 1e9 if n_cases else (float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
 DEV = 'cuda:0'
