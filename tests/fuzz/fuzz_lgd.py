@@ -51,15 +51,23 @@ while time.time() < t_end and (n_cases is None or n < n_cases):
     # under the missing sensors), the forward in two parts on two streams
     from em_pose_amd import _lib
     tile, fuse = int(rng.choice([0, 2])), int(rng.integers(0, 2))
+    force = [int(v) for v in sys.argv[3][6:].split(',')] if len(sys.argv) > 3 and sys.argv[3].startswith('force=') else None
+    if force:   # replay with given variants (the random draws below are still made, so the case sequence is unchanged)
+        tile, fuse = force[0], force[1]
     _lib.check(_lib.lib().empose_set_option(b'smpl_tile', tile))
     _lib.check(_lib.lib().empose_set_option(b'smpl_fuse', fuse))
     mp, mo, kw = inp['marker_pos'], inp['marker_oris'], {}
-    if inp['marker_masks'] is not None and rng.integers(0, 2):
+    want_supp = inp['marker_masks'] is not None and bool(rng.integers(0, 2))
+    if force and inp['marker_masks'] is not None:
+        want_supp = bool(force[2])
+    if want_supp:
         miss = (inp['marker_masks'] != 1).reshape(B, F, 12, 1)
         mp = torch.where(miss.expand(B, F, 12, 3).reshape(B, F, 36), torch.full_like(mp, 9.0), mp)
         mo = torch.where(miss.expand(B, F, 12, 9).reshape(B, F, 108), torch.full_like(mo, -2.0), mo)
         kw['suppress_mask_value'] = 0.0
     two_parts = bool(rng.integers(0, 2))
+    if force:
+        two_parts = bool(force[3])
     net.iter_stream = side if two_parts else None
     res = net.forward_tensors(g(mp), g(mo), g(inp['offset_t']), g(inp['offset_r']),
                               marker_masks=g(inp['marker_masks']), seq_lengths=g(inp['seq_lengths']),
