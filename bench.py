@@ -3,7 +3,8 @@
 Headline benchmark: frames/sec of the LGD-RNN-12 inference forward (N=4 iterations, window size 32, 12 sensors,
 batch 1024 windows per GPU -- BASELINE.json configs[2], model 1615200973's architecture) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: spawns its own N ranks, one per GPU; also runs as the
+                                                          ranks of `python -m torch.distributed.run --nproc-per-node N`)
 
 A step is one call of IterativeErrorFeedback.forward_tensors -> empose_lgd_forward on a device-resident batch of
 synthetic 12-sensor windows (synthetic SMPL-H-shaped body model, V=6890; random-init weights of the released
@@ -83,6 +84,16 @@ def flops_per_frame(net):
     else:
         fl += mlp(d_in, 66) + mlp(d_in, 10)
     return fl
+
+
+def baseline_config_label(net, n_markers, F, B):
+    """Which entry of BASELINE.json `configs` the command-line shape is (the headline is configs[2])."""
+    if n_markers == 12 and net.N == 4 and F == 32:
+        if net.rnn_init and B == 1024:
+            return 'BASELINE configs[2]'
+        if not net.rnn_init and B == 256:
+            return 'BASELINE configs[1]'
+    return 'custom shape (not a BASELINE config)'
 
 
 def cpu_baseline(net, model, w, hip_out=None, seconds_target=20.0):
@@ -296,16 +307,29 @@ def main():
                     help='kernel-variant switch of the library (empose_set_option), for A/B runs; repeatable')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world and world > 1:
+    # `python bench.py --gpus N` as a plain command spawns its own N ranks (one per GPU, RCCL over 127.0.0.1); under
+    # `python -m torch.distributed.run` the ranks already exist and this returns at once.  --force_dist sends even one
+    # rank through the same spawn + process-group path (single-GPU self-test of the multi-GPU entry).
+    from em_pose_amd.helpers import distributed as D
+    if args.workload == 'vertices' and args.gpus > 1:
+        raise SystemExit('the vertices workload is a single-GPU micro-benchmark')
+    D.maybe_self_launch(os.path.abspath(__file__), args.gpus, force=args.force_dist, what='bench.py')
+    launched = D.launched_by_a_launcher()
+    world = int(os.environ.get('WORLD_SIZE', '1')) if launched else 1
+    rank = int(os.environ.get('RANK', '0')) if launched else 0
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
+    if args.gpus != world:
         raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node {} bench.py ...'
-                         .format(args.gpus))
+    dist = None
+    if D.dist_backend(torch.device('cuda')) == 'gloo' and launched:
+        # device-less rendezvous (EMPOSE_DIST_BACKEND=gloo: the launcher's CPU test): join, meet the other ranks, then
+        # go on to the device check below like any other run
+        dist, rank, world = D.init_process_group(None, log=lambda m: print(m, file=sys.stderr, flush=True))
+        dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('bench.py --gpus {} needs {} GPUs, found {}'.format(world, world, torch.cuda.device_count()))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     for kv in args.option:
@@ -313,17 +337,9 @@ def main():
         name, _, value = kv.partition('=')
         _lib.check(_lib.lib().empose_set_option(name.encode(), int(value)))
     if args.workload == 'vertices':
-        if world > 1:
-            raise SystemExit('the vertices workload is a single-GPU micro-benchmark')
         return run_vertices(args, dev)
-    dist = None
-    if world > 1 or args.force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+    if dist is None and (launched and (world > 1 or args.force_dist)):
+        dist, rank, world = D.init_process_group(dev)
 
     from em_pose_amd import _lib
     net, model = build_net(args.n_markers, not args.no_rnn, args.iterations)
@@ -367,14 +383,18 @@ def main():
         value = frames_total * args.steps / elapsed
         fpf = flops_per_frame(net)
         result = {
-            'metric': 'frames/sec LGD-RNN N=4 12-sensor ws=32; MPJPE vs ref (mm)',
+            'metric': 'frames/sec LGD%s N=%d %d-sensor ws=%d; MPJPE vs ref (mm)' % ('-RNN' if net.rnn_init else '', net.N,
+                                                                                   args.n_markers, F),
             'value': value, 'unit': 'frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1000.0 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: LGD%s %d-sensor, N=%d, ws=%d, batch %d windows per GPU, '
-                                   '2x512 update MLPs, 2x512 LSTM init, synthetic SMPL-H-shaped body model (V=6890), '
-                                   'random-init weights' % ('-RNN' if net.rnn_init else '', args.n_markers, net.N, F, B),
+            'config': {'workload': '%s: LGD%s %d-sensor, N=%d, ws=%d, batch %d windows per GPU, '
+                                   '2x512 update MLPs, %s, synthetic SMPL-H-shaped body model (V=6890), '
+                                   'random-init weights' % (baseline_config_label(net, args.n_markers, F, B),
+                                                            '-RNN' if net.rnn_init else '', args.n_markers, net.N, F, B,
+                                                            '2x512 LSTM init' if net.rnn_init else 'MLP init'),
                        'windows_per_gpu': B, 'frames_per_window': F, 'parallelism': 'window-sharded x%d' % world,
+                       'process_group': None if dist is None else dist.get_backend(),
                        'keep_history': False,   # forward_tensors(); the five history tensors (N+1 entries each, 190 MB
                                                 # per step at this batch) are written only when a caller asks for them
 

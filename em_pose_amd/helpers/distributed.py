@@ -10,6 +10,118 @@ of DistributedDataParallel hooks.  BatchNorm statistics stay per-rank, as in the
 import torch
 
 
+LAUNCH_BACKEND_ENV = 'EMPOSE_DIST_BACKEND'   # 'gloo' = rendezvous without devices (the CPU test of the launcher)
+
+
+def launched_by_a_launcher():
+    """True inside a rank process (torch.distributed.run or `launch_ranks` set RANK and WORLD_SIZE)."""
+    import os
+    return 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+
+
+def dist_backend(device=None):
+    import os
+    forced = os.environ.get(LAUNCH_BACKEND_ENV)
+    if forced:
+        return forced
+    return 'nccl' if (device is not None and device.type == 'cuda') else 'gloo'
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script, argv, n, poll_s=0.2):
+    """
+    Run `script argv` as `n` rank processes of ONE node, one per GPU -- what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node n script argv` does, without needing the caller to type it: RANK / LOCAL_RANK / WORLD_SIZE /
+    LOCAL_WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT (a free port) in each child's environment, stdout / stderr
+    inherited (rank 0 is the one that prints results).  Fresh interpreters (no fork: the parent may already hold a HIP
+    context).  If a rank exits non-zero the others are terminated (by PID) and its code is returned; otherwise 0.
+    """
+    import os
+    import subprocess
+    import sys
+    import time
+    port = _free_port()
+    cores = os.cpu_count() or n
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.setdefault('OMP_NUM_THREADS', str(max(1, cores // n)))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code
+                    break
+            else:
+                time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc == 0:
+                    p.wait()
+                else:
+                    p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc
+
+
+def maybe_self_launch(script, n, force=False, what='this script'):
+    """
+    `python script --gpus n` as a plain command: when no launcher set up the ranks, become the launcher.  Returns
+    normally inside a rank process (or when one un-distributed process is all that is asked for); otherwise spawns the
+    ranks, waits and exits with their status.  With fewer than `n` visible GPUs: exit non-zero, "needs n GPUs, found m"
+    (unless EMPOSE_DIST_BACKEND=gloo asks for a device-less rendezvous, the launcher's CPU test).
+    """
+    import os
+    import sys
+    if launched_by_a_launcher() or (n <= 1 and not force):
+        return
+    if os.environ.get(LAUNCH_BACKEND_ENV) != 'gloo':
+        found = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if found < n:
+            raise SystemExit('{} --gpus {} needs {} GPUs, found {}'.format(what, n, n, found))
+    sys.stdout.flush()
+    sys.exit(launch_ranks(script, sys.argv[1:], n))
+
+
+def init_process_group(device=None, log=None):
+    """Rank-side: join the process group the launcher described in the environment (RCCL with the rank's device, or
+    gloo).  Returns (dist module, rank, world)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
+    backend = dist_backend(device)
+    kwargs = {'device_id': device} if backend == 'nccl' else {}
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, **kwargs)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if log is not None:
+        log('rank {}/{} joined the process group over {}'.format(rank, world, backend))
+    return dist, rank, world
+
+
 def init_from_env(device=None, backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (127.0.0.1 by default). Returns (rank, world)."""
     import os

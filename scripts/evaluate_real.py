@@ -21,9 +21,9 @@ the reference's `C.DEVICE` fallback (reference configuration.py:23, scripts/eval
 Only that model has a CPU path (the LGD models are the HIP path and refuse CPU tensors); without a device the joint
 position metrics, which need an SMPL-H evaluation, are skipped and the joint-angle metric is reported.
 
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N scripts/evaluate_real.py ...`; whole
-recordings are assigned to ranks longest-first (chunks of one recording are serially dependent), and the per-rank metric
-accumulators are combined with one all_gather over RCCL.
+Multi-GPU: `--gpus N` (spawns one rank per GPU; `python -m torch.distributed.run --nproc-per-node N
+scripts/evaluate_real.py ...` works too); whole recordings are assigned to ranks longest-first (chunks of one
+recording are serially dependent), and the per-rank metric accumulators are combined with one all_gather over RCCL.
 """
 import argparse
 import glob
@@ -144,6 +144,8 @@ def main():
     p.add_argument('--repeat', type=int, default=1,
                    help='Evaluate the set this many times and report every pass; the first pass still pays one-time '
                         'costs (kernels and allocations of every batch shape that occurs), later ones do not.')
+    p.add_argument('--gpus', type=int, default=1,
+                   help='Shard whole recordings over this many GPUs of the node (spawns one rank per GPU).')
     p.add_argument('--force_dist', action='store_true',
                    help='Initialise the process group (RCCL) and run the metric gather even with one rank (self-test).')
     p.add_argument('--no_warmup', action='store_true',
@@ -151,29 +153,41 @@ def main():
                         '(code-object loading, workspace allocation).')
     args = p.parse_args()
 
-    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # `--gpus N` as a plain command spawns its own N ranks (helpers/distributed.py); under torch.distributed.run the ranks
+    # exist already.  --force_dist sends one rank through the same spawn + RCCL path (single-GPU self-test).
+    from em_pose_amd.helpers import distributed as D
     on_cpu = args.device == 'cpu'
+    if on_cpu and (args.gpus > 1 or not (args.synthetic and args.m_type == 'resnet')):
+        raise SystemExit("--device cpu is the single-process plumbing configuration of the ResNet baseline "
+                         "(--synthetic --m_type resnet); the LGD models run the HIP path and need an MI355X.")
+    if not on_cpu:
+        D.maybe_self_launch(os.path.abspath(__file__), args.gpus, force=args.force_dist, what='evaluate_real.py')
+    launched = D.launched_by_a_launcher()
+    world = int(os.environ.get('WORLD_SIZE', '1')) if launched else 1
+    rank = int(os.environ.get('RANK', '0')) if launched else 0
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
+    if args.gpus not in (1, world):
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    dist = None
     if on_cpu:
-        if not (args.synthetic and args.m_type == 'resnet') or world > 1:
-            raise SystemExit("--device cpu is the single-process plumbing configuration of the ResNet baseline "
-                             "(--synthetic --m_type resnet); the LGD models run the HIP path and need an MI355X.")
+        if world > 1:
+            raise SystemExit('--device cpu is a single-process configuration')
         device = torch.device('cpu')
     else:
+        if launched and D.dist_backend(torch.device('cuda')) == 'gloo':   # device-less rendezvous: the launcher's CPU test
+            dist, rank, world = D.init_process_group(None, log=lambda m: print(m, file=sys.stderr, flush=True))
+            dist.barrier()
         if not torch.cuda.is_available():
             raise SystemExit('evaluate_real.py runs the HIP path and needs an MI355X; there is no CPU fallback '
                              '(the ResNet plumbing configuration: --synthetic --m_type resnet --device cpu).')
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit('evaluate_real.py --gpus {} needs {} GPUs, found {}'.format(world, world,
+                                                                                         torch.cuda.device_count()))
         device = torch.device('cuda', local_rank)
         torch.cuda.set_device(device)
     sync = (lambda: None) if on_cpu else torch.cuda.synchronize
-    dist = None
-    if world > 1 or (args.force_dist and not on_cpu):
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29534')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend='nccl', device_id=device)
+    if dist is None and launched and (world > 1 or args.force_dist) and not on_cpu:
+        dist, rank, world = D.init_process_group(device)
 
     net, smpl, lengths, load, name = (synthetic_setup if args.synthetic else real_setup)(args, device)
     mine = partition_sequences(lengths, world)[rank]
@@ -202,7 +216,9 @@ def main():
             me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256)
         sync()
         passes.append(time.perf_counter() - t0)
-    elapsed = passes[-1]
+    # what is reported: the median of the warm passes (pass 0 still pays for every batch shape that occurs for the first
+    # time); all passes are listed in `seconds_per_pass`
+    elapsed = float(np.median(passes[1:])) if len(passes) > 1 else passes[0]
     rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]
     if dist is not None:
         me_all.gather(device=device, force=args.force_dist)

@@ -6,7 +6,7 @@ model.backward -> optimizer.step, Adam, per-step loss line) on SYNTHETIC windows
 (the role of SMPLFK + SampleMarkersWithOffsets in the reference).  BASELINE.json configs[4].
 
     python scripts/train.py --steps 20                       # LGD-RNN-12, N=4, ws=32, 12 windows per GPU
-    python -m torch.distributed.run --nproc-per-node 8 scripts/train.py --steps 20
+    python scripts/train.py --steps 20 --gpus 8              # spawns 8 ranks; torch.distributed.run works too
 
 Data parallel over windows; gradients averaged with bucketed RCCL all-reduces (em_pose_amd/helpers/distributed.py).
 Forward, losses, backward and the optimiser step are the library's own kernels (em_pose_amd/nn/train_engine.py,
@@ -176,8 +176,8 @@ def train_on_amass(args, dev, rank, world):
                 break
         if done:
             break
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and args.json:
@@ -203,6 +203,8 @@ def main():
                                                      'synthetic step benchmark to real training')
     p.add_argument('--force_dist', action='store_true', help='initialise the process group (RCCL) and run the gradient '
                                                            'collectives even with one rank (self-test)')
+    p.add_argument('--gpus', type=int, default=1, help='data-parallel over this many GPUs of the node (spawns one rank '
+                                                      'per GPU)')
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
     p.add_argument('--option', action='append', default=[], metavar='NAME=INT',
                    help='kernel-variant switch of the library (empose_set_option), e.g. train_fused=0; repeatable')
@@ -218,12 +220,29 @@ def main():
     p.add_argument('--offset_noise_level', type=int, default=0)
     p.add_argument('--data_workers', type=int, default=0)
     args = p.parse_args()
+    # `--gpus N` as a plain command spawns its own N ranks (helpers/distributed.py); under torch.distributed.run the ranks
+    # exist already.  --force_dist sends one rank through the same spawn + RCCL path (single-GPU self-test).
+    from em_pose_amd.helpers import distributed as D
+    D.maybe_self_launch(os.path.abspath(__file__), args.gpus, force=args.force_dist, what='train.py')
+    launched = D.launched_by_a_launcher()
+    world = int(os.environ.get('WORLD_SIZE', '1')) if launched else 1
+    rank = int(os.environ.get('RANK', '0')) if launched else 0
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
+    if args.gpus not in (1, world):
+        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    joined = False
+    if launched and D.dist_backend(torch.device('cuda')) == 'gloo':   # device-less rendezvous: the launcher's CPU test
+        dist_, rank, world = D.init_process_group(None, log=lambda m: print(m, file=sys.stderr, flush=True))
+        dist_.barrier()
+        joined = True
     if not torch.cuda.is_available():
         raise SystemExit('train.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit('train.py --gpus {} needs {} GPUs, found {}'.format(world, world, torch.cuda.device_count()))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
-    rank, world = init_from_env(dev)
+    if not joined and launched and (world > 1 or args.force_dist):
+        _, rank, world = D.init_process_group(dev)
     for kv in args.option:
         from em_pose_amd import _lib
         name, value = kv.split('=')
@@ -267,14 +286,14 @@ def main():
     if args.graph:
         from em_pose_amd.helpers.graphed import GraphedTrainStep
         graphed = GraphedTrainStep(net, opt, batches[0])
-    times = []
+    times, n_coll = [], 0
     for step in range(args.warmup + args.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         batch = batches[step % len(batches)]
         if graphed is not None:
             vals = graphed(batch)            # forward + backward replayed; gradients in the static .grad tensors
-            average_gradients(buckets, params)
+            n_coll = average_gradients(buckets, params)
             opt.step()
             torch.cuda.synchronize()
             vals = {k: float(v) for k, v in vals.items()}
@@ -282,7 +301,7 @@ def main():
             opt.zero_grad()
             out = net(batch)
             loss, vals = net.backward(batch, out)     # finished buckets are already being averaged on a side stream
-            average_gradients(buckets, params)
+            n_coll = average_gradients(buckets, params)
             opt.step()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -291,8 +310,8 @@ def main():
         if rank == 0:
             print('[TRAIN {:0>5d}] '.format(step + 1) + ' '.join('{}: {:.6f}'.format(k, v) for k, v in vals.items()) +
                   ' elapsed: {:.3f} secs'.format(dt))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         t = torch.tensor([float(np.median(times))], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         med = float(t.item())
@@ -300,10 +319,12 @@ def main():
         med = float(np.median(times))
     if rank == 0:
         res = {'steps_per_sec': 1.0 / med, 'frames_per_sec': world * B * F / med, 'n_gpus': world,
-               'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3, 'hip_graph': bool(args.graph)}
+               'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3, 'hip_graph': bool(args.graph),
+               'process_group': dist.get_backend() if dist.is_initialized() else None,
+               'gradient_collectives_per_step': n_coll}
         print(json.dumps(res) if args.json else res)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

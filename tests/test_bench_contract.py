@@ -24,10 +24,93 @@ def test_bench_refuses_to_run_without_a_gpu():
     assert 'no CPU fallback' in (r.stderr + r.stdout)
 
 
-def test_bench_multi_gpu_needs_the_launcher():
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason='checks the too-few-GPUs exit')
+def test_bench_multi_gpu_says_how_many_gpus_it_found():
+    """`python bench.py --gpus N` is a plain command (no torch.distributed.run needed): with fewer than N devices it
+    exits non-zero and says so."""
     r = _run(['--gpus', '2'], env={'WORLD_SIZE': '1'})
     assert r.returncode != 0
-    assert 'torch.distributed.run' in (r.stderr + r.stdout)
+    assert 'needs 2 GPUs, found' in (r.stderr + r.stdout)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='drives the launcher up to the point where a device is needed')
+@pytest.mark.parametrize('script,needle', [('bench.py', 'no CPU fallback'),
+                                           (os.path.join('scripts', 'evaluate_real.py'), 'no CPU fallback'),
+                                           (os.path.join('scripts', 'train.py'), 'no CPU fallback')])
+def test_plain_command_spawns_its_own_ranks(script, needle):
+    """--gpus 2 without a launcher: two rank processes are spawned, rendezvous over 127.0.0.1 (gloo here: the
+    EMPOSE_DIST_BACKEND switch skips the device count), pass a barrier and only then stop at the device check."""
+    env = dict(os.environ, EMPOSE_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    extra = ['--synthetic'] if 'evaluate_real' in script else []
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script), '--gpus', '2'] + extra, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    text = r.stderr + r.stdout
+    assert r.returncode != 0
+    assert 'rank 0/2 joined the process group over gloo' in text, text[-2000:]
+    assert 'rank 1/2 joined the process group over gloo' in text, text[-2000:]
+    assert needle in text
+
+
+def test_launch_ranks_returns_the_failing_status_and_stops_the_others(tmp_path):
+    from em_pose_amd.helpers.distributed import launch_ranks
+    script = tmp_path / 'ranks.py'
+    script.write_text('import os, sys, time\n'
+                      'r = int(os.environ["RANK"]); assert os.environ["WORLD_SIZE"] == "3"\n'
+                      'assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0\n'
+                      'open(sys.argv[1] + "/r%d" % r, "w").write(os.environ["LOCAL_RANK"])\n'
+                      'if sys.argv[2] == "fail" and r == 1: sys.exit(7)\n'
+                      'if sys.argv[2] == "fail": time.sleep(120)\n')
+    assert launch_ranks(str(script), [str(tmp_path), 'ok'], 3) == 0
+    assert sorted(p.name for p in tmp_path.glob('r*') if p.name != 'ranks.py') == ['r0', 'r1', 'r2']
+    import time
+    t0 = time.time()
+    assert launch_ranks(str(script), [str(tmp_path), 'fail'], 3) == 7
+    assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_goes_through_the_spawn_path_and_agrees_with_the_plain_run():
+    """`bench.py --gpus 1 --force_dist`: the SAME self-launch + RCCL process-group path `--gpus 8` takes, on one GPU;
+    its value agrees with the plain single-process run."""
+    common = ['--steps', '10', '--warmup', '3', '--no_cpu_baseline', '--no_traffic']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    runs = {}
+    for name, extra in (('plain', []), ('spawn', ['--gpus', '1', '--force_dist'])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + common + extra, cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1
+        runs[name] = json.loads(lines[0])
+    assert runs['spawn']['n_gpus'] == 1 and runs['spawn']['config']['process_group'] == 'nccl'
+    assert runs['plain']['config']['process_group'] is None
+    assert runs['spawn']['value'] == pytest.approx(runs['plain']['value'], rel=0.02)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('script,extra,key', [
+    (os.path.join('scripts', 'evaluate_real.py'), ['--synthetic', '--max_sequences', '3', '--json'], 'frames_per_sec'),
+    (os.path.join('scripts', 'train.py'), ['--steps', '3', '--warmup', '1', '--bs_train', '4', '--json'], 'frames_per_sec')])
+def test_eval_and_train_scripts_spawn_their_own_rank_with_rccl(script, extra, key):
+    """configs[3] / [4] entry points: `--gpus 1 --force_dist` is the path `--gpus 8` takes (self-launch, RCCL group, the
+    metric gather / the gradient buckets), on the one GPU of this box."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script), '--gpus', '1', '--force_dist'] + extra, cwd=ROOT,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d[key] > 0
+    if 'train' in script:
+        assert d['process_group'] == 'nccl' and d['gradient_collectives_per_step'] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_with_more_gpus_than_the_box_has_exits_with_the_count():
+    n = torch.cuda.device_count() + 1
+    r = _run(['--gpus', str(n)])
+    assert r.returncode != 0 and 'needs %d GPUs, found %d' % (n, n - 1) in (r.stderr + r.stdout)
 
 
 @pytest.mark.gpu
