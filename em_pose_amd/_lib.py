@@ -118,6 +118,8 @@ SIGNATURES = {
     'empose_arch': (C.c_char_p, []),
     'empose_set_option': (C.c_int, [C.c_char_p, C.c_int]),
     'empose_get_option': (C.c_int, [C.c_char_p]),
+    'empose_reset_options': (C.c_int, []),
+    'empose_async_status': (C.c_int, []),
     'empose_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     'empose_model_destroy': (None, [C.c_void_p]),
     'empose_lgd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -508,6 +510,11 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
              const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
   const int H = r.H, L = r.num_layers, D = r.dirs, U = L * D;
   const size_t bh = (size_t)B * H;
+  // a poll of a cooperative kernel of an EARLIER call gave up: everything that call (and what was fed from it) produced
+  // is NaN.  Reported once, here, without synchronising (the counter is a host-mapped word).
+  if (const unsigned n = poll_timeouts_take())
+    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative LSTM kernel launched by an earlier call timed out waiting for "
+                "another workgroup's exchange word; that call's outputs are NaN (the state it carried too)", n);
   // the wavefront kernel addresses its operands with 32-bit byte offsets from a per-segment base
   if ((size_t)B * F * (size_t)(ldx > 2 * H ? ldx : 2 * H) * sizeof(float) >= ((size_t)1 << 32))
     return fail(EMPOSE_EINVAL, "LSTM batch of %d x %d frames is too large for one call; split the batch", B, F);
@@ -729,6 +736,64 @@ Options& options() {
   static Options o;
   return o;
 }
+
+namespace {
+unsigned* g_timeout_host = nullptr;   // host-mapped, device-visible (fine-grained): written by kernels, read here
+unsigned* g_timeout_dev = nullptr;
+}  // namespace
+unsigned* poll_timeout_word() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::memset(h, 0, 64);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+    g_timeout_host = static_cast<unsigned*>(h);
+    g_timeout_dev = static_cast<unsigned*>(d);
+  });
+  return g_timeout_dev;
+}
+unsigned poll_timeouts_take() {
+  if (!g_timeout_host) return 0;
+  return __atomic_exchange_n(g_timeout_host, 0u, __ATOMIC_RELAXED);
+}
+
+hipError_t coresident_blocks(const void* fn, int threads, size_t lds_bytes, int* blocks) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev)) return e;
+  struct Entry { size_t lds = 0; int blocks = -1; };
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, Entry> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry& c = cache[{dev, fn}];
+  if (c.blocks < 0 || lds_bytes > c.lds) {   // (a figure computed for more LDS is a safe one for less)
+    if (hipError_t e = allow_dynamic_lds(fn, lds_bytes)) return e;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes);
+    if (e != hipSuccess) return e;
+    c.lds = lds_bytes;
+    c.blocks = per_cu * prop.multiProcessorCount;
+  }
+  *blocks = c.blocks;
+  return hipSuccess;
+}
+
+hipError_t allow_dynamic_lds(const void* fn, size_t bytes) {
+  if (bytes > LDS_BYTES_PER_CU) return hipErrorInvalidValue;
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev)) return e;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> allowed;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = allowed[{dev, fn}];
+  if (bytes <= have) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
+  have = bytes;
+  return hipSuccess;
+}
 }  // namespace empose
 
 extern "C" {
@@ -743,10 +808,23 @@ int empose_set_option(const char* name, int value) {
       {"smpl_tile", &o.smpl_tile}, {"smpl_fuse", &o.smpl_fuse}, {"heads_rows", &o.heads_rows}, {"lstm_seq", &o.lstm_seq}, {"bptt_wave", &o.bptt_wave}, {"train_fused", &o.train_fused},
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
-      {"atb_chunk", &o.atb_chunk}};
+      {"atb_chunk", &o.atb_chunk},
+      {"spin_limit", &o.spin_limit}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
+}
+
+int empose_async_status(void) {
+  if (const unsigned n = poll_timeouts_take())
+    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative LSTM kernel timed out waiting for another workgroup's exchange "
+                "word; the outputs of that call are NaN", n);
+  return EMPOSE_OK;
+}
+
+int empose_reset_options(void) {
+  options() = Options{};
+  return EMPOSE_OK;
 }
 
 int empose_get_option(const char* name) {
@@ -757,7 +835,8 @@ int empose_get_option(const char* name) {
       {"smpl_tile", o.smpl_tile}, {"smpl_fuse", o.smpl_fuse}, {"heads_rows", o.heads_rows}, {"lstm_seq", o.lstm_seq}, {"bptt_wave", o.bptt_wave}, {"train_fused", o.train_fused},
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
-      {"atb_chunk", o.atb_chunk}};
+      {"atb_chunk", o.atb_chunk},
+      {"spin_limit", o.spin_limit}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;

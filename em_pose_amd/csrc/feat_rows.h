@@ -158,7 +158,7 @@ __device__ __forceinline__ void rodrigues_bwd_joint(const float (&th)[3], int ro
 // ~300 floats).  Ends with the rows written; contains one __syncthreads.
 template <bool FAST = false, class DF>
 __device__ __forceinline__ void rodrigues_bwd_tile(const RodBwdTArgs& a, int tile, float* sg, DF df) {
-  constexpr int FR = TL_FR, LD = 77;
+  constexpr int FR = TL_FR, LD = ROD_BWD_LD;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int t = tile * FR + lane;

@@ -311,13 +311,7 @@ static hipError_t launch_cfg(const GemmBatch& batch, hipStream_t stream) {
   }
   if (blocks == 0) return hipSuccess;
   constexpr size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr = false;
-  if (!attr && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<C, ROLE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_f32_kernel<C, ROLE>), lds)) return e;
   hipLaunchKernelGGL((gemm_tn_f32_kernel<C, ROLE>), dim3(blocks, batch.count), dim3(C::NT), lds, stream, batch);
   return hipGetLastError();
 }
@@ -514,13 +508,7 @@ static hipError_t launch_wide(const GemmBatch& batch, hipStream_t stream) {
     blocks = t > blocks ? t : blocks;
   }
   if (blocks == 0) return hipSuccess;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_f32_kernel<ROLE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_wide_f32_kernel<ROLE>), wide::LDS_BYTES)) return e;
   hipLaunchKernelGGL((gemm_wide_f32_kernel<ROLE>), dim3(blocks, batch.count), dim3(wide::NT), wide::LDS_BYTES, stream,
                      batch);
   return hipGetLastError();
@@ -819,13 +807,7 @@ size_t gemm_ksplit_workspace_floats(int M, int N, int K) {
 hipError_t launch_gemm_ksplit(const GemmProb& p, float* workspace, hipStream_t stream, const LstmCellBwdArgs* cell) {
   const int tiles = ((p.M + ks::BT - 1) / ks::BT) * ((p.N + ks::BT - 1) / ks::BT);
   const int S = (p.K + ks::KS - 1) / ks::KS;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ksplit_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_ksplit_kernel), ks::LDS_BYTES)) return e;
   hipLaunchKernelGGL(gemm_ksplit_kernel, dim3(tiles, S), dim3(256), ks::LDS_BYTES, stream, p, workspace);
   hipLaunchKernelGGL(gemm_ksplit_reduce_kernel, dim3(tiles * 16), dim3(256), 0, stream, p, (const float*)workspace, S, tiles,
                      cell ? *cell : LstmCellBwdArgs{}, cell ? 1 : 0);
@@ -932,14 +914,9 @@ __global__ __launch_bounds__(256) void gemm_fewrows_kernel(GemmBatch b, LstmCell
 template <int MB>
 static hipError_t launch_fewrows_cfg(const GemmBatch& batch, int maxN, int maxK, hipStream_t stream,
                                      const LstmCellBwdArgs* cell = nullptr) {
-  const size_t lds = (size_t)MB * maxK * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fewrows_kernel<MB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FEWROWS_MAX_LDS);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  const size_t lds = (size_t)MB * maxK * sizeof(float);   // arow[MB][K of the widest problem]
+  if (lds > FEWROWS_MAX_LDS) return hipErrorInvalidValue;
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_fewrows_kernel<MB>), lds)) return e;
   dim3 grid((maxN + 3) / 4, batch.count);
   hipLaunchKernelGGL(gemm_fewrows_kernel<MB>, grid, dim3(256), lds, stream, batch, cell ? *cell : LstmCellBwdArgs{},
                      cell ? 1 : 0);
@@ -1078,13 +1055,7 @@ hipError_t launch_rec_ksplit(const RecBatch& b, const LstmCellBwdArgs* cells, fl
     if (i > 0 && t != tiles) return hipErrorInvalidValue;   // the problems of a wavefront step share M and N
     tiles = t;
   }
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec_ksplit_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(rec_ksplit_kernel), ks::LDS_BYTES)) return e;
   hipLaunchKernelGGL(rec_ksplit_kernel, dim3(tiles, s_max, b.count), dim3(256), ks::LDS_BYTES, stream, b, workspace, tiles,
                      s_max);
   hipLaunchKernelGGL(rec_ksplit_reduce_kernel, dim3(tiles * 16, b.count), dim3(256), 0, stream, b, (const float*)workspace,
@@ -1169,14 +1140,9 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
 template <int MB>
 static hipError_t launch_rec_fewrows_cfg(const RecBatch& b, const LstmCellBwdArgs* cells, int maxN, int maxK,
                                          hipStream_t stream) {
-  const size_t lds = (size_t)MB * maxK * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rec_fewrows_kernel<MB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)FEWROWS_MAX_LDS);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  const size_t lds = (size_t)MB * maxK * sizeof(float);   // arow[MB][K of the widest segment]
+  if (lds > FEWROWS_MAX_LDS) return hipErrorInvalidValue;
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(rec_fewrows_kernel<MB>), lds)) return e;
   hipLaunchKernelGGL(rec_fewrows_kernel<MB>, dim3((maxN + 3) / 4, b.count), dim3(256), lds, stream, b, cells[0],
                      cells[b.count > 1 ? 1 : 0]);
   return hipGetLastError();

@@ -11,7 +11,8 @@
 namespace empose {
 
 // Kernel-variant selection for A/B and bit-identity tests (empose_set_option in the C ABI).  Plain process-wide ints set
-// by an explicit call -- the library never reads the environment.  All default to 1 (variant enabled).
+// by an explicit call -- the library never reads the environment.  Defaults as initialised below (empose_reset_options
+// restores them).
 struct Options {
   int mlp_fused = 1;      // one-launch LDS-resident update MLPs (0: layer by layer)
   int lstm_persist = 1;   // whole-sequence small-batch LSTM kernel (0: step launches)
@@ -26,8 +27,25 @@ struct Options {
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
+  int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
 };
 Options& options();
+
+// Dynamic LDS above the 64 KB a kernel may use by default: hipFuncAttributeMaxDynamicSharedMemorySize of `fn` on the
+// CURRENT device, raised when `bytes` exceeds what was already allowed there (cached per (device, kernel): a process that
+// drives several GPUs sets it on each).  More than a CU has (LDS_BYTES_PER_CU) is refused here instead of at the launch.
+// The cooperative whole-sequence LSTM kernels poll exchange words written by other workgroups; a poll that exceeds its
+// spin limit gives up, poisons the outputs with NaN (it does not hang) and counts itself in ONE host-mapped word that the
+// entry points read without synchronising: the next empose_* call that runs a recurrence returns EMPOSE_ETIMEOUT, and
+// empose_async_status() reports it to a caller that has synchronised.  Option "spin_limit" (0 = the kernels' own limits)
+// forces a limit, for tests.
+unsigned* poll_timeout_word();          // device-visible address of the counter
+unsigned poll_timeouts_take();          // host: read and clear
+constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
+hipError_t allow_dynamic_lds(const void* fn, size_t bytes);
+// Workgroups of `fn` (block size `threads`, `lds_bytes` of dynamic LDS) that can be resident at once on the CURRENT device:
+// what a cooperative launch may ask for.  Cached per (device, kernel); the attribute above is set on the way.
+hipError_t coresident_blocks(const void* fn, int threads, size_t lds_bytes, int* blocks);
 
 // ---------------------------------------------------------------------------------------------------------------
 // fp32 matrix-core linear layer:  C[m][n] = act( (sum_k A[m][k] * W[n][k]) * scale[n] + shift[n] ) (+ resid[m][n])
@@ -225,6 +243,7 @@ struct LstmSeqArgs {
   int B, F, H;
   unsigned* counters;
   int spin_limit;
+  unsigned* timeouts;   // poll_timeout_word(): counts the polls that gave up (the outputs are NaN from there on)
 };
 constexpr int LSTM_SEQ_MIN_B = 257;   // below: lstm_mid_kernel / the small-batch kernels
 size_t lstm_seq_counter_uints(int B);
@@ -454,6 +473,7 @@ hipError_t launch_rodrigues_bwd(const RodBwdArgs& a, hipStream_t stream);
 // "Tile layout" of a per-frame matrix X[T][C]: X_t[tile = t / 64][c][t % 64] -- a column of 64 frames is contiguous.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int TL_FR = 64;             // frames per tile = lanes of a wave
+constexpr int ROD_BWD_LD = 77;        // row stride of rodrigues_bwd_tile's staging block [TL_FR][77] (66 g_theta | 10 g_beta | pad)
 constexpr int TL_NR = 8;              // largest ring (= sensor vertex degree) the kernel takes
 constexpr int TL_NLOC = TL_NR + 1;    // local vertices of a sensor patch: centre + ring
 constexpr int TL_NBL = 8;              // distinct bones under one patch

@@ -601,6 +601,7 @@ __global__ __launch_bounds__(256) void lstm_seq_kernel(LstmSeqArgs a) {
         int spins = 0;
         while (dep_seen < need) {
           if (++spins > a.spin_limit) {
+            if (!failed && lane == 0) __hip_atomic_fetch_add(a.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             failed = true;
             break;
           }
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(256) void lstm_mid_kernel(LstmWaveArgs a) {
 
   // ---- partial sums of the four k chunks -> LDS [wave][element e][gate q][lane], summed in wave order
   float* red = lds;
+  static_assert(4 * 8 * 4 * 64 <= 2 * STAGE, "the partial-sum block [4 waves][8][4 gates][64 lanes] reuses the K-tile stages");
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -959,10 +961,18 @@ struct LstmPersistArgs {
   int B, F, H;
   unsigned long long* xch;   // [2][n_units][B][H] exchange words, zeroed before the launch
   int spin_limit;
+  unsigned* timeouts;        // poll_timeout_word()
 };
 
 __device__ __forceinline__ unsigned long long xch_pack(float v, unsigned tag) {
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// LDS of the kernel below, one definition for its indexing and its launcher: rows[B][x_t (layer 0's stored input) | h^0 |
+// h^1 | ...]
+__host__ __device__ constexpr int lstm_persist_row_floats(int in_k0, int n_units, int H) { return in_k0 + n_units * H; }
+__host__ __device__ constexpr size_t lstm_persist_lds_floats(int B, int in_k0, int n_units, int H) {
+  return (size_t)B * lstm_persist_row_floats(in_k0, n_units, H);
 }
 
 template <int P0, int P1>   // 256-wide pieces of the input / recurrent segment (K <= 256 * P)
@@ -981,7 +991,7 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
   const bool have_unit = wave < upb * NL && unit < H;
   const LstmUnitArgs& U = a.unit[l];
   const int KX = a.unit[0].in_k;              // stored input of layer 0
-  const int ldr = KX + NL * H;
+  const int ldr = lstm_persist_row_floats(KX, NL, H);
   const int K0 = U.in_k, K1 = H;
   const int in_off = l == 0 ? 0 : KX + (l - 1) * H, rec_off = KX + l * H;
   const int* __restrict__ lens = a.seq_lengths;
@@ -1085,7 +1095,10 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
       if (bad) fail_lds[0] = 1;
     }
     __syncthreads();
-    if (fail_lds[0]) failed = true;
+    if (fail_lds[0]) {
+      if (!failed && tid == 0) __hip_atomic_fetch_add(a.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      failed = true;
+    }
     if (have_unit && k >= 0 && k < F) {
       for (int b0 = 0; b0 < B; b0 += 4) {
         float acc[4][4];
@@ -1183,24 +1196,9 @@ __global__ __launch_bounds__(256) void lstm_persist_kernel(LstmPersistArgs a) {
 
 template <int P0, int P1>
 static hipError_t launch_lstm_persist_cfg(LstmPersistArgs& a, size_t lds, int grid, hipStream_t stream, bool* fits) {
-  static int capacity = -1;
-  static size_t attr = 0;
   const void* fn = reinterpret_cast<const void*>(lstm_persist_kernel<P0, P1>);
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
-    capacity = -1;
-  }
-  if (capacity < 0) {
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, attr);
-    if (e != hipSuccess) return e;
-    capacity = per_cu * prop.multiProcessorCount;
-  }
+  int capacity = 0;
+  if (hipError_t e = coresident_blocks(fn, 256, lds, &capacity)) return e;
   *fits = grid <= capacity;
   if (!*fits) return hipSuccess;
   void* params[] = {&a};
@@ -1229,8 +1227,11 @@ hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t st
   LstmPersistArgs a;
   for (int u = 0; u < 4; ++u) a.unit[u] = w.unit[u < w.n_units ? u : 0];
   a.n_units = w.n_units; a.seq_lengths = w.seq_lengths; a.B = w.B; a.F = w.F; a.H = w.H;
-  a.xch = reinterpret_cast<unsigned long long*>(xch); a.spin_limit = 1 << 20;
-  const size_t lds = (size_t)w.B * (w.unit[0].in_k + w.n_units * w.H) * sizeof(float);
+  a.xch = reinterpret_cast<unsigned long long*>(xch);
+  a.spin_limit = options().spin_limit > 0 ? options().spin_limit : 1 << 20;
+  a.timeouts = poll_timeout_word();
+  if (!a.timeouts) return hipErrorOutOfMemory;
+  const size_t lds = lstm_persist_lds_floats(w.B, w.unit[0].in_k, w.n_units, w.H) * sizeof(float);
   const int upb = 4 / w.n_units;
   const int grid = (w.H + upb - 1) / upb;
   if (lds > 128 * 1024) return hipSuccess;
@@ -1260,13 +1261,7 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   }
   if (a.B <= LSTM_MID_B) {   // K split over the waves of 32 x 16 tiles, one z slice per unit
     lstm_build_chain(a, 1);
-    static bool mid_attr = false;
-    if (!mid_attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_mid_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm::LDS_BYTES);
-      if (e != hipSuccess) return e;
-      mid_attr = true;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(lstm_mid_kernel), lm::LDS_BYTES)) return e;
     dim3 grid((a.H + lm::BU - 1) / lm::BU, (a.B + lm::BM - 1) / lm::BM, a.n_units);
     hipLaunchKernelGGL(lstm_mid_kernel, grid, dim3(256), lm::LDS_BYTES, stream, a);
     return hipGetLastError();
@@ -1275,13 +1270,7 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   // Chain all units in one block (equal work per block) once the tiles alone fill the CUs; spread them otherwise.
   const int units_per_block = tiles >= 192 ? a.n_units : 1;
   lstm_build_chain(a, units_per_block);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_chain_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(lstm_chain_kernel), lc::LDS_BYTES)) return e;
   dim3 grid((a.H + lc::BU - 1) / lc::BU, (a.B + lc::BM - 1) / lc::BM,
             (a.n_units + units_per_block - 1) / units_per_block);
   hipLaunchKernelGGL(lstm_chain_kernel, grid, dim3(256), lc::LDS_BYTES, stream, a);
@@ -1309,21 +1298,14 @@ hipError_t launch_lstm_seq(const LstmWaveArgs& w, float* const* h_third, unsigne
     a.hs[u][0] = w.unit[uu].h[0]; a.hs[u][1] = w.unit[uu].h[1]; a.hs[u][2] = h_third[uu];
   }
   a.n_units = w.n_units; a.seq_lengths = w.seq_lengths; a.B = w.B; a.F = w.F; a.H = w.H;
-  a.counters = counters; a.spin_limit = 1 << 16;   // ~0.1 s per poll at most: a lost counter poisons, it does not hang
+  a.counters = counters;
+  a.spin_limit = options().spin_limit > 0 ? options().spin_limit : 1 << 16;   // ~0.1 s per poll at most: a lost counter
+  a.timeouts = poll_timeout_word();                                            // poisons and is counted, it does not hang
+  if (!a.timeouts) return hipErrorOutOfMemory;
   const dim3 grid((w.H + lc::BU - 1) / lc::BU, (w.B + lc::BM - 1) / lc::BM);
-  static int capacity = -1;
   const void* fn = reinterpret_cast<const void*>(lstm_seq_kernel);
-  if (capacity < 0) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    int dev = 0, per_cu = 0;
-    hipDeviceProp_t prop;
-    e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lc::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    capacity = per_cu * prop.multiProcessorCount;
-  }
+  int capacity = 0;
+  if (hipError_t e = coresident_blocks(fn, 256, lc::LDS_BYTES, &capacity)) return e;
   if ((int)(grid.x * grid.y) > capacity) return hipSuccess;
   hipError_t e = hipMemsetAsync(counters, 0, lstm_seq_counter_uints(w.B) * sizeof(unsigned), stream);
   if (e != hipSuccess) return e;

@@ -480,16 +480,8 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
 }
 
 hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)mb::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<false>), mb::LDS_BYTES)) return e;
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<true>), mb::LDS_BYTES)) return e;
   const int bx = (a.T + mb::BM - 1) / mb::BM;
   const int n_tiles = (a.V + 31) / 32;
   int by = bx >= 256 ? 1 : (256 + bx - 1) / bx;
@@ -503,16 +495,8 @@ hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mr::LDS_BYTES);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_rows_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)mr::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_kernel<false>), mr::LDS_BYTES)) return e;
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_kernel<true>), mr::LDS_BYTES)) return e;
   const int bx = (a.T + mr::BM - 1) / mr::BM;
   const int n_tiles = (a.V + 31) / 32;
   // fewer than one workgroup per CU: split the mesh's tiles over grid.y (at least one tile per wave)

@@ -29,6 +29,29 @@ constexpr size_t LDS_BYTES = (size_t)BM * LDA * sizeof(float) + 64;   // + the l
 constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100;
 }  // namespace fm
 
+// LDS layout of the single-layer row-block kernels below -- ONE definition: the kernels take their strides and region
+// offsets from it and the launchers their byte count (a launcher that re-derived the size by hand once sized
+// heads_rows_kernel for its staged rows only, while the transposed result that later overwrites them was larger).
+//   [0, a)        the staged A block: row-major [rows][lda] plus the 16 floats the last fragment's look-ahead reads
+//                 (fused_layer_t's fread(g + 4)), or K-major [kpad][64] (look-ahead clamped, nothing behind it)
+//   [0, ct)       C^T [32-column tiles x 32][64] written over the A block after the K loop (OUT_T == 1), if any
+//   [extra_off, extra_off + extra)   a kernel-specific region: behind both blocks, or -- `extra_over_a`: it is only used
+//                 once the A block is dead -- behind C^T alone
+struct RowsLds {
+  int kpad, lda, extra_off, total;   // floats
+  __host__ __device__ constexpr size_t bytes() const { return (size_t)total * sizeof(float); }
+};
+__host__ __device__ constexpr RowsLds rows_lds(int K, int rows, bool a_kmajor, int ct_cols = 0, int extra = 0,
+                                               bool extra_over_a = false) {
+  const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;   // whole quads of k-groups: a multiple of 32
+  const int lda = a_kmajor ? 64 : kpad + 4;
+  const int a = a_kmajor ? kpad * 64 : rows * lda + 16;
+  const int ct = ((ct_cols + 31) / 32) * 32 * 64;
+  const int extra_off = extra_over_a ? ct : (a > ct ? a : ct);
+  const int end = extra_off + extra;
+  return RowsLds{kpad, lda, extra_off, end > a ? (end > ct ? end : ct) : (a > ct ? a : ct)};
+}
+
 #define FM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 #ifdef EMPOSE_FUSED_TRACE   // dev lab only: shader-clock stamps of block (0,0): per layer start, loop start, loop end, end
@@ -308,8 +331,8 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_kernel(FusedMlpArgs args) {
   const int M = args.M, m0 = blockIdx.x * BM_;
   const int tid = threadIdx.x;
   const int K0 = L.K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
-  const int lda = kpad + 4;
+  const RowsLds lay = rows_lds(K0, BM_, false);
+  const int kpad = lay.kpad, lda = lay.lda;
   {
     const int c4n = kpad / 4;
     for (int i0 = tid; i0 < BM_ * c4n; i0 += 4 * fm::NT) {   // four 16-byte pieces per thread in flight
@@ -338,16 +361,8 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_kernel(FusedMlpArgs args) {
 
 template <int BM_, int WM, int WN, int WCOLS>
 static hipError_t launch_gemm_rows_cfg(const FusedMlpArgs& args, hipStream_t stream) {
-  const int K0 = args.net[0].layer[0].K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
-  const size_t lds = (size_t)BM_ * (kpad + 4) * sizeof(float) + 64;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_kernel<BM_, WM, WN, WCOLS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
-  }
+  const size_t lds = rows_lds(args.net[0].layer[0].K, BM_, false).bytes();
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_rows_kernel<BM_, WM, WN, WCOLS>), lds)) return e;
   hipLaunchKernelGGL((gemm_rows_kernel<BM_, WM, WN, WCOLS>), dim3((args.M + BM_ - 1) / BM_), dim3(fm::NT), lds, stream,
                      args);
   return hipGetLastError();
@@ -446,8 +461,8 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) 
   const FusedLayer& L = net.layer[0];
   const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
   const int K0 = L.K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;   // multiple of 32
-  const int lda = kpad + 4;
+  const RowsLds lay = rows_lds(K0, 64, A_T);
+  const int kpad = lay.kpad, lda = lay.lda;
   if (A_T) rt::stage_a_tile(net.x, net.ldx, tile, K0, kpad, act);
   else rt::stage_a_rows(net.x, net.ldx, m0, M, K0, kpad, lda, act);
   __syncthreads();
@@ -458,6 +473,8 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) 
 // The blend-shape GEMM of the frame-per-lane path with the iteration's pose / shape update, Rodrigues and the feature
 // row as its PROLOGUE (feat_rows.h: the body of update_feat_kernel): the 64 x 200 feature block is built in LDS from
 // 76 floats per frame and never exists in HBM.  out_t = feat . Wc2^T in tile layout.
+constexpr int BLEND_FEAT_K = 200;   // feature columns (feat_rows.h); a tile of 64 frames touches at most 64 windows
+__host__ __device__ constexpr RowsLds blend_feat_lds() { return rows_lds(BLEND_FEAT_K, 64, false, 0, 64 * 10); }
 template <int WN>
 __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs args, FeatArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float act[];
@@ -465,12 +482,14 @@ __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs ar
   const FusedLayer& L = net.layer[0];
   const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
   const int tid = threadIdx.x;
-  constexpr int K0 = 200, kpad = 224, lda = kpad + 4;
+  constexpr int K0 = BLEND_FEAT_K;
+  constexpr RowsLds lay = blend_feat_lds();
+  constexpr int lda = lay.lda;
   for (int i = tid; i < 64 * (lda - K0); i += fm::NT) act[(i / (lda - K0)) * lda + K0 + i % (lda - K0)] = 0.f;
   const int fl = tid >> 5, slot = tid & 31;
   // window means of the shape update, once per window of the tile (32 lanes per window), through the pad columns'
   // neighbours in LDS: s_mean[window in tile][10] behind the A block
-  float* s_mean = act + 64 * lda;
+  float* s_mean = act + lay.extra_off;   // [<= 64 windows of the tile][10]
   const bool avg = fa.d_beta && fa.shape_avg;
   const int t_last = min(m0 + 63, M - 1);
   const int w_first = m0 / fa.F, n_win = avg ? t_last / fa.F - w_first + 1 : 0;   // <= 64
@@ -503,6 +522,10 @@ __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs ar
 // The transposed blend-shape GEMM of the frame-per-lane path (d_feat = d_out . Wc2, both in tile layout) with the
 // Rodrigues reverse as its EPILOGUE (feat_rows.h: the body of rodrigues_bwd_t_kernel): the feature cotangents stay in
 // LDS, what leaves is g_theta / g_beta in the caller's rows.
+constexpr int BLEND_T_N = 200;   // feature cotangent columns; rodrigues_bwd_tile's staging: TL_FR x 77 floats (feat_rows.h)
+__host__ __device__ constexpr RowsLds blend_t_rod_lds(int K) {
+  return rows_lds(K, 64, true, BLEND_T_N, TL_FR * ROD_BWD_LD, true);
+}
 template <int WN>
 __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs args, RodBwdTArgs ra) {
   extern __shared__ __attribute__((aligned(16))) float act[];
@@ -510,30 +533,20 @@ __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs a
   const FusedLayer& L = net.layer[0];
   const int M = args.M, tile = blockIdx.x, m0 = tile * 64;
   const int K0 = L.K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
-  const int lda = kpad + 4;
-  rt::stage_a_tile(net.x, net.ldx, tile, K0, kpad, act);
+  const RowsLds lay = blend_t_rod_lds(K0);
+  rt::stage_a_tile(net.x, net.ldx, tile, K0, lay.kpad, act);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fused_layer_t<1, WN, 1, true>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
-  const int NT32 = (L.N + 31) / 32;
-  float* sg = act + NT32 * 32 * 64;
+  fused_layer_t<1, WN, 1, true>(net, L, M, m0, act, lay.lda, wave >> 1, (wave & 1) * WN, 0, true);
+  float* sg = act + lay.extra_off;   // behind C^T (the A block is dead by now)
   const int lane = threadIdx.x & 63;
   rodrigues_bwd_tile<true>(ra, tile, sg, [&](int col) { return act[col * 64 + ((lane + col) & 63)]; });
 }
 
 template <int WN, bool A_T>
 static hipError_t launch_gemm_rows_t_cfg(const FusedMlpArgs& args, hipStream_t stream) {
-  const FusedLayer& L = args.net[0].layer[0];
-  const int kpad = (((L.K + 7) / 8 + 3) & ~3) * 8;
-  const size_t lds = (size_t)64 * (A_T ? kpad : kpad + 4) * sizeof(float);
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rows_t_kernel<WN, A_T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
-  }
+  const size_t lds = rows_lds(args.net[0].layer[0].K, 64, A_T).bytes();
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_rows_t_kernel<WN, A_T>), lds)) return e;
   hipLaunchKernelGGL((gemm_rows_t_kernel<WN, A_T>), dim3((args.M + 63) / 64), dim3(fm::NT), lds, stream, args);
   return hipGetLastError();
 }
@@ -567,12 +580,11 @@ __global__ __launch_bounds__(fm::NT) void heads_rows_kernel(FusedMlpArgs args, H
   const FusedLayer& L = net.layer[0];
   const int M = args.M, m0 = blockIdx.x * 64;
   const int K0 = L.K;
-  const int kpad = (((K0 + 7) / 8 + 3) & ~3) * 8;
-  const int lda = kpad + 4;
-  rt::stage_a_rows(net.x, net.ldx, m0, M, K0, kpad, lda, act);
+  const RowsLds lay = rows_lds(K0, 64, false, h.n_all);
+  rt::stage_a_rows(net.x, net.ldx, m0, M, K0, lay.kpad, lay.lda, act);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fused_layer_t<1, 2, 1>(net, L, M, m0, act, lda, wave & 1, (wave >> 1) * 2, 0, true);
+  fused_layer_t<1, 2, 1>(net, L, M, m0, act, lay.lda, wave & 1, (wave >> 1) * 2, 0, true);
   // C^T in LDS ([column][64], rows rotated by the column)
   for (int i = threadIdx.x; i < 64 * h.n_all; i += fm::NT) {
     const int row = i / h.n_all, n = i - row * h.n_all;
@@ -594,38 +606,25 @@ static FusedMlpArgs rows_t_args(const float* A, int lda, const float* Wp, float*
 }
 
 template <class Kern, class Extra>
-static hipError_t launch_rows_t_fused(Kern kern, size_t lds, size_t* attr, const FusedMlpArgs& a, const Extra& x,
-                                      hipStream_t stream) {
-  if (lds > *attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    *attr = lds;
-  }
+static hipError_t launch_rows_t_fused(Kern kern, size_t lds, const FusedMlpArgs& a, const Extra& x, hipStream_t stream) {
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
   hipLaunchKernelGGL(kern, dim3((a.M + 63) / 64), dim3(fm::NT), lds, stream, a, x);
   return hipGetLastError();
 }
 
 hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream) {
   if (N > 320 || ldc_t != ((N + 31) / 32) * 32) return hipErrorInvalidValue;
-  const FusedMlpArgs a = rows_t_args(nullptr, 0, Wp, C_t, ldc_t, fa.T, N, 200);
-  const size_t lds = (size_t)(64 * 228 + 64 * 10) * sizeof(float);   // the A block + the tile's window means
-  static size_t attr5 = 0, attr4 = 0;
-  if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5>, lds, &attr5, a, fa, stream);
-  return launch_rows_t_fused(blend_feat_gemm_kernel<4>, lds, &attr4, a, fa, stream);
+  const FusedMlpArgs a = rows_t_args(nullptr, 0, Wp, C_t, ldc_t, fa.T, N, BLEND_FEAT_K);
+  const size_t lds = blend_feat_lds().bytes();   // the A block + the tile's window means
+  if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5>, lds, a, fa, stream);
+  return launch_rows_t_fused(blend_feat_gemm_kernel<4>, lds, a, fa, stream);
 }
 
 hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
                                    hipStream_t stream) {
-  constexpr int N = 200;
   if (K % 4 != 0) return hipErrorInvalidValue;
-  const FusedMlpArgs a = rows_t_args(A_t, lda_t, Wp, nullptr, 0, ra.T, N, K);
-  const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;
-  const size_t a_bytes = (size_t)64 * kpad * sizeof(float);
-  const size_t c_bytes = ((size_t)((N + 31) / 32) * 32 * 64 + (size_t)TL_FR * 77) * sizeof(float);
-  const size_t lds = a_bytes > c_bytes ? a_bytes : c_bytes;
-  static size_t attr = 0;
-  return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, lds, &attr, a, ra, stream);
+  const FusedMlpArgs a = rows_t_args(A_t, lda_t, Wp, nullptr, 0, ra.T, BLEND_T_N, K);
+  return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, blend_t_rod_lds(K).bytes(), a, ra, stream);
 }
 
 bool heads_rows_applicable(int M, int K) { return M >= 4096 && K % 4 == 0 && K <= FUSED_MAX_WIDTH; }
@@ -635,31 +634,16 @@ hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const flo
   if (n_pose + n_shape > 128) return hipErrorInvalidValue;
   const FusedMlpArgs a = rows_t_args(y, ldy, Wp, nullptr, 0, M, n_pose + n_shape, K);
   HeadsArgs h{bias, theta, ld_theta, shape, ld_shape, n_pose, n_pose + n_shape};
-  const int kpad = (((K + 7) / 8 + 3) & ~3) * 8;
   // the staged rows of y, later the transposed result (whole 32-column tiles): whichever is larger (a narrow LSTM's
-  // row block is smaller than the 96 x 64 result)
-  const size_t a_bytes = (size_t)64 * (kpad + 4) * sizeof(float) + 64;
-  const size_t c_bytes = (size_t)((n_pose + n_shape + 31) / 32) * 32 * 64 * sizeof(float);
-  const size_t lds = a_bytes > c_bytes ? a_bytes : c_bytes;
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = lds;
-  }
+  // row block is smaller than the 96 x 64 result) -- rows_lds, the layout the kernel indexes with
+  const size_t lds = rows_lds(K, 64, false, n_pose + n_shape).bytes();
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel), lds)) return e;
   hipLaunchKernelGGL(heads_rows_kernel, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
   return hipGetLastError();
 }
 
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)fm::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_kernel), fm::LDS_BYTES)) return e;
   dim3 grid((args.M + fm::BM - 1) / fm::BM, args.count);
   hipLaunchKernelGGL(mlp_fused_kernel, grid, dim3(fm::NT), fm::LDS_BYTES, stream, args);
   return hipGetLastError();

@@ -726,13 +726,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_sensors_kernel(ChainArgs a) 
 template <int FR, int NT>
 static hipError_t launch_chain_cfg(const ChainArgs& a, hipStream_t stream) {
   const size_t lds = chain_lds_bytes(a.tab, FR);
-  static size_t attr_set = 0;
-  if (lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_sensors_kernel<FR, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = lds;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(chain_sensors_kernel<FR, NT>), lds)) return e;
   const int blocks = (a.T + FR - 1) / FR;
   hipLaunchKernelGGL((chain_sensors_kernel<FR, NT>), dim3(blocks), dim3(NT), lds, stream, a);
   return hipGetLastError();

@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64 * NW) void smpl_tile_kernel(TileArgs a) {
 // of a frame leave through LDS as contiguous row pieces (the caller's rows have a stride of ~300 floats).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rodrigues_bwd_t_kernel(RodBwdTArgs a) {
-  __shared__ float sg[TL_FR * 77];
+  __shared__ float sg[TL_FR * ROD_BWD_LD];
   const int tile = blockIdx.x;
   const float* df_t = a.d_feat_t + (size_t)tile * a.ld_feat_t * TL_FR + (threadIdx.x & 63);
   rodrigues_bwd_tile(a, tile, sg, [&](int col) { return df_t[(size_t)col * TL_FR]; });   // feat_rows.h
@@ -772,13 +772,8 @@ static hipError_t launch_tile_cfg(const TileArgs& a, hipStream_t stream) {
 #define TL_BWD_WAVES 4
 #endif
   constexpr int NWAVES = BWD ? TL_BWD_WAVES : 8;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smpl_tile_kernel<BWD, NLOC, NBL, NWAVES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(smpl_tile_kernel<BWD, NLOC, NBL, NWAVES>), tl::LDS_BYTES))
+    return e;
   const int tiles = (a.T + TL_FR - 1) / TL_FR;
   hipLaunchKernelGGL((smpl_tile_kernel<BWD, NLOC, NBL, NWAVES>), dim3(tiles), dim3(64 * NWAVES), tl::LDS_BYTES, stream, a);
   return hipGetLastError();

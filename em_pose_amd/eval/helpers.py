@@ -139,6 +139,14 @@ def partition_sequences(lengths, world_size):
     return [sorted(p) for p in parts]
 
 
+def _check_async(dev):
+    """After a synchronisation: a cooperative LSTM kernel that gave up on a poll poisoned its outputs with NaN and counted
+    itself (include/empose_hip.h, empose_async_status) -- raise instead of averaging NaNs into the metrics table."""
+    if torch.device(dev).type == 'cuda':
+        from em_pose_amd import _lib
+        _lib.check(_lib.lib().empose_async_status())
+
+
 class _nothing(object):
     def __enter__(self):
         return self
@@ -185,6 +193,10 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                                                    chunk.marker_masks)
                 chunk = chunk.to_gpu(device)
                 out = net(chunk, is_new_sequence=(c == 0))
+                if side is not None and net.outputs_ready is None:
+                    # the forward did not go through the two-stream path (autograd forward of a `differentiable` net with
+                    # grad enabled): its outputs are on the current stream, the metrics below are on the side stream
+                    side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side) if side is not None else _nothing():
                     if side is not None:   # the chunk lives in memory of the current stream's pool
                         for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
@@ -199,7 +211,8 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)   # the recording's rows are complete
             me_all.merge(me_ind.state())
-            per_sequence.append((batch.ids[0], me_ind.get_metrics()))
+            per_sequence.append((batch.ids[0], me_ind.get_metrics()))   # (reads the rows back: the device is in sync)
+            _check_async(dev)
     finally:
         if pipelined:
             net.iter_stream = None
@@ -267,6 +280,8 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             out = net(chunk, is_new_sequence=(c == 0))
             if net.rnn_init:
                 state, rows_prev = net.rnn.final_state, rows
+            if side is not None and net.outputs_ready is None:   # (see evaluate_sequences)
+                side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side) if side is not None else _nothing():
                 if side is not None:   # the chunk lives in memory of the current stream's pool
                     for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
@@ -284,6 +299,9 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             frames += sum(lens)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
+        if dev.type == 'cuda':
+            torch.cuda.synchronize(dev)
+            _check_async(dev)
         for me_tmp, rows, counts in deferred:
             st = me_tmp.state()
             at = 0

@@ -826,6 +826,7 @@ class IterativeErrorFeedback(BaseModel):
             self.rnn.init_state = self.rnn.final_state
         if self.training or torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and \
                 getattr(self, 'differentiable', False):
+            self.outputs_ready = None   # everything on the current stream (a caller's iter_stream is not used here)
             return self._forward_with_graph(batch, window_size)
         outs, hists, traces = [], [], []
         # (on the GPU the packing kernel replaces the readings of missing sensors; see RealBatch.get_inputs)

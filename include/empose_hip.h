@@ -26,6 +26,7 @@ extern "C" {
 #define EMPOSE_EINVAL (-1)   /* bad argument / unsupported configuration */
 #define EMPOSE_EHIP (-2)     /* a HIP runtime call failed */
 #define EMPOSE_ENOMEM (-3)   /* workspace too small / allocation failed */
+#define EMPOSE_ETIMEOUT (-4) /* a cooperative kernel gave up waiting for another workgroup: outputs poisoned with NaN */
 
 #define EMPOSE_N_BODY 22      /* root + 21 body joints, reference configuration.py:104 */
 #define EMPOSE_N_SENSORS 12   /* virtual sensors always evaluated, reference models.py:383,538 */
@@ -65,6 +66,19 @@ const char* empose_arch(void);
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
 int empose_set_option(const char* name, int value);
 int empose_get_option(const char* name);
+int empose_reset_options(void);   /* every option back to its default */
+
+/* Launches are asynchronous, so a failure INSIDE a kernel cannot be the return value of the call that launched it.  The
+ * one such failure this library has: the whole-sequence LSTM kernels (small batches: lstm_persist; opt-in lstm_seq) are
+ * cooperative -- workgroups poll exchange words written by other workgroups -- and a poll that exceeds its spin limit
+ * gives up, writes NaN from there on (it never hangs the GPU) and counts itself in a host-visible word.
+ *   - the next empose_lstm_fwd / empose_rnn_fwd / empose_lgd_forward[_phase] call returns EMPOSE_ETIMEOUT (once) instead
+ *     of running, with the count in empose_last_error();
+ *   - empose_async_status() returns EMPOSE_ETIMEOUT (once) or EMPOSE_OK: call it after synchronising the stream, before
+ *     trusting / averaging outputs (em_pose_amd.eval.helpers does).
+ * Option "spin_limit" (> 0) forces the limit of those polls (tests).  The reference's forward has no counterpart (a
+ * single Python thread, reference nn/layers.py:133-157). */
+int empose_async_status(void);
 
 /* ---- model description (host pointers) ------------------------------------------------------------------------ */
 

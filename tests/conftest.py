@@ -26,5 +26,4 @@ def _reset_kernel_variant_options():
     yield
     from em_pose_amd import _lib
     if _lib._lib is not None:
-        for name in (b'mlp_fused', b'lstm_persist', b'gemm_splitk', b'gemm_wide'):
-            _lib._lib.empose_set_option(name, 1)
+        _lib._lib.empose_reset_options()

@@ -8,43 +8,72 @@ PReLU kink): the two paths run different forward kernels, ~1e-7 apart, and that 
 orders of magnitude.  So every configuration also measures its own sensitivity -- the engine's step on inputs perturbed
 by one unit in the last place -- and the comparison allows 2e-4 of the tensor scale plus eight times that sensitivity
 (the same rule as tests/test_hip_parity.py::test_training_step_matches_reference_gradients, where the sensitivity was
-recorded from the reference itself)."""
-import sys, time
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-import numpy as np, torch
-import helpers as H
-from em_pose_amd.bodymodels.smpl import SMPLLayer
-from em_pose_amd.data.data import SyntheticBatch
-from em_pose_amd.helpers.configuration import CONSTANTS as C, lgd_config
-from em_pose_amd.nn.models import create_model
-from em_pose_amd import synthetic
-from oracle import torch_ref as R
-from em_pose_amd.nn import layers as _layers
-_layers.FORCE_LARGE_LINEAR[0] = True   # same forward GEMM kernel in both paths: no PReLU kink flips from rounding
+recorded from the reference itself).
 
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
-if len(sys.argv) > 3 and sys.argv[3] == 'per_iteration':   # weight gradients per iteration instead of once over all
+    python tests/fuzz/fuzz_train.py <seed> <seconds | n=CASES> [per_iteration]
+
+`run()` is shared with tests/test_fuzz_slice.py (a fixed-seed slice inside `pytest -m gpu`)."""
+import sys
+import time
+
+if __name__ == '__main__':
+    sys.path.insert(0, '.')
+    sys.path.insert(0, 'tests')
+
+import numpy as np
+import torch
+
+
+def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print):
+    """Returns {'n', 'worst' (gradient error / tolerance), 'flips', 'stats'}; AssertionError on a mismatch."""
+    try:
+        import helpers as H
+    except ImportError:
+        from tests import helpers as H
+    from em_pose_amd import _lib, synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn import layers as _layers
+    from em_pose_amd.nn.models import create_model
     from em_pose_amd.nn.train_engine import LgdTrainEngine
-    LgdTrainEngine.batched_wgrad = False
-dev = torch.device('cuda:0')
-model = H.small_model()
-bm = R.BodyModelTensors(model)
-vids = [int(v) for v in np.random.default_rng(5).choice(model['v_template'].shape[0], 12, replace=False)]
-tables = R.sensor_tables(model['f'], vids)
+    from oracle import torch_ref as R
+    force_large0, batched0 = _layers.FORCE_LARGE_LINEAR[0], LgdTrainEngine.batched_wgrad
+    _layers.FORCE_LARGE_LINEAR[0] = True   # same forward GEMM kernel in both paths: no PReLU kink flips from rounding
+    if per_iteration:                      # weight gradients per iteration instead of once over all
+        LgdTrainEngine.batched_wgrad = False
+    rng = np.random.default_rng(seed)
+    dev = torch.device('cuda:0')
+    model = H.small_model()
+    bm = R.BodyModelTensors(model)
+    vids = [int(v) for v in np.random.default_rng(5).choice(model['v_template'].shape[0], 12, replace=False)]
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+
+    stats, flips = {}, set()
+    t_end, n, worst = time.time() + (seconds if seconds is not None else 1e9), 0, 0.0
+    try:
+        while time.time() < t_end and (n_cases is None or n < n_cases):
+            n, worst = _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, seed)
+    finally:
+        _layers.FORCE_LARGE_LINEAR[0], LgdTrainEngine.batched_wgrad = force_large0, batched0
+        _lib.check(_lib.lib().empose_set_option(b'train_fused', 0))
+    assert len(flips) <= max(3, n // 3), 'too many to be kink flips'
+    return {'n': n, 'worst': worst, 'flips': len(flips), 'stats': stats}
 
 
-def sensors(poses, betas, o_r, o_t):
-    with torch.no_grad():
-        p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
-                                      torch.from_numpy(o_r), torch.from_numpy(o_t))
-    return p.numpy(), o.numpy()
-
-
-stats = {}
-flips = set()
-t_end, n, worst = time.time() + budget, 0, 0.0
-while time.time() < t_end:
+def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, seed):
+    from em_pose_amd import _lib, synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn.models import create_model
+    from oracle import torch_ref as R
     rnn, n_markers, N = bool(rng.integers(0, 2)), int(rng.choice([6, 12])), int(rng.integers(1, 4))
     B, F = int(rng.integers(1, 10)), int(rng.choice([8, 16, 32, 40]))
     torch.manual_seed(int(rng.integers(0, 1 << 30)))
@@ -52,7 +81,6 @@ while time.time() < t_end:
     # round 3: one case in eight with a 256-wide LSTM (the wavefront form of its reverse recurrences needs 4H >= 1024);
     # the train-mode layer with BatchNorm / PReLU inside the GEMMs in half of the cases
     rnn_hidden = 256 if (rnn and rng.integers(0, 8) == 0) else hidden
-    from em_pose_amd import _lib
     fused = int(rng.choice([0, 2]))
     _lib.check(_lib.lib().empose_set_option(b'train_fused', fused))
     cfg = lgd_config(n_markers, rnn, N, hidden=hidden, rnn_hidden=rnn_hidden)
@@ -108,10 +136,10 @@ while time.time() < t_end:
             flips.add(n)
             continue
         if not err <= tol:
-            print('TRAIN MISMATCH', dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, tol)
+            print('TRAIN MISMATCH', seed, n, dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, tol)
             for kk, vv in res[False][1].items():
                 print('  grad %-50s engine-vs-autograd %.2e of %.2e (sensitivity %.2e)' % (kk, float((res[True][1][kk] - vv).abs().max()), float(vv.abs().max()), sens_g[kk]))
-            sys.exit(1)
+            raise AssertionError('training fuzz mismatch, seed %d case %d' % (seed, n))
     for k, v in res[False][2].items():
         err = float((res[True][2][k] - v).abs().max())
         # train-mode BatchNorm over a few dozen rows amplifies the one-ulp differences between the two paths' kernels
@@ -119,11 +147,17 @@ while time.time() < t_end:
         # sensitivity only perturbs the inputs once
         if not err <= 3e-4 + 16.0 * sens_o[k]:
             print('OUTPUT MISMATCH', dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, sens_o[k])
-            sys.exit(1)
+            raise AssertionError('training fuzz mismatch, seed %d case %d' % (seed, n))
     assert abs(res[True][0] - res[False][0]) <= 1e-3 * max(1.0, abs(res[False][0])), (res[True][0], res[False][0])
-    n += 1
-print('train: %d random configurations, worst gradient error / tolerance %.2f; %d configurations with a PReLU kink flip' % (n, worst, len(flips)))
-assert len(flips) <= max(3, n // 3), 'too many to be kink flips'
-for k, v in stats.items():
-    v = np.sort(np.array(v))
-    print('  %s: median %.1e, 99%% %.1e, max %.1e' % (k, np.median(v), v[int(0.99 * (len(v) - 1))], v[-1]))
+    return n + 1, worst
+
+
+if __name__ == '__main__':
+    arg = sys.argv[2] if len(sys.argv) > 2 else '60'
+    r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, n_cases=int(arg[2:]) if arg.startswith('n=') else None,
+            seconds=None if arg.startswith('n=') else float(arg), per_iteration='per_iteration' in sys.argv[3:])
+    print('train: %d random configurations, worst gradient error / tolerance %.2f; %d configurations with a PReLU kink flip'
+          % (r['n'], r['worst'], r['flips']))
+    for k, v in r['stats'].items():
+        v = np.sort(np.array(v))
+        print('  %s: median %.1e, 99%% %.1e, max %.1e' % (k, np.median(v), v[int(0.99 * (len(v) - 1))], v[-1]))

@@ -1,0 +1,76 @@
+"""A fixed-seed slice of the randomized checks under tests/fuzz/, inside `pytest -m gpu` (round-3 lesson: the only
+memory-safety bug of that round, an LDS overrun of `heads_rows_kernel` with narrow LSTMs, was found by a fuzzer that
+pytest never ran).  Same generators as the command-line fuzzers, fixed seeds, fixed case counts; every case above 1e-5
+is logged with its kernel variants.  Reference semantics being protected: reference empose/nn/models.py:485-632,
+empose/nn/layers.py:133-157 (RNNLayer), empose/nn/layers.py:13-77 (MLP)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _show(capsys, text):
+    with capsys.disabled():
+        print('\n[fuzz slice] ' + text, flush=True)
+
+
+def test_lgd_forward_slice_all_kernel_variants_narrow_and_wide_nets(capsys):
+    """100 LGD / LGD-RNN forwards vs the oracle: golden nets + random-init nets with LSTMs of 8 / 16 / 64 units next to
+    update nets of 16..128 units (hidden < input and LSTM < heads' staging tile included), B in {1..257}, ragged
+    lengths, missing sensors (host- or device-side suppression), carried state, all 16 combinations of (frame-per-lane
+    SMPL kernels, fused blend GEMMs, on-device suppression, two-part forward on two streams)."""
+    from tests.fuzz import fuzz_lgd
+    r = fuzz_lgd.run(seed=4101, n_cases=100, extra_nets=True, batches=fuzz_lgd.BATCHES_SLICE, log=lambda m: _show(capsys, m))
+    _show(capsys, 'lgd: %d cases, worst %.2e at %s; %d above 1e-5; variants %s'
+          % (r['n'], r['worst'], r['worst_case'], len(r['above_1e5']), sorted(r['variants'].items())))
+    assert r['n'] == 100 and r['worst'] < 1e-4
+    assert len(r['variants']) >= 12     # the slice does visit the variant combinations
+    # errors of a few 1e-5 are input conditioning when they occur (see the regression below): HIP must then be no
+    # further from the float64 oracle than twice what the fp32 oracle itself is
+    for case, err, desc, f64 in r['above_1e5']:
+        assert f64['hip_vs_f64'] <= max(1e-5, 2.0 * f64['oracle_f32_vs_f64']), (case, err, desc, f64)
+
+
+@pytest.mark.parametrize('force', [(0, 0, 1, 1), (2, 1, 1, 1)], ids=['general_kernels', 'frame_per_lane'])
+def test_regression_short_masked_carried_windows_b257_f3(force, capsys):
+    """The one case above 1e-5 in 700 (seed 3602, case 20: 257 windows of 3 frames, missing sensors, carried LSTM state;
+    round 3 measured 1.57e-5 on the general kernels and 1.34e-5 on the frame-per-lane ones).  Pinned with its measured
+    bound, and with its conditioning: against the float64 oracle the HIP path is no worse than the fp32 oracle is."""
+    from tests.fuzz import fuzz_lgd
+    r = fuzz_lgd.run(seed=3602, n_cases=21, start=20, force=list(force), log=lambda m: _show(capsys, m))
+    assert r['n'] == 1 and r['worst_case'][1] == 'lgdrnn12_n4_carry'
+    assert r['worst_case'][2] == dict(B=257, F=3, masks=True, state=True)
+    assert r['worst'] < 2.5e-5, r['worst']
+    for case, err, desc, f64 in r['above_1e5']:
+        assert f64['hip_vs_f64'] <= max(1e-5, 2.0 * f64['oracle_f32_vs_f64']), f64
+
+
+def test_lstm_slice(capsys):
+    """300 random LSTM stacks vs torch.nn.LSTM on packed sequences: 1-4 layers, uni / bidirectional, 4..64 units,
+    B in {1..700} (all batch regimes + the opt-in whole-sequence kernel), ragged lengths, given state."""
+    from tests.fuzz import fuzz_lstm
+    r = fuzz_lstm.run(seed=4102, n_cases=300, log=lambda m: _show(capsys, m))
+    _show(capsys, 'lstm: %d cases, worst %.2e at %s' % (r['n'], r['worst'], r['worst_case']))
+    assert r['n'] == 300 and r['worst'] < 1e-4
+
+
+def test_linear_and_mesh_slice(capsys):
+    """300 random linear layers (every GEMM tile regime, bias / PReLU / residual) vs float64; 60 full-mesh evaluations
+    x (fp32, split-bf16) x both Rodrigues conventions vs the oracle."""
+    from tests.fuzz import fuzz_linear_mesh as F
+    r = F.run_linear(seed=4103, n_cases=300)
+    _show(capsys, 'linear: %d cases, worst %.2e at %s' % (r['n'], r['worst'], r['worst_case']))
+    assert r['n'] == 300
+    m = F.run_mesh(seed=4104, n_cases=60)
+    _show(capsys, 'mesh: %d cases, worst %.2e (f32) / %.2e (bf16x3)' % (m['n'], m['worst']['f32'], m['worst']['bf16x3']))
+    assert m['n'] == 60 and max(m['worst'].values()) < 3e-5
+
+
+def test_training_step_slice(capsys):
+    """60 random training configurations: the engine's hand-written reverse sweep vs autograd over the same kernels,
+    every parameter gradient within 2e-4 of scale + 8x the step's own one-ulp sensitivity."""
+    from tests.fuzz import fuzz_train
+    r = fuzz_train.run(seed=4105, n_cases=60)
+    _show(capsys, 'train: %d configurations, worst gradient error / tolerance %.2f, %d PReLU kink flips'
+          % (r['n'], r['worst'], r['flips']))
+    assert r['n'] == 60 and r['flips'] <= 6

@@ -28,15 +28,10 @@ ATOL = 1e-4
 DEV = 'cuda:0'
 
 
-class _OptionGuard(object):
-    """Sets a kernel-variant option of the library now and puts the old value back when it is dropped (monkeypatch undo)."""
-
-    def __init__(self, name, value):
-        self.name, self.old = name, _lib.lib().empose_get_option(name)
-        _lib.check(_lib.lib().empose_set_option(name, value))
-
-    def __del__(self):
-        _lib.lib().empose_set_option(self.name, self.old)
+def _set_option(name, value):
+    """Selects a kernel variant for the rest of THIS test: tests/conftest.py's autouse fixture puts every option back to
+    its default (empose_reset_options) when the test ends, passed or failed."""
+    _lib.check(_lib.lib().empose_set_option(name, value))
 
 
 def gpu(x, dtype=torch.float32):
@@ -178,7 +173,7 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
     lib = _lib.lib()
     outs = {}
     small = (theta, beta, off_r, off_t, tgt, scale)
-    tile_guard = _OptionGuard(b'smpl_tile', 0)   # this test is about the general kernel behind both GEMM kernels
+    _set_option(b'smpl_tile', 0)   # this test is about the general kernel behind both GEMM kernels
     for key, T, (th_, be_, or_, ot_, tg_, sc_) in (('splitk', T_small, small), (T_small, T_small, small),
                                                   (T_big, T_big, (theta_b, beta_b, off_r_b, off_t_b, tgt_b, scale_b))):
         _lib.check(lib.empose_set_option(b'gemm_splitk', 1 if key == 'splitk' else 0))   # kernel-variant switch
@@ -199,7 +194,6 @@ def test_smpl_sensors_large_batch_blend_gemm_path(big_model, monkeypatch):
         assert np.isfinite(b).all()
         # orientations and gradients amplify last-bit differences of the vertices (tolerances of the fwd/bwd test above)
         np.testing.assert_allclose(c, a, atol=2e-4 * max(1.0, float(np.abs(a).max())), rtol=1e-3)
-    del tile_guard
 
 
 def test_smpl_forward_only_matches(big_model):
@@ -773,10 +767,10 @@ def test_linear_train_function_vs_torch_autograd(M, K, N):
 def test_training_step_matches_reference_gradients(name, fused):
     """forward (train mode) + backward: losses and EVERY parameter gradient against the reference's own training
     step recorded in tests/golden (incl. the in-forward E.backward() deposits, ragged lengths, train-mode BatchNorm).
-    `fused`: the BatchNorm / PReLU passes folded into the GEMMs (csrc/train_fused.hip; by default from 1024 rows on,
-    forced here onto the recorded 48-frame batch)."""
+    `fused`: the BatchNorm / PReLU passes folded into the GEMMs (csrc/train_fused.hip; off by default -- measured no
+    faster --, forced here onto the recorded 48-frame batch)."""
     from em_pose_amd.data.data import SyntheticBatch
-    guard = _OptionGuard(b'train_fused', 2 if fused else 0)
+    _set_option(b'train_fused', 2 if fused else 0)
     case = H.load_case(name)
     meta, w, rec = case['meta'], case['in'], case['run']
     net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
@@ -829,7 +823,6 @@ def test_training_step_matches_reference_gradients(name, fused):
     net.zero_grad()
     net.backward(batch, net(batch))
     assert net._smpl_handle.value == h1
-    del guard
 
 
 def test_training_weight_gradients_once_over_all_iterations_equal_per_iteration_sums():

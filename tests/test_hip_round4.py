@@ -1,0 +1,136 @@
+"""
+GPU tests added in round 4: the status path of the cooperative whole-sequence LSTM kernels -- a poll
+that gives up poisons the outputs with NaN AND is reported (EMPOSE_ETIMEOUT from the next recurrence call /
+empose_async_status) instead of returning 0 and letting NaNs be averaged into a metrics table -- and the single LDS
+layout definition the row-block kernels and their launchers share.
+Reference semantics being replaced: reference nn/layers.py:133-157 (RNNLayer.forward; one Python thread, no such failure).
+"""
+import numpy as np
+import pytest
+import torch
+
+from em_pose_amd import _lib
+from em_pose_amd.nn.layers import RNNLayer
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ETIMEOUT = -4
+
+
+def _layer(In, H, L, seed):
+    torch.manual_seed(seed)
+    layer = RNNLayer(In, H, L).eval()
+    sd = {'lstm.' + k: v.detach().clone() for k, v in layer.lstm.state_dict().items()}
+    return layer.to(DEV), sd
+
+
+def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
+    """spin_limit = 1: the polls of the small-batch whole-sequence kernel (lstm_persist, B <= 16) give up almost at once.
+    The call itself is asynchronous and returns 0; after a synchronisation empose_async_status() says EMPOSE_ETIMEOUT
+    exactly when the outputs hold NaN, the NEXT recurrence call refuses with the same code (once), and with the normal
+    limit the same layer gives the oracle's numbers again."""
+    lib = _lib.lib()
+    assert lib.empose_async_status() == 0
+    B, F, In, H, L = 4, 48, 64, 128, 2
+    g, sd = _layer(In, H, L, 11)
+    x = torch.randn(B, F, In)
+    lens = torch.full((B,), F, dtype=torch.int64)
+    with torch.no_grad():
+        want, _ = R.lstm_forward(sd, 'lstm.', x, lens, None, L, False)
+    timed_out = 0
+    for attempt in range(4):
+        _lib.check(lib.empose_set_option(b'spin_limit', 1))
+        g.init_state = None
+        got = g(x.to(DEV), lens.to(DEV))          # returns normally: the failure happens later, on the device
+        torch.cuda.synchronize()
+        _lib.check(lib.empose_set_option(b'spin_limit', 0))
+        has_nan = bool(torch.isnan(got).any()) or bool(torch.isnan(g.final_state[0]).any())
+        status = lib.empose_async_status()
+        assert (status == ETIMEOUT) == has_nan, (status, has_nan)
+        if status == ETIMEOUT:
+            timed_out += 1
+            assert b'timed out' in lib.empose_last_error()
+            assert lib.empose_async_status() == 0       # reported once
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    assert timed_out >= 1, 'spin_limit = 1 never made a poll give up: the test does not exercise the status path'
+
+    # the other way of learning about it: the next call that runs a recurrence refuses, once
+    _lib.check(lib.empose_set_option(b'spin_limit', 1))
+    for attempt in range(8):
+        g.init_state = None
+        got = g(x.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        if torch.isnan(got).any():
+            break
+    else:
+        pytest.fail('no poll gave up in 8 launches with spin_limit = 1')
+    _lib.check(lib.empose_set_option(b'spin_limit', 0))
+    with pytest.raises(_lib.EmposeError, match='error -4'):
+        g(x.to(DEV), lens.to(DEV))
+    g.init_state = None
+    got = g(x.to(DEV), lens.to(DEV))               # the counter was taken by the refusal: back to normal
+    torch.cuda.synchronize()
+    assert lib.empose_async_status() == 0
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    g.release()
+
+
+def test_poll_timeout_of_the_large_batch_whole_sequence_kernel_is_reported():
+    """The opt-in cooperative kernel for batches above 256 rows (lstm_seq) shares the counter."""
+    lib = _lib.lib()
+    B, F, In, H, L = 300, 12, 64, 128, 2
+    g, sd = _layer(In, H, L, 12)
+    x = torch.randn(B, F, In)
+    lens = torch.full((B,), F, dtype=torch.int64)
+    with torch.no_grad():
+        want, _ = R.lstm_forward(sd, 'lstm.', x, lens, None, L, False)
+    _lib.check(lib.empose_set_option(b'lstm_seq', 1))
+    seen = 0
+    for attempt in range(6):
+        _lib.check(lib.empose_set_option(b'spin_limit', 1))
+        g.init_state = None
+        got = g(x.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        _lib.check(lib.empose_set_option(b'spin_limit', 0))
+        status = lib.empose_async_status()
+        has_nan = bool(torch.isnan(got).any()) or bool(torch.isnan(g.final_state[0]).any())
+        assert (status == ETIMEOUT) == has_nan
+        seen += status == ETIMEOUT
+    g.init_state = None
+    got = g(x.to(DEV), lens.to(DEV))
+    torch.cuda.synchronize()
+    assert lib.empose_async_status() == 0
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    g.release()
+    if seen == 0:
+        pytest.skip('no poll of lstm_seq gave up with spin_limit = 1 on this run (its waits are short); status path '
+                    'covered by the lstm_persist test')
+
+
+def test_evaluation_driver_raises_instead_of_averaging_nan():
+    """em_pose_amd.eval.helpers._check_async: what evaluate_sequences / evaluate_sequences_batched call once the device is
+    in sync."""
+    from em_pose_amd.eval.helpers import _check_async
+    lib = _lib.lib()
+    B, F, In, H, L = 2, 64, 32, 64, 2
+    g, _ = _layer(In, H, L, 13)
+    x = torch.randn(B, F, In)
+    lens = torch.full((B,), F, dtype=torch.int64)
+    _check_async(DEV)
+    _lib.check(lib.empose_set_option(b'spin_limit', 1))
+    raised = False
+    for attempt in range(8):
+        g.init_state = None
+        got = g(x.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        if torch.isnan(got).any():
+            with pytest.raises(_lib.EmposeError, match='timed out'):
+                _check_async(DEV)
+            raised = True
+            break
+    _lib.check(lib.empose_set_option(b'spin_limit', 0))
+    lib.empose_async_status()
+    g.release()
+    assert raised
