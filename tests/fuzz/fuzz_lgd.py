@@ -172,9 +172,27 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
                     ref64 = want64[k].numpy()
                     e_hip = max(e_hip, float(np.abs(got.cpu().numpy()[:, :, sl_] - ref64)[valid].max()))
                     e_o32 = max(e_o32, float(np.abs(want[k].numpy() - ref64)[valid].max()))
-                above.append((n, err, desc, {'hip_vs_f64': e_hip, 'oracle_f32_vs_f64': e_o32}))
-                log('case %d above 1e-5: %.3e %s; vs the float64 oracle: HIP %.3e, fp32 oracle %.3e'
-                    % (n, err, desc, e_hip, e_o32))
+                # ... and the case's own sensitivity, free of any implementation's rounding luck: the float64 oracle with
+                # the body-model constants (template, blend shapes, regressor, skin weights) and the inputs moved by one
+                # fp32 unit in the last place (random signs, four draws) -- the noise any fp32 evaluation of the vertices
+                # commits -- and how far the outputs move
+                sens = 0.0
+                prng = np.random.default_rng(12345 + n)
+                ulp = lambda a: a.astype(np.float64) * (1.0 + 6e-8 * np.sign(prng.standard_normal(a.shape)))
+                for draw in range(4):
+                    wp = dict(w)
+                    for k in ('marker_pos', 'marker_oris', 'offset_t'):
+                        wp[k] = ulp(w[k])
+                    model_p = {k: (ulp(v) if v.dtype.kind == 'f' else v) for k, v in model.items()}
+                    want_p, _ = R.ief_forward(sd64, R.BodyModelTensors(model_p, dtype=torch.float64), tables, vids,
+                                              H.oracle_inputs(wp, sl=lens, dtype=torch.float64),
+                                              n_markers=int(meta['n_markers']), N=int(meta['N']), rnn_init=rnn,
+                                              rnn_state=None if state is None else tuple(t.double() for t in state))
+                    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+                        sens = max(sens, float(np.abs(want_p[k].numpy() - want64[k].numpy())[valid].max()))
+                above.append((n, err, desc, {'hip_vs_f64': e_hip, 'oracle_f32_vs_f64': e_o32, 'one_ulp_sensitivity': sens}))
+                log('case %d above 1e-5: %.3e %s; vs the float64 oracle: HIP %.3e, fp32 oracle %.3e; the float64 outputs '
+                    'move by %.3e when body-model constants and inputs move by one fp32 ulp' % (n, err, desc, e_hip, e_o32, sens))
             if err > worst or not np.isfinite(err):
                 worst_case = (n,) + desc
             worst = max(worst, err) if np.isfinite(err) else float('nan')

@@ -9,6 +9,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _explained_by_conditioning(f64):
+    """A case above 1e-5 is accepted as conditioning -- not a kernel's inaccuracy -- when the HIP outputs are no further
+    from the float64 oracle than (a) twice what the fp32 oracle is, or (b) twice what the float64 outputs themselves
+    move when the body-model constants and the inputs move by ONE fp32 unit in the last place (the noise every fp32
+    evaluation of the vertices commits; the rule of the training goldens, tests/golden/train_sensitivity.json).
+    Round 4 replayed the B=257 / F=3 case stage by stage (scripts/dev/replay_case20.py, profiles/r04_replay_case20_*.txt):
+    one frame -- the only valid frame of its window, so its gradient is scaled by F / n_frames = 3 -- has a sensor whose
+    estimated orientation is within rounding of its target (the residual direction r / |r| is then decided by the last
+    bits of the vertices): orientation error 1e-5 already in the FORWARD pass of both implementations, gradient 675
+    against a typical 40.  Over the other 287 frames the per-frame gradient errors of HIP and of the fp32 oracle have the
+    same distribution (median ratio 0.97-1.04); one-ulp noise on the model constants moves the float64 outputs by 2.6e-5,
+    one-ulp noise on the inputs alone by 2.4e-7: the error belongs to fp32 vertices, not to a kernel."""
+    return f64['hip_vs_f64'] <= max(1e-5, 2.0 * f64['oracle_f32_vs_f64'], 2.0 * f64['one_ulp_sensitivity'])
+
+
 def _show(capsys, text):
     with capsys.disabled():
         print('\n[fuzz slice] ' + text, flush=True)
@@ -25,10 +40,9 @@ def test_lgd_forward_slice_all_kernel_variants_narrow_and_wide_nets(capsys):
           % (r['n'], r['worst'], r['worst_case'], len(r['above_1e5']), sorted(r['variants'].items())))
     assert r['n'] == 100 and r['worst'] < 1e-4
     assert len(r['variants']) >= 12     # the slice does visit the variant combinations
-    # errors of a few 1e-5 are input conditioning when they occur (see the regression below): HIP must then be no
-    # further from the float64 oracle than twice what the fp32 oracle itself is
+    # errors of a few 1e-5 are input conditioning when they occur (see the regression below)
     for case, err, desc, f64 in r['above_1e5']:
-        assert f64['hip_vs_f64'] <= max(1e-5, 2.0 * f64['oracle_f32_vs_f64']), (case, err, desc, f64)
+        assert _explained_by_conditioning(f64), (case, err, desc, f64)
 
 
 @pytest.mark.parametrize('force', [(0, 0, 1, 1), (2, 1, 1, 1)], ids=['general_kernels', 'frame_per_lane'])
@@ -41,8 +55,9 @@ def test_regression_short_masked_carried_windows_b257_f3(force, capsys):
     assert r['n'] == 1 and r['worst_case'][1] == 'lgdrnn12_n4_carry'
     assert r['worst_case'][2] == dict(B=257, F=3, masks=True, state=True)
     assert r['worst'] < 2.5e-5, r['worst']
+    assert r['above_1e5'], 'the case is expected above 1e-5 (if a change made it better, tighten the bound above)'
     for case, err, desc, f64 in r['above_1e5']:
-        assert f64['hip_vs_f64'] <= max(1e-5, 2.0 * f64['oracle_f32_vs_f64']), f64
+        assert _explained_by_conditioning(f64), f64
 
 
 def test_lstm_slice(capsys):
