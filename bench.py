@@ -203,6 +203,10 @@ def pmc_traffic_live(argv_tail, kernel_name, timeout_s=240):
         finally:
             shutil.rmtree(out, ignore_errors=True)
     nbytes = (2.0 * means['FETCH_SIZE'][0] + means['WRITE_SIZE'][0]) * 1024.0
+    pmc_traffic_live.raw = {'FETCH_SIZE_KiB_per_launch': means['FETCH_SIZE'][0],
+                            'WRITE_SIZE_KiB_per_launch': means['WRITE_SIZE'][0],
+                            'formula': 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM [CDNA4]: on '
+                                       'gfx950 FETCH_SIZE reports half of a wide coalesced read; WRITE_SIZE uncalibrated)'}
     return nbytes, ('measured by this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this command '
                     '(2 timed steps each; %d / %d dispatches of the kernel), bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB'
                     % (means['FETCH_SIZE'][1], means['WRITE_SIZE'][1]))
@@ -428,17 +432,20 @@ def main():
         timing = {'avg_launch_ms_all_launches_bracketed': avg_ms}
         if 'mlp_fused' in prof:
             # The pass above puts an event between ALL launches of the step (for the breakdown), which inflates every
-            # interval by the cost of the event packets.  The dominant kernel is therefore timed again inside the step
-            # with events around its launches only, minus the cost of an empty event pair measured in the same pass.
+            # interval by the cost of the event packets.  The dominant kernel is therefore timed again INSIDE the step, over
+            # as many steps as the timed region ran, with events around its launches only.  `avg_launch_ms` is the plain
+            # average of those intervals -- launch gap and event cost included, nothing subtracted: an upper bound of the
+            # kernel's duration, the figure `rocprofv3 --kernel-trace --stats` reports as its average for the same command
+            # (profiles/) agrees with it from below.  The cost of an empty event pair is reported beside it.
             _lib.check(lib.empose_profile_enable_only(b'mlp_fused'))
-            for _ in range(psteps):
+            for _ in range(max(args.steps, psteps)):
                 net.forward_tensors(*inputs)
             solo = _lib.profile_read()
             lib.empose_profile_enable(0)
-            raw = solo['mlp_fused'][0] / solo['mlp_fused'][1]
+            avg_ms = solo['mlp_fused'][0] / solo['mlp_fused'][1]
             pair = solo['event_pair'][0] / solo['event_pair'][1] if 'event_pair' in solo else 0.0
-            avg_ms = raw - pair
-            timing.update({'avg_launch_ms_bracketed_alone': raw, 'empty_event_pair_ms': pair})
+            timing.update({'avg_launch_ms_bracketed_alone_in_step': avg_ms, 'launches_averaged': solo['mlp_fused'][1],
+                           'empty_event_pair_ms': pair})
         ach = flops / (avg_ms * 1e-3) / 1e12
         traffic, traffic_src = (None, 'skipped (--no_traffic)')
         if world == 1 and not args.no_traffic:   # hardware counters: two child passes of this command under rocprofv3
@@ -455,6 +462,7 @@ def main():
         result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                               'traffic_source': traffic_src,
+                              'traffic_raw_counters': getattr(pmc_traffic_live, 'raw', None),
                               'kernel': kname + what,
                               'avg_launch_ms': avg_ms, 'timing': timing, 'launches_per_step': cnt / psteps,
                               'flops_per_launch': flops,
