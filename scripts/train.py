@@ -205,6 +205,8 @@ def main():
                                                            'collectives even with one rank (self-test)')
     p.add_argument('--gpus', type=int, default=1, help='data-parallel over this many GPUs of the node (spawns one rank '
                                                       'per GPU)')
+    p.add_argument('--single_stream', action='store_true',
+                   help='A/B: the training engine on one stream (default: shape network, weight gradients on a side stream)')
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
     p.add_argument('--option', action='append', default=[], metavar='NAME=INT',
                    help='kernel-variant switch of the library (empose_set_option), e.g. train_fused=0; repeatable')
@@ -248,6 +250,9 @@ def main():
         name, value = kv.split('=')
         _lib.check(_lib.lib().empose_set_option(name.encode(), int(value)))
 
+    if args.single_stream:
+        from em_pose_amd.nn.train_engine import LgdTrainEngine
+        LgdTrainEngine.two_streams = False
     if args.amass_dir or args.amass_lmdb:
         return train_on_amass(args, dev, rank, world)
     model = synthetic.make_model()
