@@ -809,7 +809,8 @@ int empose_set_option(const char* name, int value) {
       {"gemm_wide", &o.gemm_wide},
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk},
-      {"spin_limit", &o.spin_limit}};
+      {"spin_limit", &o.spin_limit},
+      {"train_epi", &o.train_epi}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
@@ -836,7 +837,8 @@ int empose_get_option(const char* name) {
       {"gemm_wide", o.gemm_wide},
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk},
-      {"spin_limit", o.spin_limit}};
+      {"spin_limit", o.spin_limit},
+      {"train_epi", o.train_epi}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;
@@ -1579,9 +1581,20 @@ bool mlp_train_fused(const empose_mlp_params* p, int M) {
   const int opt = options().train_fused;
   return opt != 0 && (opt == 2 || M > BN_SINGLE_PASS_ROWS) && p->hidden % 4 == 0 && p->in_dim % 4 == 0;
 }
-// per hidden layer: unfused  z [M][H] | a [M][H] | mean [H] | rstd [H];  fused  y [M][H] | mean | rstd | s | t
+// Round 4, the default above BN_SINGLE_PASS_ROWS rows: the statistics still come out of the GEMM epilogues, but the
+// activations / cotangents are materialised by ONE combine-and-apply launch per layer and direction (train_fused.hip,
+// bn_finish_*): GEMM + 1 launch instead of GEMM + 3, and every consumer reads a ready operand.  Option "train_epi":
+// 0 never, 1 above BN_SINGLE_PASS_ROWS rows (default), 2 always (tests).  "train_fused" takes precedence when both apply.
+bool mlp_train_epi(const empose_mlp_params* p, int M) {
+  const int opt = options().train_epi;
+  return !mlp_train_fused(p, M) && opt != 0 && (opt == 2 || M > BN_SINGLE_PASS_ROWS) && p->hidden % 4 == 0 &&
+         p->in_dim % 4 == 0;
+}
+// per hidden layer: passes  z [M][H] | a [M][H] | mean [H] | rstd [H];  fused  y [M][H] | mean | rstd | s | t;
+//                   epi     y [M][H] | a [M][H] | mean | rstd | s | t
 size_t mlp_layer_save(const empose_mlp_params* p, int M) {
   if (mlp_train_fused(p, M)) return (size_t)M * p->hidden + 4 * (size_t)p->hidden;
+  if (mlp_train_epi(p, M)) return (size_t)2 * M * p->hidden + 4 * (size_t)p->hidden;
   return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden;
 }
 }  // namespace
@@ -1608,6 +1621,33 @@ int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int 
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
   const int H = p->hidden, L = p->n_layers;
+  if (mlp_train_epi(p, M)) {
+    // y_l = a_{l-1} W_l^T + b_l on the materialised a_{l-1}; the epilogue leaves the column statistics of y_l per row
+    // block; ONE launch turns them into (mean, rstd, s, t), updates the running statistics and writes a_l = PReLU(s y_l + t)
+    const size_t lsz = mlp_layer_save(p, M);
+    for (int l = 0; l < L; ++l) {
+      const bool last = l == L - 1;
+      float* sv = save + (size_t)l * lsz;                      // this layer's y | a | mean | rstd | s | t
+      const float* pa = l > 0 ? save + (size_t)(l - 1) * lsz + (size_t)M * H : nullptr;
+      TrainGemmArgs g{};
+      g.A = l == 0 ? x : pa; g.lda = l == 0 ? ldx : H; g.W = p->weight[l]; g.ldw = l == 0 ? p->in_dim : H;
+      g.C = last ? out : sv; g.ldc = last ? ld_out : H;
+      g.M = M; g.N = last ? p->out_dim : H; g.K = l == 0 ? p->in_dim : H; g.bias = p->bias[l];
+      g.part = w.part;
+      hipError_t e = launch_gemm_train(g, 0, last ? 0 : 1, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "mlp forward gemm (statistics epilogue): %s", hipGetErrorString(e));
+      if (last) break;
+      BnFinishFwdArgs c{};
+      c.M = M; c.C = H; c.part = w.part; c.gamma = p->bn_weight[l]; c.beta = p->bn_bias[l];
+      c.eps = p->bn_eps; c.momentum = p->bn_momentum; c.running_mean = p->bn_running_mean[l];
+      c.running_var = p->bn_running_var[l]; c.num_batches_tracked = p->bn_num_batches[l];
+      c.mean = sv + (size_t)2 * M * H; c.rstd = c.mean + H; c.s = c.rstd + H; c.t = c.s + H;
+      c.y = sv; c.ldy = H; c.act = sv + (size_t)M * H; c.ld_act = H; c.slope = p->prelu[l];
+      e = launch_bn_finish_fwd(c, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn finish forward: %s", hipGetErrorString(e));
+    }
+    return EMPOSE_OK;
+  }
   if (mlp_train_fused(p, M)) {
     // y_l = a_{l-1} W_l^T + b_l with a_{l-1} = PReLU(s y_{l-1} + t) formed while the GEMM stages its A operand; the
     // epilogue leaves the column statistics of y_l per row block, a small kernel turns them into (mean, rstd, s, t)
@@ -1685,7 +1725,8 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
   // the last-arriver counter of the single-pass BatchNorm reverse kernel (it re-arms itself; the workspace may be fresh)
-  if (M <= BN_SINGLE_PASS_ROWS) HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
+  const bool epi = mlp_train_epi(p, M);
+  if (M <= BN_SINGLE_PASS_ROWS || epi) HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
   auto gemm = [&](const float* A, int lda, const float* W, int ldw, float* C, int ldc, int N, int K) -> hipError_t {
     GemmBatch b;
     b.count = 1;
@@ -1695,21 +1736,21 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
     return launch_gemm(b, stream);
   };
   auto layer_save = [&](int l) { return save + (size_t)l * mlp_layer_save(p, M); };
-  if (mlp_train_fused(p, M)) {
+  if (mlp_train_fused(p, M) || epi) {
     // The dX GEMM's epilogue writes dyh_l = dA_l * PReLU'(yhat_l) and the column sums BatchNorm's reverse needs; a
     // small kernel turns the sums into dgamma / dbeta / dslope and three per-column coefficients, one pass forms
-    // dY_l = c1 dyh_l + c3 y_l + c0 in place.  The layer inputs a_{l-1} are not stored: the A^T B product re-forms them
-    // from y_{l-1} while it stages its B operand.
-    auto stats_of = [&](int l) { return layer_save(l) + (size_t)M * H; };   // mean | rstd | s | t
+    // dY_l = c1 dyh_l + c3 y_l + c0 in place (`epi`: both in ONE launch, bn_finish_bwd).  Fused: the layer inputs a_{l-1}
+    // are not stored, the A^T B product re-forms them from y_{l-1} while it stages its B operand; `epi`: they are.
+    auto stats_of = [&](int l) { return layer_save(l) + (size_t)(epi ? 2 : 1) * M * H; };   // mean | rstd | s | t
     auto dz_of = [&](int l) -> float* { return stash ? stash + (size_t)M * l * H : w.d[l & 1]; };
     auto atb = [&](int l) -> int {   // dW_l, db_l (not deferred)
       const bool last = l == L - 1;
       AtbArgs ab{};
       ab.A = last ? d_out : dz_of(l); ab.lda = last ? ld_dout : H;
-      ab.B = l == 0 ? x : layer_save(l - 1); ab.ldb = l == 0 ? ldx : H;
+      ab.B = l == 0 ? x : layer_save(l - 1) + (epi ? (size_t)M * H : 0); ab.ldb = l == 0 ? ldx : H;
       ab.C = gr->weight[l]; ab.ldc = l == 0 ? p->in_dim : H; ab.bias = gr->bias[l];
       ab.M = M; ab.N = last ? p->out_dim : H; ab.K = l == 0 ? p->in_dim : H; ab.accumulate = accumulate;
-      if (l > 0) { ab.b_mode = 1; ab.Bs_seg[0] = stats_of(l - 1) + 2 * H; ab.b_slope = p->prelu[l - 1]; }
+      if (l > 0 && !epi) { ab.b_mode = 1; ab.Bs_seg[0] = stats_of(l - 1) + 2 * H; ab.b_slope = p->prelu[l - 1]; }
       hipError_t e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dW: %s", hipGetErrorString(e));
       return EMPOSE_OK;
@@ -1741,6 +1782,16 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       g.e_mean = stats_of(l - 1); g.e_rstd = g.e_mean + H; g.e_s = g.e_rstd + H; g.e_t = g.e_s + H; g.e_slope = p->prelu[l - 1];
       hipError_t e = launch_gemm_train(g, 0, 2, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dX gemm: %s", hipGetErrorString(e));
+      if (epi) {
+        BnFinishBwdArgs f{};
+        f.M = M; f.C = H; f.part = w.part; f.gamma = p->bn_weight[l - 1]; f.mean = stats_of(l - 1); f.rstd = f.mean + H;
+        f.dgamma = gr->bn_weight[l - 1]; f.dbeta = gr->bn_bias[l - 1]; f.dslope = gr->prelu[l - 1];
+        f.dslope_partial = w.slope_partial; f.counter = w.counter; f.accumulate = accumulate;
+        f.dyh = dz_of(l - 1); f.ld = H; f.y = layer_save(l - 1); f.ldy = H;
+        e = launch_bn_finish_bwd(f, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "bn finish backward: %s", hipGetErrorString(e));
+        continue;
+      }
       BnFusedBwdArgs c{};
       c.M = M; c.C = H; c.part = w.part; c.gamma = p->bn_weight[l - 1]; c.mean = stats_of(l - 1); c.rstd = stats_of(l - 1) + H;
       c.dgamma = gr->bn_weight[l - 1]; c.dbeta = gr->bn_bias[l - 1]; c.dslope = gr->prelu[l - 1];

@@ -94,7 +94,7 @@ __device__ __forceinline__ void transform_tile(const float4 s, const float4 t, f
 // stat_part [M / 32][3][N] = sums of dyh, dyh (y - mean) rstd, (yhat <= 0) dA yhat.
 // Addressing as in gemm_epilogue.h: a wave-uniform base plus a 32-bit per-lane byte offset, row bounds resolved outside
 // the loops (FULL) -- the straightforward form of this epilogue cost 15-20 us per 8192 x 512 launch.
-template <int WM, int WN, bool FULL, bool BWD>
+template <int WM, int WN, bool FULL, bool BWD, bool CFULL>   // FULL / CFULL: no row / column of the wave's block is outside the matrix
 __device__ __forceinline__ void train_epilogue_mode(float* __restrict__ C, float* __restrict__ part,
                                                     const float* __restrict__ shift, const float* __restrict__ ey,
                                                     const float* __restrict__ e_s, const float* __restrict__ e_t,
@@ -104,14 +104,43 @@ __device__ __forceinline__ void train_epilogue_mode(float* __restrict__ C, float
   epi_gbyte_t cb = (epi_gbyte_t)(C + (long)mw0 * ldc);
   epi_cgbyte_t yb = BWD ? (epi_cgbyte_t)(ey + (long)mw0 * ldy) : nullptr;
   const unsigned ldc4 = (unsigned)ldc * 4u, ldy4 = (unsigned)ldy * 4u;
+  // Every load of the epilogue -- the per-column constants and, reverse, the wave's whole block of y -- is issued before
+  // the first store: loads and stores share one counter here (vmcnt), so a load that follows a tile's stores makes the
+  // wave wait for those stores to drain -- one memory round trip per tile column (measured: the statistics epilogue cost
+  // 10 us per 8192 x 512 x 512 launch that way).
+  float sh[WN], es[WN], et[WN], mu[WN], rs[WN];
+  bool col_ok[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int n = nw0 + j * 32 + l31;
-    if (n >= N) continue;
+    col_ok[j] = CFULL || n < N;
+    const int nc = col_ok[j] ? n : N - 1;
+    sh[j] = (!BWD && shift) ? shift[nc] : 0.f;
+    es[j] = BWD ? e_s[nc] : 0.f; et[j] = BWD ? e_t[nc] : 0.f; mu[j] = BWD ? e_mean[nc] : 0.f; rs[j] = BWD ? e_rstd[nc] : 0.f;
+  }
+  float yv[BWD ? WM : 1][BWD ? WN : 1][16];
+  if (BWD) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = nw0 + j * 32 + l31;
+      const unsigned y_lane = (unsigned)(4 * lh) * ldy4 + (unsigned)(col_ok[j] ? n : N - 1) * 4u;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          yv[BWD ? i : 0][BWD ? j : 0][r] =
+              (FULL || mw0 + 4 * lh + dm < M) ? *(epi_cgfloat_t)(yb + (y_lane + (unsigned)dm * ldy4)) : 0.f;
+        }
+    }
+  }
+  float ps[WM][WN][3];   // the partial sums: stored after the block's last row (a store under a branch in between makes
+                         // the next tile column wait for everything issued so far)
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = nw0 + j * 32 + l31;
+    if (!CFULL && !col_ok[j]) continue;
     const unsigned c_lane = (unsigned)(4 * lh) * ldc4 + (unsigned)n * 4u;
-    const unsigned y_lane = (unsigned)(4 * lh) * ldy4 + (unsigned)n * 4u;
-    const float sh = (!BWD && shift) ? shift[n] : 0.f;
-    const float es = BWD ? e_s[n] : 0.f, et = BWD ? e_t[n] : 0.f, mu = BWD ? e_mean[n] : 0.f, rs = BWD ? e_rstd[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int mb = mw0 + i * 32;
@@ -123,13 +152,13 @@ __device__ __forceinline__ void train_epilogue_mode(float* __restrict__ C, float
         for (int r = 0; r < 16; ++r) {
           const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
           if (!FULL && mw0 + 4 * lh + dm >= M) continue;
-          const float y = acc[i][j][r] + sh;
+          const float y = acc[i][j][r] + sh[j];
           *(epi_gfloat_t)(cb + (c_lane + (unsigned)dm * ldc4)) = y;
           s1 += y;
         }
         // the block's sum and centred sum of squares (the two halves of the wave hold 16 rows each)
         s1 += __shfl_xor(s1, 32, 64);
-        const float shift_mean = sh - s1 * (1.f / (float)rows_valid);   // y - mean = acc + (sh - mean)
+        const float shift_mean = sh[j] - s1 * (1.f / (float)rows_valid);   // y - mean = acc + (sh - mean)
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -138,40 +167,42 @@ __device__ __forceinline__ void train_epilogue_mode(float* __restrict__ C, float
           if (FULL || mw0 + 4 * lh + dm < M) s2 += d * d;
         }
         s2 += __shfl_xor(s2, 32, 64);
-        if (lh == 0 && part) {
-          float* pp = part + (size_t)(mb >> 5) * 2 * N;
-          pp[n] = s1;
-          pp[N + n] = s2;
-        }
+        ps[i][j][0] = s1; ps[i][j][1] = s2; ps[i][j][2] = 0.f;
       } else {
-        float yv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {   // all loads of the tile column first
-          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
-          yv[r] = (FULL || mw0 + 4 * lh + dm < M) ? *(epi_cgfloat_t)(yb + (y_lane + (unsigned)dm * ldy4)) : 0.f;
-        }
         float sb = 0.f, sg = 0.f, sa = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
           if (!FULL && mw0 + 4 * lh + dm >= M) continue;
-          const float yh = es * yv[r] + et;
+          const float y = yv[BWD ? i : 0][BWD ? j : 0][r];
+          const float yh = es[j] * y + et[j];
           const float dA = acc[i][j][r];
           const float dyh = yh > 0.f ? dA : slope * dA;
           *(epi_gfloat_t)(cb + (c_lane + (unsigned)dm * ldc4)) = dyh;
           sb += dyh;
-          sg += dyh * ((yv[r] - mu) * rs);
+          sg += dyh * ((y - mu[j]) * rs[j]);
           sa += yh > 0.f ? 0.f : dA * yh;
         }
         sb += __shfl_xor(sb, 32, 64);
         sg += __shfl_xor(sg, 32, 64);
         sa += __shfl_xor(sa, 32, 64);
-        if (lh == 0) {
-          float* pp = part + (size_t)(mb >> 5) * 3 * N;
-          pp[n] = sb;
-          pp[N + n] = sg;
-          pp[2 * N + n] = sa;
-        }
+        ps[i][j][0] = sb; ps[i][j][1] = sg; ps[i][j][2] = sa;
+      }
+    }
+  }
+  if (lh == 0 && part) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = nw0 + j * 32 + l31;
+      if (!CFULL && !col_ok[j]) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int mb = mw0 + i * 32;
+        if (!FULL && mb >= M) continue;
+        float* pp = part + (size_t)(mb >> 5) * (BWD ? 3 : 2) * N;
+        pp[n] = ps[i][j][0];
+        pp[N + n] = ps[i][j][1];
+        if (BWD) pp[2 * N + n] = ps[i][j][2];
       }
     }
   }
@@ -188,10 +219,10 @@ __device__ __forceinline__ void train_epilogue(const GemmProb& p, const f32x16 (
   const float slope = BWD ? p.e_slope[0] : 0.f;
   mw0 = __builtin_amdgcn_readfirstlane(mw0);
   nw0 = __builtin_amdgcn_readfirstlane(nw0);
-  const bool full = mw0 + 32 * WM <= M;
-#define EMPOSE_TEPI(FULL, BWD) \
-  train_epilogue_mode<WM, WN, FULL, BWD>(C, part, shift, ey, e_s, e_t, e_mean, e_rstd, slope, M, N, ldc, ldy, acc, mw0, nw0, l31, lh)
-  if (full) EMPOSE_TEPI(true, BWD); else EMPOSE_TEPI(false, BWD);
+  const bool full = mw0 + 32 * WM <= M, cfull = nw0 + 32 * WN <= N;
+#define EMPOSE_TEPI(FULL, BWD, CFULL) \
+  train_epilogue_mode<WM, WN, FULL, BWD, CFULL>(C, part, shift, ey, e_s, e_t, e_mean, e_rstd, slope, M, N, ldc, ldy, acc, mw0, nw0, l31, lh)
+  if (full && cfull) EMPOSE_TEPI(true, BWD, true); else if (full) EMPOSE_TEPI(true, BWD, false); else EMPOSE_TEPI(false, BWD, false);
 #undef EMPOSE_TEPI
 }
 
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(C::NT) void gemm_tn_f32_kernel(GemmBatch batch) {
     }
   }
 
-  if (ROLE >= 2) {
+  if (ROLE >= 2) {   // 2, 4: forward statistics epilogue (2: + the optional A-operand transform above); 3: reverse
     train_epilogue<WM, WN, ROLE == 3>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
   } else {
     epilogue<WM, WN>(p, acc, m0 + wrow * 32 * WM, n0 + wcol * 32 * WN, l31, lh);
@@ -1229,7 +1260,11 @@ hipError_t launch_gemm_train(const TrainGemmArgs& t, int amode, int emode, hipSt
     g.e_y = t.e_y; g.ld_ey = t.ld_ey; g.e_s = t.e_s; g.e_t = t.e_t; g.e_mean = t.e_mean; g.e_rstd = t.e_rstd;
     g.e_slope = t.e_slope;
   }
-  return emode == 2 ? launch_cfg<CfgS12, 3>(b, stream) : launch_cfg<CfgS12, 2>(b, stream);
+  if (emode == 2) return launch_cfg<CfgS12, 3>(b, stream);
+  // without the operand transform: an instantiation that does not carry its code in the K loop (ROLE 2 ran 8 us slower
+  // per 8192 x 512 x 512 launch than the plain tile even with the transform switched off at run time)
+  if (amode == 0) return emode == 1 ? launch_cfg<CfgS12, 4>(b, stream) : launch_cfg<CfgS12, 0>(b, stream);
+  return launch_cfg<CfgS12, 2>(b, stream);
 }
 
 // Name (as a profiler prints it) of the kernel `launch_gemm` runs for `count` problems of this shape.

@@ -27,6 +27,8 @@ struct Options {
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
+  int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
+                          // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
 };
 Options& options();
@@ -162,6 +164,29 @@ struct BnFusedBwdArgs {
 };
 hipError_t launch_bn_fused_combine_bwd(const BnFusedBwdArgs& a, hipStream_t stream);
 size_t bn_fused_partial_floats(int M, int C);
+// Round 4: combine + apply in one launch on materialised activations / cotangents (train_fused.hip, "finish" kernels).
+struct BnFinishFwdArgs {
+  int M, C; const float* part;                        // [ceil(M / 32)][2][C] from the GEMM's statistics epilogue
+  const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; long long* num_batches_tracked;   // may be null
+  float* mean; float* rstd; float* s; float* t;       // [C] each (out)
+  const float* y; int ldy;                            // the GEMM's output
+  float* act; int ld_act;                             // a = PReLU(s y + t)
+  const float* slope;
+  int rows_per_block = 0;                             // (set by the launcher)
+};
+hipError_t launch_bn_finish_fwd(BnFinishFwdArgs a, hipStream_t stream);
+struct BnFinishBwdArgs {
+  int M, C; const float* part;                        // [ceil(M / 32)][3][C] from the dX GEMM's epilogue
+  const float* gamma; const float* mean; const float* rstd;
+  float* dgamma; float* dbeta; float* dslope;         // [C], [C], [1]
+  float* dslope_partial; int* counter;                // [ceil(C / 32)] scratch; a zeroed int (re-arms itself)
+  int accumulate;
+  float* dyh; int ld;                                 // in: dA * PReLU'(yhat); out: dY (in place)
+  const float* y; int ldy;
+  int rows_per_block = 0;
+};
+hipError_t launch_bn_finish_bwd(BnFinishBwdArgs a, hipStream_t stream);
 hipError_t launch_bn_fused_apply_bwd(float* dyh, const float* y, const float* coef, int M, int C, hipStream_t stream);
 
 // Launches one grid covering all problems of the batch (blockIdx.y selects the problem).

@@ -126,29 +126,35 @@ class LgdTrainEngine(object):
     # launches and the cross-stream hand-offs cost more than the overlap gives (12 windows: 4.2 -> 4.9 ms).
     two_streams = True
     two_streams_min_frames = 2048
+    # which uses of the side streams are on (A/B: scripts/train.py --streams): 'fwd' the shape network's forward beside the
+    # pose network's; 'bwd' its backward; 'bwd3' the pose network's backward on a second side stream, so that the main
+    # stream is only the cotangent chain, the heads and back-propagation through time; 'wgrad' the weight-gradient products
+    # behind them.  Measured at 256 windows (frames/s): none 684 k, fwd 713 k, bwd 714 k, wgrad 695 k, all 795-810 k.
+    side_parts = ('fwd', 'bwd', 'bwd3', 'wgrad')
 
     def __init__(self, net):
         self.net = net
         self.ctx = None
-        self._side_stream = None
+        self._side_streams = {}
         self._use_side = False
         self._held = []
 
     # ---- the side stream ------------------------------------------------------------------------------------------
-    def _side(self):
-        if self._side_stream is None or self._side_stream.device != self.dev:
-            self._side_stream = torch.cuda.Stream(device=self.dev)
-        return self._side_stream
+    def _side(self, k=0):
+        st = self._side_streams.get(k)
+        if st is None or st.device != self.dev:
+            st = self._side_streams[k] = torch.cuda.Stream(device=self.dev)
+        return st
 
-    def _fork(self):
-        """The side stream continues from what the main stream has enqueued so far."""
+    def _fork(self, k=0):
+        """Side stream k continues from what the main stream has enqueued so far."""
         if self._use_side:
-            self._side().wait_stream(torch.cuda.current_stream(self.dev))
+            self._side(k).wait_stream(torch.cuda.current_stream(self.dev))
 
-    def _join(self):
-        """The main stream continues after what the side stream has enqueued so far."""
+    def _join(self, k=0):
+        """The main stream continues after what side stream k has enqueued so far."""
         if self._use_side:
-            torch.cuda.current_stream(self.dev).wait_stream(self._side())
+            torch.cuda.current_stream(self.dev).wait_stream(self._side(k))
             self._held = []
 
     def _hold(self, t):
@@ -160,7 +166,7 @@ class LgdTrainEngine(object):
         return t
 
     @contextlib.contextmanager
-    def _on_side(self):
+    def _on_side(self, k=0):
         """Launches (and transient allocations: workspaces, freed right after the launch, must belong to the stream that
         uses them) inside go to the side stream.  Long-lived tensors are allocated outside, on the main stream's pool,
         and freed only after a join."""
@@ -168,7 +174,7 @@ class LgdTrainEngine(object):
             yield
             return
         main_raw = self.stream
-        with torch.cuda.stream(self._side()):
+        with torch.cuda.stream(self._side(k)):
             self.stream = _lib.current_stream()
             try:
                 yield
@@ -191,12 +197,12 @@ class LgdTrainEngine(object):
     def _axpby(self, rows, cols, alpha, x, ldx, beta, y, ldy, out, ldo):
         _lib.check(self.lib.empose_axpby2d(rows, cols, alpha, x, ldx, beta, y, ldy, out, ldo, self.stream))
 
-    def _mlp_fwd(self, view, x, ldx, out, ld_out, M, side=False):
+    def _mlp_fwd(self, view, x, ldx, out, ld_out, M, side=None):
         p = view.params()
         save = self.new(self.lib.empose_mlp_train_save_floats(C.byref(p), M))
         nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
-        with (self._on_side() if side else _nothing()):
-            ws = self.ws(nbytes) if side else self._hold(self.ws(nbytes))
+        with (self._on_side(side) if side is not None else _nothing()):
+            ws = self.ws(nbytes) if side is not None else self._hold(self.ws(nbytes))
             _lib.check(self.lib.empose_mlp_train_fwd(C.byref(p), M, x, ldx, out, ld_out, save.data_ptr(), ws.data_ptr(),
                                                      nbytes, self.stream))
         from em_pose_amd.nn import layers as _layers
@@ -218,15 +224,15 @@ class LgdTrainEngine(object):
         stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
         return stash, stash.data_ptr() + 4 * M * (view.n_layers - 1) * view.hidden
 
-    def _mlp_bwd_deferred(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M, stash=None, side=False):
+    def _mlp_bwd_deferred(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M, stash=None, side=None):
         """Backward of one application that keeps the layer cotangents instead of forming dW / db; returns the stash."""
         p = view.params()
         g = view.grads(grads)
         if stash is None:
             stash = self.new(self.lib.empose_mlp_train_stash_floats(C.byref(p), M))
         nbytes = self.lib.empose_mlp_train_workspace_bytes(C.byref(p), M)
-        with (self._on_side() if side else _nothing()):
-            ws = self.ws(nbytes) if side else self._hold(self.ws(nbytes))
+        with (self._on_side(side) if side is not None else _nothing()):
+            ws = self.ws(nbytes) if side is not None else self._hold(self.ws(nbytes))
             _lib.check(self.lib.empose_mlp_train_bwd_deferred(C.byref(p), M, x, ldx, d_out, ld_dout, save.data_ptr(),
                                                               C.byref(g), int(accumulate), stash.data_ptr(),
                                                               ws.data_ptr(), nbytes, self.stream))
@@ -385,10 +391,13 @@ class LgdTrainEngine(object):
                 # network input rows [x0 | pose_i | shape_i | g_pose | g_shape] (the gradients are already there)
                 _lib.check(lib.empose_lgd_assemble_inputs(T, d_in, x0.data_ptr(), d_in, pose_hist[i].data_ptr(),
                                                           shape_hist[i].data_ptr(), Xi.data_ptr(), d_x, self.stream))
-                self._fork()                                   # the two networks side by side
+                side_fwd = 'fwd' in self.side_parts
+                if side_fwd:
+                    self._fork()                               # the two networks side by side
                 sp = self._mlp_fwd(views[0], Xi.data_ptr(), d_x, dp.data_ptr(), 66, T)
-                ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T, side=True)
-                self._join()
+                ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T, side=0 if side_fwd else None)
+                if side_fwd:
+                    self._join()
                 saves.append((sp, ss))
                 # pose_{i+1} = pose_i + s dp, shape_{i+1} = shape_i + s (window mean of) ds
                 _lib.check(lib.empose_lgd_additive_update(B, F, s, int(bool(net.shape_avg)), pose_hist[i].data_ptr(),
@@ -481,21 +490,30 @@ class LgdTrainEngine(object):
                     # weight gradients once over all N applications (one A^T B per layer instead of N).  Nothing below
                     # reads what these two calls write until the weight-gradient products: the shape network's backward
                     # of every iteration trails on the side stream, in order, without a join
-                    self._fork()
+                    side_bwd = 'bwd' in self.side_parts
+                    side_pose = 1 if (side_bwd and 'bwd3' in self.side_parts) else None   # third stream: the pose net too
+                    if side_bwd:
+                        self._fork(0)
+                    if side_pose is not None:
+                        self._fork(1)
                     pend[0].append((X[i - 1].data_ptr(), sp,
                                     self._mlp_bwd_deferred(views[0], X[i - 1].data_ptr(), d_x, dp_ptr, 68, sp,
-                                                           grads[0], acc, T, stash=st_p)))
+                                                           grads[0], acc, T, stash=st_p, side=side_pose)))
                     pend[1].append((X[i - 1].data_ptr(), ss,
                                     self._mlp_bwd_deferred(views[1], X[i - 1].data_ptr(), d_x, ds_ptr, 12, ss,
-                                                           grads[1], acc, T, stash=st_s, side=True)))
+                                                           grads[1], acc, T, stash=st_s, side=0 if side_bwd else None)))
                 else:
                     self._mlp_bwd(views[0], X[i - 1].data_ptr(), d_x, dpad.data_ptr(), 68, sp, grads[0], acc, T)
                     self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)
             # Both networks' weight gradients on the side stream (after the pose network's backward, which ran on the main
             # stream), beside the initial estimate's backward below on the main stream.
-            self._fork()
-            with self._on_side():
-                for k in (0, 1):
+            three = 'bwd3' in self.side_parts and 'bwd' in self.side_parts and 'wgrad' in self.side_parts
+            if not three:
+                self._fork(0)
+            for k in (0, 1):
+                # (three streams: each network's products follow its own backward on its own stream, no fork needed)
+                where = (1 - k) if three else 0
+                with (self._on_side(where) if 'wgrad' in self.side_parts else _nothing()):
                     if pend[k]:
                         self._mlp_wgrad(views[k], [q[0] for q in pend[k]], d_x, [q[1] for q in pend[k]],
                                         [q[2] for q in pend[k]], grads[k], T)
@@ -548,7 +566,9 @@ class LgdTrainEngine(object):
                     self._mlp_bwd(v, ctx['x0'].data_ptr(), d_in, dpd.data_ptr(), ld, sv, gi, False, T)
                     named += list(zip(v.parameter_list(), gi))
             self._deposit(named)
-            self._join()
+            self._join(0)
+            if 'bwd3' in self.side_parts:
+                self._join(1)
         self.ctx = None
         total = loss_vals[4]
         keys = ('pose', 'shape', 'reconstruction', 'fk', 'total_loss')

@@ -62,7 +62,9 @@ const char* empose_arch(void);
  * "lstm_seq" (batches above 256 rows: the LSTM's whole sequence in one cooperative launch; 0 [default] = one launch per
  * wavefront step, which measured faster), "bptt_wave" (training: reverse LSTM recurrences of two layers as a wavefront),
  * "train_fused" (train-mode MLP layer with BatchNorm / PReLU folded into the GEMMs: 0 never [default], 1 above 1024
- * rows, 2 always).
+ * rows, 2 always), "train_epi" (train-mode MLP layer with the BatchNorm statistics in the GEMM epilogues and ONE
+ * combine-and-apply launch per layer and direction: 0 never, 1 above 1024 rows [default], 2 always), "spin_limit"
+ * (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
 int empose_set_option(const char* name, int value);
 int empose_get_option(const char* name);

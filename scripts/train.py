@@ -207,6 +207,8 @@ def main():
                                                       'per GPU)')
     p.add_argument('--single_stream', action='store_true',
                    help='A/B: the training engine on one stream (default: shape network, weight gradients on a side stream)')
+    p.add_argument('--streams', default=None, help="A/B: which parts of the step use the engine's side stream, e.g. 'bwd,wgrad' "
+                                                   "(default: fwd,bwd,wgrad)")
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
     p.add_argument('--option', action='append', default=[], metavar='NAME=INT',
                    help='kernel-variant switch of the library (empose_set_option), e.g. train_fused=0; repeatable')
@@ -250,6 +252,9 @@ def main():
         name, value = kv.split('=')
         _lib.check(_lib.lib().empose_set_option(name.encode(), int(value)))
 
+    if args.streams is not None:
+        from em_pose_amd.nn.train_engine import LgdTrainEngine
+        LgdTrainEngine.side_parts = tuple(x for x in args.streams.split(',') if x)
     if args.single_stream:
         from em_pose_amd.nn.train_engine import LgdTrainEngine
         LgdTrainEngine.two_streams = False

@@ -63,6 +63,7 @@ def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print):
     finally:
         _layers.FORCE_LARGE_LINEAR[0], LgdTrainEngine.batched_wgrad = force_large0, batched0
         _lib.check(_lib.lib().empose_set_option(b'train_fused', 0))
+        _lib.check(_lib.lib().empose_set_option(b'train_epi', 1))
     assert len(flips) <= max(3, n // 3), 'too many to be kink flips'
     return {'n': n, 'worst': worst, 'flips': len(flips), 'stats': stats}
 
@@ -83,6 +84,8 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
     rnn_hidden = 256 if (rnn and rng.integers(0, 8) == 0) else hidden
     fused = int(rng.choice([0, 2]))
     _lib.check(_lib.lib().empose_set_option(b'train_fused', fused))
+    # round 4: of the cases without it, half with the statistics in the GEMM epilogues + one finish launch per layer
+    _lib.check(_lib.lib().empose_set_option(b'train_epi', 2 if (fused == 0 and n % 2 == 0) else 0))
     cfg = lgd_config(n_markers, rnn, N, hidden=hidden, rnn_hidden=rnn_hidden)
     net = create_model(cfg, SMPLLayer(model))
     net.vertex_ids = vids

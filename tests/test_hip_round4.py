@@ -134,3 +134,67 @@ def test_evaluation_driver_raises_instead_of_averaging_nan():
     lib.empose_async_status()
     g.release()
     assert raised
+
+
+@pytest.mark.parametrize('rnn', [True, False], ids=['lgd_rnn', 'lgd'])
+def test_training_step_on_side_streams_equals_the_single_stream_step(rnn):
+    """nn/train_engine.py with `two_streams` (from 2048 frames per step on: the shape network, the pose network's backward
+    and the weight-gradient products on side streams): same kernels, same order per accumulator -- losses, outputs and
+    every parameter gradient are bit-identical to the single-stream step.  64 windows x 32 frames = 2048 rows, so the
+    BatchNorm statistics also take the GEMM-epilogue + finish-kernel route (train_epi, above 1024 rows)."""
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn.models import create_model
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    from tests import helpers as H
+    model = H.small_model()
+    bm = R.BodyModelTensors(model)
+    vids = [int(v) for v in np.random.default_rng(5).choice(model['v_template'].shape[0], 12, replace=False)]
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    B, F = 64, 32
+    w = synthetic.make_windows(B, F, 3, sensors)
+    torch.manual_seed(7)
+    net = create_model(lgd_config(12, rnn, 2, hidden=64, rnn_hidden=64), SMPLLayer(model))
+    net.vertex_ids = vids
+    net = net.to(DEV).train()
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lens = torch.full((B,), F, dtype=torch.int64, device=DEV)
+    lens[3] = 17
+    with torch.no_grad():
+        _, _, jgt = R.estimated_markers(bm, tables, vids, torch.from_numpy(w['poses'].reshape(-1, 66)),
+                                        torch.from_numpy(np.repeat(w['shapes'], F, axis=0)),
+                                        torch.from_numpy(np.repeat(w['offset_r'], F, axis=0)),
+                                        torch.from_numpy(np.repeat(w['offset_t'], F, axis=0)))
+    res = {}
+    try:
+        for two in (False, True):
+            LgdTrainEngine.two_streams = two
+            net.load_state_dict(state0)
+            batch = SyntheticBatch(w, lens, device=DEV)
+            batch.joints_gt = jgt.reshape(B, F, -1).to(DEV).float()
+            net.zero_grad()
+            out = net(batch)
+            assert net._engine is not None and net._engine._use_side == two
+            total, vals = net.backward(batch, out)
+            torch.cuda.synchronize()
+            res[two] = (vals, {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None},
+                        {k: v.detach().clone() for k, v in out.items()},
+                        {k: v.clone() for k, v in net.state_dict().items() if 'running' in k})
+    finally:
+        LgdTrainEngine.two_streams = True
+    assert res[True][0] == res[False][0]
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 20
+    for k, v in res[False][1].items():
+        assert torch.equal(res[True][1][k], v), k
+    for k, v in res[False][2].items():
+        assert torch.equal(res[True][2][k], v), k
+    for k, v in res[False][3].items():
+        assert torch.equal(res[True][3][k], v), k
