@@ -219,13 +219,22 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
     return me_all, per_sequence, frames
 
 
-def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256):
+def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256, host_times=None):
     """
     Same results as `evaluate_sequences`, but chunk c of ALL recordings runs as one ragged batch (rows = recordings
     that still have frames, `seq_lengths` = frames left in this chunk, LSTM state carried per row).  Windows are
     independent of each other in the model, so this only changes how much work one launch carries:
     36 recordings need 14 launches of the loop instead of 211.
+    `host_times` (a dict, optional): seconds of host time per section of the pass (dev: where a slow pass spends it).
     """
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def lap(key):
+        if host_times is not None:
+            now = _time.perf_counter()
+            host_times[key] = host_times.get(key, 0.0) + now - _t[0]
+            _t[0] = now
     from em_pose_amd.nn.models import IterativeErrorFeedback
     assert isinstance(net, IterativeErrorFeedback)
     # rows shorter than the chunk are padded: average the shape over their valid frames only, which is what the
@@ -233,87 +242,92 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
     was_valid_only = net.shape_avg_valid_only
     net.shape_avg_valid_only = True
     try:
+        import numpy as np
+        from torch.nn.utils.rnn import pad_sequence
         n = len(batches)
         lengths = [int(b.seq_lengths[0]) for b in batches]
-        engines = [MetricsEngine(smpl_model) for _ in range(n)]
-        first_shape = [None] * n
-        state = None       # (h, c) for the rows of `rows_prev`
-        rows_prev = []
-        n_chunks = (max(lengths) + window_size - 1) // window_size
-        frames = 0
-        pad = lambda t, f: torch.nn.functional.pad(t, (0, 0, 0, f - t.shape[1]))
-        # the recordings go to the device once; chunks are cut and padded there
-        fields = ('poses', 'shapes', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks', 'offset_t', 'offset_r')
-        on_dev = [{k: getattr(b, k).to(device=device, dtype=C.DTYPE) for k in fields} for b in batches]
-        # As in `evaluate_sequences`: chunk c + 1's cutting, packing and LSTM (current stream) beside chunk c's refinement
-        # iterations and metrics (side stream); nothing in the loop reads device results back -- the valid frames come
-        # from the host copies of lengths and masks, the metric rows are merged after the last chunk.
+        # Longest recording first: the rows that still have frames in chunk c are then a PREFIX of the batch, so a chunk is
+        # a slice [:k, sf:sf + f] of one padded block per field (no per-row cutting, padding and concatenating: that was
+        # 47 of the 82 ms of a pass, all of it host time -- the device waits for the host in this driver).
+        order = sorted(range(n), key=lambda i: (-lengths[i], i))
+        sl = [lengths[i] for i in order]
+        n_chunks = (sl[0] + window_size - 1) // window_size
         dev = torch.device(device)
+        fields = ('poses', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks')
+        packed = {k: pad_sequence([getattr(batches[i], k)[0].to(device=device, dtype=C.DTYPE) for i in order],
+                                  batch_first=True) for k in fields}
+        whole = {k: torch.cat([getattr(batches[i], k).to(device=device, dtype=C.DTYPE) for i in order])
+                 for k in ('shapes', 'offset_t', 'offset_r')}
+        # the frames that count -- inside the recording and every sensor present -- from the host copies of the masks
+        # (numpy: a torch CPU op on a 36 x 256 x 12 block wakes the whole intra-op thread pool)
+        valid_all = np.zeros((n, sl[0]), dtype=bool)
+        for j, i in enumerate(order):
+            valid_all[j, :sl[j]] = (batches[i].marker_masks[0].numpy() != 0).all(axis=-1)
+        # As in `evaluate_sequences`: chunk c + 1's packing and LSTM (current stream) beside chunk c's refinement
+        # iterations and metrics (side stream); nothing in the loop reads device results back.
         side = None
         if dev.type == 'cuda' and not net.training:
             side = getattr(net, '_side_stream', None)
             if side is None or side.device != dev:
                 side = net._side_stream = torch.cuda.Stream(device=dev)
             net.iter_stream = side
-        import numpy as np
-        masks_host = [b.marker_masks.cpu().numpy() for b in batches]   # numpy: a torch CPU op on a 36 x 256 x 12 block
-        # wakes the whole intra-op thread pool (milliseconds per chunk on a 128-core host)
-        deferred = []      # (engine of the chunk, rows, valid frames per row)
+        me_chunks = MetricsEngine(smpl_model)   # every chunk's rows, in (chunk, row, frame) order; read back ONCE
+        counts = []                             # per chunk: valid frames of each of its rows
+        state, first_shape, frames = None, None, 0
+        lap('setup')
         for c in range(n_chunks):
             sf = c * window_size
-            rows = [i for i in range(n) if lengths[i] > sf]
-            lens = [min(window_size, lengths[i] - sf) for i in rows]
-            f = max(lens)
-            cut = lambda name: torch.cat([pad(on_dev[i][name][:, sf:sf + f], f) for i in rows])
-            whole = lambda name: torch.cat([on_dev[i][name] for i in rows])
-            chunk = RealBatch([batches[i].ids[0] for i in rows], torch.tensor(lens), cut('poses'), whole('shapes'),
-                              cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'), cut('marker_masks'),
-                              whole('offset_t'), whole('offset_r')).to_gpu(device)
-            valid_np = np.zeros((len(rows), f), dtype=bool)   # inside the row's length and every sensor present
-            for k, i in enumerate(rows):
-                valid_np[k, :lens[k]] = (masks_host[i][0, sf:sf + lens[k]] != 0).all(axis=-1)
-            valid = torch.from_numpy(valid_np)
-            if net.rnn_init and c > 0:
-                keep = torch.tensor([rows_prev.index(i) for i in rows], device=device)
-                net.rnn.final_state = (state[0].index_select(1, keep).contiguous(),
-                                       state[1].index_select(1, keep).contiguous())
+            k = sum(1 for L in sl if L > sf)
+            lens = [min(window_size, L - sf) for L in sl[:k]]
+            f = lens[0]
+            cut = lambda name: packed[name][:k, sf:sf + f]
+            chunk = RealBatch([batches[i].ids[0] for i in order[:k]], torch.tensor(lens), cut('poses'),
+                              whole['shapes'][:k], cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'),
+                              cut('marker_masks'), whole['offset_t'][:k], whole['offset_r'][:k]).to_gpu(device)
+            valid_np = valid_all[:k, sf:sf + f]
+            if net.rnn_init and c > 0:   # the rows that go on are the first k of the previous chunk's
+                net.rnn.final_state = (state[0][:, :k].contiguous(), state[1][:, :k].contiguous())
+            lap('chunk_prep')
             out = net(chunk, is_new_sequence=(c == 0))
+            lap('forward_enqueue')
             if net.rnn_init:
-                state, rows_prev = net.rnn.final_state, rows
+                state = net.rnn.final_state
             if side is not None and net.outputs_ready is None:   # (see evaluate_sequences)
                 side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side) if side is not None else _nothing():
                 if side is not None:   # the chunk lives in memory of the current stream's pool
                     for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
                         t.record_stream(side)
-                if c == 0:
-                    for k, i in enumerate(rows):
-                        first_shape[i] = out['shape_hat'][k:k + 1, 0]
-                # one metrics pass over the whole chunk; its per-frame rows come back in (row, frame) order, so each
-                # recording's rows are a contiguous slice
-                me_tmp = MetricsEngine(smpl_model)
-                me_tmp.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], torch.cat([first_shape[i] for i in rows]),
-                               chunk.seq_lengths, chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks,
-                               valid=valid)
-            deferred.append((me_tmp, rows, valid_np.sum(axis=1).tolist()))
+                if c == 0:   # the first chunk's shape estimate stands for the whole recording (evaluate_real.py:63-68)
+                    first_shape = out['shape_hat'][:, 0].contiguous()
+                me_chunks.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape[:k], chunk.seq_lengths,
+                                  chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks,
+                                  valid=torch.from_numpy(np.ascontiguousarray(valid_np)))
+            counts.append(valid_np.sum(axis=1).tolist())
             frames += sum(lens)
+            lap('metrics_enqueue')
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
         if dev.type == 'cuda':
             torch.cuda.synchronize(dev)
             _check_async(dev)
-        for me_tmp, rows, counts in deferred:
-            st = me_tmp.state()
-            at = 0
-            for k, i in enumerate(rows):
-                engines[i].merge({key: v[at:at + counts[k]] for key, v in st.items()})
-                at += counts[k]
+        lap('wait_for_device')
+        st = me_chunks.state()    # one device-side gather of the valid rows, one copy to (cached) pinned host memory
+        engines = [MetricsEngine(smpl_model) for _ in range(n)]
+        at = 0
+        for cnt in counts:
+            for j, m in enumerate(cnt):
+                if m:
+                    engines[order[j]].merge({key: v[at:at + m] for key, v in st.items()})
+                at += m
     finally:
         net.shape_avg_valid_only = was_valid_only
         net.iter_stream = None
+    lap('merge_rows')
     me_all = MetricsEngine(smpl_model)
     per_sequence = []
     for i in range(n):  # recording order, exactly as the sequential driver accumulates
         me_all.merge(engines[i].state())
         per_sequence.append((batches[i].ids[0], engines[i].get_metrics()))
+    lap('per_recording_metrics')
     return me_all, per_sequence, frames

@@ -206,14 +206,17 @@ def main():
     if dist is not None:
         dist.barrier()
     log = print if world == 1 else None
-    passes = []
+    passes, host_times = [], []
     for rep in range(max(args.repeat, 1)):
         t0 = time.perf_counter()
         if sequential:
             me_all, per_seq, frames = evaluate_sequences(net, batches, smpl, device, window_size=256,
                                                          log=log if rep == 0 else None)
         else:
-            me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256)
+            ht = {}
+            me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256,
+                                                                 host_times=ht)
+            host_times.append({k: round(v, 4) for k, v in ht.items()})
         sync()
         passes.append(time.perf_counter() - t0)
     # what is reported: the median of the warm passes (pass 0 still pays for every batch shape that occurs for the first
@@ -237,7 +240,8 @@ def main():
               .format(frames, elapsed, 'the host CPU' if on_cpu else '{} GPU(s)'.format(world), frames / elapsed))
         if args.json:
             print(json.dumps({'frames': frames, 'seconds': elapsed, 'n_gpus': world, 'frames_per_sec': frames / elapsed,
-                              'seconds_per_pass': passes, 'metrics': metrics}))
+                              'seconds_per_pass': passes, 'host_seconds_per_section_per_pass': host_times,
+                              'metrics': metrics}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
