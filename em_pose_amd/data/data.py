@@ -122,24 +122,32 @@ class RealBatch(ABatch):
 
     def to_gpu(self, device=None):
         device = C.DEVICE if device is None else device
-        self.seq_lengths = self.seq_lengths.to(dtype=torch.int, device=device)
         names = ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes',
                  'trans', 'offset_t', 'offset_r')
         fields = [getattr(self, name) for name in names]
-        if torch.device(device).type == 'cuda' and all(not f.is_cuda for f in fields):
-            # host fields: ONE staged copy (nine separate blocking copies of a 256-frame chunk cost more than its forward)
-            # every field starts on a 256-byte boundary of the staging buffer (kernels read 16-byte pieces)
+        if torch.device(device).type == 'cuda' and all(not f.is_cuda for f in fields) and not self.seq_lengths.is_cuda \
+                and C.DTYPE == torch.float32:
+            # host fields: ONE staged copy (nine separate blocking copies of a 256-frame chunk cost more than its forward),
+            # every field on a 256-byte boundary of the staging buffer (kernels read 16-byte pieces), the lengths riding
+            # along as int32 bit patterns.  The staging buffer is PINNED and the copy does not block: a copy from pageable
+            # memory makes the host wait until the stream has reached it -- i.e. for the previous chunk's LSTM -- and the
+            # streaming driver then alternates between host and device instead of running them side by side.  (torch keeps
+            # pinned blocks in a cache and does not hand this one out again before the copy has executed.)
             starts, at = [], 0
             for f in fields:
                 starts.append(at)
                 at += (f.numel() + 63) // 64 * 64
-            host = torch.empty(at, dtype=C.DTYPE)   # (not zeros: a fill of this size wakes the whole CPU thread pool, 2 ms)
+            n_len = self.seq_lengths.numel()
+            host = torch.empty(at + (n_len + 63) // 64 * 64, dtype=torch.float32, pin_memory=True)
             for f, st in zip(fields, starts):
                 host[st:st + f.numel()] = f.reshape(-1)
-            flat = host.to(device)
+            host[at:at + n_len].view(torch.int32).copy_(self.seq_lengths.reshape(-1).to(torch.int32))
+            flat = host.to(device, non_blocking=True)
             for name, f, st in zip(names, fields, starts):
                 setattr(self, name, flat[st:st + f.numel()].view(f.shape))
+            self.seq_lengths = flat[at:at + n_len].view(torch.int32).view(self.seq_lengths.shape)
             return self
+        self.seq_lengths = self.seq_lengths.to(dtype=torch.int, device=device)
         for name, f in zip(names, fields):
             setattr(self, name, f.to(dtype=C.DTYPE, device=device))
         return self

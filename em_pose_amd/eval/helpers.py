@@ -155,14 +155,26 @@ class _nothing(object):
         return False
 
 
-def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=None):
+def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=None, host_times=None):
     """
     :param batches: iterable of single-recording `RealBatch`es (root already normalised), on the CPU.
     :return: (overall MetricsEngine, [(recording id, metrics dict)], frames processed)
     """
     from em_pose_amd.nn.models import IterativeErrorFeedback
-    me_all, me_ind = MetricsEngine(smpl_model), MetricsEngine(smpl_model)
-    per_sequence, frames = [], 0
+    import time as _time
+    _t = [_time.perf_counter()]
+
+    def lap(key):   # (dev) host seconds per section of the loop
+        if host_times is not None:
+            now = _time.perf_counter()
+            host_times[key] = host_times.get(key, 0.0) + now - _t[0]
+            _t[0] = now
+    # ONE engine collects the rows of every chunk of every recording (on the device, in call order); they are read back
+    # once, after the last recording, and split by the per-recording counts of valid frames.  Reading them back per
+    # recording (as the reference's two engines would) drains the two-stream pipeline 36 times: 3.3 ms each, 0.12 of the
+    # 0.25 s of a pass.
+    me_rows = MetricsEngine(smpl_model)
+    ids, counts, frames = [], [], 0
     is_lgd = isinstance(net, IterativeErrorFeedback)
     ws = window_size if is_lgd else None
     # Chunks of a recording depend on each other only through the LSTM state, so chunk c + 1's packing + LSTM (current
@@ -183,7 +195,8 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
             if log:
                 log('Evaluate {} ({} frames)'.format(batch.ids[0], int(batch.seq_lengths[0])))
             first_shape_hat = None
-            me_ind.reset()
+            ids.append(batch.ids[0])
+            counts.append(0)
             # (Staging the whole recording on the device once and slicing views was measured slower: recordings have 36
             # different lengths, and every new size costs the caching allocator a ~50 ms hipMalloc/hipFree round.)
             for c, chunk in enumerate(window_generator(batch, ws)):
@@ -191,8 +204,12 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                 # the frames that count, while lengths and masks are still on the host (no device kernels for it)
                 valid = MetricsEngine.valid_frames(chunk.seq_lengths, chunk.batch_size, chunk.seq_length,
                                                    chunk.marker_masks)
+                counts[-1] += int(valid.sum())
+                lap('cut_chunk')
                 chunk = chunk.to_gpu(device)
+                lap('to_gpu')
                 out = net(chunk, is_new_sequence=(c == 0))
+                lap('forward_enqueue')
                 if side is not None and net.outputs_ready is None:
                     # the forward did not go through the two-stream path (autograd forward of a `differentiable` net with
                     # grad enabled): its outputs are on the current stream, the metrics below are on the side stream
@@ -204,15 +221,22 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                     if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
                         first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
                     # the reference feeds the same chunk to two engines (evaluate_real.py:70-81); compute once per chunk
-                    # into the recording's engine (its rows stay on the device until the recording is done), merge once
-                    # per recording
-                    me_ind.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
+                    me_rows.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.seq_lengths,
                                    chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks, valid=valid)
-            if side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side)   # the recording's rows are complete
+                lap('metrics_enqueue')
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)   # every recording's rows are complete
+        st = me_rows.state()        # (reads the rows back: the device is in sync afterwards)
+        _check_async(dev)
+        lap('wait_for_device_and_rows')
+        me_all, per_sequence, at = MetricsEngine(smpl_model), [], 0
+        for sid, m in zip(ids, counts):
+            me_ind = MetricsEngine(smpl_model)
+            me_ind.merge({key: v[at:at + m] for key, v in st.items()})
+            at += m
             me_all.merge(me_ind.state())
-            per_sequence.append((batch.ids[0], me_ind.get_metrics()))   # (reads the rows back: the device is in sync)
-            _check_async(dev)
+            per_sequence.append((sid, me_ind.get_metrics()))
+        lap('per_recording_metrics')
     finally:
         if pipelined:
             net.iter_stream = None
@@ -281,7 +305,11 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             lens = [min(window_size, L - sf) for L in sl[:k]]
             f = lens[0]
             cut = lambda name: packed[name][:k, sf:sf + f]
-            chunk = RealBatch([batches[i].ids[0] for i in order[:k]], torch.tensor(lens), cut('poses'),
+            # (the lengths through pinned memory, not blocking: a pageable copy would make the host wait for the stream)
+            lens_dev = torch.tensor(lens, dtype=torch.int32)
+            if dev.type == 'cuda':
+                lens_dev = lens_dev.pin_memory().to(device, non_blocking=True)
+            chunk = RealBatch([batches[i].ids[0] for i in order[:k]], lens_dev, cut('poses'),
                               whole['shapes'][:k], cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'),
                               cut('marker_masks'), whole['offset_t'][:k], whole['offset_r'][:k]).to_gpu(device)
             valid_np = valid_all[:k, sf:sf + f]

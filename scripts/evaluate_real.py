@@ -210,8 +210,10 @@ def main():
     for rep in range(max(args.repeat, 1)):
         t0 = time.perf_counter()
         if sequential:
+            ht = {}
             me_all, per_seq, frames = evaluate_sequences(net, batches, smpl, device, window_size=256,
-                                                         log=log if rep == 0 else None)
+                                                         log=log if rep == 0 else None, host_times=ht)
+            host_times.append({k: round(v, 4) for k, v in ht.items()})
         else:
             ht = {}
             me_all, per_seq, frames = evaluate_sequences_batched(net, batches, smpl, device, window_size=256,
