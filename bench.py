@@ -319,6 +319,8 @@ def main():
         raise SystemExit('the vertices workload is a single-GPU micro-benchmark')
     D.maybe_self_launch(os.path.abspath(__file__), args.gpus, force=args.force_dist, what='bench.py')
     launched = D.launched_by_a_launcher()
+    # in a rank process nothing but the result line may reach stdout (RCCL prints a version banner there)
+    results_out = D.results_stream() if launched else sys.stdout
     world = int(os.environ.get('WORLD_SIZE', '1')) if launched else 1
     rank = int(os.environ.get('RANK', '0')) if launched else 0
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
@@ -472,7 +474,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(net, model, w, hip_out=out)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), file=results_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

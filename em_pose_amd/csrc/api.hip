@@ -138,6 +138,7 @@ struct empose_mesh {
   float* skin_w4 = nullptr;
   int* parents = nullptr;
   unsigned short* wc_bf16 = nullptr;   // split-bf16 pieces of wc in fragment order (only when the handle asked for them)
+  unsigned short* skin_bf16 = nullptr; // dense skin weights per 32-vertex tile, bf16 hi + lo, B-fragment order (ditto)
 };
 
 namespace {
@@ -810,7 +811,8 @@ int empose_set_option(const char* name, int value) {
       {"atb_target", &o.atb_target},
       {"atb_chunk", &o.atb_chunk},
       {"spin_limit", &o.spin_limit},
-      {"train_epi", &o.train_epi}};
+      {"train_epi", &o.train_epi},
+      {"mesh_skin_mfma", &o.mesh_skin_mfma}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
@@ -838,7 +840,8 @@ int empose_get_option(const char* name) {
       {"atb_target", o.atb_target},
       {"atb_chunk", o.atb_chunk},
       {"spin_limit", o.spin_limit},
-      {"train_epi", o.train_epi}};
+      {"train_epi", o.train_epi},
+      {"mesh_skin_mfma", o.mesh_skin_mfma}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;
@@ -2383,6 +2386,36 @@ static int pack_mesh_tiles_bf16(empose_mesh* m, const empose_mesh_desc* d) {
       }
     }
   TRY(upload(m->allocs, buf.data(), buf.size(), &m->wc_bf16));
+  // The skin weights as a dense [32 bone slots][32 vertices] block per tile for the bone blend on the matrix cores
+  // (mesh.hip mesh_rows_bf16s_kernel): k-step ks, piece p, lane (vertex = lane & 31, half = lane >> 5) holds the eight
+  // weights of bones 16 ks + 8 half + 0..7 -- hi = bf16(w), lo = bf16(w - hi); bones a vertex does not have, and the
+  // slots past the 22 body bones, are zero.  Weights of the same bone listed twice add up.
+  {
+    const size_t tile = MESH_SKIN_BF16_TILE_BYTES / 2;
+    std::vector<unsigned short> sk((size_t)NT * tile, 0);
+    std::vector<float> dense(32);
+    for (int t = 0; t < NT; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int v = t * 32 + (lane & 31), half = lane >> 5;
+        if (v >= V) continue;
+        std::fill(dense.begin(), dense.end(), 0.f);
+        for (int k = 0; k < d->kb; ++k) {
+          const int b = d->skin_idx[(size_t)v * d->kb + k];
+          if (b < 0 || b >= NB) return fail(EMPOSE_EINVAL, "skin index %d of vertex %d outside the %d body bones", b, v, NB);
+          dense[b] += d->skin_w[(size_t)v * d->kb + k];
+        }
+        for (int ks = 0; ks < 2; ++ks)
+          for (int e = 0; e < 8; ++e) {
+            const float x = dense[ks * 16 + half * 8 + e];
+            const unsigned short hi = host_bf16_rne(x);
+            const unsigned short lo = host_bf16_rne(x - host_bf16_f32(hi));
+            unsigned short* dst = &sk[(size_t)t * tile + ((size_t)(ks * 2) * 64 + lane) * 8 + e];
+            dst[0] = hi;
+            dst[64 * 8] = lo;
+          }
+      }
+    TRY(upload(m->allocs, sk.data(), sk.size(), &m->skin_bf16));
+  }
   return EMPOSE_OK;
 }
 
@@ -2472,8 +2505,10 @@ static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const 
     sa.feat = w.feat; sa.wc = mesh->wc; sa.xf = w.xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
-    sa.wc_bf16 = mesh->wc_bf16;
-    e = bf16x3 ? launch_mesh_rows_bf16(sa, stream) : launch_mesh_rows(sa, stream);
+    sa.wc_bf16 = mesh->wc_bf16; sa.skin_bf16 = mesh->skin_bf16;
+    e = !bf16x3 ? launch_mesh_rows(sa, stream)
+                : (options().mesh_skin_mfma && mesh->skin_bf16 ? launch_mesh_rows_bf16s(sa, stream)
+                                                              : launch_mesh_rows_bf16(sa, stream));
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;

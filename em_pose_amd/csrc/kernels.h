@@ -27,6 +27,7 @@ struct Options {
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
+  int mesh_skin_mfma = 1; // split-bf16 full-mesh variant: the bone blend as a second matrix-core contraction (0: vector skinning)
   int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
                           // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
@@ -592,11 +593,15 @@ struct MeshSkinArgs {
   const float* wc_frag;        // [tiles][25][3][64][4]: wc in fragment order per 32-vertex tile (api.hip pack_mesh_tiles)
   const int* skin_idx4; const float* skin_w4;   // [tiles * 32][4]
   const void* wc_bf16 = nullptr;   // bf16 pieces of wc in fragment order per tile (api.hip pack_mesh_tiles_bf16), or nullptr
+  const void* skin_bf16 = nullptr; // dense skin weights per 32-vertex tile as bf16 pieces in fragment order (pack_mesh_skin_bf16)
 };
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream);
 // The same evaluation with the blend-shape contraction in split bf16 (mesh.hip); needs MeshSkinArgs::wc_bf16.
 hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream);
 constexpr int MESH_BF16_TILE_BYTES = 14 * 3 * 2 * 1024;
+// ... and with the bone blend as a second contraction on the matrix cores (needs MeshSkinArgs::skin_bf16 too).
+hipError_t launch_mesh_rows_bf16s(const MeshSkinArgs& a, hipStream_t stream);
+constexpr int MESH_SKIN_BF16_TILE_BYTES = 2 * 2 * 1024;
 
 struct VirtualSensorArgs {
   const float* vertices;   // [T][V][3]

@@ -479,6 +479,254 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 4: the same evaluation with the BONE BLEND as a second contraction on the matrix cores.
+//
+// In the kernel above the skinning costs more than the blend-shape contraction (12-13 k against 13-14 k cycles per tile):
+// per (vertex, frame) it gathers four 3 x 4 bone transforms from LDS -- 12 x 16 bytes per lane and frame, 393 KB per
+// tile and wave, i.e. it is bound by LDS bandwidth, not arithmetic.  But the blended transform is itself a product,
+//   T[f][v][c] = sum_b W[v][b] G[f][b][c]      (c = 12 entries of the 3 x 4 transform, b = 22 bones, W the skin weights),
+// with the same shape as the contraction before it: rows = frames, columns = the tile's 32 vertices, K = bones.  Laid out
+// so, its C/D fragments line up with the blend-shape accumulators (lane = vertex, register = frame), and what is left for
+// the vector unit is  out = T^R v + T^t  on registers: 9 FMAs per vertex and frame, no LDS access.
+//   * W as a dense 32 (bones, 22 used) x 32 (vertices) block per tile, split hi + lo in bf16, in B-fragment order
+//     (api.hip pack_mesh_skin_bf16): 4 KB per tile, prefetched with the coefficient ring;
+//   * G of the workgroup's 64 frames staged ONCE as bf16 hi + lo pieces [piece][entry c][frame][24 bones] (48-byte rows:
+//     conflict-free 16-byte fragment reads; the k-slots 24..31 of a fragment read into the next row -- finite values --
+//     and meet zero weights), 72 KB next to the 58 KB feature block;
+//   * three products per k-step (lo.hi, hi.lo, hi.hi) as for the blend shapes; what is dropped is 2^-18 relative per factor.
+// 144 MFMAs (4.6 k cycles) + 32 x 12 FMAs replace 32 x (12 LDS reads + 57 packed FMAs) per tile and lane.
+// One wave per SIMD, MFMAs in fenced groups on distinct accumulators, as above (the two-waves-per-SIMD corruption of the
+// bf16 MFMA is still unexplained: scripts/dev/bf16_hazard_repro.md).
+// ---------------------------------------------------------------------------------------------------------------
+namespace ms {
+using namespace mb;
+constexpr int G_ROW_BYTES = 48;                                   // 24 bones x bf16
+constexpr int G_PIECE_BYTES = 12 * BM * G_ROW_BYTES;              // [entry][frame][bone]
+constexpr int G_BYTES = 2 * G_PIECE_BYTES + 64;                   // + what the last row's k-slots 24..31 read
+constexpr size_t LDS_BYTES = (size_t)A_BYTES + G_BYTES + (size_t)TR_FLOATS * sizeof(float) + 64;
+constexpr int SKIN_TILE_BYTES = 2 * 2 * 1024;                     // [k-step][piece][lane][8 bf16]
+static_assert(SKIN_TILE_BYTES == MESH_SKIN_BF16_TILE_BYTES, "api.hip packs what this kernel reads");
+static_assert(NB <= 24, "the bones of a row fit its 24 slots");
+static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+}  // namespace ms
+
+__global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16s_kernel(MeshSkinArgs a) {
+  using namespace ms;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned short* Ab = reinterpret_cast<unsigned short*>(lds);
+  char* Gb = reinterpret_cast<char*>(lds) + A_BYTES;
+  float* TRs = reinterpret_cast<float*>(Gb + G_BYTES);
+  const int T = a.T, V = a.V;
+  const int f0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- staging: feature pieces (as mesh_rows_bf16_kernel), bone transforms as bf16 pieces, translations
+  {
+    const float* __restrict__ feat = a.feat;
+    for (int i = tid; i < BM * LDA; i += NW * 64) {
+      const int r = i / LDA, c = i - r * LDA;
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      const int src = c < M1 ? c : (c < M2 ? c : c - (M2 - M1));
+      const float x = c < KCOLS ? feat[(size_t)row * 200 + src] : 0.f;
+      const unsigned short p0 = bf16_rne(x);
+      const float r1 = x - bf16_f32(p0);
+      const unsigned short p1 = bf16_rne(r1);
+      const unsigned short p2 = bf16_rne(r1 - bf16_f32(p1));
+      Ab[i] = c < M2 ? p0 : p1;
+      Ab[A_PIECE_BYTES / 2 + i] = c < M1 ? p1 : (c < M2 ? p2 : p0);
+    }
+    const float* __restrict__ xf = a.xf;
+    for (int i = tid; i < BM * NB * 3; i += NW * 64) {   // (frame r, bone b, transform row q): four entries of one row
+      const int r = i / (NB * 3), bq = i - r * (NB * 3), b = bq / 3, q = bq - b * 3;
+      const int row = f0 + r < T ? f0 + r : T - 1;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(xf + ((size_t)row * NB * 3 + bq) * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned short hi = bf16_rne(g[k]);
+        const unsigned short lo = bf16_rne(g[k] - bf16_f32(hi));
+        char* dst = Gb + ((q * 4 + k) * BM + r) * G_ROW_BYTES + b * 2;
+        *reinterpret_cast<unsigned short*>(dst) = hi;
+        *reinterpret_cast<unsigned short*>(dst + G_PIECE_BYTES) = lo;
+      }
+    }
+    for (int i = tid; i < 2 * 12 * BM; i += NW * 64)     // the unused bone slots 22, 23 of every row
+      *reinterpret_cast<unsigned*>(Gb + i * G_ROW_BYTES + NB * 2) = 0u;
+    if (tid < 16) *reinterpret_cast<unsigned*>(Gb + 2 * G_PIECE_BYTES + tid * 4) = 0u;
+    if (tid < BM) {
+      const int row = f0 + tid < T ? f0 + tid : T - 1;
+      f32x4 t{0.f, 0.f, 0.f, 0.f};
+      if (a.trans) { t[0] = a.trans[(size_t)row * 3]; t[1] = a.trans[(size_t)row * 3 + 1]; t[2] = a.trans[(size_t)row * 3 + 2]; }
+      *reinterpret_cast<f32x4*>(TRs + tid * 4) = t;
+    }
+  }
+  __syncthreads();
+
+  const int n_tiles = (V + 31) / 32;
+  const int per_block = (n_tiles + gridDim.y - 1) / gridDim.y;
+  const int first = blockIdx.y * per_block;
+  const int end = min(first + per_block, n_tiles);
+  int vt = first + wave;
+  if (vt >= end) return;
+
+  const __amdgpu_buffer_rsrc_t wtab = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.wc_bf16), 0, (int)((size_t)n_tiles * TILE_BYTES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t stab = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.skin_bf16), 0, (int)((size_t)n_tiles * SKIN_TILE_BYTES), 0x00020000);
+  const int lane16 = lane * 16;
+  auto wload = [&](int tile_off, int ks, int c, int p) {
+    const int f = c * 2 + p;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wtab, lane16 + (f & 3) * 1024,
+                                                                           tile_off + ks * 6144 + (f >> 2) * 4096, 0));
+  };
+  auto bload = [&](f32x4 (&dst)[3][2], int tile_off, int ks) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) dst[c][p] = wload(tile_off, ks, c, p);
+  };
+  auto tile_off_of = [&](int t) { return __builtin_amdgcn_readfirstlane(t) * TILE_BYTES; };
+  const char* a_lane = reinterpret_cast<const char*>(Ab) + l31 * (LDA * 2) + lh * 16;
+  auto aload = [&](f32x4 (&dst)[2][2], int ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        dst[i][p] = *reinterpret_cast<const f32x4*>(a_lane + p * A_PIECE_BYTES + i * 32 * (LDA * 2) + ks * 32);
+  };
+  const char* g_lane = Gb + l31 * G_ROW_BYTES + lh * 16;   // + (entry * 64 + half * 32) rows, + k-step * 32, + piece
+  epi_gbyte_t vbase = (epi_gbyte_t)a.vertices;
+  const size_t vrow_bytes = (size_t)V * 12;
+
+  f32x4 ring[RING][3][2];
+  f32x4 fa[2][2][2];
+  {
+    const int b0 = tile_off_of(vt);
+#pragma unroll
+    for (int ks = 0; ks < RING - 1; ++ks) bload(ring[ks], b0, ks);
+  }
+  aload(fa[0], 0);
+
+#pragma unroll 1
+  for (; vt < end; vt += NW) {
+    const int bt = tile_off_of(vt);
+    const int bnext = vt + NW < end ? tile_off_of(vt + NW) : bt;
+    const int s = vt * 32 + l31;
+    // this tile's skin-weight fragments [k-step][piece]: requested now, needed after the K loop
+    f32x4 wf[2][2];
+    {
+      const int so = __builtin_amdgcn_readfirstlane(vt) * SKIN_TILE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          wf[ks][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(stab, lane16 + (ks * 2 + p) * 1024, so, 0));
+    }
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {   // (the K loop of mesh_rows_bf16_kernel)
+      const int kn = ks + RING - 1;
+      f32x4 (&bn)[3][2] = ring[kn % RING];
+      f32x4 (&fn)[2][2] = fa[(ks + 1) & 1];
+      const int an = ks + 1 < KS ? ks + 1 : 0;
+      const f32x4 (&fc)[2][2] = fa[ks & 1];
+      const f32x4 (&bc)[3][2] = ring[ks % RING];
+#pragma unroll
+      for (int prod = 0; prod < 3; ++prod) {
+        if (kn < KS) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) bn[prod][p] = wload(bt, kn, prod, p);
+        }
+        if (prod < 2) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            fn[prod][p] = *reinterpret_cast<const f32x4*>(a_lane + p * A_PIECE_BYTES + prod * 32 * (LDA * 2) + an * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, fc[i][prod == 0 ? 1 : 0]);
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, bc[c][prod == 1 ? 1 : 0]);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][c], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0x6);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < RING - 1; ++ks) bload(ring[ks], bnext, ks);
+
+    // ---- bone blend on the matrix cores + out = T^R v + T^t on registers
+    const char* trl = reinterpret_cast<const char*>(TRs) + lh * 64;
+    const unsigned lane_off = ((unsigned)(f0 + 4 * lh) * (unsigned)V + (unsigned)s) * 12u;
+    const bool full = f0 + BM <= T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        f32x16 tk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tk[k][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          // this transform row's A fragments of the k-step: [entry k][piece]
+          f32x4 ga[4][2];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              ga[k][p] = *reinterpret_cast<const f32x4*>(g_lane + p * G_PIECE_BYTES +
+                                                         ((q * 4 + k) * BM + i * 32) * G_ROW_BYTES + ks * 32);
+#pragma unroll
+          for (int prod = 0; prod < 3; ++prod) {   // lo.hi, hi.lo, hi.hi: the small terms first
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // four MFMAs on four different accumulators
+              const bf16x8 av = __builtin_bit_cast(bf16x8, ga[k][prod == 0 ? 1 : 0]);
+              const bf16x8 bv = __builtin_bit_cast(bf16x8, wf[ks][prod == 1 ? 1 : 0]);
+              tk[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, tk[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0x6);
+          }
+        }
+        if (s < V) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+            const float tr = *reinterpret_cast<const float*>(trl + dm * 16 + q * 4);
+            const float o = __builtin_fmaf(tk[0][r], acc[i][0][r],
+                                           __builtin_fmaf(tk[1][r], acc[i][1][r],
+                                                          __builtin_fmaf(tk[2][r], acc[i][2][r], tk[3][r]))) + tr;
+            if (full || f0 + 4 * lh + dm < T)
+              *(epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + (lane_off + 4u * q)) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_mesh_rows_bf16s(const MeshSkinArgs& a, hipStream_t stream) {
+  if (!a.skin_bf16 || !a.wc_bf16) return hipErrorInvalidValue;
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_bf16s_kernel), ms::LDS_BYTES)) return e;
+  const int bx = (a.T + mb::BM - 1) / mb::BM;
+  const int n_tiles = (a.V + 31) / 32;
+  int by = bx >= 256 ? 1 : (256 + bx - 1) / bx;
+  const int max_by = (n_tiles + mb::NW - 1) / mb::NW;
+  if (by > max_by) by = max_by;
+  hipLaunchKernelGGL(mesh_rows_bf16s_kernel, dim3(bx, by), dim3(mb::NW * 64), ms::LDS_BYTES, stream, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_mesh_rows_bf16(const MeshSkinArgs& a, hipStream_t stream) {
   if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<false>), mb::LDS_BYTES)) return e;
   if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mesh_rows_bf16_kernel<true>), mb::LDS_BYTES)) return e;

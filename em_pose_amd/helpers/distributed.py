@@ -103,6 +103,18 @@ def maybe_self_launch(script, n, force=False, what='this script'):
     sys.exit(launch_ranks(script, sys.argv[1:], n))
 
 
+def results_stream():
+    """In a rank process: a file object on the REAL stdout, after pointing file descriptor 1 at stderr.  Libraries that
+    write banners to stdout from native code (RCCL prints its version block there when the first communicator comes up)
+    then land on stderr, and the one JSON line rank 0 prints is the only thing on stdout."""
+    import os
+    import sys
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(real, 'w')
+
+
 def init_process_group(device=None, log=None):
     """Rank-side: join the process group the launcher described in the environment (RCCL with the rank's device, or
     gloo).  Returns (dist module, rank, world)."""

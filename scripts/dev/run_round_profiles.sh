@@ -7,7 +7,8 @@ R=$PWD
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/${TAG}_gpu_tests.log
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
-python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json
+python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json   # with its own parity sample (cpu_baseline)
+python bench.py --gpus 1 --force_dist --steps 20 --warmup 3 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024_spawned_rank_nccl.json
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
 python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
@@ -15,7 +16,7 @@ python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail
 python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
 python scripts/train.py --steps 20 --graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph.json
-( for bs in 12 64 256; do for g in "" "--graph"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt
+( for bs in 12 64 256; do for g in "" "--graph" "--single_stream"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --bs_train 256 --json > $OUT.log 2>&1 )
