@@ -27,7 +27,8 @@ struct Options {
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
-  int mesh_skin_mfma = 1; // split-bf16 full-mesh variant: the bone blend as a second matrix-core contraction (0: vector skinning)
+  int mesh_skin_mfma = 0; // split-bf16 full-mesh variant: the bone blend as a second matrix-core contraction (mesh_rows_bf16s_kernel;
+                          // measured 9 % SLOWER than vector skinning: 15.6 against 17.1 M frames/s, so off by default)
   int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
                           // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)

@@ -495,7 +495,13 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArg
 //     conflict-free 16-byte fragment reads; the k-slots 24..31 of a fragment read into the next row -- finite values --
 //     and meet zero weights), 72 KB next to the 58 KB feature block;
 //   * three products per k-step (lo.hi, hi.lo, hi.hi) as for the blend shapes; what is dropped is 2^-18 relative per factor.
-// 144 MFMAs (4.6 k cycles) + 32 x 12 FMAs replace 32 x (12 LDS reads + 57 packed FMAs) per tile and lane.
+// 144 MFMAs + 32 x 12 FMAs replace 32 x (12 LDS reads + 57 packed FMAs) per tile and lane.
+// MEASURED (T = 16384, V = 6890): correct (6e-6 of the fp32 kernel; the dropped lo.lo terms), and SLOWER than the vector
+// skinning it replaces -- 14.7 M frames/s with the MFMAs and the apply one after the other, 15.1 M software-pipelined,
+// 15.6 M with the translation folded into the accumulator, against 17.1 M for mesh_rows_bf16_kernel.  The tile then
+// carries 396 instead of 252 v_mfma_f32_32x32x16_bf16; at the ~54-64 cycles each of them takes here (13-14 k cycles for
+// the 252 of the K loop) the 144 added ones cost what the LDS-bound gather cost: padding 22 bones to a K of 32 and three
+// products per k-step make this contraction too expensive for its 0.7 MFLOP of useful work.  Opt-in ("mesh_skin_mfma").
 // One wave per SIMD, MFMAs in fenced groups on distinct accumulators, as above (the two-waves-per-SIMD corruption of the
 // bf16 MFMA is still unexplained: scripts/dev/bf16_hazard_repro.md).
 // ---------------------------------------------------------------------------------------------------------------
@@ -668,48 +674,64 @@ __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16s_kernel(MeshSkinAr
     const char* trl = reinterpret_cast<const char*>(TRs) + lh * 64;
     const unsigned lane_off = ((unsigned)(f0 + 4 * lh) * (unsigned)V + (unsigned)s) * 12u;
     const bool full = f0 + BM <= T;
+    // Six stages (frame half i, transform row q), software-pipelined: the 24 MFMAs of stage st + 1 are issued between the
+    // vector instructions that apply stage st (a wave's MFMAs run in the matrix pipe while it issues vector work; in
+    // program order "24 MFMAs, then the apply" the two phases simply followed each other and the kernel was SLOWER than
+    // vector skinning: 14.7 against 16.9 M frames/s).  Order pinned with full scheduling fences; consecutive MFMAs always
+    // go to different accumulators.
+    f32x16 tk[2][4];
+    f32x4 ga[2][4][2];   // [k-step][entry][piece] of the stage being issued
+    auto gload = [&](int st) {
+      const int i = st / 3, q = st - i * 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        f32x16 tk[4];
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tk[k][r] = 0.f;
+          for (int p = 0; p < 2; ++p)
+            ga[ks][k][p] = *reinterpret_cast<const f32x4*>(g_lane + p * G_PIECE_BYTES +
+                                                           ((q * 4 + k) * BM + i * 32) * G_ROW_BYTES + ks * 32);
+    };
+    auto zero = [&](f32x16 (&t)[4], int st) {   // the translation entry starts from the frame's global translation:
+      const int i = st / 3, q = st - i * 3;     // sixteen LDS reads in one go here instead of one (and its latency) per frame
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          // this transform row's A fragments of the k-step: [entry k][piece]
-          f32x4 ga[4][2];
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < 16; ++r) t[k][r] = 0.f;
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-              ga[k][p] = *reinterpret_cast<const f32x4*>(g_lane + p * G_PIECE_BYTES +
-                                                         ((q * 4 + k) * BM + i * 32) * G_ROW_BYTES + ks * 32);
+      for (int r = 0; r < 16; ++r)
+        t[3][r] = *reinterpret_cast<const float*>(trl + (i * 32 + (r & 3) + 8 * (r >> 2)) * 16 + q * 4);
+    };
+    auto mma = [&](f32x16 (&t)[4], int g) {   // MFMA g of a stage's 24: product g / 8, k-step (g / 4) % 2, entry g % 4
+      const int prod = g >> 3, ks = (g >> 2) & 1, k = g & 3;
+      const bf16x8 av = __builtin_bit_cast(bf16x8, ga[ks][k][prod == 0 ? 1 : 0]);
+      const bf16x8 bv = __builtin_bit_cast(bf16x8, wf[ks][prod == 1 ? 1 : 0]);
+      t[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, t[k], 0, 0, 0);
+    };
+    auto apply = [&](int st, const f32x16 (&t)[4], int r) {
+      const int i = st / 3, q = st - i * 3;
+      const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+      const float o = __builtin_fmaf(t[0][r], acc[i][0][r],
+                                     __builtin_fmaf(t[1][r], acc[i][1][r], __builtin_fmaf(t[2][r], acc[i][2][r], t[3][r])));
+      if (s < V && (full || f0 + 4 * lh + dm < T))
+        *(epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + (lane_off + 4u * q)) = o;
+    };
+    gload(0);
+    zero(tk[0], 0);
 #pragma unroll
-          for (int prod = 0; prod < 3; ++prod) {   // lo.hi, hi.lo, hi.hi: the small terms first
+    for (int g = 0; g < 24; ++g) mma(tk[0], g);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {           // four MFMAs on four different accumulators
-              const bf16x8 av = __builtin_bit_cast(bf16x8, ga[k][prod == 0 ? 1 : 0]);
-              const bf16x8 bv = __builtin_bit_cast(bf16x8, wf[ks][prod == 1 ? 1 : 0]);
-              tk[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, tk[k], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0x6);
-          }
-        }
-        if (s < V) {
+    for (int st = 0; st < 6; ++st) {
+      if (st + 1 < 6) {
+        gload(st + 1);
+        zero(tk[(st + 1) & 1], st + 1);
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
-            const float tr = *reinterpret_cast<const float*>(trl + dm * 16 + q * 4);
-            const float o = __builtin_fmaf(tk[0][r], acc[i][0][r],
-                                           __builtin_fmaf(tk[1][r], acc[i][1][r],
-                                                          __builtin_fmaf(tk[2][r], acc[i][2][r], tk[3][r]))) + tr;
-            if (full || f0 + 4 * lh + dm < T)
-              *(epi_gfloat_t)(vbase + (size_t)dm * vrow_bytes + (lane_off + 4u * q)) = o;
-          }
-        }
+      for (int g = 0; g < 24; ++g) {   // one MFMA of the next stage, then the vector work of one frame of this one
+        if (st + 1 < 6) mma(tk[(st + 1) & 1], g);
+        if (g < 16) apply(st, tk[st & 1], g);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
