@@ -812,7 +812,8 @@ int empose_set_option(const char* name, int value) {
       {"atb_chunk", &o.atb_chunk},
       {"spin_limit", &o.spin_limit},
       {"train_epi", &o.train_epi},
-      {"mesh_skin_mfma", &o.mesh_skin_mfma}};
+      {"mesh_skin_mfma", &o.mesh_skin_mfma},
+      {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
@@ -841,7 +842,8 @@ int empose_get_option(const char* name) {
       {"atb_chunk", o.atb_chunk},
       {"spin_limit", o.spin_limit},
       {"train_epi", o.train_epi},
-      {"mesh_skin_mfma", o.mesh_skin_mfma}};
+      {"mesh_skin_mfma", o.mesh_skin_mfma},
+      {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;

@@ -26,6 +26,7 @@ struct Options {
   int train_fused = 0;    // train-mode BatchNorm / PReLU folded into the GEMMs: 0 never (default: measured no faster,
                           // DESIGN.md), 1 above 1024 rows, 2 always
   int atb_target = 0;     // workgroups the A^T B weight-gradient GEMM aims for when it splits its reduction (0: by size)
+  int atb_fast = 1;       // A^T B: whole-tile / whole-chunk problems on the branch-free interior kernel (0: the general kernel)
   int atb_chunk = 0;      // rows per staged chunk of that kernel, 16 or 32 (0: by size)
   int mesh_skin_mfma = 0; // split-bf16 full-mesh variant: the bone blend as a second matrix-core contraction (mesh_rows_bf16s_kernel;
                           // measured 9 % SLOWER than vector skinning: 15.6 against 17.1 M frames/s, so off by default)

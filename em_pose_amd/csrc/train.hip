@@ -279,6 +279,132 @@ __global__ __launch_bounds__(atbl::NT) void gemm_atb_lds_kernel(AtbArgs a) {
   }
 }
 
+// The interior of the same product as its own kernel (round 4): whole 128 x 128 tiles, every workgroup the same number
+// of whole MC-row chunks inside ONE row segment, plain operands (no transform).  That is what the hidden layers of the
+// update networks give (32768 x 512 x 512 over four applications), and for it the general kernel above carries its edge
+// handling, segment walk and transform switches through the loop as branches and scalar reloads: 165 us where a stripped
+// copy of the loop measured 138 (scripts/dev/atb_lab.hip).  Same staging, same operand order, same split -- the same bits.
+struct AtbFastArgs {
+  const float* A; const float* B; int lda, ldb;      // (segment bases are resolved per workgroup on the host side of the loop)
+  const float* A_seg[ATB_MAX_SEG]; const float* B_seg[ATB_MAX_SEG];
+  int n_seg, seg_rows;
+  float* out; int ldo;            // partial tiles [S][N][K] (ldo = K) or C itself (S == 1)
+  float* bias_out;                // [S][N] partial column sums, the bias itself (S == 1), or nullptr
+  int N, K, tiles_k, chunk_rows;  // rows per workgroup (a multiple of MC)
+  int acc_c;                      // S == 1 and accumulate
+};
+
+template <int MC>
+__global__ __launch_bounds__(atbl::NT) void gemm_atb_fast_kernel(AtbFastArgs a) {
+  using namespace atbl;
+  constexpr int LDS_FLOATS = 2 * MC * (BN + BK);
+  constexpr int P = MC / 8;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  const int tn = blockIdx.x / a.tiles_k, tk = blockIdx.x - tn * a.tiles_k;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int nw = (wave >> 1) * 64, kw = (wave & 1) * 64;
+  const int n_base = tn * BN, k_base = tk * BK;
+  const int ms = blockIdx.y * a.chunk_rows;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int r8 = tid >> 5, c4 = (tid & 31) * 4;
+  // this workgroup's rows lie in one segment: two row pointers, advanced by MC rows per chunk
+  const float* pa; const float* pb;
+  {
+    const int sg = a.n_seg > 0 ? ms / a.seg_rows : 0;
+    const int mrel = a.n_seg > 0 ? ms - sg * a.seg_rows : ms;
+    const float* A0 = a.n_seg > 0 ? a.A_seg[sg] : a.A;
+    const float* B0 = a.n_seg > 0 ? a.B_seg[sg] : a.B;
+    pa = A0 + (size_t)(mrel + r8) * a.lda + n_base + c4;
+    pb = B0 + (size_t)(mrel + r8) * a.ldb + k_base + c4;
+  }
+  const size_t step_a = (size_t)MC * a.lda, step_b = (size_t)MC * a.ldb;
+  const size_t row8_a = (size_t)8 * a.lda, row8_b = (size_t)8 * a.ldb;
+  f32x16t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f4 ga[P], gb[P];
+  const bool do_bias = a.bias_out != nullptr && tk == 0;   // uniform over the workgroup
+  f4 bs = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&]() {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      ga[p] = *reinterpret_cast<const f4*>(pa + p * row8_a);
+      gb[p] = *reinterpret_cast<const f4*>(pb + p * row8_b);
+    }
+    pa += step_a; pb += step_b;
+  };
+  auto lwrite = [&](float* st) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      *reinterpret_cast<f4*>(st + (r8 + 8 * p) * BN + c4) = ga[p];
+      *reinterpret_cast<f4*>(st + MC * BN + (r8 + 8 * p) * BK + c4) = gb[p];
+      if (do_bias) bs += ga[p];
+    }
+  };
+  constexpr int STAGE = MC * (BN + BK);
+  gload();
+  lwrite(lds);
+  __syncthreads();
+  int buf = 0;
+  const int n_chunks = a.chunk_rows / MC;
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const bool more = ch + 1 < n_chunks;
+    if (more) gload();
+    const float* sA = lds + buf * STAGE + nw + l31;
+    const float* sB = lds + buf * STAGE + MC * BN + kw + l31;
+    float a0 = sA[lh * BN], a1 = sA[lh * BN + 32];
+    float b0 = sB[lh * BK], b1 = sB[lh * BK + 32];
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int q = 0; q < MC / 2; ++q) {
+      const int row = (q + 1 < MC / 2 ? 2 * (q + 1) : 0) + lh;
+      const float na0 = sA[row * BN], na1 = sA[row * BN + 32];
+      const float nb0 = sB[row * BK], nb1 = sB[row * BK + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+    if (more) lwrite(lds + (buf ^ 1) * STAGE);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const int n0 = n_base + nw, k0 = k_base + kw;
+  float* out = a.out + (gridDim.y > 1 ? (size_t)blockIdx.y * a.N * a.K : 0);   // the split's partial tile, or C itself
+  const int ldo = a.ldo;
+  const bool acc_c = a.acc_c != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        out[(size_t)n * ldo + k] = acc[i][j][r] + (acc_c ? out[(size_t)n * ldo + k] : 0.f);
+      }
+    }
+  if (do_bias) {
+    *reinterpret_cast<f4*>(lds + r8 * BN + c4) = bs;
+    __syncthreads();
+    if (tid < BN) {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += lds[g * BN + tid];
+      float* bo = a.bias_out + (gridDim.y > 1 ? (size_t)blockIdx.y * a.N : 0);
+      bo[n_base + tid] = v + (acc_c ? bo[n_base + tid] : 0.f);
+    }
+  }
+}
+
 // C[i] = sum_s partial[s][i] in split order; the same for the bias partials
 __global__ void atb_reduce_kernel(AtbArgs a) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,7 +485,23 @@ hipError_t launch_gemm_atb(AtbArgs a, float* workspace, size_t workspace_floats,
     aligned = aligned && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
   }
   if (a.b_mode && !aligned) return hipErrorInvalidValue;   // callers keep these operands aligned
-  if (aligned && atb_chunk_rows(a.M, a.N, a.K) == 16)
+  const int mc = atb_chunk_rows(a.M, a.N, a.K);
+  // the interior kernel: whole tiles, equal whole-chunk row ranges that do not straddle a segment, plain operands
+  const int rows_per_wg = a.S > 0 ? a.M / a.S : 0;
+  const bool fast = options().atb_fast && aligned && !a.b_mode && a.N % atbl::BN == 0 && a.K % atbl::BK == 0 &&
+                    a.M % a.S == 0 && rows_per_wg % mc == 0 && rows_per_wg > 0 &&
+                    (a.n_seg == 0 || a.seg_rows % rows_per_wg == 0) &&
+                    ((((a.M + a.S - 1) / a.S) + mc - 1) / mc * mc) == rows_per_wg;   // = the split the general kernel would use
+  if (fast) {
+    AtbFastArgs f{};
+    f.A = a.A; f.B = a.B; f.lda = a.lda; f.ldb = a.ldb; f.n_seg = a.n_seg; f.seg_rows = a.seg_rows;
+    for (int s = 0; s < a.n_seg; ++s) { f.A_seg[s] = a.A_seg[s]; f.B_seg[s] = a.B_seg[s]; }
+    f.out = a.S > 1 ? a.partial : a.C; f.ldo = a.S > 1 ? a.K : a.ldc;
+    f.bias_out = a.bias_partial; f.N = a.N; f.K = a.K; f.tiles_k = a.K / atbl::BK; f.chunk_rows = rows_per_wg;
+    f.acc_c = a.S == 1 && a.accumulate;
+    if (mc == 16) hipLaunchKernelGGL(gemm_atb_fast_kernel<16>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, f);
+    else hipLaunchKernelGGL(gemm_atb_fast_kernel<32>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, f);
+  } else if (aligned && mc == 16)
     hipLaunchKernelGGL(gemm_atb_lds_kernel<16>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
   else if (aligned) hipLaunchKernelGGL(gemm_atb_lds_kernel<32>, dim3(tiles, a.S), dim3(atbl::NT), 0, stream, a);
   else hipLaunchKernelGGL(gemm_atb_kernel, dim3(tiles, a.S), dim3(atb::NT), 0, stream, a);

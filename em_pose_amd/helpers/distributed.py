@@ -181,6 +181,10 @@ class GradientBuckets(object):
       when staged; `p.grad` is re-pointed to the slice.
     Averages over the ranks (sum, then 1 / world on the side stream).  `force=True` runs the collectives even with one
     rank (self-test of the RCCL path on one GPU).
+    A parameter that has no gradient on this rank when it is staged gets a zeroed slice as `.grad` (every rank must issue
+    the same collectives, and another rank may have a gradient for it): in a distributed run such parameters are stepped
+    by the optimiser with the averaged (possibly zero) gradient -- `HipAdam`'s "skipped like torch" applies to `.grad is
+    None`, which only a single-process run leaves in place.
     """
 
     def __init__(self, parameters, bucket_bytes=8 << 20, group=None, force=False):
@@ -274,16 +278,28 @@ def attach_gradient_buckets(net, buckets):
     net._grad_sink = buckets
 
 
+_ONE_SHOT_BUCKETS = {}
+
+
 def allreduce_gradients(parameters, bucket_bytes=8 << 20, group=None):
     """
     Average `.grad` of the given parameters over all ranks after the backward pass, in flat buckets of about
-    `bucket_bytes`.  One-shot form of `GradientBuckets` (which keeps the buckets and overlaps the collectives with the
-    reverse sweep); parameters without a gradient contribute zeros so that every rank issues the same collectives.
+    `bucket_bytes`.  One-shot form of `GradientBuckets` (which overlaps the collectives with the reverse sweep); the
+    buckets (and their side stream) are built once per parameter list and kept, so `.grad` has the same address from the
+    second step on and an optimiser that caches gradient pointers (`HipAdam`) does not re-upload its table every step.
+    Parameters without a gradient contribute zeros so that every rank issues the same collectives -- and therefore HAVE a
+    (zero) gradient afterwards: in a distributed run the optimiser steps them (moments decay, step count advances), unlike
+    a single-process run where a parameter whose `.grad` is None is skipped.  All ranks agree, which is what matters.
     """
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
-    buckets = GradientBuckets(parameters, bucket_bytes, group)
+    params = [p for p in parameters if p.requires_grad]
+    key = (tuple(id(p) for p in params), bucket_bytes, id(group))
+    buckets = _ONE_SHOT_BUCKETS.get(key)
+    if buckets is None or any(b.device != params[0].device for b in buckets.flat):
+        _ONE_SHOT_BUCKETS.clear()     # (one parameter list at a time: a new model replaces the old buckets)
+        buckets = _ONE_SHOT_BUCKETS[key] = GradientBuckets(params, bucket_bytes, group)
     return buckets.finish()
 
 

@@ -249,3 +249,67 @@ def test_full_mesh_split_bf16_with_the_bone_blend_on_the_matrix_cores():
         assert torch.equal(fast(**kw)[0], first)
     _lib.check(lib.empose_set_option(b'mesh_skin_mfma', 0))
     assert not torch.equal(fast(**kw)[0], first)      # (the option does select another kernel)
+
+
+def test_weight_gradient_interior_kernel_is_bit_identical_to_the_general_one():
+    """gemm_atb_fast_kernel (whole tiles, whole chunks inside one row segment, plain operands) against gemm_atb_lds_kernel:
+    same staging, operand order and split, so the same bits -- stand-alone products (with and without accumulation, one
+    and many splits) and a training step whose hidden layers take it over the row segments of two applications."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in ((4096, 128, 128), (8192, 256, 384), (1024, 128, 256), (32768, 512, 512)):
+        A, B = torch.randn(M, N, generator=g).to(DEV), torch.randn(M, K, generator=g).to(DEV)
+        outs = {}
+        for fast in (1, 0):
+            _lib.check(lib.empose_set_option(b'atb_fast', fast))
+            C0 = torch.full((N, K), 0.5, device=DEV)
+            bias = torch.full((N,), -0.25, device=DEV)
+            nb = lib.empose_gemm_atb_workspace_bytes(M, N, K)
+            ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=DEV)
+            _lib.check(lib.empose_gemm_atb_f32(M, N, K, A.data_ptr(), N, B.data_ptr(), K, C0.data_ptr(), K, bias.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), None))
+            torch.cuda.synchronize()
+            outs[fast] = (C0.clone(), bias.clone())
+        assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]), (M, N, K)
+        want = A.double().t() @ B.double()
+        assert float((outs[1][0].double() - want).abs().max()) < 2e-4 * float(want.abs().max())
+        np.testing.assert_allclose(outs[1][1].cpu().numpy(), A.double().sum(0).cpu().numpy(), rtol=0, atol=2e-3)
+
+    # a training step: 2 applications x 2048 rows, hidden 128 -> the hidden layers' dW go through the interior kernel
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.helpers.configuration import lgd_config
+    from em_pose_amd.nn.models import create_model
+    from tests import helpers as H
+    model = H.small_model()
+    bm = R.BodyModelTensors(model)
+    vids = [int(v) for v in np.random.default_rng(5).choice(model['v_template'].shape[0], 12, replace=False)]
+    tables = R.sensor_tables(model['f'], vids)
+
+    def sensors(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, vids, torch.from_numpy(poses), torch.from_numpy(betas),
+                                          torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    B_, F = 64, 32
+    w = synthetic.make_windows(B_, F, 4, sensors)
+    torch.manual_seed(8)
+    net = create_model(lgd_config(12, False, 2, hidden=128), SMPLLayer(model))
+    net.vertex_ids = vids
+    net = net.to(DEV).train()
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+    lens = torch.full((B_,), F, dtype=torch.int64, device=DEV)
+    grads = {}
+    for fast in (1, 0):
+        _lib.check(lib.empose_set_option(b'atb_fast', fast))
+        net.load_state_dict(state0)
+        batch = SyntheticBatch(w, lens, device=DEV)
+        batch.joints_gt = torch.zeros(B_, F, 66, device=DEV)
+        net.zero_grad()
+        out = net(batch)
+        net.backward(batch, out)
+        torch.cuda.synchronize()
+        grads[fast] = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    for k, v in grads[0].items():
+        assert torch.equal(grads[1][k], v), k
