@@ -174,12 +174,12 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
                     e_o32 = max(e_o32, float(np.abs(want[k].numpy() - ref64)[valid].max()))
                 # ... and the case's own sensitivity, free of any implementation's rounding luck: the float64 oracle with
                 # the body-model constants (template, blend shapes, regressor, skin weights) and the inputs moved by one
-                # fp32 unit in the last place (random signs, four draws) -- the noise any fp32 evaluation of the vertices
+                # fp32 unit in the last place (random signs, two draws) -- the noise any fp32 evaluation of the vertices
                 # commits -- and how far the outputs move
                 sens = 0.0
                 prng = np.random.default_rng(12345 + n)
                 ulp = lambda a: a.astype(np.float64) * (1.0 + 6e-8 * np.sign(prng.standard_normal(a.shape)))
-                for draw in range(4):
+                for draw in range(2):
                     wp = dict(w)
                     for k in ('marker_pos', 'marker_oris', 'offset_t'):
                         wp[k] = ulp(w[k])
