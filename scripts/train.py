@@ -296,7 +296,7 @@ def main():
     if args.graph:
         from em_pose_amd.helpers.graphed import GraphedTrainStep
         graphed = GraphedTrainStep(net, opt, batches[0])
-    times, n_coll = [], 0
+    times, n_coll, enq = [], 0, []
     for step in range(args.warmup + args.steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -313,6 +313,7 @@ def main():
             loss, vals = net.backward(batch, out)     # finished buckets are already being averaged on a side stream
             n_coll = average_gradients(buckets, params)
             opt.step()
+            enq.append(time.perf_counter() - t0)     # host time to enqueue the whole step (before waiting for the device)
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if step >= args.warmup:
@@ -331,7 +332,8 @@ def main():
         res = {'steps_per_sec': 1.0 / med, 'frames_per_sec': world * B * F / med, 'n_gpus': world,
                'windows_per_gpu': B, 'window_size': F, 'median_step_ms': med * 1e3, 'hip_graph': bool(args.graph),
                'process_group': dist.get_backend() if dist.is_initialized() else None,
-               'gradient_collectives_per_step': n_coll}
+               'gradient_collectives_per_step': n_coll,
+               'host_enqueue_ms_median': float(np.median(enq[args.warmup:]) * 1e3) if enq else None}
         print(json.dumps(res) if args.json else res)
     import torch.distributed as dist
     if dist.is_initialized():
