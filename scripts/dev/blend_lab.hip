@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iem_pose_amd/csrc scripts/dev/blend_lab.hip -o /tmp/blend_lab && /tmp/blend_lab
 #include "../../em_pose_amd/csrc/mlp_fused.hip"
 #include "../../em_pose_amd/csrc/gemm_f32.hip"
+#include "lab_stubs.h"
 #include <cstdio>
 using namespace empose;
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iem_pose_amd/csrc scripts/dev/fused_lab.hip -o /tmp/fused_lab && /tmp/fused_lab
 #define EMPOSE_FUSED_TRACE 1
 #include "../../em_pose_amd/csrc/mlp_fused.hip"
+#include "lab_stubs.h"
 
 #include <cstdio>
 #include <vector>

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iem_pose_amd/csrc scripts/dev/gemm_lab.hip -o /tmp/gemm_lab && /tmp/gemm_lab
 #define EMPOSE_GEMM_TRACE 1
 #include "../../em_pose_amd/csrc/gemm_f32.hip"
+#include "lab_stubs.h"
 
 #include <cstdio>
 #include <vector>

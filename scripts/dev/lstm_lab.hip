@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iem_pose_amd/csrc scripts/dev/lstm_lab.hip -o /tmp/lstm_lab && /tmp/lstm_lab
 #define EMPOSE_LSTM_TRACE 1
 #include "../../em_pose_amd/csrc/lstm.hip"
+#include "lab_stubs.h"
 
 #include <cstdio>
 #include <vector>

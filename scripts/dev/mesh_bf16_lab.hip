@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <vector>
 using namespace empose;
-namespace empose { Options& options() { static Options o; return o; } }
+#include "lab_stubs.h"
 #ifdef LAB_PIPE   // scripts/dev/experiments/mesh_bf16_pipe.hip pasted into mesh.hip
 #define LAB_KERNEL mesh_rows_bf16_pipe_kernel
 #else

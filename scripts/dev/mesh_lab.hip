@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iem_pose_amd/csrc -Iinclude scripts/dev/mesh_lab.hip -o /tmp/mesh_lab && /tmp/mesh_lab
 #define EMPOSE_MESH_TRACE 1
 #include "../../em_pose_amd/csrc/mesh.hip"
+#include "lab_stubs.h"
 
 #include <algorithm>
 #include <cstdio>
