@@ -175,6 +175,11 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
     # 0.25 s of a pass.
     me_rows = MetricsEngine(smpl_model)
     ids, counts, frames = [], [], 0
+    # ... and on the device path the metrics themselves are computed ONCE, over the frames of all chunks: a chunk only
+    # leaves its tensors in `deferred` (the per-chunk forward-kinematics + metrics launches and the tensor plumbing around
+    # them were 0.27 ms of host time per chunk, a quarter of a pass that is bound by the host).
+    deferred = []
+    defer = getattr(me_rows, 'angle_glob', False) and hasattr(smpl_model, 'fk_joints')
     is_lgd = isinstance(net, IterativeErrorFeedback)
     ws = window_size if is_lgd else None
     # Chunks of a recording depend on each other only through the LSTM state, so chunk c + 1's packing + LSTM (current
@@ -214,6 +219,13 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                     # the forward did not go through the two-stream path (autograd forward of a `differentiable` net with
                     # grad enabled): its outputs are on the current stream, the metrics below are on the side stream
                     side.wait_stream(torch.cuda.current_stream(dev))
+                if defer and side is not None and out['pose_hat'].is_cuda:
+                    if c == 0:  # the first chunk's shape is used for the whole recording (evaluate_real.py:63-68)
+                        first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
+                    deferred.append((chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.poses_root,
+                                     out['root_ori_hat'], valid))
+                    lap('metrics_enqueue')
+                    continue
                 with torch.cuda.stream(side) if side is not None else _nothing():
                     if side is not None:   # the chunk lives in memory of the current stream's pool
                         for t in (chunk.poses, chunk.shapes, chunk.seq_lengths):
@@ -225,7 +237,17 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                                    chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks, valid=valid)
                 lap('metrics_enqueue')
         if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)   # every recording's rows are complete
+            torch.cuda.current_stream(dev).wait_stream(side)   # every chunk's outputs / rows are complete
+        if deferred:
+            # one forward-kinematics launch and one metrics launch over every frame of the pass, in chunk order; shapes per
+            # frame (ground truth: the recording's; estimate: the recording's first chunk's, evaluate_real.py:63-68)
+            frames_of = lambda t: t.reshape(-1, t.shape[-1])
+            cat = lambda k: torch.cat([frames_of(d[k]) for d in deferred]).unsqueeze(0)
+            per_frame = lambda k, alt: torch.cat([(d[k] if d[k] is not None else d[alt]).reshape(1, -1)
+                                                  .expand(d[0].shape[1], -1) for d in deferred]).unsqueeze(0)
+            me_rows.compute(cat(0), per_frame(1, 1), cat(2), per_frame(3, 1), None, cat(4), cat(5),
+                            valid=torch.cat([d[6].reshape(-1) for d in deferred]).unsqueeze(0))
+            deferred = []
         st = me_rows.state()        # (reads the rows back: the device is in sync afterwards)
         _check_async(dev)
         lap('wait_for_device_and_rows')
