@@ -54,7 +54,7 @@ def launch_ranks(script, argv, n, poll_s=0.2):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, cores // n)))
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
-    rc = 0
+    rc, clean = 0, False
     try:
         live = list(procs)
         while live and rc == 0:
@@ -68,16 +68,16 @@ def launch_ranks(script, argv, n, poll_s=0.2):
                     break
             else:
                 time.sleep(poll_s)
+        clean = True
     finally:
+        # a rank failed, or this process is being interrupted (KeyboardInterrupt, SystemExit from a signal handler): the
+        # ranks still running are stopped -- by PID -- before the status (or the exception) goes up
         for p in procs:
-            if p.poll() is None:
-                if rc == 0:
-                    p.wait()
-                else:
-                    p.terminate()
+            if p.poll() is None and (rc != 0 or not clean):
+                p.terminate()
         for p in procs:
             try:
-                p.wait(timeout=20)
+                p.wait(timeout=20 if (rc != 0 or not clean) else None)
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
