@@ -334,9 +334,7 @@ def main():
         dist.barrier()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit('bench.py --gpus {} needs {} GPUs, found {}'.format(world, world, torch.cuda.device_count()))
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', D.local_device_index(local_rank, 'bench.py'))
     torch.cuda.set_device(dev)
     for kv in args.option:
         from em_pose_amd import _lib
@@ -368,12 +366,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = D.collective_device(dev)     # the GPU under RCCL (the host under the gloo self-test)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the only data-path-adjacent collective: gather per-rank result checksums over RCCL
         mine = torch.stack([out['pose'].double().sum(), out['joints'].double().sum(),
-                            torch.tensor(float(B * F), dtype=torch.float64, device=dev)])
+                            torch.tensor(float(B * F), dtype=torch.float64, device=dev)]).to(cdev)
         allm = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
         frames_total = int(sum(m[2].item() for m in allm))

@@ -95,12 +95,36 @@ def maybe_self_launch(script, n, force=False, what='this script'):
     import sys
     if launched_by_a_launcher() or (n <= 1 and not force):
         return
-    if os.environ.get(LAUNCH_BACKEND_ENV) != 'gloo':
+    if os.environ.get(LAUNCH_BACKEND_ENV) != 'gloo' and os.environ.get(SHARE_DEVICES_ENV) != '1':
         found = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if found < n:
             raise SystemExit('{} --gpus {} needs {} GPUs, found {}'.format(what, n, n, found))
     sys.stdout.flush()
     sys.exit(launch_ranks(script, sys.argv[1:], n))
+
+
+SHARE_DEVICES_ENV = 'EMPOSE_SHARE_DEVICES'   # '1': several ranks may sit on one GPU (single-GPU self-test of the N > 1 paths)
+
+
+def local_device_index(local_rank, what='this script'):
+    """The rank's GPU.  One rank per GPU; with fewer GPUs than ranks: exit "needs N GPUs, found M" -- unless
+    EMPOSE_SHARE_DEVICES=1 (together with EMPOSE_DIST_BACKEND=gloo: RCCL refuses two ranks on one device), which wraps
+    the ranks around the devices there are: the multi-rank logic (sharding, reductions, the result line) then runs on
+    real device code on a one-GPU box."""
+    import os
+    n = torch.cuda.device_count()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if os.environ.get(SHARE_DEVICES_ENV) == '1' and n > 0:
+        return local_rank % n
+    if n <= local_rank:
+        raise SystemExit('{} --gpus {} needs {} GPUs, found {}'.format(what, world, world, n))
+    return local_rank
+
+
+def collective_device(device):
+    """Where tensors must live for collectives of the active backend (gloo: the host)."""
+    import torch.distributed as dist
+    return device if (dist.is_initialized() and dist.get_backend() == 'nccl') else torch.device('cpu')
 
 
 def results_stream():

@@ -180,10 +180,7 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit('evaluate_real.py runs the HIP path and needs an MI355X; there is no CPU fallback '
                              '(the ResNet plumbing configuration: --synthetic --m_type resnet --device cpu).')
-        if torch.cuda.device_count() <= local_rank:
-            raise SystemExit('evaluate_real.py --gpus {} needs {} GPUs, found {}'.format(world, world,
-                                                                                         torch.cuda.device_count()))
-        device = torch.device('cuda', local_rank)
+        device = torch.device('cuda', D.local_device_index(local_rank, 'evaluate_real.py'))
         torch.cuda.set_device(device)
     sync = (lambda: None) if on_cpu else torch.cuda.synchronize
     if dist is None and launched and (world > 1 or args.force_dist) and not on_cpu:
@@ -226,7 +223,7 @@ def main():
     elapsed = float(np.median(passes[1:])) if len(passes) > 1 else passes[0]
     rows = [(i, sid, m) for i, (sid, m) in zip(mine, per_seq)]
     if dist is not None:
-        me_all.gather(device=device, force=args.force_dist)
+        me_all.gather(device=D.collective_device(device), force=args.force_dist)
         gathered = [None] * world
         dist.all_gather_object(gathered, (rows, frames, elapsed, passes))
         rows = sorted(r for g in gathered for r in g[0])

@@ -241,9 +241,7 @@ def main():
         joined = True
     if not torch.cuda.is_available():
         raise SystemExit('train.py runs the HIP path and needs an MI355X; there is no CPU fallback.')
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit('train.py --gpus {} needs {} GPUs, found {}'.format(world, world, torch.cuda.device_count()))
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cuda', D.local_device_index(local_rank, 'train.py'))
     torch.cuda.set_device(dev)
     if not joined and launched and (world > 1 or args.force_dist):
         _, rank, world = D.init_process_group(dev)

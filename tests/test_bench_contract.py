@@ -107,6 +107,38 @@ def test_eval_and_train_scripts_spawn_their_own_rank_with_rccl(script, extra, ke
 
 
 @pytest.mark.gpu
+def test_two_ranks_on_one_gpu_run_the_multi_rank_logic_on_device_results():
+    """No second GPU on this box: EMPOSE_SHARE_DEVICES=1 wraps the ranks around the devices there are and
+    EMPOSE_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device).  Everything else is the N > 1
+    path as the driver launches it: self-spawned ranks, window / sequence shards, MAX over ranks of the timed region, the
+    checksum gather, the metric gather, ONE result line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(EMPOSE_SHARE_DEVICES='1', EMPOSE_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '64', '--no_cpu_baseline', '--no_traffic', '--no_profile'], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['process_group'] == 'gloo' and d['scaling'] == 'weak'
+    assert d['value'] == pytest.approx(2 * 64 * 32 / (d['ms_per_step'] * 1e-3), rel=1e-6)   # whole-job frames / max-over-ranks time
+
+    common = [sys.executable, os.path.join(ROOT, 'scripts', 'evaluate_real.py'), '--synthetic', '--max_sequences', '5',
+              '--json']
+    one = subprocess.run(common, cwd=ROOT, env={k: v for k, v in env.items() if not k.startswith('EMPOSE_')},
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    two = subprocess.run(common + ['--gpus', '2'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=900)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr[-1500:], two.stderr[-1500:])
+    m1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith('{')][-1])
+    m2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith('{')][-1])
+    assert m2['n_gpus'] == 2 and m2['frames'] == m1['frames']
+    for k, v in m1['metrics'].items():      # recordings sharded over two ranks, rows gathered: the same table
+        assert m2['metrics'][k] == pytest.approx(v, rel=1e-5), k
+
+
+@pytest.mark.gpu
 def test_bench_with_more_gpus_than_the_box_has_exits_with_the_count():
     n = torch.cuda.device_count() + 1
     r = _run(['--gpus', str(n)])
