@@ -137,6 +137,15 @@ def test_two_ranks_on_one_gpu_run_the_multi_rank_logic_on_device_results():
     for k, v in m1['metrics'].items():      # recordings sharded over two ranks, rows gathered: the same table
         assert m2['metrics'][k] == pytest.approx(v, rel=1e-5), k
 
+    # data-parallel training: persistent gradient buckets all-reduced (device tensors through gloo here) every step
+    t = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train.py'), '--gpus', '2', '--steps', '3', '--warmup',
+                        '1', '--bs_train', '4', '--json'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+    assert t.returncode == 0, t.stderr[-3000:]
+    d = json.loads([ln for ln in t.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['process_group'] == 'gloo' and d['gradient_collectives_per_step'] >= 1
+    assert d['frames_per_sec'] > 0 and 'nan' not in t.stdout.lower()
+
 
 @pytest.mark.gpu
 def test_bench_with_more_gpus_than_the_box_has_exits_with_the_count():
