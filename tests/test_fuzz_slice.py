@@ -30,16 +30,16 @@ def _show(capsys, text):
 
 
 def test_lgd_forward_slice_all_kernel_variants_narrow_and_wide_nets(capsys):
-    """64 LGD / LGD-RNN forwards vs the oracle: golden nets + random-init nets with LSTMs of 8 / 16 / 64 units next to
+    """48 LGD / LGD-RNN forwards vs the oracle: golden nets + random-init nets with LSTMs of 8 / 16 / 64 units next to
     update nets of 16..128 units (hidden < input and LSTM < heads' staging tile included), B in {1..257}, ragged
     lengths, missing sensors (host- or device-side suppression), carried state, all 16 combinations of (frame-per-lane
     SMPL kernels, fused blend GEMMs, on-device suppression, two-part forward on two streams)."""
     from tests.fuzz import fuzz_lgd
-    r = fuzz_lgd.run(seed=4101, n_cases=64, extra_nets=True, batches=fuzz_lgd.BATCHES_SLICE, log=lambda m: _show(capsys, m))
+    r = fuzz_lgd.run(seed=4101, n_cases=48, extra_nets=True, batches=fuzz_lgd.BATCHES_SLICE, log=lambda m: _show(capsys, m))
     _show(capsys, 'lgd: %d cases, worst %.2e at %s; %d above 1e-5; variants %s'
           % (r['n'], r['worst'], r['worst_case'], len(r['above_1e5']), sorted(r['variants'].items())))
-    assert r['n'] == 64 and r['worst'] < 1e-4
-    assert len(r['variants']) >= 11     # the slice does visit the variant combinations
+    assert r['n'] == 48 and r['worst'] < 1e-4
+    assert len(r['variants']) >= 10     # the slice does visit the variant combinations
     # errors of a few 1e-5 are input conditioning when they occur (see the regression below)
     for case, err, desc, f64 in r['above_1e5']:
         assert _explained_by_conditioning(f64), (case, err, desc, f64)
@@ -61,12 +61,12 @@ def test_regression_short_masked_carried_windows_b257_f3(force, capsys):
 
 
 def test_lstm_slice(capsys):
-    """200 random LSTM stacks vs torch.nn.LSTM on packed sequences: 1-4 layers, uni / bidirectional, 4..64 units,
+    """150 random LSTM stacks vs torch.nn.LSTM on packed sequences: 1-4 layers, uni / bidirectional, 4..64 units,
     B in {1..700} (all batch regimes + the opt-in whole-sequence kernel), ragged lengths, given state."""
     from tests.fuzz import fuzz_lstm
-    r = fuzz_lstm.run(seed=4102, n_cases=200, log=lambda m: _show(capsys, m))
+    r = fuzz_lstm.run(seed=4102, n_cases=150, log=lambda m: _show(capsys, m))
     _show(capsys, 'lstm: %d cases, worst %.2e at %s' % (r['n'], r['worst'], r['worst_case']))
-    assert r['n'] == 200 and r['worst'] < 1e-4
+    assert r['n'] == 150 and r['worst'] < 1e-4
 
 
 def test_linear_and_mesh_slice(capsys):
