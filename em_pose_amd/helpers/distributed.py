@@ -236,6 +236,7 @@ class GradientBuckets(object):
         self.n_buckets = len(self.flat)
         self.side = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
         self._staged = [set() for _ in self.flat]
+        self._ready = [[] for _ in self.flat]   # per bucket: events recorded where its members' gradients became final
         self._launched = [False] * self.n_buckets
         self._pending = []
         self.hold = False   # True: stage() is a no-op (a step being captured into a HIP graph must not enqueue
@@ -255,10 +256,15 @@ class GradientBuckets(object):
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world)
             return
-        ready = torch.cuda.Event()
-        ready.record()                           # on the compute stream: the bucket's gradients are complete here
+        # The bucket's gradients are complete where each member was staged -- not necessarily on ONE stream: the training
+        # engine finishes the two update networks' weight gradients on two side streams, and a bucket boundary can fall
+        # inside either network.  The collective waits for every member's event (stage() records them).
+        ready = self._ready[b] + [torch.cuda.Event()]
+        ready[-1].record()
+        self._ready[b] = []
         with torch.cuda.stream(self.side):
-            self.side.wait_event(ready)
+            for ev in ready:
+                self.side.wait_event(ev)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
                 flat.div_(self.world)
@@ -278,6 +284,10 @@ class GradientBuckets(object):
             view.copy_(p.grad)
             p.grad = view
         self._staged[b].add(id(p))
+        if self.side is not None and self.active:
+            ev = torch.cuda.Event()
+            ev.record()                           # on the stream that produced (or just copied / zeroed) this gradient
+            self._ready[b].append(ev)
         if not self._launched[b] and len(self._staged[b]) == len(self._members[b]):
             self._launch(b)
 
@@ -292,6 +302,7 @@ class GradientBuckets(object):
             torch.cuda.current_stream().wait_event(done)
         self._pending = []
         self._staged = [set() for _ in self.flat]
+        self._ready = [[] for _ in self.flat]
         n, self._launched = sum(self._launched), [False] * self.n_buckets
         return n if self.active else 0
 

@@ -107,6 +107,22 @@ def test_eval_and_train_scripts_spawn_their_own_rank_with_rccl(script, extra, ke
 
 
 @pytest.mark.gpu
+def test_training_with_buckets_rccl_and_side_streams_equals_the_plain_step():
+    """64 windows = 2048 frames per step: the engine's side streams are on; with `--gpus 1 --force_dist` the gradients go
+    through the persistent buckets and RCCL (a bucket whose members become final on two different side streams waits for
+    both).  One rank: averaging changes nothing, so every loss value of every step equals the plain run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    outs = []
+    for extra in ([], ['--gpus', '1', '--force_dist']):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'train.py'), '--steps', '3', '--warmup', '1',
+                            '--bs_train', '64'] + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, universal_newlines=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append([ln.split(' elapsed')[0] for ln in r.stdout.splitlines() if ln.startswith('[TRAIN')])
+    assert len(outs[0]) == 4 and outs[0] == outs[1]
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_one_gpu_run_the_multi_rank_logic_on_device_results():
     """No second GPU on this box: EMPOSE_SHARE_DEVICES=1 wraps the ranks around the devices there are and
     EMPOSE_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device).  Everything else is the N > 1
