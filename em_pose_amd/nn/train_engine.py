@@ -507,13 +507,18 @@ class LgdTrainEngine(object):
                     self._mlp_bwd(views[1], X[i - 1].data_ptr(), d_x, dspad.data_ptr(), 12, ss, grads[1], acc, T)
             # Both networks' weight gradients on the side stream (after the pose network's backward, which ran on the main
             # stream), beside the initial estimate's backward below on the main stream.
-            three = 'bwd3' in self.side_parts and 'bwd' in self.side_parts and 'wgrad' in self.side_parts
-            if not three:
+            # (per-application gradients -- `deferred` off -- were formed on the main stream: nothing to move aside)
+            side_w = deferred and 'wgrad' in self.side_parts
+            three = side_w and 'bwd3' in self.side_parts and 'bwd' in self.side_parts
+            if deferred and not side_w:     # (A/B: backward on side streams but the products on the main one)
+                self._join(0)
+                self._join(1)
+            if side_w and not three:
                 self._fork(0)
             for k in (0, 1):
                 # (three streams: each network's products follow its own backward on its own stream, no fork needed)
                 where = (1 - k) if three else 0
-                with (self._on_side(where) if 'wgrad' in self.side_parts else _nothing()):
+                with (self._on_side(where) if side_w else _nothing()):
                     if pend[k]:
                         self._mlp_wgrad(views[k], [q[0] for q in pend[k]], d_x, [q[1] for q in pend[k]],
                                         [q[2] for q in pend[k]], grads[k], T)
