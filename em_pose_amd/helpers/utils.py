@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from em_pose_amd.eval.helpers import get_model_dir  # noqa: F401  (reference utils.py:36-39)
-from em_pose_amd.nn.models import mask_from_seq_lengths  # noqa: F401  (reference utils.py:105-123)
+from em_pose_amd.nn.loss import mask_from_seq_lengths  # noqa: F401  (reference utils.py:105-123)
 
 
 def create_model_dir(experiment_dir, experiment_id, model_summary, other_summary=None):

@@ -23,6 +23,7 @@ from em_pose_amd.bodymodels import tables as TB
 from em_pose_amd.helpers.configuration import CONSTANTS as CONST
 from em_pose_amd.nn import layers as _layers
 from em_pose_amd.nn.layers import MLP, FeedForwardResidualBlock, RNNLayer, fill_dense_desc, linear_hip, linear_train
+from em_pose_amd.nn.loss import mask_from_seq_lengths, normal_mse, padded_loss, reconstruction_loss  # noqa: F401
 
 
 def create_model(config, *args):
@@ -34,37 +35,6 @@ def create_model(config, *args):
     elif m_type == 'rnn':
         return SimpleRNN(config, *args)
     raise ValueError("Model type '{}' unknown.".format(m_type))
-
-
-def mask_from_seq_lengths(seq_lengths, max_seq_len=None):
-    """reference helpers/utils.py:105-123"""
-    max_seq_len = int(seq_lengths.max()) if max_seq_len is None else max_seq_len
-    t = torch.arange(max_seq_len, device=seq_lengths.device, dtype=seq_lengths.dtype)
-    return t[None, :] < seq_lengths[:, None]
-
-
-def reconstruction_loss(markers_gt, markers_hat, seq_lengths=None, marker_mask=None):
-    """reference nn/loss.py:23-41 (used for reporting loss values only; the in-loop residual lives in the kernels)."""
-    diff = markers_hat - markers_gt
-    per = torch.sqrt((diff * diff).sum(dim=-1)).sum(dim=-1)
-    if marker_mask is not None:
-        per = per * marker_mask.logical_not().any(dim=-1).logical_not()
-    if seq_lengths is not None:
-        mask = mask_from_seq_lengths(seq_lengths, per.shape[1]).to(per.dtype)
-        per = (per * mask).sum(-1) / seq_lengths.to(per.dtype)
-    return per.mean()
-
-
-def normal_mse(x_gt, x_hat, seq_lengths=None, marker_mask=None):
-    """reference nn/loss.py:44-62: squared error summed over joints, padded mean over frames, mean over the batch."""
-    diff = x_hat - x_gt
-    per = (diff * diff).sum(dim=-1).sum(dim=-1)
-    if marker_mask is not None:
-        per = per * marker_mask.logical_not().any(dim=-1).logical_not()
-    if seq_lengths is not None:
-        mask = mask_from_seq_lengths(seq_lengths, per.shape[1]).to(per.dtype)
-        per = (per * mask).sum(-1) / seq_lengths.to(per.dtype)
-    return per.mean()
 
 
 # Counts registrations of parameters / buffers / submodules anywhere in the process: what invalidates the per-network
@@ -85,13 +55,6 @@ for _register in ('register_module_parameter_registration_hook', 'register_modul
 def _cat_windows(parts):
     """Per-window results along the frame axis; a single window is returned as it is (a view, no device copy)."""
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
-
-
-def padded_loss(gt, hat, loss_fn, seq_lengths):
-    """reference nn/loss.py:13-20"""
-    unreduced = loss_fn(gt, hat).mean(-1)
-    mask = mask_from_seq_lengths(seq_lengths, unreduced.shape[1]).to(unreduced.dtype)
-    return ((unreduced * mask).sum(-1) / seq_lengths.to(unreduced.dtype)).mean()
 
 
 class _SmplSensorsFn(torch.autograd.Function):
