@@ -63,8 +63,10 @@ const char* empose_arch(void);
  * wavefront step, which measured faster), "bptt_wave" (training: reverse LSTM recurrences of two layers as a wavefront),
  * "train_fused" (train-mode MLP layer with BatchNorm / PReLU folded into the GEMMs: 0 never [default], 1 above 1024
  * rows, 2 always), "train_epi" (train-mode MLP layer with the BatchNorm statistics in the GEMM epilogues and ONE
- * combine-and-apply launch per layer and direction: 0 never, 1 above 1024 rows [default], 2 always), "spin_limit"
- * (see empose_async_status).
+ * combine-and-apply launch per layer and direction: 0 never, 1 above 1024 rows [default], 2 always), "atb_fast" (weight
+ * gradients: whole-tile / whole-chunk products on a branch-free interior kernel, bit-identical; 0 = the general kernel),
+ * "mesh_skin_mfma" (split-bf16 full-mesh variant only: the bone blend as a second matrix-core contraction; 0 [default,
+ * measured faster] = vector skinning), "spin_limit" (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
 int empose_set_option(const char* name, int value);
 int empose_get_option(const char* name);
