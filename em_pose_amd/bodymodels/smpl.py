@@ -40,12 +40,12 @@ class _BodyModelBuffers(nn.Module):
 
     def __init__(self, model, num_betas):
         super(_BodyModelBuffers, self).__init__()
-        t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))
-        self.register_buffer('f', torch.from_numpy(np.asarray(model['f']).astype(np.int64)))
+        t = lambda a: torch.from_numpy(np.array(a, dtype=np.float32))     # own memory: `model` must not alias buffers
+        self.register_buffer('f', torch.from_numpy(np.array(model['f'], dtype=np.int64)))
         self.register_buffer('v_template', t(model['v_template'])[None])
         self.register_buffer('shapedirs', t(model['shapedirs'][:, :, :num_betas]))
         pd = np.asarray(model['posedirs'], dtype=np.float32)
-        self.register_buffer('posedirs', t(pd.reshape(pd.shape[0] * 3, -1).T))
+        self.register_buffer('posedirs', t(pd.reshape(pd.shape[0] * 3, -1).T).contiguous())
         self.register_buffer('J_regressor', t(model['J_regressor']))
         self.register_buffer('weights', t(model['weights']))
         # The fork registers its default pose/shape as nn.Parameters (169 values, reference README.md:228).
@@ -73,6 +73,27 @@ class SMPLLayer(nn.Module):
         self._faces = None
         self._vertex_faces = None
         self._mesh = None  # (handle, device index)
+        self.tables_version = 0   # bumped when the arrays change: holders of tables derived from `self.model` rebuild
+        # A released `model.pth` carries the body model as `smpl.bm.*` buffers and the reference's network computes with
+        # THOSE after `load_state_dict` (reference eval/helpers.py:131-137), whatever `model.npz` was read at construction.
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._adopt_buffers())
+
+    def _adopt_buffers(self):
+        """Make the kernel tables follow the `bm` buffers (after load_state_dict).  No-op when they already agree."""
+        bm, m, nb = self.bm, self.model, self.num_betas
+        V = bm.v_template.shape[1]
+        new = {'v_template': bm.v_template[0], 'shapedirs': bm.shapedirs, 'J_regressor': bm.J_regressor,
+               'weights': bm.weights, 'posedirs': bm.posedirs.t().reshape(V, 3, -1), 'f': bm.f}
+        new = {k: v.detach().cpu().numpy() for k, v in new.items()}
+        old = {k: (np.asarray(m[k])[:, :, :nb] if k == 'shapedirs' else np.asarray(m[k])) for k in new}
+        if all(old[k].shape == new[k].shape and np.array_equal(old[k].astype(new[k].dtype), new[k]) for k in new):
+            return
+        model = dict(m)
+        model.update(new)
+        self.model = model
+        self._faces = self._vertex_faces = None
+        self._release()
+        self.tables_version += 1
 
     # -- topology ----------------------------------------------------------------------------------------------
     @property

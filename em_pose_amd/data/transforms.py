@@ -43,9 +43,9 @@ class NormalizeRealMarkers(object):
     def __call__(self, sample):
         n_markers = sample.marker_pos_real.shape[-1] // 3
         R0 = rotvec_to_matrix(np.asarray(sample.smpl_poses[0, :3], dtype=np.float64))  # (3,3)
-        trans = np.asarray(sample.smpl_trans, dtype=np.float64)[:, None, :]
-        pos = np.asarray(sample.marker_pos_real, dtype=np.float64).reshape(-1, n_markers, 3) - trans
-        pos = pos @ R0  # R0^T p for row vectors
+        # the translation is removed in the dtype of the recording (reference transforms.py:109), the rotation in float64
+        pos = np.asarray(sample.marker_pos_real).reshape(-1, n_markers, 3) - np.asarray(sample.smpl_trans)[:, None, :]
+        pos = pos.astype(np.float64) @ R0  # R0^T p for row vectors
         ori = R0.T @ np.asarray(sample.marker_ori_real, dtype=np.float64).reshape(-1, n_markers, 3, 3)
         sample.marker_pos_real = pos.reshape(-1, n_markers * 3).astype(np.float32)
         sample.marker_ori_real = ori.reshape(-1, n_markers * 9).astype(np.float32)

@@ -462,7 +462,7 @@ class IterativeErrorFeedback(BaseModel):
     def _state_key(self, device):
         ps = self._own_parameters()
         return (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self.N, self.shape_avg_valid_only,
-                self._rodrigues(), _layers.BN_STATS_GENERATION[0],
+                (self._rodrigues(), getattr(self.smpl, 'tables_version', 0)), _layers.BN_STATS_GENERATION[0],
                 tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def release(self):
@@ -516,7 +516,8 @@ class IterativeErrorFeedback(BaseModel):
     def _ensure_smpl_handle(self, device):
         """Body-model-only handle for the training path: its key ignores the network parameters, which change with
         every optimiser step."""
-        key = (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self._rodrigues())
+        key = (device.index, tuple(self.vertex_ids), tuple(self.helper_ids or ()), self._rodrigues(),
+               getattr(self.smpl, 'tables_version', 0))
         if self._smpl_handle is not None and key == self._smpl_handle_key:
             return self._smpl_handle
         if self._smpl_handle is not None:

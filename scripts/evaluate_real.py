@@ -240,7 +240,8 @@ def main():
         if args.json:
             print(json.dumps({'frames': frames, 'seconds': elapsed, 'n_gpus': world, 'frames_per_sec': frames / elapsed,
                               'seconds_per_pass': passes, 'host_seconds_per_section_per_pass': host_times,
-                              'metrics': metrics}))
+                              'metrics': metrics, 'headers': list(metrics.keys()),
+                              'rows': [[r[0], str(r[1])] + [float(v) for v in r[2:]] for r in table]}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,6 +25,12 @@ REF = '/root/reference'
 _tmp = tempfile.mkdtemp(prefix='empose_golden_')
 for k in ('EM_DATA_SYNTH', 'EM_EXPERIMENTS', 'SMPL_MODELS', 'EM_DATA_REAL'):
     os.environ[k] = _tmp
+EVAL_ASSETS = os.path.join(HERE, 'eval_assets')
+if '--only-eval-assets' in sys.argv:
+    # the reference reads its four directories from the environment when `empose.helpers.configuration` is imported
+    # (configuration.py:25-28): the asset tree under tests/golden/eval_assets/ IS those directories
+    os.environ['EM_EXPERIMENTS'] = os.path.join(EVAL_ASSETS, 'experiments')
+    os.environ['EM_DATA_REAL'] = os.path.join(EVAL_ASSETS, 'data_real')
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle', 'refstubs'))
 sys.path.insert(0, REF)
@@ -360,11 +366,171 @@ def make_lmdb_schema():
     print('wrote lmdb_schema.npz')
 
 
+def _write_recording(path, seq_id, n_frames, seed, sensors_fn, missing_rate, forced_missing=()):
+    """One `*_clean.npz` recording in the key layout the reference reads (data.py:162-171): a synthetic recording with
+    a non-trivial global root orientation and a drifting root translation, so that the reference's NormalizeRealMarkers
+    (transforms.py:99-129) and NormalizeRoot (:229-256) have something to undo."""
+    from scipy.spatial.transform import Rotation as Rot
+    d = synthetic.make_sequence(n_frames, seed, sensors_fn, missing_rate=missing_rate)
+    rng = np.random.default_rng(seed + 99)
+    Rg = Rot.from_rotvec(rng.normal(0, 0.8, 3)).as_matrix()
+    trans = np.cumsum(rng.normal(0, 0.01, size=(n_frames, 3)), axis=0) + rng.normal(0, 1.0, 3)
+    poses = d['smpl_poses'].astype(np.float64).copy()
+    poses[:, :3] = Rot.from_matrix(Rg @ Rot.from_rotvec(poses[:, :3]).as_matrix()).as_rotvec()
+    pos = d['sensor_pos'].astype(np.float64) @ Rg.T + trans[:, None]
+    ori = Rg @ d['sensor_oris'].astype(np.float64)
+    masks = d['sensor_masks'].copy()
+    for f0, f1, m in forced_missing:
+        masks[f0:f1, m] = False
+    np.savez_compressed(path, id=np.asarray(seq_id), sensor_pos=pos.astype(np.float32), sensor_oris=ori.astype(np.float32),
+                        sensor_masks=masks, smpl_poses=poses.astype(np.float32), smpl_shape=d['smpl_shape'],
+                        smpl_trans=trans.astype(np.float32), offset_means=d['offset_means'],
+                        offset_covs=d['offset_covs'], offset_r=d['offset_r'])
+
+
+def make_eval_assets(vids):
+    """
+    Case H: the reference's own evaluation ENTRY POINT, end to end.
+
+    A small asset tree is written with the reference's writers where it has them -- `create_model_dir`
+    (helpers/utils.py:42), `Configuration.to_json` (configuration.py:221), the checkpoint dict of scripts/train.py:195-205
+    (so the `smpl.bm.*` buffers are inside `model.pth`) -- and in the key layouts its readers expect where it has none
+    (`*_clean.npz` data.py:162-171, `*_offsets.npz` transforms.py:145-159).  Then the UNMODIFIED
+    /root/reference/scripts/evaluate_real.py::main and empose/eval/helpers.py::evaluate run on it (under oracle/refstubs),
+    and what they print / return is recorded in eval_assets/expected.npz + expected.json.
+
+    Two deviations from a licensed tree, both DATA: the body model is the 160-vertex stand-in (the test copies
+    tests/golden/smpl_small.npz to <SMPL_MODELS>/smplh_amass/neutral/model.npz), so the reference's constant
+    `C.VERTEX_IDS` (sites up to vertex 5430) is set to the small mesh's sensor sites before the model is built -- the
+    same ids the tree's `*_offsets.npz` carry in `vertex_ids` (in a real tree the two agree, transforms.py:159).
+    """
+    import importlib.util
+    import shutil
+    from empose.bodymodels.smpl import create_default_smpl_model
+    from empose.helpers import utils as U
+    from empose.helpers.configuration import CONSTANTS as C
+    from empose.nn.models import create_model
+    import empose.eval.helpers as H
+    from empose.eval.metrics import MetricsEngine
+    C.VERTEX_IDS = list(vids)
+    exp_dir, real_dir = os.environ['EM_EXPERIMENTS'], os.environ['EM_DATA_REAL']
+    for d in (exp_dir, real_dir):
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+    os.makedirs(os.path.join(real_dir, 'hold_out'))
+    smpl = create_default_smpl_model(torch.device('cpu'))
+
+    # ---- the models: the two released LGD-RNN configurations at hidden width 32
+    models = {1615631737: lgd_flags(6, True, 2, 32, 32), 1615200973: dict(lgd_flags(12, True, 4, 32, 32), lr=0.001)}
+    nets = {}
+    for model_id, fl in models.items():
+        torch.manual_seed(model_id)
+        cfg = ref_config(experiment_id=model_id, **fl)
+        net = create_model(cfg, smpl)
+        with torch.no_grad():
+            randomize_bn(net, model_id + 1)
+            for name, p in net.named_parameters():
+                if 'hidden_to_output' in name or name.startswith(('pose_net_init', 'shape_net_init')):
+                    p.mul_(3.0)
+        name = net.model_name() + '-pos-ori'                       # scripts/train.py:84-87
+        model_dir = U.create_model_dir(C.EXPERIMENT_DIR, model_id, name)
+        cfg.to_json(os.path.join(model_dir, 'config.json'))        # scripts/train.py:112
+        optimizer = torch.optim.Adam(net.parameters(), lr=cfg.lr)
+        torch.save({'iteration': 0, 'epoch': 0, 'global_step': 0, 'model_state_dict': net.state_dict(),
+                    'optimizer_state_dict': optimizer.state_dict(), 'train_loss': 0.0, 'valid_loss': 0.0,
+                    'test_eucl_mean': 0.0, 'test_angle_mean': 0.0}, os.path.join(model_dir, 'model.pth'))
+        nets[model_id] = net.eval()
+
+    # ---- offsets files (only their `vertex_ids` and shapes matter on this path: real batches feed the real readings)
+    rng = np.random.RandomState(71)
+    for subject in ('0714', '0715'):
+        A = rng.normal(0, 0.01, size=(12, 3, 3))
+        np.savez(os.path.join(real_dir, subject + '_offsets.npz'), means=rng.normal(0, 0.02, size=(12, 3)),
+                 covs=A @ np.swapaxes(A, -1, -2) + 1e-5 * np.eye(3),
+                 r=synthetic._exp_so3(rng.normal(0, 0.2, size=(12, 3))), vertex_ids=np.asarray(vids))
+
+    # ---- recordings; lengths straddle the 256-frame chunking of evaluate_real.py:39
+    sensors = sensors_from_reference(nets[1615200973], smpl)
+    recs = [('0714_arms_clean.npz', '0714_arms', 70, 501, 0.01, ((10, 14, 3),)),
+            ('0714_jump_clean.npz', '0714_jump', 256, 502, 0.004, ()),
+            ('0714_lunges_clean.npz', '0714_lunges', 300, 503, 0.004, ((250, 262, 7), (0, 1, 0))),
+            ('0714_walk_clean.npz', '0714_walk', 520, 504, 0.002, ((511, 520, 11),)),
+            ('hold_out/0715_arms_clean.npz', '0715_arms', 40, 505, 0.02, ()),
+            ('hold_out/0715_walk_clean.npz', '0715_walk', 270, 506, 0.004, ((255, 258, 5),))]
+    for fname, sid, n, seed, miss, forced in recs:
+        _write_recording(os.path.join(real_dir, fname), sid, n, seed, sensors, miss, forced)
+
+    # ---- run the reference's entry point
+    spec = importlib.util.spec_from_file_location('ref_evaluate_real', os.path.join(REF, 'scripts', 'evaluate_real.py'))
+    ref_main = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_main)
+    expected, arrays = {}, {}
+    captured = {}
+    orig_loader, orig_tab = ref_main.load_model_and_eval_data, ref_main.tabulate
+
+    def loader_spy(config, **kw):
+        net, loader, pre, mc = orig_loader(config, **kw)
+        captured['outs'] = []
+        net.register_forward_hook(lambda m, i, o: captured['outs'].append({k: v.detach().clone().numpy()
+                                                                           for k, v in o.items()}))
+        return net, loader, pre, mc
+
+    def tab_spy(rows, headers=()):
+        captured['rows'], captured['headers'] = [list(r) for r in rows], list(headers)
+        return orig_tab(rows, headers=headers)
+    ref_main.load_model_and_eval_data, ref_main.tabulate = loader_spy, tab_spy
+
+    class _Args(object):
+        pass
+    for tag, model_id, cross in (('lgdrnn6_test_real', 1615631737, False), ('lgdrnn6_hold_out', 1615631737, True),
+                                 ('lgdrnn12_hold_out', 1615200973, True)):
+        args = _Args()
+        args.model_id, args.visualize, args.cross_subject = model_id, -1, cross
+        ref_main.main(args)
+        rows = captured['rows']
+        expected[tag] = {'model_id': model_id, 'cross_subject': cross, 'headers': captured['headers'],
+                         'rows': [[r[0], str(r[1])] + [float(x) for x in r[2:]] for r in rows]}
+        lens = [r[2] for r in recs if r[0].startswith('hold_out/') == cross]
+        n_chunks = [n // 256 + int(n % 256 > 0) for n in lens]
+        assert sum(n_chunks) == len(captured['outs']), (n_chunks, len(captured['outs']))
+        it = iter(captured['outs'])
+        for s, nc in enumerate(n_chunks):
+            for c in range(nc):
+                o = next(it)
+                for k in ('pose_hat', 'root_ori_hat', 'shape_hat'):
+                    arrays['{}/seq{}/chunk{}/{}'.format(tag, s, c, k)] = o[k]
+    ref_main.load_model_and_eval_data, ref_main.tabulate = orig_loader, orig_tab
+
+    # ---- and its library-level evaluation loop (eval/helpers.py:51-111): losses + metrics, chunked at 256
+    class _Cfg(object):
+        model_id, n_samples = 1615631737, 1
+    net, loader, pre, _ = H.load_model_and_eval_data(_Cfg(), partition='test_real')
+    me = MetricsEngine(create_default_smpl_model(torch.device('cpu')))
+    losses = H.evaluate(loader, net, pre, me, window_size=256)
+    expected['evaluate_lgdrnn6_test_real'] = {'losses': {k: float(v) for k, v in losses.items()},
+                                              'metrics': {k: float(v) for k, v in me.get_metrics().items()}}
+    expected['vertex_ids'] = [int(v) for v in vids]
+    with open(os.path.join(EVAL_ASSETS, 'expected.json'), 'w') as f:
+        json.dump(expected, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(EVAL_ASSETS, 'expected.npz'), **arrays)
+    total = sum(os.path.getsize(os.path.join(r, fn)) for r, _, fs in os.walk(EVAL_ASSETS) for fn in fs)
+    print('wrote', EVAL_ASSETS, '%.0f KB' % (total / 1024))
+    for tag in expected:
+        if tag.startswith('lgdrnn'):
+            print(tag)
+            for r in expected[tag]['rows']:
+                print('  ', r)
+    print(expected['evaluate_lgdrnn6_test_real'])
+
+
 def main():
     if '--only-lmdb' in sys.argv:
         return make_lmdb_schema()
     model = build_small_model()
     vids = synthetic.small_vertex_ids(160)
+    if '--only-eval-assets' in sys.argv:
+        sys.argv.remove('--only-eval-assets')
+        return make_eval_assets(vids)
     if '--only-train-sensitivity' in sys.argv:
         sys.argv.remove('--only-train-sensitivity')
         return train_sensitivity(vids)
@@ -536,6 +702,9 @@ def main():
     make_baselines(vids)
     train_sensitivity(vids)
     make_lmdb_schema()
+    # the entry-point fixture needs its own environment (the asset tree's directories), hence its own process
+    import subprocess
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), '--only-eval-assets'])
 
 
 if __name__ == '__main__':

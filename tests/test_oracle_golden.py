@@ -122,3 +122,33 @@ def test_baselines_carry():
         _check_baseline(case['chunk0'], out0, st)
         out1, st1 = H.run_oracle_baseline(case, H.oracle_inputs(case['in'], sf=24, ef=48), state=st)
         _check_baseline(case['chunk1'], out1, st1)
+
+
+EVAL_ASSETS = os.path.join(H.GOLDEN, 'eval_assets')
+
+
+@pytest.mark.parametrize('tag', ['lgdrnn6_test_real', 'lgdrnn6_hold_out', 'lgdrnn12_hold_out'])
+def test_evaluate_real_entry_point(tag):
+    """The reference's scripts/evaluate_real.py::main ran on tests/golden/eval_assets/ (config.json + model.pth written
+    by its own writers, `*_clean.npz` recordings of 70 / 256 / 300 / 520 and 40 / 270 frames with missing sensors);
+    what it printed and its model returned per 256-frame chunk is the fixture.  The oracle's restatement of that entry
+    point (oracle/eval_ref.py) reproduces every row of the table and every chunk's outputs."""
+    from oracle import eval_ref as E
+    with open(os.path.join(EVAL_ASSETS, 'expected.json')) as f:
+        exp = json.load(f)
+    z = np.load(os.path.join(EVAL_ASSETS, 'expected.npz'))
+    e = exp[tag]
+    assert e['headers'][2:] == E.HEADERS
+    rows, outs = E.evaluate_real(os.path.join(EVAL_ASSETS, 'experiments'), os.path.join(EVAL_ASSETS, 'data_real'),
+                                 os.path.join(H.GOLDEN, 'smpl_small.npz'), exp['vertex_ids'], e['model_id'],
+                                 e['cross_subject'])
+    assert [r[0] for r in rows] == [r[1] for r in e['rows']]
+    for r, w in zip(rows, e['rows']):
+        np.testing.assert_allclose(r[1:], w[2:], atol=1e-3, rtol=0, err_msg=r[0])    # mm / degrees
+    n_chunks = 0
+    for s, seq in enumerate(outs):
+        for c, o in enumerate(seq):
+            for k, v in o.items():
+                np.testing.assert_allclose(v, z['{}/seq{}/chunk{}/{}'.format(tag, s, c, k)], atol=TOL, rtol=0)
+            n_chunks += 1
+    assert n_chunks == len([k for k in z.files if k.startswith(tag + '/') and k.endswith('/pose_hat')])
