@@ -366,6 +366,75 @@ def make_lmdb_schema():
     print('wrote lmdb_schema.npz')
 
 
+def make_train_fingerprints(vids):
+    """
+    Case I: the reference's TRAINING step (models.py:485-688 in train mode, incl. the in-forward
+    deposits of :576) at the RELEASED width -- 2x512 update networks, 2x512 LSTM -- on the per-GPU batch of BASELINE
+    configs[4] (12 windows x 32 frames), for LGD-RNN-12 N=4 and LGD-RNN-6 N=2.  5.9 M parameters and their gradients are
+    not storable, so the weights are `tests.helpers.seeded_state_dict` (a pure function of name / shape / seed on torch's
+    CPU generator, re-made by the GPU test) and every parameter gradient is stored as a FINGERPRINT
+    (`tests.helpers.tensor_fingerprint`: max-abs, L2 norm, 8 seeded Gaussian projections, 256 seeded entries), together
+    with the same fingerprints' sensitivity to a one-ulp change of the inputs (the conditioning of the reference's own
+    step, as in train_sensitivity.json), the losses, the outputs and the BatchNorm running statistics after the step.
+    """
+    from tests import helpers as TH
+    for tag, nm, N, seed in (('train_fp_lgdrnn12_n4_h512', 12, 4, 51), ('train_fp_lgdrnn6_n2_h512', 6, 2, 52)):
+        B, F = 12, 32
+        runs = []
+        w0 = None
+        for eps in (0.0, 1e-7, -1e-7):
+            net, smpl = make_net(lgd_flags(nm, True, N, 512, 512), seed, vids)
+            sd = TH.seeded_state_dict(net.state_dict(), seed)
+            missing, unexpected = net.load_state_dict(sd, strict=False)
+            assert not unexpected and all(k.startswith('smpl.') or k.endswith('num_batches_tracked') for k in missing)
+            if w0 is None:
+                w0 = synthetic.make_windows(B, F, seed, sensors_from_reference(net, smpl))
+                with torch.no_grad():
+                    _, jgt = smpl(poses_body=torch.from_numpy(w0['poses'].reshape(B * F, 66)[:, 3:]),
+                                  betas=torch.from_numpy(np.repeat(w0['shapes'], F, axis=0)),
+                                  poses_root=torch.from_numpy(w0['poses'].reshape(B * F, 66)[:, :3]))
+                w0['joints_gt'] = jgt[:, :22].reshape(B, F, 66).numpy()
+            w = {k: v.copy() for k, v in w0.items()}
+            rng = np.random.RandomState(0)
+            for k in ('marker_pos', 'marker_oris'):
+                w[k] = (w[k] * (1.0 + eps * rng.choice([-1.0, 1.0], size=w[k].shape))).astype(np.float32)
+            lengths = torch.tensor([32] * 9 + [27, 32, 13])
+            batch = _SynthBatch(w, lengths)
+            batch.joints_gt = torch.from_numpy(w['joints_gt'])
+            net.train()
+            net.zero_grad()
+            out = net(batch)
+            total, loss_vals = net.backward(batch, out)
+            rec = {'out': {k: v.detach().numpy().copy() for k, v in out.items()},
+                   'loss': dict(loss_vals, total=float(total.detach())),
+                   'grad': {k: TH.tensor_fingerprint(k, p_.grad) for k, p_ in net.named_parameters()
+                            if not k.startswith('smpl.') and p_.grad is not None},
+                   'after': {k: v.numpy().copy() for k, v in net.state_dict().items() if 'running_' in k}}
+            runs.append(rec)
+            print(tag, 'eps', eps, {k: round(v, 6) for k, v in rec['loss'].items()})
+        base = runs[0]
+        data = {'in/' + k: v for k, v in w0.items()}
+        data['in/seq_lengths'] = lengths.numpy()
+        for k, v in base['out'].items():
+            data['out/' + k] = v
+            data['sens_out/' + k] = np.asarray(max(np.abs(r['out'][k].astype(np.float64) - v).max() for r in runs[1:]))
+        for k, v in base['loss'].items():
+            data['loss/' + k] = np.asarray(v)
+        for k, v in base['after'].items():
+            data['after/' + k] = v
+        for k, fp in base['grad'].items():
+            for f in ('max', 'l2', 'n', 'proj', 'sample'):
+                data['grad/{}/{}'.format(k, f)] = np.asarray(fp[f])
+            for f in ('l2', 'proj', 'sample'):
+                data['sens/{}/{}'.format(k, f)] = np.asarray(max(np.abs(np.asarray(r['grad'][k][f]) - np.asarray(fp[f])).max()
+                                                                for r in runs[1:]))
+        data['meta/n_markers'], data['meta/N'], data['meta/rnn'] = np.asarray(nm), np.asarray(N), np.asarray(1)
+        data['meta/seed'], data['meta/vertex_ids'], data['meta/hidden'] = np.asarray(seed), np.asarray(vids), np.asarray(512)
+        path = os.path.join(HERE, tag + '.npz')
+        np.savez_compressed(path, **data)
+        print('wrote', path, '%.0f KB' % (os.path.getsize(path) / 1024))
+
+
 def _write_recording(path, seq_id, n_frames, seed, sensors_fn, missing_rate, forced_missing=()):
     """One `*_clean.npz` recording in the key layout the reference reads (data.py:162-171): a synthetic recording with
     a non-trivial global root orientation and a drifting root translation, so that the reference's NormalizeRealMarkers
@@ -531,6 +600,9 @@ def main():
     if '--only-eval-assets' in sys.argv:
         sys.argv.remove('--only-eval-assets')
         return make_eval_assets(vids)
+    if '--only-train-fingerprints' in sys.argv:
+        sys.argv.remove('--only-train-fingerprints')
+        return make_train_fingerprints(vids)
     if '--only-train-sensitivity' in sys.argv:
         sys.argv.remove('--only-train-sensitivity')
         return train_sensitivity(vids)
@@ -702,6 +774,7 @@ def main():
     make_baselines(vids)
     train_sensitivity(vids)
     make_lmdb_schema()
+    make_train_fingerprints(vids)
     # the entry-point fixture needs its own environment (the asset tree's directories), hence its own process
     import subprocess
     subprocess.check_call([sys.executable, os.path.abspath(__file__), '--only-eval-assets'])

@@ -74,3 +74,50 @@ def run_oracle_baseline(case, inp, state=None, dtype=torch.float32):
         return R.resnet_forward(sd, bm, inp, **common), None
     return R.simple_rnn_forward(sd, bm, inp, bidirectional=fl.get('m_bidirectional', False),
                                 learn_init_state=fl.get('m_learn_init_state', False), state=state, **common)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Full-width training fixtures (tests/golden/train_fp_*.npz): 6 M parameters cannot be stored, so the weights are a
+# deterministic function of (name, shape, seed) on torch's CPU generator -- the generating script (reference network) and
+# the GPU test (this repository's network) both call `seeded_state_dict` -- and the fixture holds FINGERPRINTS of every
+# parameter gradient instead of the gradients.
+# ----------------------------------------------------------------------------------------------------------------------
+def seeded_state_dict(template, seed):
+    """:param template: a state_dict (names + shapes; values ignored).  Body-model entries are skipped."""
+    out = {}
+    for i, (k, v) in enumerate(template.items()):
+        if k.startswith('smpl.') or k.endswith('num_batches_tracked'):
+            continue
+        g = torch.Generator().manual_seed(int(seed) * 1000 + i)
+        shape = tuple(v.shape)
+        if 'running_var' in k:
+            t = torch.rand(shape, generator=g) + 0.5
+        elif 'running_mean' in k:
+            t = torch.randn(shape, generator=g) * 0.1
+        elif 'batch_norm' in k or (k.split('.')[-2].isdigit() and len(shape) == 1 and '.layers.' in k
+                                   and int(k.split('.')[-2]) in (1, 5)):
+            t = (torch.rand(shape, generator=g) + 0.5) if k.endswith('weight') else torch.randn(shape, generator=g) * 0.1
+        elif shape == (1,):                       # PReLU slope
+            t = torch.full(shape, 0.25) + 0.1 * torch.rand(shape, generator=g)
+        else:
+            fan_in = shape[-1] if len(shape) > 1 else 512
+            t = (torch.rand(shape, generator=g) * 2.0 - 1.0) / float(np.sqrt(fan_in))
+            if 'hidden_to_output' in k or k.startswith(('pose_net_init', 'shape_net_init')):
+                t = t * 3.0
+        out[k] = t.to(torch.float32)
+    return out
+
+
+N_PROJ, N_SAMPLE = 8, 256
+
+
+def tensor_fingerprint(name, t):
+    """max-abs, L2 norm, N_PROJ seeded Gaussian projections and N_SAMPLE seeded entries of a tensor (float64); the seed is
+    a function of the tensor's NAME (the same in the reference's module and in this repository's)."""
+    import zlib
+    x = torch.as_tensor(t).detach().to('cpu', torch.float64).reshape(-1)
+    g = torch.Generator().manual_seed(770000 + zlib.crc32(name.encode()) % 100000)
+    z = torch.randn(N_PROJ, x.numel(), generator=g, dtype=torch.float64)
+    idx = torch.randperm(x.numel(), generator=g)[:N_SAMPLE]
+    return {'max': float(x.abs().max()), 'l2': float(x.norm()), 'n': int(x.numel()), 'proj': (z @ x).numpy(),
+            'sample': x[idx].numpy()}

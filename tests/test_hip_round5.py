@@ -1,0 +1,160 @@
+"""
+Round 5 GPU tests (run with `-m gpu` on an MI355X).
+
+  * the training step at the RELEASED width against fingerprints of the reference's own step
+  * sampled-window parity at BASELINE configs[1]'s exact launch shape and across the T >= 16384 kernel switch (item 6)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from em_pose_amd import _lib, synthetic
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.helpers.configuration import lgd_config
+from em_pose_amd.nn.models import create_model
+from oracle import torch_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ATOL = 1e-4
+
+
+def _load_fp(tag):
+    z = np.load(os.path.join(H.GOLDEN, tag + '.npz'))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize('variant', ['default', 'epilogue_stats_side_streams', 'bn_kernels_one_stream'])
+@pytest.mark.parametrize('tag', ['train_fp_lgdrnn12_n4_h512', 'train_fp_lgdrnn6_n2_h512'])
+def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
+    """LGD-RNN-12 N=4 / LGD-RNN-6 N=2 with 2x512 update networks and a 2x512 LSTM, 12 windows x 32 frames (BASELINE
+    configs[4]'s per-GPU batch), ragged lengths: the REFERENCE's train-mode forward + backward (models.py:485-688, with
+    the in-forward deposits of :576) was run on these inputs and these weights (`tests.helpers.seeded_state_dict`, re-made
+    here) and left, per parameter tensor, the max-abs, L2 norm, 8 seeded Gaussian projections and 256 seeded entries of
+    its gradient, plus losses, outputs, BatchNorm running statistics -- and how far each of those moves when the
+    reference's inputs change by one unit in the last place.  Tolerance rule of test_hip_parity.py:814:
+    max(1e-4 of the tensor's scale, 4 x that sensitivity)."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from em_pose_amd.nn.train_engine import LgdTrainEngine
+    fp = _load_fp(tag)
+    nm, N, seed = int(fp['meta/n_markers']), int(fp['meta/N']), int(fp['meta/seed'])
+    lib = _lib.lib()
+    saved = (LgdTrainEngine.two_streams_min_frames,)
+    if variant == 'epilogue_stats_side_streams':      # what a 256-window step uses, forced onto these 384 frames
+        _lib.check(lib.empose_set_option(b'train_epi', 2))
+        LgdTrainEngine.two_streams_min_frames = 0
+    elif variant == 'bn_kernels_one_stream':
+        _lib.check(lib.empose_set_option(b'train_epi', 0))
+        _lib.check(lib.empose_set_option(b'train_fused', 0))
+    try:
+        net = create_model(lgd_config(nm, True, N), SMPLLayer(H.small_model()))
+        net.vertex_ids = [int(v) for v in fp['meta/vertex_ids']]
+        missing, unexpected = net.load_state_dict(H.seeded_state_dict(net.state_dict(), seed), strict=False)
+        assert not unexpected and all(k.startswith('smpl.') or k.endswith('num_batches_tracked') for k in missing)
+        net = net.to(DEV).train()
+        w = {k[3:]: v for k, v in fp.items() if k.startswith('in/')}
+        batch = SyntheticBatch(w, torch.from_numpy(w['seq_lengths']).to(DEV), device=DEV)
+        batch.joints_gt = torch.from_numpy(w['joints_gt']).to(DEV)
+        net.zero_grad()
+        out = net(batch)
+        assert net._engine is not None
+        if variant == 'epilogue_stats_side_streams':
+            assert net._engine._use_side
+        total, loss_vals = net.backward(batch, out)
+        torch.cuda.synchronize()
+    finally:
+        LgdTrainEngine.two_streams_min_frames = saved[0]
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), fp['out/' + k],
+                                   atol=max(ATOL, 4.0 * float(fp['sens_out/' + k])), rtol=0, err_msg=k)
+    for k in ('pose', 'shape', 'reconstruction', 'fk', 'total_loss'):
+        assert loss_vals[k] == pytest.approx(float(fp['loss/' + k]), rel=2e-4, abs=1e-6), k
+    names = sorted({k.split('/')[1] for k in fp if k.startswith('grad/')})
+    gmax = max(float(fp['grad/{}/max'.format(k)]) for k in names)
+    params = dict(net.named_parameters())
+    checked, worst = 0, 0.0
+    for k in names:
+        g = params[k].grad
+        assert g is not None, k
+        mine = H.tensor_fingerprint(k, g)
+        want = {f: fp['grad/{}/{}'.format(k, f)] for f in ('max', 'l2', 'n', 'proj', 'sample')}
+        sens = {f: float(fp['sens/{}/{}'.format(k, f)]) for f in ('l2', 'proj', 'sample')}
+        assert mine['n'] == int(want['n']), k
+        scale = max(float(want['max']), 1e-4 * gmax)
+        pre_bn_bias = k.endswith('.bias') and ('input_to_hidden' in k or '.layers.0.' in k or '.layers.4.' in k)
+        if pre_bn_bias:      # mathematically zero in both implementations (a bias in front of a train-mode BatchNorm)
+            assert mine['max'] < 1e-4 * gmax and float(want['max']) < 1e-4 * gmax, k
+            continue
+        tol_e = max(1e-4 * scale, 4.0 * sens['sample'])
+        tol_p = max(1e-4 * scale * np.sqrt(mine['n']), 4.0 * sens['proj'])
+        tol_l = max(1e-4 * float(want['l2']), 4.0 * sens['l2'])
+        np.testing.assert_allclose(mine['sample'], want['sample'], atol=tol_e, rtol=0, err_msg=k + ' (entries)')
+        np.testing.assert_allclose(mine['proj'], want['proj'], atol=tol_p, rtol=0, err_msg=k + ' (projections)')
+        assert abs(mine['l2'] - float(want['l2'])) <= tol_l, (k, mine['l2'], float(want['l2']))
+        worst = max(worst, float(np.abs(mine['sample'] - want['sample']).max()) / tol_e,
+                    float(np.abs(mine['proj'] - want['proj']).max()) / tol_p)
+        checked += 1
+    assert checked >= 40, checked
+    print('%s [%s]: %d gradient fingerprints, worst error / tolerance %.3f' % (tag, variant, checked, worst))
+    for k, v in net.state_dict().items():
+        if 'running_' in k:
+            np.testing.assert_allclose(v.cpu().numpy(), fp['after/' + k], atol=1e-5, err_msg=k)
+
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def big_model():
+    return synthetic.make_model()
+
+
+def _randomize_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+@pytest.mark.parametrize('B', [256, 512])
+def test_config1_launch_shape_sampled_windows_vs_oracle(big_model, B):
+    """BASELINE configs[1] at its own launch shape: LGD-12 WITHOUT the RNN (MLP init networks, reference models.py:517-526),
+    N = 4, 2 x 512 MLPs, B = 256 windows x 32 frames = 8192 rows, V = 6890: fused update-network kernel + the general SMPL
+    kernels + MLP init.  B = 512 crosses the T >= 16384 switch to the frame-per-lane SMPL kernels (api.hip) with MLP init.
+    Eight windows sampled across workgroup boundaries against the oracle run on those windows alone."""
+    torch.manual_seed(1614785570)
+    net = create_model(lgd_config(12, False, 4), SMPLLayer(big_model))
+    _randomize_bn(net, 1614785571)
+    net = net.eval()
+    bm = R.BodyModelTensors(big_model)
+    tables = R.sensor_tables(big_model['f'], CONST.VERTEX_IDS)
+
+    def fn(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, CONST.VERTEX_IDS, torch.from_numpy(poses),
+                                          torch.from_numpy(betas), torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    F = 32
+    pool = synthetic.make_windows(64, F, 2121, fn)
+    pick = [0, 1, 3, 4, 127, 128, B // 2 + 1, B - 1]          # 128 rows = 4 windows per row block of the fused kernel
+    keys = ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')
+    order = np.random.default_rng(B).permutation(B) % 64
+    batch = {k: np.ascontiguousarray(pool[k][order]) for k in keys}
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    inp = {k: torch.from_numpy(batch[k][pick]) for k in keys}
+    inp['marker_masks'] = None
+    inp['seq_lengths'] = torch.full((len(pick),), F, dtype=torch.int64)
+    want, _ = R.ief_forward(sd, bm, tables, CONST.VERTEX_IDS, inp, n_markers=12, N=4, rnn_init=False)
+    net = net.to(DEV)
+    res = net.forward_tensors(*(torch.from_numpy(batch[k]).to(DEV) for k in keys))
+    torch.cuda.synchronize()
+    pose = res['pose'][pick].cpu().numpy()
+    np.testing.assert_allclose(pose[:, :, 3:], want['pose_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(pose[:, :, :3], want['root_ori_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['shape'][pick].cpu().numpy(), want['shape_hat'].numpy(), atol=ATOL)
+    np.testing.assert_allclose(res['joints'][pick].cpu().numpy(), want['joints_hat'].numpy(), atol=ATOL)
