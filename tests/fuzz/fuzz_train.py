@@ -64,7 +64,7 @@ def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print):
         _layers.FORCE_LARGE_LINEAR[0], LgdTrainEngine.batched_wgrad = force_large0, batched0
         _lib.check(_lib.lib().empose_set_option(b'train_fused', 0))
         _lib.check(_lib.lib().empose_set_option(b'train_epi', 1))
-    assert len(flips) <= max(3, n // 3), 'too many to be kink flips'
+    assert len(flips) <= max(3, n // 6), 'too many to be kink flips'
     return {'n': n, 'worst': worst, 'flips': len(flips), 'stats': stats}
 
 
@@ -123,26 +123,34 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
     sens_o = {k: float((res['engine_perturbed'][2][k] - v).abs().max()) for k, v in res['engine'][2].items()}
     res = {True: res['engine'], False: res['autograd']}
     gmax = max(float(v.abs().max()) for v in res[False][1].values())
+    errs, tols = {}, {}
     for k, v in res[False][1].items():
-        err = float((res[True][1][k] - v).abs().max())
+        errs[k] = float((res[True][1][k] - v).abs().max())
         # 2e-4 of the tensor's scale (plus round-off at the scale of the largest gradient: biases in front of a train-mode
         # BatchNorm have a mathematically zero gradient) plus eight times the step's own sensitivity to a one-ulp input change
-        tol = 2e-4 * (float(v.abs().max()) + 1e-2 * gmax) + 8.0 * sens_g[k]
-        stats.setdefault('grad err / tol', []).append(err / tol)
+        tols[k] = 2e-4 * (float(v.abs().max()) + 1e-2 * gmax) + 8.0 * sens_g[k]
         stats.setdefault('grad sensitivity / scale', []).append(sens_g[k] / (float(v.abs().max()) + 1e-2 * gmax))
-        worst = max(worst, err / tol)
-        if not err <= tol and err <= max(5e-2, 24.0 / (B * F)) * (float(v.abs().max()) + 1e-2 * gmax):   # one element of B F rows
-            # A kink flip: the two forward kernels differ by ~1e-7, an element of a BatchNorm output within that distance
-            # of zero takes different sides of the PReLU in the two backward passes, and the Linear in front of it (and
-            # that BatchNorm's bias, and everything upstream) moves by (1 - slope) dz of ONE element. ~0.1 per
-            # configuration at these sizes (7e5 activations, density 0.4 near zero); counted and bounded below.
-            flips.add(n)
-            continue
-        if not err <= tol:
-            print('TRAIN MISMATCH', seed, n, dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), k, err, tol)
+    bad = sorted(k for k in errs if not errs[k] <= tols[k])
+    if bad:
+        # A kink flip?  The two paths run different forward kernels, ~1e-7 apart; an element of a BatchNorm output within
+        # that distance of zero takes different sides of the PReLU in the two backward passes.  That has a PATTERN, and only
+        # that pattern is accepted (round 5; the magnitude bound of round 4 is gone): every tensor out of tolerance belongs
+        # to ONE network; in its most downstream layer among them -- a layer with a PReLU -- the Linear's weight gradient
+        # is out of tolerance in the row(s) of the flipped channel(s) only (at most two), its bias / BatchNorm gradients
+        # at those channels only; the layers above it (towards the input) may move densely (the BatchNorm backward
+        # spreads one channel over all rows), the layers below it, the other network, the LSTM and the heads not at all.
+        why = _kink_flip_pattern(bad, {k: (res[True][1][k] - res[False][1][k]).abs() for k in bad}, tols)
+        if why is not None:
+            print('TRAIN MISMATCH', seed, n, dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), why)
             for kk, vv in res[False][1].items():
-                print('  grad %-50s engine-vs-autograd %.2e of %.2e (sensitivity %.2e)' % (kk, float((res[True][1][kk] - vv).abs().max()), float(vv.abs().max()), sens_g[kk]))
-            raise AssertionError('training fuzz mismatch, seed %d case %d' % (seed, n))
+                print('  grad %-50s engine-vs-autograd %.2e of %.2e (tolerance %.2e, sensitivity %.2e)'
+                      % (kk, errs[kk], float(vv.abs().max()), tols[kk], sens_g[kk]))
+            raise AssertionError('training fuzz mismatch, seed %d case %d: %s' % (seed, n, why))
+        flips.add(n)
+    for k in errs:
+        if k not in bad:    # `worst` is over what was compared against its tolerance: the flipped tensors are excluded
+            stats.setdefault('grad err / tol', []).append(errs[k] / tols[k])
+            worst = max(worst, errs[k] / tols[k])
     for k, v in res[False][2].items():
         err = float((res[True][2][k] - v).abs().max())
         # train-mode BatchNorm over a few dozen rows amplifies the one-ulp differences between the two paths' kernels
@@ -153,6 +161,48 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
             raise AssertionError('training fuzz mismatch, seed %d case %d' % (seed, n))
     assert abs(res[True][0] - res[False][0]) <= 1e-3 * max(1.0, abs(res[False][0])), (res[True][0], res[False][0])
     return n + 1, worst
+
+
+def _layer_of(name):
+    """(network, layer index, kind) of a parameter of an MLP (reference nn/layers.py:13-77), None for anything else."""
+    for net in ('pose_net_iter.', 'shape_net_iter.', 'pose_net_init.', 'shape_net_init.'):
+        if name.startswith(net):
+            rest = name[len(net):].split('.')
+            if rest[0] == 'input_to_hidden':
+                return net, 0, 'linear'
+            if rest[0] == 'batch_norm':
+                return net, 0, 'bn'
+            if rest[0] == 'activation_fn':
+                return net, 0, 'prelu'
+            if rest[0] == 'hidden_layers' and len(rest) >= 4:
+                j, i = int(rest[1]), int(rest[3])
+                return net, 1 + 2 * j + (i >= 4), {0: 'linear', 1: 'bn', 2: 'prelu'}[i % 4]
+            if rest[0] == 'hidden_to_output':
+                return net, 99, 'linear'
+    return None
+
+
+def _kink_flip_pattern(bad, diffs, tols):
+    """None if the out-of-tolerance tensors `bad` have the footprint of a PReLU kink flip, else a sentence saying why not."""
+    where = {k: _layer_of(k) for k in bad}
+    if any(v is None for v in where.values()):
+        return 'out of tolerance outside the update / init MLPs: ' + ', '.join(k for k in bad if where[k] is None)
+    nets = {v[0] for v in where.values()}
+    if len(nets) != 1:
+        return 'out of tolerance in more than one network: ' + ', '.join(sorted(nets))
+    last = max(v[1] for v in where.values())
+    if last == 99:
+        return 'the output layer (no PReLU behind it) is out of tolerance'
+    channels = set()
+    for k in bad:
+        if where[k][1] != last or where[k][2] == 'prelu':
+            continue
+        d = diffs[k]
+        rows = (d.reshape(d.shape[0], -1) > tols[k]).any(dim=1).nonzero().flatten().tolist()
+        channels.update(rows)
+    if not 1 <= len(channels) <= 2:
+        return 'layer %d of %s is out of tolerance in %d channels (a flip touches one)' % (last, next(iter(nets)), len(channels))
+    return None
 
 
 if __name__ == '__main__':

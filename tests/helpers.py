@@ -84,11 +84,13 @@ def run_oracle_baseline(case, inp, state=None, dtype=torch.float32):
 # ----------------------------------------------------------------------------------------------------------------------
 def seeded_state_dict(template, seed):
     """:param template: a state_dict (names + shapes; values ignored).  Body-model entries are skipped."""
+    import zlib
     out = {}
-    for i, (k, v) in enumerate(template.items()):
+    for k, v in template.items():
         if k.startswith('smpl.') or k.endswith('num_batches_tracked'):
             continue
-        g = torch.Generator().manual_seed(int(seed) * 1000 + i)
+        # seeded by NAME: positions differ between the reference's module and this repository's (body-model entries)
+        g = torch.Generator().manual_seed(int(seed) * 1000003 + zlib.crc32(k.encode()) % 1000003)
         shape = tuple(v.shape)
         if 'running_var' in k:
             t = torch.rand(shape, generator=g) + 0.5

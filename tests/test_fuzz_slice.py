@@ -83,9 +83,13 @@ def test_linear_and_mesh_slice(capsys):
 
 def test_training_step_slice(capsys):
     """60 random training configurations: the engine's hand-written reverse sweep vs autograd over the same kernels,
-    every parameter gradient within 2e-4 of scale + 8x the step's own one-ulp sensitivity."""
+    every parameter gradient within 2e-4 of scale + 8x the step's own one-ulp sensitivity.  (A property test -- two
+    derivations of one backward; parity with the reference is tests/test_hip_parity.py::test_training_step_matches_
+    reference_gradients and tests/test_hip_round5.py::test_full_width_training_step_matches_reference_fingerprints.)"""
     from tests.fuzz import fuzz_train
     r = fuzz_train.run(seed=4105, n_cases=60)
     _show(capsys, 'train: %d configurations, worst gradient error / tolerance %.2f, %d PReLU kink flips'
           % (r['n'], r['worst'], r['flips']))
-    assert r['n'] == 60 and r['flips'] <= 6
+    # `worst` is over every compared gradient tensor; a configuration with a PReLU kink flip (accepted only by its
+    # footprint, tests/fuzz/fuzz_train.py::_kink_flip_pattern) contributes its unaffected tensors
+    assert r['n'] == 60 and r['flips'] <= 6 and r['worst'] <= 1.0
