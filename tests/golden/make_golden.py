@@ -424,19 +424,26 @@ def make_train_fingerprints(vids):
         base = runs[0]
         data = {'in/' + k: v for k, v in w0.items()}
         data['in/seq_lengths'] = lengths.numpy()
+
+        def scatter(get):
+            # the largest difference between ANY two of the five fp32 realisations of the reference's step (the recorded
+            # one and the four one-ulp draws): what two faithful fp32 implementations of this step may differ by
+            vals = [np.asarray(get(r), dtype=np.float64) for r in runs]
+            return np.asarray(max(np.abs(a - b).max() for i, a in enumerate(vals) for b in vals[i + 1:]))
         for k, v in base['out'].items():
             data['out/' + k] = v
-            data['sens_out/' + k] = np.asarray(max(np.abs(r['out'][k].astype(np.float64) - v).max() for r in runs[1:]))
+            data['sens_out/' + k] = scatter(lambda r: r['out'][k])
         for k, v in base['loss'].items():
             data['loss/' + k] = np.asarray(v)
+            data['sens_loss/' + k] = scatter(lambda r: r['loss'][k])
         for k, v in base['after'].items():
             data['after/' + k] = v
+            data['sens_after/' + k] = scatter(lambda r: r['after'][k])
         for k, fp in base['grad'].items():
             for f in ('max', 'l2', 'n', 'proj', 'sample'):
                 data['grad/{}/{}'.format(k, f)] = np.asarray(fp[f])
             for f in ('l2', 'proj', 'sample'):
-                data['sens/{}/{}'.format(k, f)] = np.asarray(max(np.abs(np.asarray(r['grad'][k][f]) - np.asarray(fp[f])).max()
-                                                                for r in runs[1:]))
+                data['sens/{}/{}'.format(k, f)] = scatter(lambda r: r['grad'][k][f])
         data['meta/n_markers'], data['meta/N'], data['meta/rnn'] = np.asarray(nm), np.asarray(N), np.asarray(1)
         data['meta/seed'], data['meta/vertex_ids'], data['meta/hidden'] = np.asarray(seed), np.asarray(vids), np.asarray(512)
         path = os.path.join(HERE, tag + '.npz')

@@ -35,9 +35,11 @@ def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
     configs[4]'s per-GPU batch), ragged lengths: the REFERENCE's train-mode forward + backward (models.py:485-688, with
     the in-forward deposits of :576) was run on these inputs and these weights (`tests.helpers.seeded_state_dict`, re-made
     here) and left, per parameter tensor, the max-abs, L2 norm, 8 seeded Gaussian projections and 256 seeded entries of
-    its gradient, plus losses, outputs, BatchNorm running statistics -- and how far each of those moves when the
-    reference's inputs change by one unit in the last place.  Tolerance rule of test_hip_parity.py:814:
-    max(1e-4 of the tensor's scale, 4 x that sensitivity)."""
+    its gradient, plus losses, outputs, BatchNorm running statistics -- and the SCATTER of each of those: the largest
+    difference between any two of five fp32 realisations of the reference's own step (the recorded one and four draws
+    with inputs and weights moved by one unit in the last place; N = 4 train-mode iterations amplify fp32 noise, the
+    reference's FK loss alone moves by 2e-5 relative).  Tolerance rule of test_hip_parity.py:814:
+    max(1e-4 of the tensor's scale, 4 x that scatter)."""
     from em_pose_amd.data.data import SyntheticBatch
     from em_pose_amd.nn.train_engine import LgdTrainEngine
     fp = _load_fp(tag)
@@ -72,7 +74,7 @@ def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), fp['out/' + k],
                                    atol=max(ATOL, 4.0 * float(fp['sens_out/' + k])), rtol=0, err_msg=k)
     for k in ('pose', 'shape', 'reconstruction', 'fk', 'total_loss'):
-        assert loss_vals[k] == pytest.approx(float(fp['loss/' + k]), rel=2e-4, abs=1e-6), k
+        assert loss_vals[k] == pytest.approx(float(fp['loss/' + k]), rel=1e-4, abs=max(1e-6, 4.0 * float(fp['sens_loss/' + k]))), k
     names = sorted({k.split('/')[1] for k in fp if k.startswith('grad/')})
     gmax = max(float(fp['grad/{}/max'.format(k)]) for k in names)
     params = dict(net.named_parameters())
@@ -108,7 +110,8 @@ def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
     print('%s [%s]: %d gradient fingerprints, worst error / tolerance %.3f' % (tag, variant, checked, worst))
     for k, v in net.state_dict().items():
         if 'running_' in k:
-            np.testing.assert_allclose(v.cpu().numpy(), fp['after/' + k], atol=1e-5, err_msg=k)
+            np.testing.assert_allclose(v.cpu().numpy(), fp['after/' + k], rtol=0, err_msg=k,
+                                       atol=max(1e-5, 4.0 * float(fp['sens_after/' + k])))
 
 
 
