@@ -72,6 +72,7 @@ struct Dense {
   int in_dim = 0, out_dim = 0;
   float* w = nullptr;      // [out][in]
   float* wp = nullptr;     // the same weights in MFMA fragment order (mlp_fused.hip), only for MLP layers
+  float* wp3 = nullptr;    // ... and as three bf16 pieces per weight in bf16-MFMA fragment order (mlp_fused_x3.hip)
   float* scale = nullptr;  // nullptr => 1
   float* shift = nullptr;  // bias (and folded BN)
   int act = 0;
@@ -305,7 +306,53 @@ int pack_fragments_raw(std::vector<void*>& allocs, const float* weight, int N, i
   return upload(allocs, buf.data(), buf.size(), out);
 }
 
+// The same weights as THREE bf16 pieces each (w = h + m + l, every piece the round-to-nearest bf16 of what the previous
+// ones leave: 8 + 8 + 8 mantissa bits, all of an fp32's 24) in the order v_mfma_f32_32x32x16_bf16 consumes them
+// (mlp_fused_x3.hip): for every k-step of 16, every 32-column tile and every piece one 1 KB wave fragment -- lane
+// (n = lane & 31, half = lane >> 5) owns piece[tile * 32 + n][ks * 16 + half * 8 .. + 7]; k-steps padded with zeros to a
+// multiple of four (the kernel walks quads).  6 bytes per weight.
+static unsigned short bf16_round(float x) {
+  unsigned u;
+  std::memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan: as they are
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static float bf16_value(unsigned short h) {
+  const unsigned u = (unsigned)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+int pack_fragments_x3_raw(std::vector<void*>& allocs, const float* weight, int N, int K, float** out) {
+  const int KS = (K + 15) / 16, NT = (N + 31) / 32;
+  const int KS4 = (KS + 3) & ~3;
+  std::vector<unsigned short> buf((size_t)KS4 * NT * 3 * 512, 0);
+  for (int ks = 0; ks < KS; ++ks)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = nt * 32 + (lane & 31);
+        if (n >= N) continue;
+        for (int e = 0; e < 8; ++e) {
+          const int k = ks * 16 + (lane >> 5) * 8 + e;
+          if (k >= K) continue;
+          const float w = weight[(size_t)n * K + k];
+          const unsigned short h = bf16_round(w);
+          const float r = w - bf16_value(h);
+          const unsigned short m = bf16_round(r);
+          const unsigned short l = bf16_round(r - bf16_value(m));
+          const size_t at = (((size_t)ks * NT + nt) * 3) * 512 + (size_t)lane * 8 + e;
+          buf[at] = h; buf[at + 512] = m; buf[at + 1024] = l;
+        }
+      }
+  static_assert(sizeof(float) == 2 * sizeof(unsigned short), "");
+  std::vector<float> as_f(buf.size() / 2);
+  std::memcpy(as_f.data(), buf.data(), buf.size() * 2);
+  return upload(allocs, as_f.data(), as_f.size(), out);
+}
+
 int pack_fragments(std::vector<void*>& allocs, const empose_dense_desc& d, Dense* out) {
+  TRY(pack_fragments_x3_raw(allocs, d.weight, d.out_dim, d.in_dim, &out->wp3));
   return pack_fragments_raw(allocs, d.weight, d.out_dim, d.in_dim, &out->wp);
 }
 
@@ -437,6 +484,12 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
       }
     }
     if (ok) {
+      // fp32 products from three bf16 pieces per operand on the bf16 matrix path (mlp_fused_x3.hip; fp32-equivalent, 2.7
+      // times the fp32 instruction's rate): needs every hidden width to be whole quads of k-steps of the next layer
+      bool x3 = options().mlp_x3 != 0;
+      for (int i = 0; i < n_nets && x3; ++i)
+        for (int l = 0; l + 1 < L; ++l)
+          if (nets[i]->layers[l].out_dim % 64 != 0 || !nets[i]->layers[l].wp3) x3 = false;
       FusedMlpArgs fa;
       fa.count = n_nets; fa.M = T;
       for (int i = 0; i < n_nets; ++i) {
@@ -446,12 +499,12 @@ int run_mlps(const Mlp* nets[2], int n_nets, float* outs[2], const int out_ld[2]
         for (int l = 0; l < L; ++l) {
           const Dense& d = nets[i]->layers[l];
           FusedLayer& fl = fn.layer[l];
-          fl.W = d.wp; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
+          fl.W = x3 ? d.wp3 : d.wp; fl.K = d.in_dim; fl.N = d.out_dim; fl.scale = d.scale; fl.shift = d.shift;
           fl.slope = d.slope; fl.act = d.act;
         }
       }
       prof_mark(init_net ? P_INIT_MLP : P_MLP_FUSED, stream);
-      hipError_t e = launch_mlp_fused(fa, stream);
+      hipError_t e = x3 ? launch_mlp_fused_x3(fa, stream) : launch_mlp_fused(fa, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mlp launch: %s", hipGetErrorString(e));
       prof_mark(P_END, stream);   // close the dominant kernel's interval at its completion, not at the next launch
       return EMPOSE_OK;
@@ -813,6 +866,7 @@ int empose_set_option(const char* name, int value) {
       {"spin_limit", &o.spin_limit},
       {"train_epi", &o.train_epi},
       {"mesh_skin_mfma", &o.mesh_skin_mfma},
+      {"mlp_x3", &o.mlp_x3},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -843,6 +897,7 @@ int empose_get_option(const char* name) {
       {"spin_limit", o.spin_limit},
       {"train_epi", o.train_epi},
       {"mesh_skin_mfma", o.mesh_skin_mfma},
+      {"mlp_x3", o.mlp_x3},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;

@@ -33,6 +33,9 @@ struct Options {
   int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
                           // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
+  int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
+                          // (mlp_fused_x3.hip: fp32-equivalent accuracy, measured equal to the fp32 instruction's against
+                          // float64); 0: the fp32 MFMA instruction (mlp_fused.hip)
 };
 Options& options();
 
@@ -213,6 +216,9 @@ struct FusedNet {
 };
 struct FusedMlpArgs { FusedNet net[2]; int count; int M; };
 hipError_t launch_mlp_fused(const FusedMlpArgs& args, hipStream_t stream);
+// The same launch with FusedLayer::W = three bf16 pieces per weight in bf16-MFMA fragment order (api.hip
+// pack_fragments_x3_raw): mlp_fused_x3.hip.  Hidden widths must be multiples of 64.
+hipError_t launch_mlp_fused_x3(const FusedMlpArgs& args, hipStream_t stream);
 // One linear layer C = A . W^T with A's row block resident in LDS and W (fragment order) streamed from L2.
 bool gemm_rows_applicable(int M, int N, int K);
 hipError_t launch_gemm_rows(const float* A, int lda, const float* Wp, float* C, int ldc, int M, int N, int K,

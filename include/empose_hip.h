@@ -65,6 +65,9 @@ const char* empose_arch(void);
  * rows, 2 always), "train_epi" (train-mode MLP layer with the BatchNorm statistics in the GEMM epilogues and ONE
  * combine-and-apply launch per layer and direction: 0 never, 1 above 1024 rows [default], 2 always), "atb_fast" (weight
  * gradients: whole-tile / whole-chunk products on a branch-free interior kernel, bit-identical; 0 = the general kernel),
+ * "mlp_x3" (the fused update MLPs form every fp32 product from three bf16 pieces per operand -- six bf16 matrix-core
+ * products with fp32 accumulation, fp32-equivalent and 2.7 times the fp32 instruction's rate -- when every hidden width
+ * is a multiple of 64: 1 [default]; 0 = the fp32 MFMA instruction),
  * "mesh_skin_mfma" (split-bf16 full-mesh variant only: the bone blend as a second matrix-core contraction; 0 [default,
  * measured faster] = vector skinning), "spin_limit" (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */

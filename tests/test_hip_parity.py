@@ -265,10 +265,14 @@ def test_update_nets_and_lstm_vs_oracle():
 
 @pytest.mark.parametrize('hidden,skip,T', [(32, False, 12800 + 77), (512, False, 12800), (256, True, 13000),
                                            (100, False, 8192 + 5), (36, False, 9000)])
-def test_update_nets_large_batch_single_launch_path(hidden, skip, T, monkeypatch):
+@pytest.mark.parametrize('x3', [1, 0], ids=['three_piece_bf16', 'fp32_mfma'])
+def test_update_nets_large_batch_single_launch_path(hidden, skip, T, x3, monkeypatch):
     """Large batches run both update MLPs in ONE launch (csrc/mlp_fused.hip: a workgroup keeps 128 rows through all six
     layers): same results as the oracle's layer-by-layer MLP, incl. the ragged first layer (K = 296), the narrow output
     layers (66 / 10 columns), a ragged last row panel, skip connections, and the per-layer path on the first rows."""
+    if x3 and (hidden % 64 != 0 or skip):
+        pytest.skip('the three-piece kernel takes hidden widths of whole 64s without skip connections')
+    _set_option(b'mlp_x3', x3)
     torch.manual_seed(hidden + T)
     cfg = lgd_config(12, False, 1, hidden=hidden, m_skip_connections=skip)
     net = create_model(cfg, SMPLLayer(H.small_model()))
@@ -302,8 +306,14 @@ def test_update_nets_large_batch_single_launch_path(hidden, skip, T, monkeypatch
         np.testing.assert_allclose(dp.cpu().numpy(), want_p[:rows], atol=ATOL)
         np.testing.assert_allclose(ds.cpu().numpy(), want_s[:rows], atol=ATOL)
         outs[key] = (dp.cpu().numpy(), ds.cpu().numpy())
-    # both paths accumulate every dot product in the same k order: identical bits, not just close
-    assert np.array_equal(outs[T][0][:200], outs[200][0]) and np.array_equal(outs[T][1][:200], outs[200][1])
+    # both paths accumulate every dot product in the same k order: identical bits, not just close -- for the fp32-MFMA fused
+    # kernel; the three-piece bf16 kernel (mlp_fused_x3.hip, what hidden widths of whole 64s take by default) forms the
+    # same products in another order
+    if lib.empose_get_option(b'mlp_x3') == 0 or hidden % 64 != 0 or skip:
+        assert np.array_equal(outs[T][0][:200], outs[200][0]) and np.array_equal(outs[T][1][:200], outs[200][1])
+    else:
+        np.testing.assert_allclose(outs[T][0][:200], outs[200][0], atol=2e-5)
+        np.testing.assert_allclose(outs[T][1][:200], outs[200][1], atol=2e-5)
 
 
 def test_mlp_module_forward_vs_oracle():

@@ -173,3 +173,51 @@ def test_config1_launch_shape_sampled_windows_vs_oracle(big_model, B):
     np.testing.assert_allclose(pose[:, :, :3], want['root_ori_hat'].numpy(), atol=ATOL)
     np.testing.assert_allclose(res['shape'][pick].cpu().numpy(), want['shape_hat'].numpy(), atol=ATOL)
     np.testing.assert_allclose(res['joints'][pick].cpu().numpy(), want['joints_hat'].numpy(), atol=ATOL)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('scale', [1.0, 30.0], ids=['unit_inputs', 'gradient_scale_inputs'])
+def test_three_piece_bf16_update_nets_are_as_accurate_as_the_fp32_mfma_ones(scale):
+    """mlp_fused_x3.hip forms every fp32 product from three bf16 pieces per operand (six bf16 MFMA products, fp32
+    accumulation).  Claim: fp32-EQUIVALENT -- against a float64 evaluation of the same released-width networks (2 x 512,
+    296 inputs, 66 / 10 outputs, random BatchNorm statistics) its error is no larger than that of the kernel built on the
+    fp32 MFMA instruction (mlp_fused.hip), for O(1) inputs and for inputs at the scale of the gradient features (O(30)).
+    Also: repeated launches are bit-identical (one wave per SIMD; scripts/dev/bf16_hazard_repro.md)."""
+    T = 16384 + 64 + 7
+    torch.manual_seed(11)
+    net = create_model(lgd_config(12, False, 1), SMPLLayer(H.small_model()))
+    _randomize_bn(net, 12)
+    net.vertex_ids = synthetic.small_vertex_ids(160)
+    net = net.to(DEV).eval()
+    sd64 = {k: v.detach().cpu().double() for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(T, 296, generator=g) * scale
+    rows = [0, 1, 63, 64, 8191, 16383, 16384, T - 1]
+    with torch.no_grad():
+        want_p = R.mlp_forward(sd64, 'pose_net_iter.', x[rows].double()).numpy()
+        want_s = R.mlp_forward(sd64, 'shape_net_iter.', x[rows].double()).numpy()
+    lib = _lib.lib()
+    handle = net._ensure_handle(torch.device(DEV))
+    xg = x.to(DEV)
+    err, outs = {}, {}
+    for x3 in (0, 1):
+        _lib.check(lib.empose_set_option(b'mlp_x3', x3))
+        reps = []
+        for rep in range(3 if x3 else 1):
+            dp, ds = torch.full((T, 66), 7.0, device=DEV), torch.full((T, 10), 7.0, device=DEV)
+            nbytes = lib.empose_update_workspace_bytes(handle, T)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.empose_update_nets_fwd(handle, T, _lib.dptr(xg), 296, _lib.dptr(dp), _lib.dptr(ds), _lib.dptr(ws),
+                                                  nbytes, _lib.current_stream()))
+            torch.cuda.synchronize()
+            reps.append((dp.cpu().numpy(), ds.cpu().numpy()))
+        for r in reps[1:]:
+            assert np.array_equal(r[0], reps[0][0]) and np.array_equal(r[1], reps[0][1])
+        outs[x3] = reps[0]
+        err[x3] = max(np.abs(reps[0][0][rows] - want_p).max(), np.abs(reps[0][1][rows] - want_s).max())
+    out_scale = max(np.abs(want_p).max(), np.abs(want_s).max())
+    print('update nets vs float64 (|out| <= %.2f): fp32 MFMA %.2e, three-piece bf16 %.2e; between them %.2e'
+          % (out_scale, err[0], err[1], np.abs(outs[0][0] - outs[1][0]).max()))
+    assert err[1] <= 1.5 * err[0] + 1e-7 * out_scale, err
+    assert err[1] < 2e-5 * max(1.0, out_scale)
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-4 * max(1.0, out_scale)
