@@ -37,6 +37,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD)
+X3_PRODUCTS = 6                 # bf16 piece products per fp32 product in mlp_fused_x3.hip (three pieces per operand)
 PEAK_HBM_GBS = 8000.0
 MODEL_SEED = 1615200973  # the released LGD-RNN-12 model id (BASELINE.json configs[2])
 
@@ -304,6 +306,8 @@ def main():
                          "contraction (not the reference's arithmetic; the headline never uses it)")
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_profile', action='store_true')
+    ap.add_argument('--no_fp32_line', action='store_true',
+                    help='skip the second timed region on the fp32 MFMA instruction (option mlp_x3=0)')
     ap.add_argument('--no_traffic', action='store_true',
                     help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic (~25 s each)')
     ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
@@ -381,6 +385,32 @@ def main():
         frames_total = B * F
         assert torch.isfinite(out['pose']).all()
     barrier()
+    # The same timed region once more on the fp32 MFMA instruction (option mlp_x3 = 0) when the headline ran the update
+    # MLPs as three-piece bf16 products: reported beside the headline, never as `value`.
+    lib0 = _lib.lib()
+    x3_on = lib0.empose_get_option(b'mlp_x3') != 0 and net.config.m_hidden_size % 64 == 0 and B * F >= 64 * 128
+    fp32_line = None
+    if x3_on and not args.no_fp32_line:
+        _lib.check(lib0.empose_set_option(b'mlp_x3', 0))
+        for _ in range(max(args.warmup, 1)):
+            out32 = net.forward_tensors(*inputs)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out32 = net.forward_tensors(*inputs)
+        torch.cuda.synchronize()
+        e32 = time.perf_counter() - t1
+        _lib.check(lib0.empose_set_option(b'mlp_x3', 1))
+        if dist is not None:
+            t = torch.tensor([e32], dtype=torch.float64, device=D.collective_device(dev))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e32 = float(t.item())
+        fp32_line = {'value': frames_total * args.steps / e32, 'ms_per_step': 1000.0 * e32 / args.steps,
+                     'max_abs_diff_to_headline_outputs': float(max((out32[k] - out[k]).abs().max() for k in
+                                                                   ('pose', 'shape', 'joints'))),
+                     'what': 'option mlp_x3=0: the update MLPs on v_mfma_f32_32x32x2_f32 (mlp_fused.hip), everything else '
+                             'unchanged; same inputs, same timed region'}
+        barrier()
 
     result = None
     if rank == 0:
@@ -404,8 +434,15 @@ def main():
                                                 # per step at this batch) are written only when a caller asks for them
 
                        'dense_mflop_per_frame': fpf / 1e6,
-                       'whole_path_tflops': value * fpf / 1e12},
+                       'whole_path_tflops': value * fpf / 1e12,
+                       'arithmetic': ('fp32 operands and fp32 accumulation; the update MLPs form every fp32 product from '
+                                      'three bf16 pieces per operand (8+8+8 mantissa bits) as six bf16 matrix-core products '
+                                      '(mlp_fused_x3.hip): fp32-equivalent, error against float64 measured equal to the fp32 '
+                                      'MFMA instruction\'s (tests/test_hip_round5.py); LSTM, heads and SMPL GEMMs on the fp32 '
+                                      'MFMA instruction') if x3_on else 'fp32 MFMA instruction throughout'},
         }
+        if fp32_line is not None:
+            result['fp32_mfma_path'] = fp32_line
     if rank == 0 and not args.no_profile:
         lib = _lib.lib()
         lib.empose_profile_enable(1)
@@ -422,7 +459,7 @@ def main():
             flops = 0.0
             for mlp in (net.pose_net_iter, net.shape_net_iter):
                 flops += sum(2.0 * (B * F) * lin.in_features * lin.out_features for lin, _, _ in mlp.dense_specs())
-            kname = 'mlp_fused_kernel'
+            kname = 'mlp_fused_x3_kernel' if x3_on else 'mlp_fused_kernel'
             what = ' (the two update MLPs, 6 dense layers each, one launch per LGD iteration)'
         else:
             ms, cnt = prof['mlp_hidden_gemm']
@@ -460,8 +497,18 @@ def main():
             if traffic_src:
                 traffic_src += (' (rocprofv3 --pmc passes of this command in an EARLIER run, not measured by this '
                                 'process: %s)' % why)
-        result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                              'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+        # The roof of the kernel in ALGORITHMIC flops: the fp32 MFMA peak for the fp32 instruction; for the three-piece bf16
+        # kernel the bf16 dense peak divided by the six piece products it executes per fp32 product (frac is then also
+        # executed bf16 flops / bf16 peak).
+        x3_kernel = kname == 'mlp_fused_x3_kernel'
+        peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3_kernel else PEAK_FP32_MFMA_TFLOPS
+        result['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                              'frac': ach / peak, 'traffic': traffic,
+                              'peak_derivation': ('bf16 dense MFMA peak %.0f TFLOP/s / %d bf16 piece products per fp32 product'
+                                                  % (PEAK_BF16_MFMA_TFLOPS, X3_PRODUCTS)) if x3_kernel else
+                                                 'fp32 MFMA peak (v_mfma_f32_32x32x2_f32)',
+                              'executed_matrix_tflops': ach * (X3_PRODUCTS if x3_kernel else 1),
+                              'achieved_over_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
                               'traffic_source': traffic_src,
                               'traffic_raw_counters': getattr(pmc_traffic_live, 'raw', None),
                               'kernel': kname + what,
