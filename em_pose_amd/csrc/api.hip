@@ -89,6 +89,9 @@ struct Lstm {   // unit u = layer * dirs + direction
   float* w_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* w_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   float* bias[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // b_ih + b_hh
+  // the same matrices as three bf16 pieces per weight in the fragment order of lstm_x3.hip (uni-directional stacks only)
+  unsigned short* w3_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned short* w3_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -434,7 +437,19 @@ struct LstmWs {
   float* xch;     // exchange words of the whole-sequence small-batch kernel (lstm_persist_kernel), or nullptr
   float* h3[8];   // third hidden-state buffer per unit + counters of the whole-sequence large-batch kernel, or nullptr
   unsigned* seq_cnt;
+  // lstm_x3.hip: the stored input of every time step and the hidden states (ping-pong) as bf16 piece planes, or nullptr
+  unsigned short* x3; size_t x3_t_stride;
+  unsigned short* a3[8][2];
 };
+// bf16 elements of one set of A planes: [32-row tiles][k-steps][3 pieces][512]
+size_t lstm_x3_plane_elems(int B, int K) { return (size_t)((B + 31) / 32) * ((K + 15) / 16) * 3 * 512; }
+bool lstm_x3_covers(const Lstm& r, int B) {
+  if (options().lstm_x3 == 0 || r.dirs != 1 || r.num_layers > 4 || B < LSTM_SEQ_MIN_B) return false;
+  if (r.H % 32 != 0 || r.input_size % 4 != 0) return false;
+  for (int l = 0; l < r.num_layers; ++l)
+    if (!r.w3_ih[l] || !r.w3_hh[l]) return false;
+  return true;
+}
 LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
   const int H = r.H, U = r.num_layers * r.dirs;
@@ -451,6 +466,12 @@ LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   const bool seq = r.dirs == 1 && B >= LSTM_SEQ_MIN_B && r.num_layers <= 4;
   for (int u = 0; u < 8; ++u) w.h3[u] = (seq && u < U) ? c.f((size_t)B * H) : nullptr;
   w.seq_cnt = seq ? reinterpret_cast<unsigned*>(c.f(lstm_seq_counter_uints(B))) : nullptr;
+  const bool x3 = lstm_x3_covers(r, B);
+  w.x3_t_stride = lstm_x3_plane_elems(B, r.input_size);
+  w.x3 = x3 ? reinterpret_cast<unsigned short*>(c.f((w.x3_t_stride * F + 1) / 2)) : nullptr;
+  for (int u = 0; u < 8; ++u)
+    for (int k = 0; k < 2; ++k)
+      w.a3[u][k] = (x3 && u < U) ? reinterpret_cast<unsigned short*>(c.f((lstm_x3_plane_elems(B, H) + 1) / 2)) : nullptr;
   return w;
 }
 LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) { return carve_lstm_of(c, m->rnn, B, F); }
@@ -619,6 +640,38 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel (large batch): %s", hipGetErrorString(e));
       seq_done = done;
     }
+    // Large batches, inference: the steps on the bf16 matrix path with three bf16 pieces per operand (lstm_x3.hip)
+    if (!done && ws.x3 && !a.unit[0].sv_gates && lstm_x3_covers(r, B)) {
+      prof_mark(P_COPY, stream);
+      const int KS_in = (r.input_size + 15) / 16, KS_h = H / 16;
+      hipError_t e = launch_lstm_split_rows(x, (long)F * ldx, ldx, F, B, r.input_size, KS_in, ws.x3, (long)ws.x3_t_stride, stream);
+      for (int l = 0; l < L && e == hipSuccess; ++l) {
+        e = launch_lstm_split_rows(ws.h[l][0], H, 0, 1, B, H, KS_h, ws.a3[l][0], 0, stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ws.a3[l][1], 0, lstm_x3_plane_elems(B, H) * sizeof(unsigned short), stream);
+      }
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm operand split: %s", hipGetErrorString(e));
+      const int tiles = (H / 32) * ((B + 63) / 64);
+      for (int s = 0; s < F + L - 1; ++s) {
+        LstmX3Args xa;
+        xa.n_units = 0; xa.seq_lengths = seq_lengths; xa.B = B; xa.F = F; xa.H = H;
+        for (int l = 0; l < L; ++l) {
+          const int t = s - l;
+          if (t < 0 || t >= F) continue;
+          LstmX3Unit& xu = xa.unit[xa.n_units++];
+          xu.w3_ih = r.w3_ih[l]; xu.w3_hh = r.w3_hh[l]; xu.bias = r.bias[l];
+          xu.a3_in = l == 0 ? ws.x3 + (size_t)t * ws.x3_t_stride : ws.a3[l - 1][(t + 1) & 1];
+          xu.ks_in = l == 0 ? KS_in : KS_h;
+          xu.a3_rec = ws.a3[l][t & 1]; xu.a3_out = ws.a3[l][(t + 1) & 1];
+          xu.h_prev = ws.h[l][t & 1]; xu.h_next = ws.h[l][(t + 1) & 1]; xu.c = ws.c[l];
+          xu.y = l == L - 1 ? y : nullptr; xu.y_ld = H; xu.y_col = 0; xu.t = t;
+        }
+        xa.units_per_block = tiles >= 192 ? xa.n_units : 1;
+        prof_mark(P_LSTM_STEP, stream);
+        e = launch_lstm_chain_x3(xa, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step (bf16 pieces): %s", hipGetErrorString(e));
+      }
+      done = true;
+    }
     for (int s = 0; !done && s < F + L - 1; ++s) {
       a.s = s;
       prof_mark(P_LSTM_STEP, stream);
@@ -659,6 +712,36 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   return EMPOSE_OK;
 }
 
+// An LSTM weight matrix [4H][K] (gate-major rows) as three bf16 pieces per weight in the fragment order of lstm_x3.hip:
+// [k-step of 16][32-unit block][gate][piece] -> one wave fragment of 512 bf16, lane (n = lane & 31, half = lane >> 5) owns
+// W[gate * H + block * 32 + n][ks * 16 + half * 8 .. + 7]; k past K is zero.
+int pack_lstm_x3(std::vector<void*>& allocs, const float* w, int H, int K, unsigned short** out) {
+  const int KS = (K + 15) / 16, JB = H / 32;
+  std::vector<unsigned short> buf((size_t)KS * JB * 4 * 3 * 512, 0);
+  for (int ks = 0; ks < KS; ++ks)
+    for (int jb = 0; jb < JB; ++jb)
+      for (int q = 0; q < 4; ++q)
+        for (int lane = 0; lane < 64; ++lane) {
+          const float* row = w + (size_t)(q * H + jb * 32 + (lane & 31)) * K;
+          for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + (lane >> 5) * 8 + e;
+            if (k >= K) continue;
+            const unsigned short h = bf16_round(row[k]);
+            const float r1 = row[k] - bf16_value(h);
+            const unsigned short m = bf16_round(r1);
+            const unsigned short l = bf16_round(r1 - bf16_value(m));
+            const size_t at = ((((size_t)ks * JB + jb) * 4 + q) * 3) * 512 + (size_t)lane * 8 + e;
+            buf[at] = h; buf[at + 512] = m; buf[at + 1024] = l;
+          }
+        }
+  std::vector<float> as_f((buf.size() + 1) / 2);
+  std::memcpy(as_f.data(), buf.data(), buf.size() * 2);
+  float* dev = nullptr;
+  TRY(upload(allocs, as_f.data(), as_f.size(), &dev));
+  *out = reinterpret_cast<unsigned short*>(dev);
+  return EMPOSE_OK;
+}
+
 int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, const float* const* w_ih,
               const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, Lstm* out) {
   if (r.num_layers < 1 || r.num_layers * dirs > 8 || r.hidden_size % 4 != 0 || r.input_size % 4 != 0)
@@ -674,6 +757,10 @@ int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, c
       std::vector<float> bias(4 * r.hidden_size);
       for (int i = 0; i < 4 * r.hidden_size; ++i) bias[i] = b_ih[u][i] + b_hh[u][i];
       TRY(upload(allocs, bias.data(), bias.size(), &out->bias[u]));
+      if (dirs == 1 && r.hidden_size % 32 == 0) {
+        TRY(pack_lstm_x3(allocs, w_ih[u], r.hidden_size, k_in, &out->w3_ih[u]));
+        TRY(pack_lstm_x3(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3_hh[u]));
+      }
     }
   return EMPOSE_OK;
 }
@@ -867,6 +954,7 @@ int empose_set_option(const char* name, int value) {
       {"train_epi", &o.train_epi},
       {"mesh_skin_mfma", &o.mesh_skin_mfma},
       {"mlp_x3", &o.mlp_x3},
+      {"lstm_x3", &o.lstm_x3},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -898,6 +986,7 @@ int empose_get_option(const char* name) {
       {"train_epi", o.train_epi},
       {"mesh_skin_mfma", o.mesh_skin_mfma},
       {"mlp_x3", o.mlp_x3},
+      {"lstm_x3", o.lstm_x3},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;

@@ -33,6 +33,8 @@ struct Options {
   int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
                           // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
+  int lstm_x3 = 1;        // large-batch LSTM steps (inference, uni-directional): fp32 products as six bf16-MFMA products of three
+                          // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
                           // (mlp_fused_x3.hip: fp32-equivalent accuracy, measured equal to the fp32 instruction's against
                           // float64); 0: the fp32 MFMA instruction (mlp_fused.hip)
@@ -279,6 +281,30 @@ struct LstmSeqArgs {
   int spin_limit;
   unsigned* timeouts;   // poll_timeout_word(): counts the polls that gave up (the outputs are NaN from there on)
 };
+// The wavefront step of large batches on the bf16 matrix path, three bf16 pieces per fp32 operand (lstm_x3.hip).  All
+// operands arrive in fragment order: weights packed at model creation (api.hip pack_lstm_x3: [k-step][32-unit block][gate]
+// [piece][512 bf16]), activations as A planes [32-row tile][k-step][piece][512 bf16] written by the producing step (hidden
+// states) or by launch_lstm_split_rows (stored input, initial state).
+struct LstmX3Unit {
+  const unsigned short* w3_ih; const unsigned short* w3_hh;
+  const float* bias;                 // [4H] = b_ih + b_hh
+  const unsigned short* a3_in;       // the unit's input at this step: planes of x_t, or of the unit below's new hidden state
+  int ks_in;                         // k-steps of 16 of that input
+  const unsigned short* a3_rec;      // planes of h_{t-1}
+  unsigned short* a3_out;            // planes of h_t
+  const float* h_prev; float* h_next; float* c;   // [B][H] fp32: state hand-over and rows past their length
+  float* y; int y_ld, y_col;         // output sequence [B][F][y_ld] or nullptr
+  int t;                             // the unit's time step in this launch
+};
+struct LstmX3Args {
+  LstmX3Unit unit[4];
+  int n_units, units_per_block;      // blockIdx.z walks units [z * units_per_block, ...)
+  const int* seq_lengths;
+  int B, F, H;
+};
+hipError_t launch_lstm_chain_x3(const LstmX3Args& a, hipStream_t stream);
+hipError_t launch_lstm_split_rows(const float* src, long row_stride, long z_stride, int n_z, int B, int K, int KS,
+                                  unsigned short* dst, long dst_z_stride, hipStream_t stream);
 constexpr int LSTM_SEQ_MIN_B = 257;   // below: lstm_mid_kernel / the small-batch kernels
 size_t lstm_seq_counter_uints(int B);
 hipError_t launch_lstm_seq(const LstmWaveArgs& a, float* const* h_third, unsigned* counters, hipStream_t stream, bool* done);

@@ -24,6 +24,7 @@
 //     k-steps deep; 12 KB per wave and k-step.
 //   * one wave per SIMD (132 KB of LDS per workgroup), as everything in this tree that issues the bf16 32x32x16 MFMA
 //     (scripts/dev/bf16_hazard_repro.md).
+#include "bf16x3.h"
 #include "gemm_epilogue.h"
 
 namespace empose {
@@ -36,44 +37,19 @@ constexpr int RING = 4;                      // weight ring: three k-steps in fl
 constexpr int SG_MFMA = 0x008, SG_VALU = 0x002, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100;
 }  // namespace fx
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4_t* fx_gvec_t;
 typedef const __attribute__((address_space(1))) char* fx_gbyte_t;
 
 #define FX_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-// two fp32 -> their three bf16 pieces, packed (element 0 in the low half)
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{x0, x1}, bf16x2_t));
-  const float r0 = x0 - __builtin_bit_cast(float, h << 16);
-  const float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
-  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{r0, r1}, bf16x2_t));
-  const float s0 = r0 - __builtin_bit_cast(float, m << 16);
-  const float s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
-  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{s0, s1}, bf16x2_t));
-}
-
-struct Pieces { u32x4_t p[3]; };   // (h, m, l) of 8 consecutive k of one row
-
-__device__ __forceinline__ Pieces split8(const f32x4& lo, const f32x4& hi) {
+// the pieces of a lane's 8 consecutive k
+__device__ __forceinline__ Pieces fx_split8(const f32x4& lo, const f32x4& hi) {
 #ifdef FX_LAB_NOSPLIT   // dev lab: no arithmetic on the A side (what the loop costs without the split)
   Pieces z;
   z.p[0] = __builtin_bit_cast(u32x4_t, lo); z.p[1] = __builtin_bit_cast(u32x4_t, hi); z.p[2] = z.p[0];
   return z;
 #endif
-  unsigned h[4], m[4], l[4];
-  split_pair(lo[0], lo[1], h[0], m[0], l[0]);
-  split_pair(lo[2], lo[3], h[1], m[1], l[1]);
-  split_pair(hi[0], hi[1], h[2], m[2], l[2]);
-  split_pair(hi[2], hi[3], h[3], m[3], l[3]);
-  Pieces q;
-  q.p[0] = u32x4_t{h[0], h[1], h[2], h[3]};
-  q.p[1] = u32x4_t{m[0], m[1], m[2], m[3]};
-  q.p[2] = u32x4_t{l[0], l[1], l[2], l[3]};
-  return q;
+  return split8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
 }
 
 // One layer for the workgroup's 64 rows.  `act`: fp32 [64][lda], columns [0, 16 * KS4) valid or zero.
@@ -141,20 +117,19 @@ __device__ __forceinline__ void x3_layer(const FusedNet& net, const FusedLayer& 
   };
   auto split = [&](const f32x4 (&a)[WM][2], Pieces (&q)[WM]) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i) q[i] = split8(a[i][0], a[i][1]);
+    for (int i = 0; i < WM; ++i) q[i] = fx_split8(a[i][0], a[i][1]);
   };
   // the six products of a k-step, the small ones first so that they meet in the accumulator before the large one rounds;
   // consecutive MFMAs go to different accumulator tiles
   auto mma = [&](const Pieces (&a)[WM], const u32x4_t (&b)[WN][3]) {
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i].p[PA[t]]),
-                                                              __builtin_bit_cast(bf16x8_t, b[j][PB[t]]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i].p[X3_PA[t]]),
+                                                              __builtin_bit_cast(bf16x8_t, b[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
   };
   // one k-step: its MFMAs with the next step's split (VALU), the weight loads of step s + 3 and the LDS reads of step s + 2
   // spread between them
