@@ -648,6 +648,9 @@ def test_whole_sequence_lstm_on_large_batches_equals_step_launches(B, F, In, Hd,
     lens[0], lens[-1] = F, 1
     state = (0.5 * torch.randn(L, B, Hd, device=DEV), 0.5 * torch.randn(L, B, Hd, device=DEV))
     res = {}
+    # (the step launches it is compared with bit for bit are the fp32-MFMA ones: option lstm_x3 = 0; the default steps of
+    # such batches form the same products from bf16 pieces in another order, tests/test_hip_round5.py)
+    _lib.check(_lib.lib().empose_set_option(b'lstm_x3', 0))
     for opt in (0, 1, 1):
         with _Option(b'lstm_seq', opt):
             outs = []

@@ -221,3 +221,51 @@ def test_three_piece_bf16_update_nets_are_as_accurate_as_the_fp32_mfma_ones(scal
     assert err[1] <= 1.5 * err[0] + 1e-7 * out_scale, err
     assert err[1] < 2e-5 * max(1.0, out_scale)
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-4 * max(1.0, out_scale)
+
+
+@pytest.mark.parametrize('B,F,In,Hd,L', [(1024, 8, 144, 512, 2), (300, 7, 72, 512, 2), (333, 5, 200, 192, 3)])
+def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F, In, Hd, L):
+    """lstm_x3.hip (the wavefront step of batches above 256 rows: weights and hidden states as three bf16 pieces in
+    fragment order, six bf16 MFMA products per fp32 product, K split over the waves) against a float64 LSTM
+    (reference nn/layers.py:133-157 semantics: ragged rows, carried state, zero-padded outputs): its error is no larger
+    than that of the fp32-MFMA step kernel, outputs and final state; repeated runs are bit-identical."""
+    from em_pose_amd.nn.layers import RNNLayer
+    torch.manual_seed(B + F)
+    layer = RNNLayer(In, Hd, L).eval()
+    with torch.no_grad():
+        for p in layer.lstm.parameters():
+            p.mul_(2.0)
+    x = torch.randn(B, F, In)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0], lens[-1] = F, 1
+    h0, c0 = 0.5 * torch.randn(L, B, Hd), 0.5 * torch.randn(L, B, Hd)
+    sd64 = {'lstm.' + k: v.detach().double() for k, v in layer.lstm.state_dict().items()}
+    with torch.no_grad():
+        want = {st is not None: R.lstm_forward(sd64, 'lstm.', x.double(), lens, None if st is None else (h0.double(), c0.double()),
+                                               L, False) for st in (None, 1)}
+    g = layer.to(DEV)
+    err = {}
+    lib = _lib.lib()
+    for x3 in (0, 1):
+        _lib.check(lib.empose_set_option(b'lstm_x3', x3))
+        worst, first = 0.0, None
+        for rep in range(2 if x3 else 1):
+            outs = []
+            for carried in (False, True):
+                g.init_state = (h0.to(DEV), c0.to(DEV)) if carried else None
+                y = g(x.to(DEV), lens.to(DEV))
+                torch.cuda.synchronize()
+                wy, (wh, wc) = want[carried]
+                got = (y.cpu(), g.final_state[0].cpu(), g.final_state[1].cpu())
+                outs += [t.numpy() for t in got]
+                worst = max(worst, float((got[0].double() - wy).abs().max()), float((got[1].double() - wh).abs().max()),
+                            float((got[2].double() - wc).abs().max()))
+            if first is None:
+                first = outs
+            else:
+                for a_, b_ in zip(first, outs):
+                    assert np.array_equal(a_, b_)
+        err[x3] = worst
+    print('lstm %s vs float64: fp32 MFMA %.2e, three-piece bf16 %.2e' % ((B, F, In, Hd, L), err[0], err[1]))
+    assert err[1] <= 1.5 * err[0] + 2e-7 and err[1] < 1e-5
+    g.release()
