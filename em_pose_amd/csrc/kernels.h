@@ -37,7 +37,8 @@ struct Options {
                           // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
                           // (mlp_fused_x3.hip: fp32-equivalent accuracy, measured equal to the fp32 instruction's against
-                          // float64); 0: the fp32 MFMA instruction (mlp_fused.hip)
+                          // float64); 0: the fp32 MFMA instruction (mlp_fused.hip); 2: the variant whose waves share the
+                          // A-side split through LDS (a barrier per k-step; measured 9 % slower)
 };
 Options& options();
 

@@ -215,6 +215,224 @@ __device__ __forceinline__ void x3_layer(const FusedNet& net, const FusedLayer& 
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer with the A-side split done ONCE per element instead of once per wave: the four waves each split a quarter
+// of the k-step's 64 x 16 block (16 rows: one fp32 ds_read_b128 and 22 VALU per lane instead of 88) and leave the pieces
+// in a small LDS stage in FRAGMENT order ([piece][row tile] -> 1 KB, so a wave's A fragment is one conflict-free
+// ds_read_b128); one workgroup barrier per k-step hands them over.  Pieces of step k: raw read at the start of step k - 2,
+// split + written at its end, barrier at the start of step k - 1, fragments read right after it, multiplied in step k.
+// Two stages of 6 KB behind the activation buffer.  Every wave runs the loop, also one that owns no column of a narrow
+// layer (it still splits its rows and meets the barriers).
+// MEASURED (T = 32768, two nets, scripts/dev/fused_x3_lab.hip): 853-879 us per launch against 780-798 us for the kernel above
+// -- the 66 VALU per lane and k-step it saves cost less than the barrier per k-step that replaces them (the four waves then
+// run in lock step: every stall of one is a stall of all; split early or late in the step, raw values read one or two steps
+// ahead: within 3 %).  Opt-in (option mlp_x3 = 2); kept for what it shows.
+namespace fx {
+constexpr int STAGE_U32 = 3 * 2 * 64 * 4;                          // one k-step's pieces: [piece][row tile][lane][4 x u32]
+constexpr int ACT_FLOATS = BM * LDA + 16;
+constexpr size_t LDS_BYTES_C = ((size_t)ACT_FLOATS + 2 * STAGE_U32) * sizeof(float);   // 144,448 bytes
+}  // namespace fx
+
+template <int WM, int WN>
+__device__ __forceinline__ void x3c_layer(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act, int lda,
+                                          int row_tile0, int col_tile0, bool last) {
+  using namespace fx;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int K = L.K, N = L.N;
+  const int NT32 = (N + 31) / 32;
+  const int KS4 = ((K + 15) / 16 + 3) & ~3;
+  const bool active = col_tile0 < NT32;     // wave-uniform
+  unsigned* stage = reinterpret_cast<unsigned*>(act + ACT_FLOATS);
+  unsigned b_voff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+    b_voff[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 3072 + lane * 16);
+  fx_gbyte_t wb = (fx_gbyte_t)L.W;
+  // producer side: this lane's four raw values of a k-step and where their pieces go
+  const int p_row = wave * 16 + (lane >> 2), p_k4 = (lane & 3) * 4;
+  const float* p_rd = act + p_row * lda + p_k4;
+  const int p_wr = ((p_row >> 5) * 64 + (p_row & 31) + 32 * (p_k4 >> 3)) * 4 + ((p_k4 >> 2) & 1) * 2;   // u32 index in a piece plane
+  // consumer side: fragment (piece pc, row tile i) of a stage = 64 lanes x 16 bytes
+  const int c_rd = (row_tile0 * 64 + lane) * 4;
+
+  float e_sc[WN], e_sh[WN];
+  const float e_slope = L.act == 1 ? L.slope : 1.f;
+  const bool slope_unit = e_slope >= 0.f && e_slope <= 1.f;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = (col_tile0 + j) * 32 + l31;
+    const bool real = n < N;
+    const int nc = real ? n : N - 1;
+    e_sc[j] = real ? (L.scale ? L.scale[nc] : 1.f) : 0.f;
+    e_sh[j] = real ? (L.shift ? L.shift[nc] : 0.f) : 0.f;
+  }
+
+  f32x16 acc[WM][WN];
+  f32x4 raw[2];                    // this lane's raw values of k-steps s + 2 (split in step s) and s + 3: read TWO steps
+                                   // before their split, so that the split has its data at the start of the step
+  Pieces ap[2][WM];                // fragments of k-steps s (multiplied) and s + 1 (in flight from the stage)
+  u32x4_t fb[RING][WN][3];
+
+  auto rawread = [&](int ks, f32x4& r) {
+    const int kc = ks < KS4 ? ks : KS4 - 1;
+    r = *reinterpret_cast<const f32x4*>(p_rd + kc * 16);
+  };
+  auto produce = [&](int ks, const f32x4& r) {     // split r (the raw values of k-step ks) into stage ks & 1
+    unsigned h0, m0_, l0, h1, m1, l1;
+    split_pair(r[0], r[1], h0, m0_, l0);
+    split_pair(r[2], r[3], h1, m1, l1);
+    unsigned* st = stage + (ks & 1) * STAGE_U32 + p_wr;
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2_t*>(st) = u32x2_t{h0, h1};
+    *reinterpret_cast<u32x2_t*>(st + 2 * 64 * 4) = u32x2_t{m0_, m1};
+    *reinterpret_cast<u32x2_t*>(st + 2 * 2 * 64 * 4) = u32x2_t{l0, l1};
+  };
+  auto fetch = [&](int ks, Pieces (&q)[WM]) {   // fragments of k-step ks out of its stage
+    const unsigned* st = stage + (ks & 1) * STAGE_U32 + c_rd;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) q[i].p[pc] = *reinterpret_cast<const u32x4_t*>(st + (pc * 2 + i) * 64 * 4);
+  };
+  auto bload = [&](u32x4_t (&b)[WN][3], int ks) {
+    const int kc = ks < KS4 ? ks : KS4 - 1;
+    fx_gbyte_t p = wb + (size_t)kc * NT32 * 3072;
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[j][q] = *(fx_gvec_t)(p + b_voff[j] + q * 1024);
+  };
+  auto mma = [&](const Pieces (&a)[WM], const u32x4_t (&b)[WN][3]) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i].p[X3_PA[t]]),
+                                                              __builtin_bit_cast(bf16x8_t, b[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
+  };
+  auto pattern = [&]() {
+    constexpr int NM = WM * WN * 6, NVM = 3 * WN, NDS = 3 * WM + 1;
+    if constexpr (NM >= 48) {      // (the narrow output layers are left to the compiler's own order)
+      // the split of step s + 2 and its three LDS writes FIRST (they must have landed long before the next barrier, which
+      // waits for this wave's LDS operations), then the fragment reads, then the weight loads
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { FX_SGB(SG_MFMA, 1); FX_SGB(SG_VALU, 2); }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { FX_SGB(SG_MFMA, 1); FX_SGB(0x200, 1); }
+#pragma unroll
+      for (int q = 0; q < NDS; ++q) { FX_SGB(SG_MFMA, 1); FX_SGB(SG_DS_RD, 1); }
+#pragma unroll
+      for (int q = 0; q < NVM; ++q) { FX_SGB(SG_MFMA, 1); FX_SGB(SG_VMEM_RD, 1); }
+      FX_SGB(SG_MFMA, NM - 15 - NDS - NVM);
+    }
+  };
+  // step s: barrier (stage (s + 1) & 1 is complete) | split + write of s + 2 | fragments of s + 1, raw of s + 3 | weights of
+  // s + 3 | MFMAs of s
+  auto step = [&](int s, const Pieces (&ap_cur)[WM], Pieces (&ap_nxt)[WM], const u32x4_t (&b_cur)[WN][3],
+                  u32x4_t (&b_free)[WN][3], f32x4& r) {
+    __syncthreads();
+    produce(s + 2, r);             // (r holds k-step s + 2, read during step s - 2; stage s & 1 was last read in step s - 1)
+    fetch(s + 1, ap_nxt);
+    rawread(s + 4, r);
+    if (active) {
+      bload(b_free, s + 3);
+      mma(ap_cur, b_cur);
+      pattern();
+    }
+  };
+  auto quad = [&](int g) {
+    step(g, ap[0], ap[1], fb[0], fb[3], raw[0]);
+    step(g + 1, ap[1], ap[0], fb[1], fb[0], raw[1]);
+    step(g + 2, ap[0], ap[1], fb[2], fb[1], raw[0]);
+    step(g + 3, ap[1], ap[0], fb[3], fb[2], raw[1]);
+  };
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue: pieces of steps 0 and 1 into their stages, fragments of step 0 into registers, raw of steps 2, 3 in flight
+  if (active) {
+    bload(fb[0], 0);
+    bload(fb[1], 1);
+    bload(fb[2], 2);
+  }
+  rawread(0, raw[0]);
+  rawread(1, raw[1]);
+  produce(0, raw[0]);
+  produce(1, raw[1]);
+  rawread(2, raw[0]);
+  rawread(3, raw[1]);
+  __syncthreads();
+  fetch(0, ap[0]);
+  quad(0);
+  for (int g = 4; g < KS4; g += 4) quad(g);
+
+  __syncthreads();   // every wave has read its last raw values and fragments: the buffer may be overwritten
+  if (active) {
+    if (last) {
+      GemmProb p;
+      p.C = net.out; p.ldc = net.ld_out;
+      p.M = M; p.N = N; p.K = K;
+      p.scale = L.scale; p.shift = L.shift; p.resid = nullptr; p.ldr = 0;
+      p.act = L.act; p.slope = L.slope;
+      p.A = nullptr; p.W = nullptr; p.lda = 0; p.ldw = 0;
+      epilogue<WM, WN>(p, acc, m0 + row_tile0 * 32, col_tile0 * 32, l31, lh);
+    } else {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int n = (col_tile0 + j) * 32 + l31;
+        if (col_tile0 + j >= NT32) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float y = acc[i][j][r] * e_sc[j] + e_sh[j];
+            act[row * lda + n] = slope_unit ? fmaxf(y, y * e_slope) : (y >= 0.f ? y : y * e_slope);
+          }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(fx::NT) void mlp_fused_x3c_kernel(FusedMlpArgs args) {
+  using namespace fx;
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const FusedNet& net = args.net[blockIdx.y];
+  const int M = args.M, m0 = blockIdx.x * BM;
+  const int tid = threadIdx.x;
+  {
+    const int K0 = net.layer[0].K;
+    const int kpad = (K0 + 63) / 64 * 64;
+    const int c4n = kpad / 4;
+    for (int i = tid; i < BM * c4n; i += NT) {
+      const int r = i / c4n, c = (i % c4n) * 4;
+      const int row = m0 + r < M ? m0 + r : M - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < K0) v = *reinterpret_cast<const f32x4*>(net.x + (size_t)row * net.ldx + c);
+      *reinterpret_cast<f32x4*>(act + r * LDA + c) = v;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < net.n_layers; ++l) {
+    const FusedLayer& L = net.layer[l];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool last = l == net.n_layers - 1;
+    if (L.N <= 32) x3c_layer<1, 1>(net, L, M, m0, act, LDA, wave & 1, wave >> 1, last);
+    else if (L.N <= 128) x3c_layer<1, 2>(net, L, M, m0, act, LDA, wave & 1, (wave >> 1) * 2, last);
+    else x3c_layer<2, 4>(net, L, M, m0, act, LDA, 0, wave * 4, last);
+  }
+}
+
 __global__ __launch_bounds__(fx::NT) void mlp_fused_x3_kernel(FusedMlpArgs args) {
   using namespace fx;
   extern __shared__ __attribute__((aligned(16))) float act[];
@@ -245,8 +463,13 @@ __global__ __launch_bounds__(fx::NT) void mlp_fused_x3_kernel(FusedMlpArgs args)
 }
 
 hipError_t launch_mlp_fused_x3(const FusedMlpArgs& args, hipStream_t stream) {
-  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_x3_kernel), fx::LDS_BYTES)) return e;
   dim3 grid((args.M + fx::BM - 1) / fx::BM, args.count);
+  if (options().mlp_x3 >= 2) {   // opt-in: the cooperative split (measured slower, see x3c_layer)
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_x3c_kernel), fx::LDS_BYTES_C)) return e;
+    hipLaunchKernelGGL(mlp_fused_x3c_kernel, grid, dim3(fx::NT), fx::LDS_BYTES_C, stream, args);
+    return hipGetLastError();
+  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(mlp_fused_x3_kernel), fx::LDS_BYTES)) return e;
   hipLaunchKernelGGL(mlp_fused_x3_kernel, grid, dim3(fx::NT), fx::LDS_BYTES, stream, args);
   return hipGetLastError();
 }

@@ -100,11 +100,14 @@ int main(int argc, char** argv) {
       float ms; (void)hipEventElapsedTime(&ms, e0, e1);
       best = ms / 10 < best ? ms / 10 : best;
     }
-    printf("%-10s T=%d: %.1f us/launch  %.1f TFLOP/s fp32-equivalent  (%s)\n", name, T, best * 1e3, flops / best * 1e-9,
+    printf("%-30s T=%d: %.1f us/launch  %.1f TFLOP/s fp32-equivalent  (%s)\n", name, T, best * 1e3, flops / best * 1e-9,
            hipGetErrorString(hipGetLastError()));
   };
   time_it("fp32 mfma", [&] { return launch_mlp_fused(a32, 0); });
-  time_it("3 x bf16", [&] { return launch_mlp_fused_x3(ax3, 0); });
+  options().mlp_x3 = 2;
+  time_it("3 x bf16 (cooperative split)", [&] { return launch_mlp_fused_x3(ax3, 0); });
+  options().mlp_x3 = 1;
+  time_it("3 x bf16 (every wave splits)", [&] { return launch_mlp_fused_x3(ax3, 0); });
 
   // accuracy on sampled rows
   std::vector<int> rows;
