@@ -329,7 +329,9 @@ def main():
     rank = int(os.environ.get('RANK', '0')) if launched else 0
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
     if args.gpus != world:
-        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+        raise SystemExit('--gpus {} but WORLD_SIZE={} (RANK / WORLD_SIZE inherited from the environment, e.g. a SLURM step or '
+                         'a parent launcher\'s shell, count as "already launched": unset them or pass the matching --gpus)'
+                         .format(args.gpus, world))
     dist = None
     if D.dist_backend(torch.device('cuda')) == 'gloo' and launched:
         # device-less rendezvous (EMPOSE_DIST_BACKEND=gloo: the launcher's CPU test): join, meet the other ranks, then
@@ -369,6 +371,7 @@ def main():
         out = net.forward_tensors(*inputs)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _lib.check(_lib.lib().empose_async_status())   # a cooperative LSTM kernel that gave up on a poll wrote NaN: not a result
     if dist is not None:
         cdev = D.collective_device(dev)     # the GPU under RCCL (the host under the gloo self-test)
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)

@@ -84,7 +84,8 @@ class MlpParams(C.Structure):    # empose_mlp_params: DEVICE pointers
                 ('bn_weight', C.c_void_p * MAX_DENSE), ('bn_bias', C.c_void_p * MAX_DENSE),
                 ('bn_running_mean', C.c_void_p * MAX_DENSE), ('bn_running_var', C.c_void_p * MAX_DENSE),
                 ('bn_num_batches', C.c_void_p * MAX_DENSE), ('prelu', C.c_void_p * MAX_DENSE),
-                ('bn_eps', C.c_float), ('bn_momentum', C.c_float), ('weight_t', C.c_void_p * MAX_DENSE)]
+                ('bn_eps', C.c_float), ('bn_momentum', C.c_float), ('weight_t', C.c_void_p * MAX_DENSE),
+                ('save_layout', C.c_int)]
 
 
 class MlpGrads(C.Structure):     # empose_mlp_grads
@@ -161,6 +162,7 @@ SIGNATURES = {
     'empose_gemm_atb_f32': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'empose_transpose_f32': (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'empose_mlp_train_save_layout': (C.c_int, [C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_save_floats': (C.c_size_t, [C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_workspace_bytes': (C.c_size_t, [C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_fwd': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

@@ -587,9 +587,13 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   const size_t bh = (size_t)B * H;
   // a poll of a cooperative kernel of an EARLIER call gave up: everything that call (and what was fed from it) produced
   // is NaN.  Reported once, here, without synchronising (the counter is a host-mapped word).
-  if (const unsigned n = poll_timeouts_take())
+  // STICKY: the count is only looked at here; it stays set -- and every recurrence of the process keeps failing, whichever
+  // model, stream or thread it belongs to -- until empose_async_status() has reported and cleared it.  (Clearing it here
+  // let the one call that happened to come next swallow the report while the call that produced the NaNs returned OK.)
+  if (const unsigned n = poll_timeouts_peek())
     return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative LSTM kernel launched by an earlier call timed out waiting for "
-                "another workgroup's exchange word; that call's outputs are NaN (the state it carried too)", n);
+                "another workgroup's exchange word; that call's outputs are NaN (the state it carried too); "
+                "empose_async_status() reports and clears this", n);
   // the wavefront kernel addresses its operands with 32-bit byte offsets from a per-segment base
   if ((size_t)B * F * (size_t)(ldx > 2 * H ? ldx : 2 * H) * sizeof(float) >= ((size_t)1 << 32))
     return fail(EMPOSE_EINVAL, "LSTM batch of %d x %d frames is too large for one call; split the batch", B, F);
@@ -886,7 +890,8 @@ unsigned* poll_timeout_word() {
   static std::once_flag once;
   std::call_once(once, [] {
     void* h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+    // (Portable: the word is pinned for every device of the process, not only the one that happens to be current here)
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
     std::memset(h, 0, 64);
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
@@ -898,6 +903,10 @@ unsigned* poll_timeout_word() {
 unsigned poll_timeouts_take() {
   if (!g_timeout_host) return 0;
   return __atomic_exchange_n(g_timeout_host, 0u, __ATOMIC_RELAXED);
+}
+unsigned poll_timeouts_peek() {
+  if (!g_timeout_host) return 0;
+  return __atomic_load_n(g_timeout_host, __ATOMIC_RELAXED);
 }
 
 hipError_t coresident_blocks(const void* fn, int threads, size_t lds_bytes, int* blocks) {
@@ -1726,7 +1735,9 @@ MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
 // tested, but at 256 windows the step is no faster (the operand transform and the statistics epilogue cost the GEMMs
 // about what the removed passes cost: 701-711 k against 705-720 k frames/s).  Option "train_fused": 0 never (default),
 // 1 from BN_SINGLE_PASS_ROWS rows on, 2 always (tests).
+// (empose_mlp_params::save_layout != 0: the layout chosen when the step's forward ran wins over the options of the moment)
 bool mlp_train_fused(const empose_mlp_params* p, int M) {
+  if (p->save_layout) return p->save_layout == 2;
   const int opt = options().train_fused;
   return opt != 0 && (opt == 2 || M > BN_SINGLE_PASS_ROWS) && p->hidden % 4 == 0 && p->in_dim % 4 == 0;
 }
@@ -1735,6 +1746,7 @@ bool mlp_train_fused(const empose_mlp_params* p, int M) {
 // bn_finish_*): GEMM + 1 launch instead of GEMM + 3, and every consumer reads a ready operand.  Option "train_epi":
 // 0 never, 1 above BN_SINGLE_PASS_ROWS rows (default), 2 always (tests).  "train_fused" takes precedence when both apply.
 bool mlp_train_epi(const empose_mlp_params* p, int M) {
+  if (p->save_layout) return p->save_layout == 3;
   const int opt = options().train_epi;
   return !mlp_train_fused(p, M) && opt != 0 && (opt == 2 || M > BN_SINGLE_PASS_ROWS) && p->hidden % 4 == 0 &&
          p->in_dim % 4 == 0;
@@ -1747,6 +1759,12 @@ size_t mlp_layer_save(const empose_mlp_params* p, int M) {
   return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden;
 }
 }  // namespace
+
+int empose_mlp_train_save_layout(const empose_mlp_params* p, int M) {
+  if (!p || M <= 0) return fail(EMPOSE_EINVAL, "null parameters / no rows");
+  if (p->save_layout < 0 || p->save_layout > 3) return fail(EMPOSE_EINVAL, "save_layout must be 0 .. 3");
+  return mlp_train_fused(p, M) ? 2 : (mlp_train_epi(p, M) ? 3 : 1);
+}
 
 size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M) {
   if (!p || M <= 0) return 0;

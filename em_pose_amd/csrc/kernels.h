@@ -52,6 +52,7 @@ Options& options();
 // forces a limit, for tests.
 unsigned* poll_timeout_word();          // device-visible address of the counter
 unsigned poll_timeouts_take();          // host: read and clear
+unsigned poll_timeouts_peek();          // host: read
 constexpr size_t LDS_BYTES_PER_CU = 160 * 1024;
 hipError_t allow_dynamic_lds(const void* fn, size_t bytes);
 // Workgroups of `fn` (block size `threads`, `lds_bytes` of dynamic LDS) that can be resident at once on the CURRENT device:

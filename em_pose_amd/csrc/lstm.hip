@@ -879,12 +879,13 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
       for (int g = 0; g < 4; ++g) w[g] = *reinterpret_cast<const f32x4*>(wbase + (size_t)g * H * sg.ldw + k4);
 #pragma unroll
       for (int b = 0; b < MB; ++b) {
-        if (b >= B) break;   // uniform
-        const int tr = (lens ? lens[b] : F) - 1 - sg.k;
-        const float* row = sg.a + (size_t)b * sg.lda + (size_t)(tr > 0 ? tr : 0) * sg.tstride;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(row + k4);
+        if (b < B) {   // uniform; a predicate, not a `break`: the loop then unrolls completely and acc[][] stays in registers
+          const int tr = (lens ? lens[b] : F) - 1 - sg.k;
+          const float* row = sg.a + (size_t)b * sg.lda + (size_t)(tr > 0 ? tr : 0) * sg.tstride;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(row + k4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g][b] = dot4_acc(acc[g][b], w[g], v);
+          for (int g = 0; g < 4; ++g) acc[g][b] = dot4_acc(acc[g][b], w[g], v);
+        }
       }
     }
   }
@@ -893,11 +894,12 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      if (b >= B) break;
-      float v = acc[g][b];
+      if (b < B) {
+        float v = acc[g][b];
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      acc[g][b] = v;
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[g][b] = v;
+      }
     }
   // lane b finishes row b
   float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;

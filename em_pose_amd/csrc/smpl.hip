@@ -750,14 +750,16 @@ __global__ void mesh_chain_kernel(MeshChainArgs a) {
   const int t = idx / (nj * 3), jr = idx % (nj * 3), j = jr / 3, r = jr % 3;
   const float* R = a.rot + (size_t)t * NB * 9;
   const float* J = a.out + (size_t)t * a.ncp + a.j_off;
-  int path[MESH_MAX_JOINTS];
+  // the joints from the root down to j, without a per-thread array of the path (a dynamically indexed array lives in
+  // scratch memory): the ancestor k levels above j is found by walking up k times -- chains are at most a dozen joints long
   int n = 0;
-  for (int q = j; q >= 0; q = a.parents[q]) path[n++] = q;
+  for (int q = j; q >= 0; q = a.parents[q]) ++n;
   float row0 = R[r * 3 + 0], row1 = R[r * 3 + 1], row2 = R[r * 3 + 2];
   float tr = J[r];
   int prev = 0;
   for (int k = n - 2; k >= 0; --k) {
-    const int q = path[k];
+    int q = j;
+    for (int up = 0; up < k; ++up) q = a.parents[q];
     const float* Jq = J + q * 3;
     const float* Jp = J + prev * 3;
     tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;

@@ -163,6 +163,9 @@ def partition_sequences(lengths, world_size):
     return [sorted(p) for p in parts]
 
 
+DEFER_FRAME_BUDGET = 65536   # evaluate_sequences: frames whose metrics may wait for one joint launch
+
+
 def _check_async(dev):
     """After a synchronisation: a cooperative LSTM kernel that gave up on a poll poisoned its outputs with NaN and counted
     itself (include/empose_hip.h, empose_async_status) -- raise instead of averaging NaNs into the metrics table."""
@@ -202,8 +205,24 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
     # ... and on the device path the metrics themselves are computed ONCE, over the frames of all chunks: a chunk only
     # leaves its tensors in `deferred` (the per-chunk forward-kinematics + metrics launches and the tensor plumbing around
     # them were 0.27 ms of host time per chunk, a quarter of a pass that is bound by the host).
-    deferred = []
+    deferred, deferred_frames = [], 0
     defer = getattr(me_rows, 'angle_glob', False) and hasattr(smpl_model, 'fk_joints')
+
+    def flush_deferred():
+        # one forward-kinematics launch and one metrics launch over the frames of the deferred chunks, in chunk order; shapes
+        # per frame (ground truth: the recording's; estimate: the recording's first chunk's, evaluate_real.py:63-68).  Called
+        # at the end of the pass and whenever DEFER_FRAME_BUDGET frames have piled up (each deferred chunk pins its staging
+        # buffer and outputs, ~1.8 KB per frame; the rows of a flush stay on the device until the pass ends, 65 doubles per frame)
+        nonlocal deferred, deferred_frames
+        if not deferred:
+            return
+        frames_of = lambda t: t.reshape(-1, t.shape[-1])
+        cat = lambda k: torch.cat([frames_of(d[k]) for d in deferred]).unsqueeze(0)
+        per_frame = lambda k, alt: torch.cat([(d[k] if d[k] is not None else d[alt]).reshape(1, -1)
+                                              .expand(d[0].shape[1], -1) for d in deferred]).unsqueeze(0)
+        me_rows.compute(cat(0), per_frame(1, 1), cat(2), per_frame(3, 1), None, cat(4), cat(5),
+                        valid=torch.cat([d[6].reshape(-1) for d in deferred]).unsqueeze(0))
+        deferred, deferred_frames = [], 0
     is_lgd = isinstance(net, IterativeErrorFeedback)
     ws = window_size if is_lgd else None
     # Chunks of a recording depend on each other only through the LSTM state, so chunk c + 1's packing + LSTM (current
@@ -248,6 +267,10 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                         first_shape_hat = out['shape_hat'][:, 0] if out['shape_hat'] is not None else None
                     deferred.append((chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape_hat, chunk.poses_root,
                                      out['root_ori_hat'], valid))
+                    deferred_frames += chunk.seq_length
+                    if deferred_frames >= DEFER_FRAME_BUDGET:   # bound what is kept alive: row order is unchanged
+                        torch.cuda.current_stream(dev).wait_stream(side)
+                        flush_deferred()
                     lap('metrics_enqueue')
                     continue
                 with torch.cuda.stream(side) if side is not None else _nothing():
@@ -262,16 +285,7 @@ def evaluate_sequences(net, batches, smpl_model, device, window_size=256, log=No
                 lap('metrics_enqueue')
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)   # every chunk's outputs / rows are complete
-        if deferred:
-            # one forward-kinematics launch and one metrics launch over every frame of the pass, in chunk order; shapes per
-            # frame (ground truth: the recording's; estimate: the recording's first chunk's, evaluate_real.py:63-68)
-            frames_of = lambda t: t.reshape(-1, t.shape[-1])
-            cat = lambda k: torch.cat([frames_of(d[k]) for d in deferred]).unsqueeze(0)
-            per_frame = lambda k, alt: torch.cat([(d[k] if d[k] is not None else d[alt]).reshape(1, -1)
-                                                  .expand(d[0].shape[1], -1) for d in deferred]).unsqueeze(0)
-            me_rows.compute(cat(0), per_frame(1, 1), cat(2), per_frame(3, 1), None, cat(4), cat(5),
-                            valid=torch.cat([d[6].reshape(-1) for d in deferred]).unsqueeze(0))
-            deferred = []
+        flush_deferred()
         st = me_rows.state()        # (reads the rows back: the device is in sync afterwards)
         _check_async(dev)
         lap('wait_for_device_and_rows')

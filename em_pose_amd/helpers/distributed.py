@@ -51,7 +51,8 @@ def launch_ranks(script, argv, n, poll_s=0.2):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # (the host driver only supports dmabuf IPC; a user's own setting wins)
         env.setdefault('OMP_NUM_THREADS', str(max(1, cores // n)))
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
     rc, clean = 0, False
@@ -314,6 +315,12 @@ def attach_gradient_buckets(net, buckets):
 
 
 _ONE_SHOT_BUCKETS = {}
+
+
+def drop_one_shot_buckets():
+    """Forget the buckets `allreduce_gradients` keeps for the last parameter list (they hold strong references to its
+    parameters and flat gradient buffers): call it when that model is done with."""
+    _ONE_SHOT_BUCKETS.clear()
 
 
 def allreduce_gradients(parameters, bucket_bytes=8 << 20, group=None):

@@ -44,6 +44,17 @@ class _MlpView(object):
         self.hidden = self.specs[0][0].out_features
         self.out_dim = self.specs[-1][0].out_features
         self.weight_t = None
+        self.save_layout = 0      # fix_layout(): how this step's forward lays out its saved activations
+
+    def fix_layout(self, lib, M):
+        """Pin the save-buffer layout of this step to what the library's options select NOW: the backward and weight-gradient
+        calls then read the buffer the way the forward wrote it, whatever happens to the options in between."""
+        self.save_layout = 0
+        p = self.params()
+        layout = lib.empose_mlp_train_save_layout(C.byref(p), int(M))
+        if layout <= 0:
+            _lib.check(layout)
+        self.save_layout = layout
 
     @staticmethod
     def supported(mlp):
@@ -70,6 +81,7 @@ class _MlpView(object):
                     p.bn_num_batches[l] = bn.num_batches_tracked.data_ptr()
                 p.prelu[l] = act.weight.data_ptr()
                 p.bn_eps, p.bn_momentum = float(bn.eps), float(bn.momentum)
+        p.save_layout = self.save_layout
         for l, t in enumerate(self.weight_t or ()):   # transposed once per step (prepare_backward)
             if t is not None:
                 p.weight_t[l] = t.data_ptr()
@@ -138,6 +150,7 @@ class LgdTrainEngine(object):
         self._side_streams = {}
         self._use_side = False
         self._held = []
+        self._forked = set()      # side streams forked and not yet joined
 
     # ---- the side stream ------------------------------------------------------------------------------------------
     def _side(self, k=0):
@@ -150,18 +163,23 @@ class LgdTrainEngine(object):
         """Side stream k continues from what the main stream has enqueued so far."""
         if self._use_side:
             self._side(k).wait_stream(torch.cuda.current_stream(self.dev))
+            self._forked.add(k)
 
     def _join(self, k=0):
-        """The main stream continues after what side stream k has enqueued so far."""
-        if self._use_side:
+        """The main stream continues after what side stream k has enqueued so far.  Only a stream that was forked since its
+        last join is waited for: under HIP-graph capture a wait on an event of a stream that never joined the capture is an
+        isolation error, and a step whose options leave a stream unused must not touch it."""
+        if self._use_side and k in self._forked:
             torch.cuda.current_stream(self.dev).wait_stream(self._side(k))
-            self._held = []
+            self._forked.discard(k)
+        if not self._forked:
+            self._held = []       # nothing is running beside the main stream: its workspaces may go back to the allocator
 
     def _hold(self, t):
         """A main-stream workspace must not go back to the allocator between a fork and the next join: the block would be
         handed to the next main-pool allocation, and that tensor may be written by the side stream (which forked before
         the main-stream kernels that still use the workspace were enqueued)."""
-        if self._use_side:
+        if self._use_side and self._forked:
             self._held.append(t)
         return t
 
@@ -364,6 +382,8 @@ class LgdTrainEngine(object):
                                                      lin.out_features, H, None, lin.bias.data_ptr(), 0, 0.0, self.stream))
             else:
                 ctx['init_views'] = (_MlpView(net.pose_net_init), _MlpView(net.shape_net_init))
+                for v in ctx['init_views']:
+                    v.fix_layout(self.lib, T)
                 ctx['init_saves'] = (self._mlp_fwd(ctx['init_views'][0], x0.data_ptr(), d_in, pose_hist[0].data_ptr(), 66, T),
                                      self._mlp_fwd(ctx['init_views'][1], x0.data_ptr(), d_in, tmp10.data_ptr(), 10, T))
             if net.shape_avg:
@@ -372,6 +392,8 @@ class LgdTrainEngine(object):
                 self._axpby(T, 10, 1.0, tmp10.data_ptr(), 10, 0.0, None, 0, shape_hist[0].data_ptr(), 10)
 
             views = (_MlpView(net.pose_net_iter), _MlpView(net.shape_net_iter))
+            for v in views:
+                v.fix_layout(self.lib, T)
             X = self.new(max(N, 1), T, d_x)
             dp, ds = self.new(T, 66), self.new(T, 10)
             saves = []

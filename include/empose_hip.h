@@ -67,7 +67,9 @@ const char* empose_arch(void);
  * gradients: whole-tile / whole-chunk products on a branch-free interior kernel, bit-identical; 0 = the general kernel),
  * "mlp_x3" (the fused update MLPs form every fp32 product from three bf16 pieces per operand -- six bf16 matrix-core
  * products with fp32 accumulation, fp32-equivalent and 2.7 times the fp32 instruction's rate -- when every hidden width
- * is a multiple of 64: 1 [default]; 0 = the fp32 MFMA instruction),
+ * is a multiple of 64: 1 [default]; 0 = the fp32 MFMA instruction; 2 = a variant whose waves share the operand split
+ * through LDS, measured slower), "lstm_x3" (the same arithmetic for the LSTM steps of batches above 256 rows, inference,
+ * uni-directional stacks with a hidden size of whole 32s: 1 [default]; 0 = the fp32 MFMA instruction),
  * "mesh_skin_mfma" (split-bf16 full-mesh variant only: the bone blend as a second matrix-core contraction; 0 [default,
  * measured faster] = vector skinning), "spin_limit" (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
@@ -79,10 +81,12 @@ int empose_reset_options(void);   /* every option back to its default */
  * one such failure this library has: the whole-sequence LSTM kernels (small batches: lstm_persist; opt-in lstm_seq) are
  * cooperative -- workgroups poll exchange words written by other workgroups -- and a poll that exceeds its spin limit
  * gives up, writes NaN from there on (it never hangs the GPU) and counts itself in a host-visible word.
- *   - the next empose_lstm_fwd / empose_rnn_fwd / empose_lgd_forward[_phase] call returns EMPOSE_ETIMEOUT (once) instead
- *     of running, with the count in empose_last_error();
- *   - empose_async_status() returns EMPOSE_ETIMEOUT (once) or EMPOSE_OK: call it after synchronising the stream, before
- *     trusting / averaging outputs (em_pose_amd.eval.helpers does).
+ *   - every later empose_lstm_fwd / empose_rnn_fwd / empose_lgd_forward[_phase] call of the process returns
+ *     EMPOSE_ETIMEOUT instead of running (count in empose_last_error()) -- STICKY, whichever model, stream or thread it
+ *     belongs to -- until
+ *   - empose_async_status() has returned EMPOSE_ETIMEOUT once (it reports and clears; EMPOSE_OK otherwise): call it after
+ *     synchronising the stream, before trusting / averaging outputs (em_pose_amd.eval.helpers, bench.py and
+ *     scripts/train.py do), and re-create the state the failed call carried (it is NaN).
  * Option "spin_limit" (> 0) forces the limit of those polls (tests).  The reference's forward has no counterpart (a
  * single Python thread, reference nn/layers.py:133-157). */
 int empose_async_status(void);
@@ -347,6 +351,11 @@ typedef struct {
    * With NULL entries the backward transposes the weights itself on every call; a caller that applies the network
    * several times per step (the LGD loop) transposes once per step instead. */
   const float* weight_t[EMPOSE_MAX_DENSE];
+  /* How `save` is laid out: 0 = whatever the options "train_fused" / "train_epi" select AT THE TIME OF EACH CALL (every
+   * call of a step must then see the same options); 1 / 2 / 3 = the layout empose_mlp_train_save_layout() reported when
+   * the forward ran -- the backward and weight-gradient calls of that step then read the buffer the way it was written
+   * even if an option changed in between (an A/B script, another thread). */
+  int save_layout;
 } empose_mlp_params;
 typedef struct {                /* gradient outputs, shapes of the parameters */
   float* weight[EMPOSE_MAX_DENSE];
@@ -356,6 +365,9 @@ typedef struct {                /* gradient outputs, shapes of the parameters */
   float* prelu[EMPOSE_MAX_DENSE];
 } empose_mlp_grads;
 /* `save`: per hidden layer the pre-BatchNorm and the activated outputs [M][hidden] and the batch mean / rstd. */
+/* 1 (BatchNorm kernels) / 2 (BatchNorm folded into the GEMMs) / 3 (statistics in the GEMM epilogues): the layout the
+ * current options select for M rows; store it in empose_mlp_params::save_layout for the calls of the step. */
+int empose_mlp_train_save_layout(const empose_mlp_params* p, int M);
 size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M);
 size_t empose_mlp_train_workspace_bytes(const empose_mlp_params* p, int M);
 /* x [M][ldx] -> out [M][ld_out] (out_dim columns written). */

@@ -19,4 +19,5 @@ hipError_t coresident_blocks(const void* fn, int threads, size_t lds, int* block
 }
 unsigned* poll_timeout_word() { static unsigned* p = nullptr; if (!p) (void)hipMalloc(&p, 64); return p; }
 unsigned poll_timeouts_take() { return 0; }
+unsigned poll_timeouts_peek() { return 0; }
 }  // namespace empose

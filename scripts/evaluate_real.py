@@ -167,7 +167,9 @@ def main():
     rank = int(os.environ.get('RANK', '0')) if launched else 0
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
     if args.gpus not in (1, world):
-        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+        raise SystemExit('--gpus {} but WORLD_SIZE={} (RANK / WORLD_SIZE inherited from the environment, e.g. a SLURM step or '
+                         'a parent launcher\'s shell, count as "already launched": unset them or pass the matching --gpus)'
+                         .format(args.gpus, world))
     dist = None
     if on_cpu:
         if world > 1:

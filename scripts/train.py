@@ -208,7 +208,7 @@ def main():
     p.add_argument('--single_stream', action='store_true',
                    help='A/B: the training engine on one stream (default: shape network, weight gradients on a side stream)')
     p.add_argument('--streams', default=None, help="A/B: which parts of the step use the engine's side stream, e.g. 'bwd,wgrad' "
-                                                   "(default: fwd,bwd,wgrad)")
+                                                   "(default: fwd,bwd,bwd3,wgrad)")
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
     p.add_argument('--option', action='append', default=[], metavar='NAME=INT',
                    help='kernel-variant switch of the library (empose_set_option), e.g. train_fused=0; repeatable')
@@ -233,7 +233,9 @@ def main():
     rank = int(os.environ.get('RANK', '0')) if launched else 0
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if launched else 0
     if args.gpus not in (1, world):
-        raise SystemExit('--gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+        raise SystemExit('--gpus {} but WORLD_SIZE={} (RANK / WORLD_SIZE inherited from the environment, e.g. a SLURM step or '
+                         'a parent launcher\'s shell, count as "already launched": unset them or pass the matching --gpus)'
+                         .format(args.gpus, world))
     joined = False
     if launched and D.dist_backend(torch.device('cuda')) == 'gloo':   # device-less rendezvous: the launcher's CPU test
         dist_, rank, world = D.init_process_group(None, log=lambda m: print(m, file=sys.stderr, flush=True))
@@ -314,6 +316,8 @@ def main():
             enq.append(time.perf_counter() - t0)     # host time to enqueue the whole step (before waiting for the device)
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        from em_pose_amd import _lib as _L
+        _L.check(_L.lib().empose_async_status())   # (a cooperative LSTM kernel that gave up on a poll: the step's values are NaN)
         if step >= args.warmup:
             times.append(dt)
         if rank == 0:

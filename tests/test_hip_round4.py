@@ -56,7 +56,7 @@ def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
             np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
     assert timed_out >= 1, 'spin_limit = 1 never made a poll give up: the test does not exercise the status path'
 
-    # the other way of learning about it: the next call that runs a recurrence refuses, once
+    # the other way of learning about it: the next call that runs a recurrence refuses
     _lib.check(lib.empose_set_option(b'spin_limit', 1))
     refused = False
     for attempt in range(12):
@@ -71,7 +71,13 @@ def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
     _lib.check(lib.empose_set_option(b'spin_limit', 0))
     assert refused, 'no poll gave up in 12 launches with spin_limit = 1'
     torch.cuda.synchronize()
-    assert lib.empose_async_status() == 0           # the refusal took the counter; nothing was launched since
+    # STICKY: the refusal does not clear the report -- another recurrence (of any model or stream of the process)
+    # is refused too, until empose_async_status() has reported it
+    g.init_state = None
+    with pytest.raises(_lib.EmposeError, match='timed out'):
+        g(x.to(DEV), lens.to(DEV))
+    assert lib.empose_async_status() == ETIMEOUT
+    assert lib.empose_async_status() == 0           # reported and cleared; nothing was launched since
     g.init_state = None
     got = g(x.to(DEV), lens.to(DEV))               # back to normal
     torch.cuda.synchronize()
