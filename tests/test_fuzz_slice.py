@@ -50,7 +50,15 @@ def test_regression_short_masked_carried_windows_b257_f3(force, capsys):
     """The one case above 1e-5 in 700 (seed 3602, case 20: 257 windows of 3 frames, missing sensors, carried LSTM state;
     round 3 measured 1.57e-5 on the general kernels and 1.34e-5 on the frame-per-lane ones).  Pinned with its measured
     bound, and with its conditioning: against the float64 oracle the HIP path is no worse than the fp32 oracle is."""
+    from em_pose_amd import _lib
     from tests.fuzz import fuzz_lgd
+    # round 5: at 257 rows the LSTM steps now form their products from bf16 pieces (lstm_x3.hip), whose rounding differs --
+    # the default path lands BELOW 1e-5 on this case; the pinned regression is the fp32-MFMA step kernel it was found on
+    r = fuzz_lgd.run(seed=3602, n_cases=21, start=20, force=list(force), log=lambda m: _show(capsys, m))
+    assert r['n'] == 1 and r['worst'] < 2.5e-5, r['worst']
+    for case, err, desc, f64 in r['above_1e5']:
+        assert _explained_by_conditioning(f64), f64
+    _lib.check(_lib.lib().empose_set_option(b'lstm_x3', 0))
     r = fuzz_lgd.run(seed=3602, n_cases=21, start=20, force=list(force), log=lambda m: _show(capsys, m))
     assert r['n'] == 1 and r['worst_case'][1] == 'lgdrnn12_n4_carry'
     assert r['worst_case'][2] == dict(B=257, F=3, masks=True, state=True)
