@@ -25,6 +25,7 @@ def _layer(In, H, L, seed):
     return layer.to(DEV), sd
 
 
+@pytest.mark.provokes_poll_timeout
 def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
     """spin_limit = 1: the polls of the small-batch whole-sequence kernel (lstm_persist, B <= 16) give up almost at once.
     The call itself is asynchronous and returns 0; after a synchronisation empose_async_status() says EMPOSE_ETIMEOUT
@@ -86,6 +87,7 @@ def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
     g.release()
 
 
+@pytest.mark.provokes_poll_timeout
 def test_poll_timeout_of_the_large_batch_whole_sequence_kernel_is_reported():
     """The opt-in cooperative kernel for batches above 256 rows (lstm_seq) shares the counter."""
     lib = _lib.lib()
@@ -118,6 +120,7 @@ def test_poll_timeout_of_the_large_batch_whole_sequence_kernel_is_reported():
                     'covered by the lstm_persist test')
 
 
+@pytest.mark.provokes_poll_timeout
 def test_evaluation_driver_raises_instead_of_averaging_nan():
     """em_pose_amd.eval.helpers._check_async: what evaluate_sequences / evaluate_sequences_batched call once the device is
     in sync."""
