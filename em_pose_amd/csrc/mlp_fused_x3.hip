@@ -145,13 +145,53 @@ __device__ __forceinline__ void x3_layer(const FusedNet& net, const FusedLayer& 
       FX_SGB(SG_VALU, vper);
     }
   };
+  // One k-step as NCH chunks, each fenced by a scheduling barrier: 48 / NCH of the step's MFMAs, the split of ONE pair of the
+  // next step's A values (11 VALU) and 16 / NCH of the step's memory operations (the weight loads of step s + 3, the LDS
+  // reads of step s + 2).  Left to itself over a whole step (or four), the scheduler emits the split as one dependent
+  // chain behind the MFMAs and sinks the LDS reads down to their use, where the split then waits for the round trip.
   auto step = [&](int s, const Pieces (&ap_cur)[WM], Pieces (&ap_nxt)[WM], f32x4 (&ra_nxt)[WM][2], f32x4 (&ra_free)[WM][2],
                   const u32x4_t (&b_cur)[WN][3], u32x4_t (&b_free)[WN][3]) {
-    bload(b_free, s + 3);
-    split(ra_nxt, ap_nxt);
-    aread(s + 2, ra_free);
-    mma(ap_cur, b_cur);
-    pattern();
+    constexpr int NM = WM * WN * 6, NP = WM * 4, NMEM = 3 * WN + 2 * WM;   // MFMAs, pairs to split, memory operations
+    constexpr int NCH = NP;                                                // one pair per chunk
+    const int kb = s + 3 < KS4 ? s + 3 : KS4 - 1, ka = s + 2 < KS4 ? s + 2 : KS4 - 1;
+    fx_gbyte_t pb = wb + (size_t)kb * NT32 * 3072;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // ---- memory operations of this chunk
+#pragma unroll
+      for (int o = c * NMEM / NCH; o < (c + 1) * NMEM / NCH; ++o) {
+        if (o < 3 * WN) {
+#ifndef FX_LAB_NOB
+          b_free[o / 3][o % 3] = *(fx_gvec_t)(pb + b_voff[o / 3] + (o % 3) * 1024);
+#endif
+        } else {
+          const int r = o - 3 * WN;
+          ra_free[r / 2][r % 2] = *reinterpret_cast<const f32x4*>(a_rd + (r / 2) * 32 * lda + ka * 16 + (r % 2) * 4);
+        }
+      }
+      // ---- the split of pair c of the next step: row tile c / 4, k pair c % 4
+      {
+        const int i = c / 4, q = c % 4;
+        const f32x4& v = ra_nxt[i][q / 2];
+        unsigned h, m, l;
+#ifdef FX_LAB_NOSPLIT
+        h = __builtin_bit_cast(unsigned, v[(q % 2) * 2]); m = __builtin_bit_cast(unsigned, v[(q % 2) * 2 + 1]); l = h;
+#else
+        split_pair(v[(q % 2) * 2], v[(q % 2) * 2 + 1], h, m, l);
+#endif
+        ap_nxt[i].p[0][q] = h; ap_nxt[i].p[1][q] = m; ap_nxt[i].p[2][q] = l;
+      }
+      // ---- this chunk's share of the step's MFMAs, in (product, row tile, column tile) order
+#pragma unroll
+      for (int mm = c * NM / NCH; mm < (c + 1) * NM / NCH; ++mm) {
+        const int t = mm / (WM * WN), i = (mm / WN) % WM, j = mm % WN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ap_cur[i].p[X3_PA[t]]),
+                                                            __builtin_bit_cast(bf16x8_t, b_cur[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mm = 0; mm < (NM + NCH - 1) / NCH; ++mm) { FX_SGB(SG_MFMA, 1); FX_SGB(SG_VALU, 2); if (mm < 2) FX_SGB(SG_VMEM_RD | SG_DS_RD, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto quad = [&](int g) {
     step(g, ap[0], ap[1], ra[1], ra[0], fb[0], fb[3]);
