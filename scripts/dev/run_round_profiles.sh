@@ -5,7 +5,9 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -5 > gpurun_out/${TAG}_gpu_tests.log
+if [ -z "${SKIP_TESTS:-}" ]; then
+  python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|error|fuzz slice|vs float64|fingerprints" | tail -60 > gpurun_out/${TAG}_gpu_tests.log
+fi
 python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
 python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json   # with its own parity sample (cpu_baseline)
 python bench.py --gpus 1 --force_dist --steps 20 --warmup 3 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024_spawned_rank_nccl.json
@@ -16,11 +18,15 @@ python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail
 python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
 python scripts/train.py --steps 20 --graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph.json
+python scripts/train.py --steps 20 --graph --side_min_frames 0 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph_side_streams.json
 ( for bs in 12 64 256; do for g in "" "--graph" "--single_stream"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --bs_train 256 --json > $OUT.log 2>&1 )
 cp $OUT/t_kernel_stats.csv gpurun_out/${TAG}_train_kernel_stats_bs256.csv
+rm -rf $OUT
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --json > $OUT.log 2>&1 )
+cp $OUT/t_kernel_stats.csv gpurun_out/${TAG}_train_kernel_stats_bs12.csv
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vb -- python $R/bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
 cp $OUT/vb_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_bf16x3_t16384.csv
@@ -34,4 +40,5 @@ rm -rf $OUT
 python scripts/dev/bench_lstm_small.py > gpurun_out/${TAG}_lstm_small_batch_per_step.txt 2>&1
 python scripts/dev/bench_lstm_mid.py > gpurun_out/${TAG}_lstm_medium_batch_per_step.txt 2>&1
 python scripts/dev/prof_seq.py > gpurun_out/${TAG}_streaming_forward_b1_f256.txt 2>&1
+[ -x scripts/dev/bin/fused_x3_lab ] && scripts/dev/bin/fused_x3_lab 32768 > gpurun_out/${TAG}_fused_mlp_x3_lab.txt 2>&1
 ls -la gpurun_out | grep $TAG
