@@ -31,7 +31,7 @@ rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vb -- python $R/bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
 cp $OUT/vb_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_bf16x3_t16384.csv
 rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_traffic > $OUT.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_traffic --no_fp32_line > $OUT.log 2>&1 )
 cp $OUT/lgd_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_lgdrnn12_b1024.csv
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o v -- python $R/bench.py --workload vertices --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )

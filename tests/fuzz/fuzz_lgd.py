@@ -71,10 +71,46 @@ def build_nets(dev, extra_nets=False):
     return model, bm, nets
 
 
+N_FP_SAMPLES, N_FP_PROJ = 512, 4
+FP_KEYS = ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat', 'rnn_h')
+
+
+def fingerprint(case, outputs):
+    """What the fixture of a fixed-seed slice keeps of the ORACLE's outputs of one case (the outputs themselves would be
+    tens of MB): per output -- the valid frames of pose / root orientation / shape / joints, the final LSTM state -- 512
+    entries at seeded positions and 4 seeded Gaussian projections divided by sqrt(n) (an error of e in every entry moves
+    such a projection by about e).  `outputs`: {key: 1-D float array}."""
+    fp = {}
+    for j, k in enumerate(FP_KEYS):
+        if k not in outputs:
+            continue
+        x = np.asarray(outputs[k], dtype=np.float64).reshape(-1)
+        rng = np.random.default_rng(900000 + 10 * case + j)
+        idx = rng.integers(0, x.size, size=min(N_FP_SAMPLES, x.size))
+        z = rng.standard_normal((N_FP_PROJ, x.size))
+        fp[k + '/samples'] = x[idx].astype(np.float32)
+        fp[k + '/proj'] = (z @ x) / np.sqrt(x.size)
+    return fp
+
+
+def load_fixture(path):
+    z = np.load(path)
+    cache = {}
+    for key in z.files:
+        case, rest = key.split('/', 1)
+        cache.setdefault(int(case[4:]), {})[rest] = z[key]
+    return cache
+
+
 def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=0, batches=BATCHES, dev='cuda:0',
-        log=print, tol=1e-4):
+        log=print, tol=1e-4, oracle_cache=None, record=None):
     """Returns {'n', 'worst', 'worst_case', 'above_1e5': [(case, err, description)], 'variants', 'errors': [per case]}.
-    Raises AssertionError on the first case at or above `tol`."""
+    Raises AssertionError on the first case at or above `tol`.
+    `record` (a dict): CPU only -- no HIP call; the oracle's fingerprint of every case goes into it (the fixture of a
+    fixed-seed slice, generated in the build container).  `oracle_cache` (such a fixture, `load_fixture`): cases it holds
+    are compared with the recorded fingerprints instead of running the oracle on the GPU box's host (0.9 s per case, the
+    cost that kept the in-suite slice at 48 cases) -- sampled entries and projections instead of every entry; a case
+    above 1e-5 is still re-run through the oracle in full for the conditioning analysis."""
     from em_pose_amd import _lib, synthetic
     from oracle import torch_ref as R
     try:
@@ -86,7 +122,7 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
     model, bm, nets = build_nets(dev, extra_nets)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
     n, worst, worst_case, above, variants, errors = 0, 0.0, None, [], {}, []
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream() if record is None else None
     lib = _lib.lib()
     try:
         while time.time() < t_end and (n_cases is None or n < n_cases):
@@ -127,8 +163,28 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
             if masks is not None:
                 w['marker_masks'] = masks
             inp = H.oracle_inputs(w, sl=lens)
-            want, tr = R.ief_forward(sd, bm, tables, vids, inp, n_markers=int(meta['n_markers']), N=int(meta['N']),
+            valid = (torch.arange(F)[None, :] < torch.as_tensor(lens)[:, None]).numpy()
+            cached = oracle_cache.get(n) if oracle_cache is not None else None
+
+            def oracle32():
+                return R.ief_forward(sd, bm, tables, vids, inp, n_markers=int(meta['n_markers']), N=int(meta['N']),
                                      rnn_init=rnn, rnn_state=state)
+
+            def flat(pose_hat, root, shape, joints, h):
+                out = {'pose_hat': pose_hat[valid], 'root_ori_hat': root[valid], 'shape_hat': shape[valid],
+                       'joints_hat': joints[valid]}
+                if h is not None:
+                    out['rnn_h'] = h
+                return out
+            want = tr = None
+            if cached is None:
+                want, tr = oracle32()
+            if record is not None:
+                record[n] = fingerprint(n, flat(want['pose_hat'].numpy(), want['root_ori_hat'].numpy(),
+                                                want['shape_hat'].numpy(), want['joints_hat'].numpy(),
+                                                tr['rnn_state'][0].numpy() if rnn else None))
+                n += 1
+                continue
             g = lambda t: None if t is None else t.to(dev)
             _lib.check(lib.empose_set_option(b'smpl_tile', tile))
             _lib.check(lib.empose_set_option(b'smpl_fuse', fuse))
@@ -147,18 +203,28 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
             net.iter_stream = None
             vkey = (tile, fuse, 'suppress_mask_value' in kw, two_parts)
             variants[vkey] = variants.get(vkey, 0) + 1
-            valid = (torch.arange(F)[None, :] < torch.as_tensor(lens)[:, None]).numpy()
             err = 0.0
-            for got, ref in ((res['pose'].cpu().numpy()[:, :, 3:], want['pose_hat'].numpy()),
-                             (res['pose'].cpu().numpy()[:, :, :3], want['root_ori_hat'].numpy()),
-                             (res['shape'].cpu().numpy(), want['shape_hat'].numpy()),
-                             (res['joints'].cpu().numpy(), want['joints_hat'].numpy())):
-                err = max(err, float(np.abs(got - ref)[valid].max()))
-            if rnn:
-                err = max(err, float((res['state'][0].cpu() - tr['rnn_state'][0]).abs().max()))
+            pose_np = res['pose'].cpu().numpy()
+            if cached is not None:
+                mine = fingerprint(n, flat(pose_np[:, :, 3:], pose_np[:, :, :3], res['shape'].cpu().numpy(),
+                                           res['joints'].cpu().numpy(), res['state'][0].cpu().numpy() if rnn else None))
+                assert set(mine) == set(cached), (sorted(mine), sorted(cached))
+                for k, v in mine.items():
+                    assert v.shape == cached[k].shape, (n, k, v.shape, cached[k].shape)   # same case, same sizes
+                    err = max(err, float(np.abs(v.astype(np.float64) - cached[k]).max()))
+            else:
+                for got, ref in ((pose_np[:, :, 3:], want['pose_hat'].numpy()),
+                                 (pose_np[:, :, :3], want['root_ori_hat'].numpy()),
+                                 (res['shape'].cpu().numpy(), want['shape_hat'].numpy()),
+                                 (res['joints'].cpu().numpy(), want['joints_hat'].numpy())):
+                    err = max(err, float(np.abs(got - ref)[valid].max()))
+                if rnn:
+                    err = max(err, float((res['state'][0].cpu() - tr['rnn_state'][0]).abs().max()))
             desc = (name, dict(B=B, F=F, masks=masks is not None, state=state is not None), vkey)
             errors.append(err)
             if err > 1e-5 or not np.isfinite(err):
+                if want is None:
+                    want, tr = oracle32()
                 # How much of that is the input's conditioning?  The same case through the oracle in float64: the distance
                 # of the fp32 ORACLE from it is what fp32 arithmetic costs on this input whoever does it.
                 sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
@@ -199,13 +265,31 @@ def run(seed=0, seconds=None, n_cases=None, force=None, extra_nets=False, start=
             n += 1
             assert err < tol, 'LGD MISMATCH seed %d case %d %s: %r' % (seed, n - 1, desc, err)
     finally:
-        _lib.check(lib.empose_set_option(b'smpl_tile', 1))
-        _lib.check(lib.empose_set_option(b'smpl_fuse', 1))
+        if record is None:
+            _lib.check(lib.empose_set_option(b'smpl_tile', 1))
+            _lib.check(lib.empose_set_option(b'smpl_fuse', 1))
         for net in nets.values():
             net[0].iter_stream = None
     return {'n': n - start, 'worst': worst, 'worst_case': worst_case, 'above_1e5': above, 'variants': variants,
             'errors': errors}
 
+
+SLICE_SEED, SLICE_CASES = 4101, 120     # the in-suite slice (tests/test_fuzz_slice.py) and its fixture
+
+
+def slice_fixture_path():
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'golden',
+                        'fuzz_lgd_slice_%d.npz' % SLICE_SEED)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'record':
+    # build container, CPU only: the oracle's fingerprints of the in-suite slice -> tests/golden/fuzz_lgd_slice_<seed>.npz
+    rec = {}
+    run(seed=SLICE_SEED, n_cases=SLICE_CASES, extra_nets=True, batches=BATCHES_SLICE, dev='cpu', record=rec)
+    np.savez_compressed(slice_fixture_path(), **{'case%d/%s' % (c, k): v for c, fp in rec.items() for k, v in fp.items()})
+    print('wrote', slice_fixture_path(), len(rec), 'cases')
+    sys.exit(0)
 
 if __name__ == '__main__':
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
