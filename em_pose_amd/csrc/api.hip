@@ -111,6 +111,7 @@ struct empose_model {
   Lstm rnn;
   Dense pose_head, shape_head;
   float* heads_frag = nullptr;   // both heads stacked ([66 + 10][H]) in fragment order, and their stacked bias
+  float* heads_frag3 = nullptr;  // ... as three bf16 pieces per weight (x3_rows_layer)
   float* heads_bias = nullptr;
   Mlp pose_init, shape_init, pose_iter, shape_iter;
   int hidden_max = 0;
@@ -122,6 +123,8 @@ struct empose_model {
   TileTables* tile_tab = nullptr;
   float* wc2_frag = nullptr;   // [ncp2][200]
   float* wc2t_frag = nullptr;  // [200][ncp2]
+  float* wc2_frag3 = nullptr;  // the same two as three bf16 pieces per weight (x3_rows_layer)
+  float* wc2t_frag3 = nullptr;
 };
 
 struct empose_rnn {
@@ -796,7 +799,8 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, FeatArg
   if (tile) {
     // frame-per-lane path: blend GEMM -> tile layout -> smpl_tile_kernel -> tile layout -> transposed GEMM
     prof_mark(P_BLEND_GEMM, stream);
-    hipError_t e = fuse ? launch_blend_feat_gemm(fa, m->wc2_frag, ws.out, m->ncp2, m->ncp2, stream)
+    const bool rx3 = options().rows_x3 != 0 && m->wc2_frag3 && m->wc2t_frag3;
+    hipError_t e = fuse ? launch_blend_feat_gemm(fa, rx3 ? m->wc2_frag3 : m->wc2_frag, ws.out, m->ncp2, m->ncp2, rx3, stream)
                         : launch_gemm_rows_t(ws.feat, 200, false, m->wc2_frag, ws.out, m->ncp2, T, m->ncp2, 200, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend gemm (tile): %s", hipGetErrorString(e));
     TileArgs a;
@@ -820,7 +824,7 @@ int run_smpl_eval(const empose_model* m, int T, int F, const SmplWs& ws, FeatArg
       ra.T = T; ra.rod_conv = m->rod_conv;
       prof_mark(P_BLEND_T_GEMM, stream);
       if (fuse) {
-        e = launch_blend_t_gemm_rod(ws.d_out, m->ncp2, m->wc2t_frag, m->ncp2, ra, stream);
+        e = launch_blend_t_gemm_rod(ws.d_out, m->ncp2, rx3 ? m->wc2t_frag3 : m->wc2t_frag, m->ncp2, ra, rx3, stream);
         if (e != hipSuccess) return fail(EMPOSE_EHIP, "blend^T gemm + rodrigues_bwd (tile): %s", hipGetErrorString(e));
         return EMPOSE_OK;
       }
@@ -964,6 +968,7 @@ int empose_set_option(const char* name, int value) {
       {"mesh_skin_mfma", &o.mesh_skin_mfma},
       {"mlp_x3", &o.mlp_x3},
       {"lstm_x3", &o.lstm_x3},
+      {"rows_x3", &o.rows_x3},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -996,6 +1001,7 @@ int empose_get_option(const char* name) {
       {"mesh_skin_mfma", o.mesh_skin_mfma},
       {"mlp_x3", o.mlp_x3},
       {"lstm_x3", o.lstm_x3},
+      {"rows_x3", o.rows_x3},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
@@ -1116,6 +1122,8 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
       MTRY(upload(m->allocs, &tt, 1, &m->tile_tab));
       MTRY(pack_fragments_raw(m->allocs, wc2.data(), tt.ncp2, 200, &m->wc2_frag));
       MTRY(pack_fragments_raw(m->allocs, wc2t.data(), 200, tt.ncp2, &m->wc2t_frag));
+      MTRY(pack_fragments_x3_raw(m->allocs, wc2.data(), tt.ncp2, 200, &m->wc2_frag3));
+      MTRY(pack_fragments_x3_raw(m->allocs, wc2t.data(), 200, tt.ncp2, &m->wc2t_frag3));
       m->ncp2 = tt.ncp2; m->tile_nloc = tt.nloc; m->tile_nbl = tt.nbl;
       m->tile_ok = tt.ncp2 <= 320;   // the widest tile gemm_rows_t_kernel covers
     }
@@ -1149,6 +1157,7 @@ int empose_model_create(const empose_model_desc* d, empose_model_t** out) {
       for (int n = 0; n < 66; ++n) bst[n] = d->pose_head.bias ? d->pose_head.bias[n] : 0.f;
       for (int n = 0; n < 10; ++n) bst[66 + n] = d->shape_head.bias ? d->shape_head.bias[n] : 0.f;
       MTRY(pack_fragments_raw(m->allocs, wst.data(), 76, K, &m->heads_frag));
+      MTRY(pack_fragments_x3_raw(m->allocs, wst.data(), 76, K, &m->heads_frag3));
       MTRY(upload(m->allocs, bst.data(), bst.size(), &m->heads_bias));
     }
     if (m->pose_head.out_dim != 66 || m->shape_head.out_dim != 10 || m->pose_head.in_dim != r.hidden_size)
@@ -1284,8 +1293,9 @@ int empose_lgd_forward_phase(const empose_model_t* m, const empose_lgd_io* io, v
     b.p[1] = linear_prob(w.y, m->rnn.H, m->shape_head, w.d_shape, 10, T);
     prof_mark(P_HEADS, stream);
     if (m->heads_frag && options().heads_rows != 0 && heads_rows_applicable(T, m->rnn.H))
-      e = launch_heads_rows(w.y, m->rnn.H, m->heads_frag, m->heads_bias, x_theta, dx, w.d_shape, 10, T, m->rnn.H, 66, 10,
-                            stream);
+      e = launch_heads_rows(w.y, m->rnn.H, (options().rows_x3 != 0 && m->heads_frag3) ? m->heads_frag3 : m->heads_frag,
+                            m->heads_bias, x_theta, dx, w.d_shape, 10, T, m->rnn.H, 66, 10,
+                            options().rows_x3 != 0 && m->heads_frag3, stream);
     else
     e = launch_gemm(b, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "head gemm: %s", hipGetErrorString(e));

@@ -33,6 +33,8 @@ struct Options {
   int train_epi = 1;      // train-mode MLP layer: BatchNorm statistics in the GEMM epilogues + ONE combine-and-apply launch per
                           // layer and direction (train_fused.hip, finish kernels): 0 never, 1 above BN_SINGLE_PASS_ROWS rows, 2 always
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
+  int rows_x3 = 1;        // the row-block products with fused prologue / epilogue (blend GEMMs of the frame-per-lane SMPL path, init
+                          // heads) on the same three-piece bf16 arithmetic; 0: the fp32 MFMA instruction
   int lstm_x3 = 1;        // large-batch LSTM steps (inference, uni-directional): fp32 products as six bf16-MFMA products of three
                           // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
@@ -596,15 +598,17 @@ hipError_t launch_gemm_rows_t(const float* A, int lda, bool a_tile, const float*
 // The same two products with the small kernels around them folded in (mlp_fused.hip): the pose / shape update +
 // feature row as the prologue of the first (the [T][200] feature matrix never reaches HBM), the Rodrigues reverse as
 // the epilogue of the second (neither do the feature cotangents).
-hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream);
-hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
+// x3: Wp = three bf16 pieces per weight in bf16-MFMA fragment order (pack_fragments_x3_raw), product on the bf16 matrix path
+hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, bool x3,
+                                  hipStream_t stream);
+hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra, bool x3,
                                    hipStream_t stream);
 
 // The two init heads on the LSTM output as one product over their stacked columns (mlp_fused.hip): Wp = the stacked weight
 // [n_pose + n_shape][K] in fragment order, bias stacked likewise.
 bool heads_rows_applicable(int M, int K);
 hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const float* bias, float* theta, int ld_theta,
-                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, hipStream_t stream);
+                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, bool x3, hipStream_t stream);
 
 // Full-mesh: chain only (joints + relative transforms) and dense skinning.
 constexpr int MESH_MAX_JOINTS = 52;   // SMPL-H: 22 body + 2 x 15 hand joints

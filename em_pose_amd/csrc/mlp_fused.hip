@@ -17,6 +17,7 @@
 // Narrow layers (N <= 128, the output layers) split rows AND columns over the waves (32 x 64 each) so that a 66- or
 // 10-column layer does not cost a 512-column one, and write to the net's output instead of the LDS buffer.
 // Skip connections would need the block input kept besides the activations: such nets take the layer-by-layer path.
+#include "bf16x3.h"
 #include "gemm_epilogue.h"
 #include "feat_rows.h"
 
@@ -288,6 +289,177 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
   FM_STAMP(4 * layer_index + 3)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The single-layer row-block product on the bf16 matrix path, every fp32 product from three bf16 pieces per operand
+// (bf16x3.h; round 5).  Same operands and output modes as fused_layer_t<WM, WN, OUT_T, A_KMAJOR> with `last` set -- the A
+// block in LDS as fp32 (row-major or K-major), split in registers as it is read; the weights as three bf16 pieces in
+// fragment order (api.hip pack_fragments_x3_raw: [k-step of 16][32-column tile][piece] -> 1 KB) --, the K loop of
+// mlp_fused_x3.hip's x3_layer (k-steps as fenced chunks, weights three steps ahead in a four-slot ring), plus a tail for
+// step counts that are not whole quads (K = 200: 12 pipelined steps + 1).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) u32x4_t* fm_gvec3_t;
+
+template <int WM, int WN, int OUT_T, bool A_KMAJOR>
+__device__ __forceinline__ void x3_rows_layer(const FusedNet& net, const FusedLayer& L, int M, int m0, float* act, int lda,
+                                              int row_tile0, int col_tile0) {
+  using namespace fm;
+  const int lane = threadIdx.x & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int K = L.K, N = L.N;
+  const int NT32 = (N + 31) / 32;
+  const int KS = (K + 15) / 16, KSq = KS & ~3;
+  if (col_tile0 >= NT32) {
+    if (OUT_T != 2) {
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
+  unsigned b_voff[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j)
+    b_voff[j] = (unsigned)((col_tile0 + j < NT32 ? col_tile0 + j : NT32 - 1) * 3072 + lane * 16);
+  fm_gbyte_t wb = (fm_gbyte_t)L.W;
+  const float* a_rd = A_KMAJOR ? act + (lh * 8) * 64 + row_tile0 * 32 + l31 : act + (row_tile0 * 32 + l31) * lda + lh * 8;
+
+  f32x16 acc[WM][WN];
+  f32x4 ra[2][WM][2];
+  Pieces ap[2][WM];
+  u32x4_t fb[4][WN][3];
+  constexpr int NDS = A_KMAJOR ? 8 * WM : 2 * WM;        // LDS reads of a k-step
+  auto aread1 = [&](int ks, f32x4 (&a)[WM][2], int r) {   // LDS read r of k-step ks
+    if (A_KMAJOR) {
+      const int i = r / 8, e = r % 8;
+      a[i][e / 4][e % 4] = a_rd[(ks * 16 + e) * 64 + i * 32];
+    } else {
+      a[r / 2][r % 2] = *reinterpret_cast<const f32x4*>(a_rd + (r / 2) * 32 * lda + ks * 16 + (r % 2) * 4);
+    }
+  };
+  auto aread = [&](int ks, f32x4 (&a)[WM][2]) {
+    const int kc = ks < KS ? ks : KS - 1;
+#pragma unroll
+    for (int r = 0; r < NDS; ++r) aread1(kc, a, r);
+  };
+  auto bload = [&](u32x4_t (&b)[WN][3], int ks) {
+    const int kc = ks < KS ? ks : KS - 1;
+    fm_gbyte_t p = wb + (size_t)kc * NT32 * 3072;
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) b[j][q] = *(fm_gvec3_t)(p + b_voff[j] + q * 1024);
+  };
+  auto split = [&](const f32x4 (&a)[WM][2], Pieces (&q)[WM]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) q[i] = split8(a[i][0][0], a[i][0][1], a[i][0][2], a[i][0][3], a[i][1][0], a[i][1][1], a[i][1][2], a[i][1][3]);
+  };
+  auto mma = [&](const Pieces (&a)[WM], const u32x4_t (&b)[WN][3]) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i].p[X3_PA[t]]),
+                                                              __builtin_bit_cast(bf16x8_t, b[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
+  };
+  auto step = [&](int s, const Pieces (&ap_cur)[WM], Pieces (&ap_nxt)[WM], f32x4 (&ra_nxt)[WM][2], f32x4 (&ra_free)[WM][2],
+                  const u32x4_t (&b_cur)[WN][3], u32x4_t (&b_free)[WN][3]) {
+    constexpr int NM = WM * WN * 6, NP = WM * 4, NMEM = 3 * WN + NDS, NCH = NP;
+    const int kb = s + 3 < KS ? s + 3 : KS - 1, ka = s + 2 < KS ? s + 2 : KS - 1;
+    fm_gbyte_t pb = wb + (size_t)kb * NT32 * 3072;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int o = c * NMEM / NCH; o < (c + 1) * NMEM / NCH; ++o) {
+        if (o < 3 * WN) b_free[o / 3][o % 3] = *(fm_gvec3_t)(pb + b_voff[o / 3] + (o % 3) * 1024);
+        else aread1(ka, ra_free, o - 3 * WN);
+      }
+      {
+        const int i = c / 4, q = c % 4;
+        const f32x4& v = ra_nxt[i][q / 2];
+        unsigned h, m, l;
+        split_pair(v[(q % 2) * 2], v[(q % 2) * 2 + 1], h, m, l);
+        ap_nxt[i].p[0][q] = h; ap_nxt[i].p[1][q] = m; ap_nxt[i].p[2][q] = l;
+      }
+#pragma unroll
+      for (int mm = c * NM / NCH; mm < (c + 1) * NM / NCH; ++mm) {
+        const int t = mm / (WM * WN), i = (mm / WN) % WM, j = mm % WN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ap_cur[i].p[X3_PA[t]]),
+                                                            __builtin_bit_cast(bf16x8_t, b_cur[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mm = 0; mm < (NM + NCH - 1) / NCH; ++mm) { FM_SGB(SG_MFMA, 1); FM_SGB(0x002, 2); if (mm < 3) FM_SGB(SG_VMEM_RD | SG_DS_RD, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto quad = [&](int g) {
+    step(g, ap[0], ap[1], ra[1], ra[0], fb[0], fb[3]);
+    step(g + 1, ap[1], ap[0], ra[0], ra[1], fb[1], fb[0]);
+    step(g + 2, ap[0], ap[1], ra[1], ra[0], fb[2], fb[1]);
+    step(g + 3, ap[1], ap[0], ra[0], ra[1], fb[3], fb[2]);
+  };
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bload(fb[0], 0);
+  bload(fb[1], 1);
+  bload(fb[2], 2);
+  aread(0, ra[0]);
+  aread(1, ra[1]);
+  split(ra[0], ap[0]);
+  if (KSq) {
+    quad(0);
+    for (int g = 4; g < KSq; g += 4) quad(g);
+  }
+  // the 0..3 steps behind the whole quads: pieces of step KSq in ap[0], raw values of KSq + 1 in ra[1], weights in slots 0..2
+  if (KS > KSq) mma(ap[0], fb[0]);
+  if (KS > KSq + 1) {
+    split(ra[1], ap[1]);
+    mma(ap[1], fb[1]);
+  }
+  if (KS > KSq + 2) {
+    aread(KSq + 2, ra[0]);
+    split(ra[0], ap[0]);
+    mma(ap[0], fb[2]);
+  }
+
+  if (OUT_T == 2) {
+    float* dst = net.out + (size_t)(m0 >> 6) * net.ld_out * 64;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = (col_tile0 + j) * 32 + l31;
+      if (col_tile0 + j >= NT32 || n >= net.ld_out) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = (row_tile0 + i) * 32 + 8 * q + 4 * lh;
+          *reinterpret_cast<f32x4*>(dst + (size_t)n * 64 + row) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+    }
+    return;
+  }
+  __syncthreads();   // every wave has read its last A values: the buffer may be overwritten
+  static_assert(OUT_T == 1 || OUT_T == 2, "x3_rows_layer writes C^T to LDS or the tile-layout output");
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    if (col_tile0 + j >= NT32) continue;
+    const int n = (col_tile0 + j) * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (row_tile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        act[n * 64 + ((row + n) & 63)] = acc[i][j][r];
+      }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(fm::NT) void mlp_fused_kernel(FusedMlpArgs args) {
   using namespace fm;
   extern __shared__ __attribute__((aligned(16))) float act[];
@@ -475,7 +647,7 @@ __global__ __launch_bounds__(fm::NT) void gemm_rows_t_kernel(FusedMlpArgs args) 
 // 76 floats per frame and never exists in HBM.  out_t = feat . Wc2^T in tile layout.
 constexpr int BLEND_FEAT_K = 200;   // feature columns (feat_rows.h); a tile of 64 frames touches at most 64 windows
 __host__ __device__ constexpr RowsLds blend_feat_lds() { return rows_lds(BLEND_FEAT_K, 64, false, 0, 64 * 10); }
-template <int WN>
+template <int WN, bool X3 = false>
 __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs args, FeatArgs fa) {
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
@@ -516,7 +688,8 @@ __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs ar
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  fused_layer_t<1, WN, 2>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
+  if (X3) x3_rows_layer<1, WN, 2, false>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN);
+  else fused_layer_t<1, WN, 2>(net, L, M, m0, act, lda, wave >> 1, (wave & 1) * WN, 0, true);
 }
 
 // The transposed blend-shape GEMM of the frame-per-lane path (d_feat = d_out . Wc2, both in tile layout) with the
@@ -526,7 +699,7 @@ constexpr int BLEND_T_N = 200;   // feature cotangent columns; rodrigues_bwd_til
 __host__ __device__ constexpr RowsLds blend_t_rod_lds(int K) {
   return rows_lds(K, 64, true, BLEND_T_N, TL_FR * ROD_BWD_LD, true);
 }
-template <int WN>
+template <int WN, bool X3 = false>
 __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs args, RodBwdTArgs ra) {
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
@@ -537,7 +710,8 @@ __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs a
   rt::stage_a_tile(net.x, net.ldx, tile, K0, lay.kpad, act);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fused_layer_t<1, WN, 1, true>(net, L, M, m0, act, lay.lda, wave >> 1, (wave & 1) * WN, 0, true);
+  if (X3) x3_rows_layer<1, WN, 1, true>(net, L, M, m0, act, lay.lda, wave >> 1, (wave & 1) * WN);
+  else fused_layer_t<1, WN, 1, true>(net, L, M, m0, act, lay.lda, wave >> 1, (wave & 1) * WN, 0, true);
   float* sg = act + lay.extra_off;   // behind C^T (the A block is dead by now)
   const int lane = threadIdx.x & 63;
   rodrigues_bwd_tile<true>(ra, tile, sg, [&](int col) { return act[col * 64 + ((lane + col) & 63)]; });
@@ -574,6 +748,7 @@ struct HeadsArgs {
   float* shape; int ld_shape;
   int n_pose, n_all;        // 66, 76
 };
+template <bool X3>
 __global__ __launch_bounds__(fm::NT) void heads_rows_kernel(FusedMlpArgs args, HeadsArgs h) {
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
@@ -584,7 +759,8 @@ __global__ __launch_bounds__(fm::NT) void heads_rows_kernel(FusedMlpArgs args, H
   rt::stage_a_rows(net.x, net.ldx, m0, M, K0, lay.kpad, lay.lda, act);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  fused_layer_t<1, 2, 1>(net, L, M, m0, act, lay.lda, wave & 1, (wave >> 1) * 2, 0, true);
+  if (X3) x3_rows_layer<1, 2, 1, false>(net, L, M, m0, act, lay.lda, wave & 1, (wave >> 1) * 2);
+  else fused_layer_t<1, 2, 1>(net, L, M, m0, act, lay.lda, wave & 1, (wave >> 1) * 2, 0, true);
   // C^T in LDS ([column][64], rows rotated by the column)
   for (int i = threadIdx.x; i < 64 * h.n_all; i += fm::NT) {
     const int row = i / h.n_all, n = i - row * h.n_all;
@@ -612,33 +788,45 @@ static hipError_t launch_rows_t_fused(Kern kern, size_t lds, const FusedMlpArgs&
   return hipGetLastError();
 }
 
-hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, hipStream_t stream) {
+// `x3`: Wp holds three bf16 pieces per weight (api.hip pack_fragments_x3_raw) and the product runs on the bf16 matrix path
+hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_t, int ldc_t, int N, bool x3,
+                                  hipStream_t stream) {
   if (N > 320 || ldc_t != ((N + 31) / 32) * 32) return hipErrorInvalidValue;
   const FusedMlpArgs a = rows_t_args(nullptr, 0, Wp, C_t, ldc_t, fa.T, N, BLEND_FEAT_K);
   const size_t lds = blend_feat_lds().bytes();   // the A block + the tile's window means
+  if (x3) {
+    if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5, true>, lds, a, fa, stream);
+    return launch_rows_t_fused(blend_feat_gemm_kernel<4, true>, lds, a, fa, stream);
+  }
   if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5>, lds, a, fa, stream);
   return launch_rows_t_fused(blend_feat_gemm_kernel<4>, lds, a, fa, stream);
 }
 
-hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra,
+hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp, int K, const RodBwdTArgs& ra, bool x3,
                                    hipStream_t stream) {
   if (K % 4 != 0) return hipErrorInvalidValue;
   const FusedMlpArgs a = rows_t_args(A_t, lda_t, Wp, nullptr, 0, ra.T, BLEND_T_N, K);
+  if (x3) return launch_rows_t_fused(blend_t_gemm_rod_kernel<4, true>, blend_t_rod_lds(K).bytes(), a, ra, stream);
   return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, blend_t_rod_lds(K).bytes(), a, ra, stream);
 }
 
 bool heads_rows_applicable(int M, int K) { return M >= 4096 && K % 4 == 0 && K <= FUSED_MAX_WIDTH; }
 
 hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const float* bias, float* theta, int ld_theta,
-                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, hipStream_t stream) {
+                             float* shape, int ld_shape, int M, int K, int n_pose, int n_shape, bool x3, hipStream_t stream) {
   if (n_pose + n_shape > 128) return hipErrorInvalidValue;
   const FusedMlpArgs a = rows_t_args(y, ldy, Wp, nullptr, 0, M, n_pose + n_shape, K);
   HeadsArgs h{bias, theta, ld_theta, shape, ld_shape, n_pose, n_pose + n_shape};
   // the staged rows of y, later the transposed result (whole 32-column tiles): whichever is larger (a narrow LSTM's
   // row block is smaller than the 96 x 64 result) -- rows_lds, the layout the kernel indexes with
   const size_t lds = rows_lds(K, 64, false, n_pose + n_shape).bytes();
-  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel), lds)) return e;
-  hipLaunchKernelGGL(heads_rows_kernel, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
+  if (x3) {
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel<true>), lds)) return e;
+    hipLaunchKernelGGL(heads_rows_kernel<true>, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
+    return hipGetLastError();
+  }
+  if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel<false>), lds)) return e;
+  hipLaunchKernelGGL(heads_rows_kernel<false>, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
   return hipGetLastError();
 }
 

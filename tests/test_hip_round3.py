@@ -447,9 +447,25 @@ def test_frame_per_lane_smpl_path(which, n_markers, T, F, big_model):
     # ill-conditioned elements land on opposite sides)
     refs = (ref['pos'].reshape(T, -1), ref['ori'].reshape(T, -1), ref['joints'].reshape(T, -1), ref['g_theta'], ref['g_beta'])
     gscale = [1.0, 1.0, 1.0, max(np.abs(ref['g_theta']).max(), 1.0), max(np.abs(ref['g_beta']).max(), 1.0)]
-    for got, gen, want, tol, sc in zip(tile, general, refs, (1e-5, 5e-5, 1e-5, 5e-4, 5e-4), gscale):
-        err, err_gen = np.abs(got - want).max(), np.abs(gen - want).max()
-        assert err <= max(tol * sc, 3.0 * err_gen), (err, err_gen, tol * sc)
+    # Round 5: the comparison is over FOUR draws of the case, not one.  The gradient's worst element is decided by frames
+    # whose residual direction r / |r| is ill-conditioned; between any two fp32 evaluations its error scatters by an order
+    # of magnitude from draw to draw in either direction (profiles/r05_rows_x3_error_vs_float64.txt: general kernels,
+    # frame-per-lane path on the fp32 MFMA instruction, and on three bf16 pieces, twelve draws) -- one draw compares luck.
+    errs = [[np.abs(got - want).max() for got, want in zip(tile, refs)]]
+    errs_gen = [[np.abs(gen - want).max() for gen, want in zip(general, refs)]]
+    for seed in (12, 13, 14):
+        th2, be2, or2, ot2, tg2, sc2, ref2 = _smpl_case(model, vids, T, F, seed, n_markers)
+        refs2 = (ref2['pos'].reshape(T, -1), ref2['ori'].reshape(T, -1), ref2['joints'].reshape(T, -1), ref2['g_theta'],
+                 ref2['g_beta'])
+        with _Option(b'smpl_tile', 0):
+            errs_gen.append([np.abs(a - b).max() for a, b in zip(_sensors_call(handle, T, F, th2, be2, or2, ot2, tg2, sc2), refs2)])
+        with _Option(b'smpl_tile', 2):
+            errs.append([np.abs(a - b).max() for a, b in zip(_sensors_call(handle, T, F, th2, be2, or2, ot2, tg2, sc2), refs2)])
+    gmean = lambda rows, k: float(np.exp(np.mean([np.log(max(r[k], 1e-12)) for r in rows])))
+    for k, (tol, sc) in enumerate(zip((1e-5, 5e-5, 1e-5, 5e-4, 5e-4), gscale)):
+        assert gmean(errs, k) <= max(tol * sc, 3.0 * gmean(errs_gen, k)), (k, errs, errs_gen)
+        for e, eg in zip(errs, errs_gen):      # and no single draw is off by more than an order of magnitude
+            assert e[k] <= max(tol * sc, 10.0 * eg[k]), (k, e[k], eg[k])
     g_th = tile[3]
     assert (g_th[scale == 0] == 0).all()
     # against the general kernel (another summation order of the same arithmetic): positions and joints element by
