@@ -294,8 +294,8 @@ __device__ __forceinline__ void fused_layer_t(const FusedNet& net, const FusedLa
 // (bf16x3.h; round 5).  Same operands and output modes as fused_layer_t<WM, WN, OUT_T, A_KMAJOR> with `last` set -- the A
 // block in LDS as fp32 (row-major or K-major), split in registers as it is read; the weights as three bf16 pieces in
 // fragment order (api.hip pack_fragments_x3_raw: [k-step of 16][32-column tile][piece] -> 1 KB) --, the K loop of
-// mlp_fused_x3.hip's x3_layer (k-steps as fenced chunks, weights three steps ahead in a four-slot ring), plus a tail for
-// step counts that are not whole quads (K = 200: 12 pipelined steps + 1).
+// mlp_fused_x3.hip's x3_layer (k-steps as fenced chunks, weights ahead in a register ring), plus plain steps for what is
+// left behind the whole periods of the pipeline (K = 200: 12 pipelined steps + 1).
 // ---------------------------------------------------------------------------------------------------------------------
 typedef const __attribute__((address_space(1))) u32x4_t* fm_gvec3_t;
 
@@ -322,10 +322,11 @@ __device__ __forceinline__ void x3_rows_layer(const FusedNet& net, const FusedLa
   fm_gbyte_t wb = (fm_gbyte_t)L.W;
   const float* a_rd = A_KMAJOR ? act + (lh * 8) * 64 + row_tile0 * 32 + l31 : act + (row_tile0 * 32 + l31) * lda + lh * 8;
 
+  constexpr int R = WN >= 5 ? 3 : 4;                     // weight ring: R - 1 k-steps in flight + the one being multiplied
   f32x16 acc[WM][WN];
   f32x4 ra[2][WM][2];
   Pieces ap[2][WM];
-  u32x4_t fb[4][WN][3];
+  u32x4_t fb[R][WN][3];
   constexpr int NDS = A_KMAJOR ? 8 * WM : 2 * WM;        // LDS reads of a k-step
   auto aread1 = [&](int ks, f32x4 (&a)[WM][2], int r) {   // LDS read r of k-step ks
     if (A_KMAJOR) {
@@ -365,7 +366,7 @@ __device__ __forceinline__ void x3_rows_layer(const FusedNet& net, const FusedLa
   auto step = [&](int s, const Pieces (&ap_cur)[WM], Pieces (&ap_nxt)[WM], f32x4 (&ra_nxt)[WM][2], f32x4 (&ra_free)[WM][2],
                   const u32x4_t (&b_cur)[WN][3], u32x4_t (&b_free)[WN][3]) {
     constexpr int NM = WM * WN * 6, NP = WM * 4, NMEM = 3 * WN + NDS, NCH = NP;
-    const int kb = s + 3 < KS ? s + 3 : KS - 1, ka = s + 2 < KS ? s + 2 : KS - 1;
+    const int kb = s + R - 1 < KS ? s + R - 1 : KS - 1, ka = s + 2 < KS ? s + 2 : KS - 1;
     fm_gbyte_t pb = wb + (size_t)kb * NT32 * 3072;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -392,38 +393,45 @@ __device__ __forceinline__ void x3_rows_layer(const FusedNet& net, const FusedLa
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto quad = [&](int g) {
-    step(g, ap[0], ap[1], ra[1], ra[0], fb[0], fb[3]);
-    step(g + 1, ap[1], ap[0], ra[0], ra[1], fb[1], fb[0]);
-    step(g + 2, ap[0], ap[1], ra[1], ra[0], fb[2], fb[1]);
-    step(g + 3, ap[1], ap[0], ra[0], ra[1], fb[3], fb[2]);
-  };
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  bload(fb[0], 0);
-  bload(fb[1], 1);
-  bload(fb[2], 2);
-  aread(0, ra[0]);
-  aread(1, ra[1]);
-  split(ra[0], ap[0]);
-  if (KSq) {
-    quad(0);
-    for (int g = 4; g < KSq; g += 4) quad(g);
-  }
-  // the 0..3 steps behind the whole quads: pieces of step KSq in ap[0], raw values of KSq + 1 in ra[1], weights in slots 0..2
-  if (KS > KSq) mma(ap[0], fb[0]);
-  if (KS > KSq + 1) {
-    split(ra[1], ap[1]);
-    mma(ap[1], fb[1]);
-  }
-  if (KS > KSq + 2) {
-    aread(KSq + 2, ra[0]);
+  // Pipelined part: whole periods of the (A parity x weight ring) rotation -- 4 steps with the four-slot ring, 6 with the
+  // three-slot ring of the wide instantiation (five column tiles per wave: a fourth slot of 60 registers spilled).
+  constexpr int P = R == 4 ? 4 : 6;
+  const int KSp = KS / P * P;
+  if (KSp) {
+    bload(fb[0], 0);
+    bload(fb[1], 1);
+    if constexpr (R == 4) bload(fb[2], 2);
+    aread(0, ra[0]);
+    aread(1, ra[1]);
     split(ra[0], ap[0]);
-    mma(ap[0], fb[2]);
+    for (int g = 0; g < KSp; g += P) {
+      if constexpr (R == 4) {
+        step(g, ap[0], ap[1], ra[1], ra[0], fb[0], fb[3]);
+        step(g + 1, ap[1], ap[0], ra[0], ra[1], fb[1], fb[0]);
+        step(g + 2, ap[0], ap[1], ra[1], ra[0], fb[2], fb[1]);
+        step(g + 3, ap[1], ap[0], ra[0], ra[1], fb[3], fb[2]);
+      } else {
+        step(g, ap[0], ap[1], ra[1], ra[0], fb[0], fb[2]);
+        step(g + 1, ap[1], ap[0], ra[0], ra[1], fb[1], fb[0]);
+        step(g + 2, ap[0], ap[1], ra[1], ra[0], fb[2], fb[1]);
+        step(g + 3, ap[1], ap[0], ra[0], ra[1], fb[0], fb[2]);
+        step(g + 4, ap[0], ap[1], ra[1], ra[0], fb[1], fb[0]);
+        step(g + 5, ap[1], ap[0], ra[0], ra[1], fb[2], fb[1]);
+      }
+    }
+  }
+  // the steps behind the whole periods (K = 200: one of 13), one after the other: read, split, load, multiply
+  for (int t = KSp; t < KS; ++t) {
+    aread(t, ra[0]);
+    bload(fb[0], t);
+    split(ra[0], ap[0]);
+    mma(ap[0], fb[0]);
   }
 
   if (OUT_T == 2) {

@@ -476,9 +476,11 @@ def test_frame_per_lane_smpl_path(which, n_markers, T, F, big_model):
         np.testing.assert_allclose(tile_fwd[k], tile[k], atol=1e-5)   # forward-only launch: another instantiation
         np.testing.assert_allclose(tile_fwd[k], general_fwd[k], atol=2e-5)
     assert np.mean(np.abs(tile[1] - general[1]) > 1e-4) < 1e-4 and np.mean(np.abs(tile_fwd[1] - tile[1]) > 5e-5) < 1e-4
+    # gradients: one ill-conditioned frame moves every element of its row, so at T frames the share of elements allowed
+    # beyond the bound is that of a frame and a half, or 1 % where T is large
     for k in (3, 4):
         sc = max(1.0, float(np.abs(general[k]).max()))
-        assert np.mean(np.abs(tile[k] - general[k]) > 1e-3 * sc) < 1e-2
+        assert np.mean(np.abs(tile[k] - general[k]) > 1e-3 * sc) < max(1e-2, 1.5 / T)
     for a, b in zip(tile, again):                     # reproducible
         assert np.array_equal(a, b)
 
@@ -701,11 +703,21 @@ def test_init_heads_as_one_row_block_product_equal_the_two_problem_launch(big_mo
     args = [torch.randn(B, F, 36, generator=g).to(DEV), torch.randn(B, F, 108, generator=g).to(DEV),
             (0.02 * torch.randn(B, 12, 3, generator=g)).to(DEV), torch.eye(3).expand(B, 12, 3, 3).contiguous().to(DEV)]
     res = {}
-    for opt in (0, 1):
-        with _Option(b'heads_rows', opt):
-            r = net.forward_tensors(*args, keep_history=True)
-            torch.cuda.synchronize()
-            res[opt] = [r['hist']['pose'][0].cpu(), r['hist']['shape'][0].cpu(), r['pose'].cpu(), r['joints'].cpu()]
+    # (round 5: the stacked product defaults to three bf16 pieces per operand, option rows_x3 -- the bit-identity is that
+    # of its fp32 instantiation, rows_x3 = 0; the default is held against it below)
+    with _Option(b'rows_x3', 0):
+        for opt in (0, 1):
+            with _Option(b'heads_rows', opt):
+                r = net.forward_tensors(*args, keep_history=True)
+                torch.cuda.synchronize()
+                res[opt] = [r['hist']['pose'][0].cpu(), r['hist']['shape'][0].cpu(), r['pose'].cpu(), r['joints'].cpu()]
     for a, b in zip(res[0], res[1]):
         assert torch.isfinite(b).all()
         assert torch.equal(a, b)
+    with _Option(b'heads_rows', 1):
+        r = net.forward_tensors(*args, keep_history=True)
+        torch.cuda.synchronize()
+    x3 = [r['hist']['pose'][0].cpu(), r['hist']['shape'][0].cpu()]
+    for a, b in zip(res[0][:2], x3):          # the initial estimate itself: one product apart
+        assert torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
