@@ -969,6 +969,7 @@ int empose_set_option(const char* name, int value) {
       {"mlp_x3", &o.mlp_x3},
       {"lstm_x3", &o.lstm_x3},
       {"rows_x3", &o.rows_x3},
+      {"train_cols", &o.train_cols},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -1002,6 +1003,7 @@ int empose_get_option(const char* name) {
       {"mlp_x3", o.mlp_x3},
       {"lstm_x3", o.lstm_x3},
       {"rows_x3", o.rows_x3},
+      {"train_cols", o.train_cols},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;
@@ -1722,7 +1724,13 @@ struct MlpTrainWs {
   float* wt;         // transposed weight [hidden][max(hidden, out_pad)]
   float* atb; size_t atb_floats; float* bn; float* slope_partial; int* counter;
   float* part; float* coef;   // fused path: per-row-block partial sums, BatchNorm-reverse coefficients [3][H]
+  // one-launch layers (train_cols.hip): mailbox words, then the two networks' arrival counters -- zeroed together once
+  // per call; slope partial sums of the second network of a pair
+  unsigned long long* mbox; size_t mbox_bytes; int* counter2; float* slope_partial2;
 };
+size_t cols_zero_bytes(const empose_mlp_params* p) {
+  return cols_mailbox_words(p->hidden > p->out_dim ? p->hidden : p->out_dim) * sizeof(unsigned long long) + 64;
+}
 // every A^T B product of one MLP over M rows: (H, in_dim), (H, H), (out_dim, H)
 size_t mlp_atb_floats(const empose_mlp_params* p, int M) {
   return atb_workspace_floats_max(M, {{p->hidden, p->in_dim}, {p->hidden, p->hidden}, {p->out_dim, p->hidden}});
@@ -1735,10 +1743,13 @@ MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
   w.atb_floats = mlp_atb_floats(p, M);
   w.atb = c.f(w.atb_floats + 64);
   w.bn = c.f(bn_prelu_workspace_floats(M, H) + 64);
-  w.slope_partial = c.f((size_t)(H + 31) / 32 + 8);
+  w.slope_partial = c.f((size_t)(H + 15) / 16 + 8);   // (per 16 columns on the one-launch layers, per 32 otherwise)
   w.counter = reinterpret_cast<int*>(c.f(64));
   w.part = c.f(bn_fused_partial_floats(M, H) + 64);
   w.coef = c.f((size_t)3 * H + 64);
+  w.mbox_bytes = cols_zero_bytes(p);
+  w.mbox = reinterpret_cast<unsigned long long*>(c.f(w.mbox_bytes / sizeof(float)));
+  w.slope_partial2 = c.f((size_t)(H + 15) / 16 + 8);
   return w;
 }
 // The BatchNorm / PReLU passes folded into the GEMMs (train_fused.hip).  Opt-in: gradient parity with the reference is
@@ -1767,6 +1778,51 @@ size_t mlp_layer_save(const empose_mlp_params* p, int M) {
   if (mlp_train_fused(p, M)) return (size_t)M * p->hidden + 4 * (size_t)p->hidden;
   if (mlp_train_epi(p, M)) return (size_t)2 * M * p->hidden + 4 * (size_t)p->hidden;
   return (size_t)2 * M * p->hidden + 2 * (size_t)p->hidden;
+}
+// At the reference's training batch a layer is one launch: product, BatchNorm and PReLU of both update networks in
+// train_cols.hip (option "train_cols": 0 never, 1 up to COLS_MAX_ROWS rows).  Reads and writes save layout 1 (passes).
+bool mlp_train_cols(const empose_mlp_params* p, int M) {
+  if (options().train_cols == 0 || M > COLS_MAX_ROWS) return false;
+  if (mlp_train_fused(p, M) || mlp_train_epi(p, M)) return false;
+  return cols_launchable(p->hidden > p->out_dim ? p->hidden : p->out_dim, 2);
+}
+bool mlp_cols_pairable(const empose_mlp_params* a, const empose_mlp_params* b, int M) {
+  return a->n_layers == b->n_layers && a->hidden == b->hidden && a->bn_eps == b->bn_eps &&
+         a->bn_momentum == b->bn_momentum && mlp_train_cols(a, M) && mlp_train_cols(b, M) &&
+         b->out_dim <= (a->hidden > a->out_dim ? a->hidden : a->out_dim);
+}
+int* cols_counter(const MlpTrainWs& w, int i) {
+  return reinterpret_cast<int*>(reinterpret_cast<char*>(w.mbox) + w.mbox_bytes - 64) + 8 * i;
+}
+
+int mlp_fwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* x, int ldx, float* const* outs,
+                 const int* ld_outs, float* const* saves, const MlpTrainWs& w, hipStream_t stream) {
+  const int L = ps[0]->n_layers;
+  HIP_TRY(hipMemsetAsync(w.mbox, 0, w.mbox_bytes, stream));
+  for (int l = 0; l < L; ++l) {
+    const bool last = l == L - 1;
+    ColsArgs a{};
+    a.n_nets = n; a.M = M; a.eps = ps[0]->bn_eps; a.momentum = ps[0]->bn_momentum; a.tag = (unsigned)l + 1;
+    a.mailbox = w.mbox;
+    for (int i = 0; i < n; ++i) {
+      const empose_mlp_params* p = ps[i];
+      const int H = p->hidden;
+      const size_t lsz = (size_t)2 * M * H + 2 * (size_t)H;
+      float* sv = saves[i] + (size_t)l * lsz;                                   // z | a | mean | rstd
+      ColsNet& c = a.net[i];
+      c.A = l == 0 ? x : saves[i] + (size_t)(l - 1) * lsz + (size_t)M * H; c.lda = l == 0 ? ldx : H;
+      c.W = p->weight[l]; c.ldw = l == 0 ? p->in_dim : H; c.bias = p->bias[l];
+      c.N = last ? p->out_dim : H; c.K = l == 0 ? p->in_dim : H;
+      if (last) { c.out = outs[i]; c.ld_out = ld_outs[i]; continue; }
+      c.gamma = p->bn_weight[l]; c.beta = p->bn_bias[l]; c.slope = p->prelu[l];
+      c.running_mean = p->bn_running_mean[l]; c.running_var = p->bn_running_var[l]; c.num_batches = p->bn_num_batches[l];
+      c.z = sv; c.ldz = H; c.out = sv + (size_t)M * H; c.ld_out = H;
+      c.mean = sv + (size_t)2 * M * H; c.rstd = c.mean + H;
+    }
+    hipError_t e = launch_cols(a, last ? 1 : 0, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "one-launch layer forward: %s", hipGetErrorString(e));
+  }
+  return EMPOSE_OK;
 }
 }  // namespace
 
@@ -1798,6 +1854,7 @@ int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int 
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
   const int H = p->hidden, L = p->n_layers;
+  if (mlp_train_cols(p, M)) return mlp_fwd_cols(&p, 1, M, x, ldx, &out, &ld_out, &save, w, stream);
   if (mlp_train_epi(p, M)) {
     // y_l = a_{l-1} W_l^T + b_l on the materialised a_{l-1}; the epilogue leaves the column statistics of y_l per row
     // block; ONE launch turns them into (mean, rstd, s, t), updates the running statistics and writes a_l = PReLU(s y_l + t)
@@ -1886,6 +1943,72 @@ namespace {
 size_t mlp_stash_floats(const empose_mlp_params* p, int M) {
   return (size_t)M * ((size_t)(p->n_layers - 1) * p->hidden + ((p->out_dim + 3) & ~3));
 }
+// The reverse sweep of one or two MLPs on the one-launch layers: layer l's launch forms dA_{l-1} = dZ_l W_l and, in its
+// epilogue, the BatchNorm / PReLU reverse of layer l - 1 (whose column sums the row parts exchange) -> dZ_{l-1}.  With
+// stashes the weight gradients are deferred (empose_mlp_train_wgrad); without (one network only) they are formed here.
+int mlp_bwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* x, int ldx, const float* const* d_outs,
+                 const int* ld_douts, const float* const* saves, const empose_mlp_grads* const* grs, int accumulate,
+                 float* const* stashes, const MlpTrainWs& w, hipStream_t stream) {
+  const int L = ps[0]->n_layers;
+  const bool deferred = stashes && stashes[0];
+  if (!deferred && n != 1) return fail(EMPOSE_EINVAL, "a pair of networks runs its reverse sweep with deferred weight gradients");
+  HIP_TRY(hipMemsetAsync(w.mbox, 0, w.mbox_bytes, stream));
+  auto layer_save = [&](int i, int l) { return saves[i] + (size_t)l * ((size_t)2 * M * ps[i]->hidden + 2 * (size_t)ps[i]->hidden); };
+  auto dz_of = [&](int i, int l) -> float* { return deferred ? stashes[i] + (size_t)M * l * ps[i]->hidden : w.d[l & 1]; };
+  auto atb = [&](int l) -> int {   // dW_l, db_l of the single network (not deferred)
+    const empose_mlp_params* p = ps[0];
+    const int H = p->hidden;
+    const bool last = l == L - 1;
+    AtbArgs ab{};
+    ab.A = last ? d_outs[0] : dz_of(0, l); ab.lda = last ? ld_douts[0] : H;
+    ab.B = l == 0 ? x : layer_save(0, l - 1) + (size_t)M * H; ab.ldb = l == 0 ? ldx : H;
+    ab.C = grs[0]->weight[l]; ab.ldc = l == 0 ? p->in_dim : H; ab.bias = grs[0]->bias[l];
+    ab.M = M; ab.N = last ? p->out_dim : H; ab.K = l == 0 ? p->in_dim : H; ab.accumulate = accumulate;
+    hipError_t e = launch_gemm_atb(ab, w.atb, w.atb_floats, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "dW: %s", hipGetErrorString(e));
+    return EMPOSE_OK;
+  };
+  for (int i = 0; i < n && deferred; ++i) {   // keep d_out for empose_mlp_train_wgrad (no copy when it was produced in its slot)
+    const int op = (ps[i]->out_dim + 3) & ~3;
+    float* slot = stashes[i] + (size_t)M * (L - 1) * ps[i]->hidden;
+    if (d_outs[i] != slot || ld_douts[i] != op) {
+      hipError_t e = launch_axpby2d(M, op, 1.f, d_outs[i], ld_douts[i], 0.f, nullptr, 0, slot, op, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "stash: %s", hipGetErrorString(e));
+    }
+  }
+  for (int l = L - 1; l >= 1; --l) {
+    const bool last = l == L - 1;
+    if (!deferred) TRY(atb(l));
+    ColsArgs a{};
+    a.n_nets = n; a.M = M; a.eps = ps[0]->bn_eps; a.momentum = ps[0]->bn_momentum; a.accumulate = accumulate;
+    a.tag = (unsigned)l; a.mailbox = w.mbox;
+    for (int i = 0; i < n; ++i) {
+      const empose_mlp_params* p = ps[i];
+      const int H = p->hidden, op = (p->out_dim + 3) & ~3, kdim = last ? op : H;
+      const float* wt = p->weight_t[l];
+      if (!wt) {   // (single network: the pair entry point requires the transposed copies)
+        if (last) HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
+        hipError_t e = launch_transpose(p->weight[l], H, w.wt, kdim, last ? p->out_dim : H, H, stream);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
+        wt = w.wt;
+      }
+      const float* sv = layer_save(i, l - 1);
+      ColsNet& c = a.net[i];
+      c.A = last ? d_outs[i] : dz_of(i, l); c.lda = last ? ld_douts[i] : H;
+      c.W = wt; c.ldw = kdim; c.N = H; c.K = kdim;
+      c.gamma = p->bn_weight[l - 1]; c.beta = p->bn_bias[l - 1]; c.slope = p->prelu[l - 1];
+      c.z_in = sv; c.ldz = H; c.mean = const_cast<float*>(sv + (size_t)2 * M * H); c.rstd = c.mean + H;
+      c.out = dz_of(i, l - 1); c.ld_out = H;
+      c.dgamma = grs[i]->bn_weight[l - 1]; c.dbeta = grs[i]->bn_bias[l - 1]; c.dslope = grs[i]->prelu[l - 1];
+      c.dslope_partial = i == 0 ? w.slope_partial : w.slope_partial2; c.counter = cols_counter(w, i);
+    }
+    hipError_t e = launch_cols(a, 2, stream);
+    if (e != hipSuccess) return fail(EMPOSE_EHIP, "one-launch layer backward: %s", hipGetErrorString(e));
+  }
+  if (!deferred) TRY(atb(0));
+  return EMPOSE_OK;
+}
+
 int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out, int ld_dout,
                        const float* save, const empose_mlp_grads* gr, int accumulate, float* stash, void* workspace,
                        size_t workspace_bytes, empose_stream_t stream_) {
@@ -1901,6 +2024,8 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   Carver c(workspace);
   MlpTrainWs w = carve_mlp_train(c, p, M);
+  if (mlp_train_cols(p, M))
+    return mlp_bwd_cols(&p, 1, M, x, ldx, &d_out, &ld_dout, &save, &gr, accumulate, &stash, w, stream);
   // the last-arriver counter of the single-pass BatchNorm reverse kernel (it re-arms itself; the workspace may be fresh)
   const bool epi = mlp_train_epi(p, M);
   if (M <= BN_SINGLE_PASS_ROWS || epi) HIP_TRY(hipMemsetAsync(w.counter, 0, sizeof(int), stream));
@@ -2059,6 +2184,65 @@ int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float
                                   float* dz_stash, void* workspace, size_t workspace_bytes, empose_stream_t stream) {
   if (!dz_stash) return fail(EMPOSE_EINVAL, "null stash");
   return mlp_train_bwd_impl(p, M, x, ldx, d_out, ld_dout, save, gr, accumulate, dz_stash, workspace, workspace_bytes, stream);
+}
+
+// ---- both update networks of an iteration in one call: paired launches on the one-launch layers, else one after the other
+size_t empose_mlp_train_pair_workspace_bytes(const empose_mlp_params* p0, const empose_mlp_params* p1, int M) {
+  const size_t a = empose_mlp_train_workspace_bytes(p0, M), b = empose_mlp_train_workspace_bytes(p1, M);
+  return a > b ? a : b;
+}
+
+int empose_mlp_train_fwd_pair(const empose_mlp_params* p0, const empose_mlp_params* p1, int M, const float* x, int ldx,
+                              float* out0, int ld_out0, float* out1, int ld_out1, float* save0, float* save1,
+                              void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_mlp_params(p0));
+  TRY(check_mlp_params(p1));
+  if (workspace_bytes < empose_mlp_train_pair_workspace_bytes(p0, p1, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  if (M > 0 && x && out0 && out1 && save0 && save1 && workspace && ldx % 4 == 0 && ldx >= p0->in_dim && ldx >= p1->in_dim &&
+      ld_out0 >= p0->out_dim && ld_out1 >= p1->out_dim && mlp_cols_pairable(p0, p1, M)) {
+    Carver c(workspace);
+    MlpTrainWs w = carve_mlp_train(c, p0, M);
+    const empose_mlp_params* ps[2] = {p0, p1};
+    float* outs[2] = {out0, out1};
+    const int lds[2] = {ld_out0, ld_out1};
+    float* saves[2] = {save0, save1};
+    return mlp_fwd_cols(ps, 2, M, x, ldx, outs, lds, saves, w, static_cast<hipStream_t>(stream_));
+  }
+  TRY(empose_mlp_train_fwd(p0, M, x, ldx, out0, ld_out0, save0, workspace, workspace_bytes, stream_));
+  return empose_mlp_train_fwd(p1, M, x, ldx, out1, ld_out1, save1, workspace, workspace_bytes, stream_);
+}
+
+int empose_mlp_train_bwd_deferred_pair(const empose_mlp_params* p0, const empose_mlp_params* p1, int M, const float* x,
+                                       int ldx, const float* d_out0, int ld_dout0, const float* d_out1, int ld_dout1,
+                                       const float* save0, const float* save1, const empose_mlp_grads* gr0,
+                                       const empose_mlp_grads* gr1, int accumulate, float* dz_stash0, float* dz_stash1,
+                                       void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
+  TRY(check_mlp_params(p0));
+  TRY(check_mlp_params(p1));
+  if (!dz_stash0 || !dz_stash1) return fail(EMPOSE_EINVAL, "null stash");
+  if (workspace_bytes < empose_mlp_train_pair_workspace_bytes(p0, p1, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
+  bool pair = M > 0 && x && d_out0 && d_out1 && save0 && save1 && gr0 && gr1 && workspace && mlp_cols_pairable(p0, p1, M) &&
+              ld_dout0 % 4 == 0 && ld_dout1 % 4 == 0 && ld_dout0 >= ((p0->out_dim + 3) & ~3) && ld_dout1 >= ((p1->out_dim + 3) & ~3);
+  for (int l = 1; l < p0->n_layers && pair; ++l)
+    if (!p0->weight_t[l] || !p1->weight_t[l]) pair = false;          // (one scratch transpose buffer: one network at a time)
+  for (int l = 0; l < p0->n_layers - 1 && pair; ++l)
+    if (!gr0->bn_weight[l] || !gr0->bn_bias[l] || !gr0->prelu[l] || !gr1->bn_weight[l] || !gr1->bn_bias[l] || !gr1->prelu[l])
+      pair = false;
+  if (pair) {
+    Carver c(workspace);
+    MlpTrainWs w = carve_mlp_train(c, p0, M);
+    const empose_mlp_params* ps[2] = {p0, p1};
+    const float* d_outs[2] = {d_out0, d_out1};
+    const int lds[2] = {ld_dout0, ld_dout1};
+    const float* saves[2] = {save0, save1};
+    const empose_mlp_grads* grs[2] = {gr0, gr1};
+    float* stashes[2] = {dz_stash0, dz_stash1};
+    return mlp_bwd_cols(ps, 2, M, x, ldx, d_outs, lds, saves, grs, accumulate, stashes, w, static_cast<hipStream_t>(stream_));
+  }
+  TRY(empose_mlp_train_bwd_deferred(p0, M, x, ldx, d_out0, ld_dout0, save0, gr0, accumulate, dz_stash0, workspace,
+                                    workspace_bytes, stream_));
+  return empose_mlp_train_bwd_deferred(p1, M, x, ldx, d_out1, ld_dout1, save1, gr1, accumulate, dz_stash1, workspace,
+                                       workspace_bytes, stream_);
 }
 
 size_t empose_mlp_train_wgrad_workspace_bytes(const empose_mlp_params* p, int n_app, int M) {

@@ -37,6 +37,8 @@ struct Options {
                           // heads) on the same three-piece bf16 arithmetic; 0: the fp32 MFMA instruction
   int lstm_x3 = 1;        // large-batch LSTM steps (inference, uni-directional): fp32 products as six bf16-MFMA products of three
                           // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
+  int train_cols = 1;     // training at <= 512 rows: a layer's product + BatchNorm + PReLU as one launch, both update networks
+                          // side by side (train_cols.hip); 0: a product and a BatchNorm launch per layer and network
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
                           // (mlp_fused_x3.hip: fp32-equivalent accuracy, measured equal to the fp32 instruction's against
                           // float64); 0: the fp32 MFMA instruction (mlp_fused.hip); 2: the variant whose waves share the
@@ -136,6 +138,35 @@ struct BnPreluArgs {
   float* workspace = nullptr;    // bn_prelu_workspace_floats(M, C) floats: partial sums of the row-split path (large M)
   int accumulate = 0;            // backward: add to dgamma / dbeta / dslope instead of overwriting them
 };
+// One train-mode layer (product + BatchNorm + PReLU, forward or backward) of one or two MLPs as ONE launch at small
+// batches (train_cols.hip): a workgroup per 16 columns x quarter of the rows, the column statistics exchanged between
+// the row parts through a mailbox of tagged words.
+struct ColsNet {
+  const float* A; int lda;           // operand rows [M][K]: the layer input (forward) / the cotangent dZ_l (backward)
+  const float* W; int ldw;           // [N][K]: W_l (forward) / W_l^T (backward: rows = columns of the layer below)
+  const float* bias;                 // forward: [N]
+  int N, K;                          // K % 4 == 0, lda % 4 == 0, ldw % 4 == 0
+  const float* gamma; const float* beta; const float* slope;       // BatchNorm / PReLU of the N columns
+  float* running_mean; float* running_var; long long* num_batches; // forward, may be null
+  const float* z_in; float* z; int ldz;   // pre-BatchNorm rows: written by the forward, read (z_in) by the backward
+  float* out; int ld_out;            // forward: the activations (mode 1: the plain product); backward: dZ of the N columns
+  float* mean; float* rstd;          // [N]: written by the forward, read by the backward
+  float* dgamma; float* dbeta; float* dslope; float* dslope_partial; int* counter;   // backward (counter: zero, re-arms)
+};
+struct ColsArgs {
+  ColsNet net[2];
+  int n_nets, M;
+  float eps, momentum;
+  int accumulate;
+  unsigned tag;                      // unique among the launches that share the mailbox since it was zeroed; > 0
+  unsigned long long* mailbox;       // cols_mailbox_words(widest N) words
+  int R, tiles_per_part, spin_limit; unsigned* timeouts;   // set by launch_cols
+};
+constexpr int COLS_MAX_ROWS = 512;
+size_t cols_mailbox_words(int n_max);
+bool cols_launchable(int n_max, int n_nets);   // every workgroup of such a launch resident at once on this device
+hipError_t launch_cols(ColsArgs a, int mode, hipStream_t stream);   // mode 0 forward, 1 forward without BatchNorm, 2 backward
+
 constexpr int BN_SINGLE_PASS_ROWS = 1024;   // up to here one workgroup per 32 columns walks all rows
 size_t bn_prelu_workspace_floats(int M, int C);
 hipError_t launch_bn_prelu(const BnPreluArgs& a, bool backward, hipStream_t stream);

@@ -153,6 +153,10 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
     load(fa[0], fw[0], 0);
     load(fa[1], fw[1], 1);
     int i = 0;
+#ifdef LX_LAB_NOLOAD      // (lab ablation, scripts/dev/lstm_x3_lab.hip: the K loop on the first fragments only)
+    load(fa[2], fw[2], 2);
+    for (; i + 3 <= n_w; i += 3) { mma(fa[0], fw[0]); mma(fa[1], fw[1]); mma(fa[2], fw[2]); }
+#else
     for (; i + 3 <= n_w; i += 3) {
       load(fa[2], fw[2], i + 2);
       mma(fa[0], fw[0]);
@@ -164,11 +168,25 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
       mma(fa[2], fw[2]);
       pattern();
     }
+#endif
     if (i < n_w) mma(fa[0], fw[0]);
     if (i + 1 < n_w) mma(fa[1], fw[1]);
 
     // ---- partial sums -> LDS as [wave][gate][unit][row]: 16-byte pieces of four consecutive rows (the C/D layout has rows
     // 8 q + 4 lh .. + 3 of a column in one lane); the row stride of 68 floats spreads the 32 units of a store over the banks
+#ifdef LX_LAB_NOPART     // (lab ablation: no exchange, no finish -- the sums leave through one predicated store)
+    {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) sacc += acc[r][q][v];
+      if (sacc == 123.456f) U.c[tid] = sacc + e_c[0][0] + e_hp[0][0] + e_bias[0][0];
+      continue;
+    }
+#endif
     if (u > u_beg) __syncthreads();   // the previous unit's finish has read its sums
     {
       float* pw = part + (size_t)wave * 4 * BU * PLD;
@@ -183,6 +201,10 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
     }
     __syncthreads();
 
+#ifdef LX_LAB_NOFINISH   // (lab ablation: the exchange, but no cell arithmetic and no stores)
+    if (part[tid] == 123.456f) U.c[tid] = part[tid + 1] + e_c[0][0] + e_hp[0][0] + e_bias[0][0];
+    continue;
+#endif
     // ---- finish: thread (row, 8 units)
     float hv[8], cv[8], yv[8];
     const bool live = t < e_len;

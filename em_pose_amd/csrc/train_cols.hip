@@ -1,0 +1,322 @@
+// One train-mode layer of the update MLPs at the reference's training batch (12 windows x 32 frames = 384 rows, reference
+// scripts/train.py:125-152; layer = Linear -> BatchNorm1d(train) -> PReLU, nn/layers.py:13-77) as ONE launch, forward or
+// backward, both networks of an iteration side by side.
+//
+// At 384 rows a layer is 0.2 GFLOP: the step was a chain of ~390 dependent launches of 3-20 us on 24-48 workgroups (a
+// split-K product, then a BatchNorm kernel that walks all rows of 32 columns), each near the floor of a launch.  Here a
+// layer's product and its BatchNorm meet in one kernel, on the whole chip:
+//   * a workgroup owns 16 output columns x one quarter of the rows (R = 4 row parts of up to 8 tiles of 16 rows);
+//     hidden width 512 and two networks: 32 x 4 x 2 = 256 workgroups;
+//   * its four waves split K (16-k blocks w, w + 4, ...), every wave keeps all row tiles of the part in registers
+//     (v_mfma_f32_16x16x4_f32, fp32 operands straight from the row-major arrays: a lane reads 16 bytes of a row and feeds
+//     one float to each of four MFMAs -- the k order inside a block is permuted the same way on both operands);
+//     the partial sums meet in LDS and are added in wave order;
+//   * BatchNorm needs column sums over ALL rows: the R workgroups of a column slice exchange their per-column partial
+//     statistics through a mailbox of tagged 8-byte words in device memory (value | tag, relaxed agent-scope atomics: the
+//     path lstm_persist_kernel uses between its workgroups; 0.5-0.6 us per hand-over, scripts/dev/xcd_pingpong.hip) and
+//     every one of them combines the R parts in part order -- the same bits in all of them, no second launch;
+//       forward : per part (n, mean, M2 = sum (y - mean)^2), combined pairwise (Chan et al.) -> mean, biased var -> rstd
+//       backward: per part (sum dy, sum dy xhat, sum_{y <= 0} dA y), added in part order
+//   * the tag is the layer's number inside the call; the caller zeroes the mailbox once per call (a memset node when the
+//     step is captured as a graph).  A poll that exceeds its spin limit poisons the outputs and is counted
+//     (poll_timeout_word), it does not hang.  All workgroups of a launch fit the chip at once (<= 256 at width 512).
+// What it writes is what the layer-by-layer path writes (save layout 1: z | a | mean | rstd), so forward and backward
+// choose their path independently.
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace empose {
+
+namespace tc {
+constexpr int NT = 256, MAX_TILES = 8;
+constexpr int TLD = 17, TSZ = 16 * TLD;                   // padded 16 x 16 tile of partial sums
+constexpr int PART_FLOATS = 4 * MAX_TILES * TSZ;          // [wave][tile][row][col]
+}  // namespace tc
+
+__device__ __forceinline__ unsigned long long tc_pack(float v, unsigned tag) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// sum over the 16 row groups of a column (every thread of the column gets the same sum, added in group order)
+__device__ __forceinline__ float tc_reduce(float v, float* red, int rg, int c) {
+  red[rg * 16 + c] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += red[g * 16 + c];
+  __syncthreads();
+  return s;
+}
+
+// MODE 0: forward with BatchNorm + PReLU; 1: forward, plain product + bias (the output layer); 2: backward
+template <int MODE>
+__global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
+  using namespace tc;
+  __shared__ float part[PART_FLOATS];
+  __shared__ float red[256];
+  __shared__ float xs[4 * 3 * 16];     // [part][word][col]: what the parts posted
+  __shared__ int bad_lds;
+  const ColsNet& n = a.net[blockIdx.z];
+  const int slice = blockIdx.x, r = blockIdx.y;
+  const int N = n.N, K = n.K, M = a.M;
+  if (slice * 16 >= N) return;
+  const int T16 = (M + 15) >> 4;
+  const int t0 = r * a.tiles_per_part;
+  const int ntl = min(a.tiles_per_part, T16 - t0);
+  if (ntl <= 0) return;
+  const int row0 = t0 * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // ---- the product: wave w's 16-k blocks of all row tiles of this part
+  f32x4 acc[MAX_TILES];
+#pragma unroll
+  for (int t = 0; t < MAX_TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const int KB = (K + 15) >> 4;
+    const int nkb = KB > wave ? (KB - wave + 3) >> 2 : 0;
+    const float* wrow = n.W + (size_t)min(slice * 16 + r16, N - 1) * n.ldw + 4 * g;
+    int aoff[MAX_TILES];
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t) aoff[t] = min(row0 + t * 16 + r16, M - 1) * n.lda + 4 * g;
+    f32x4 fa[3][MAX_TILES], fw[3];
+    auto load = [&](f32x4 (&A)[MAX_TILES], f32x4& W, int i) {
+      if (i >= nkb) return;
+      const int k0 = (wave + 4 * i) * 16;
+      const bool in = k0 + 4 * g < K;                 // K % 4 == 0: a lane's four floats are inside or outside together
+#pragma unroll
+      for (int t = 0; t < MAX_TILES; ++t)
+        if (t < ntl) A[t] = in ? *reinterpret_cast<const f32x4*>(n.A + aoff[t] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      W = in ? *reinterpret_cast<const f32x4*>(wrow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto mma = [&](const f32x4 (&A)[MAX_TILES], const f32x4& W) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < MAX_TILES; ++t)
+          if (t < ntl) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][s], W[s], acc[t], 0, 0, 0);
+    };
+    load(fa[0], fw[0], 0);
+    load(fa[1], fw[1], 1);
+    for (int i = 0; i < nkb; i += 3) {
+      load(fa[2], fw[2], i + 2);
+      mma(fa[0], fw[0]);
+      if (i + 1 < nkb) {
+        load(fa[0], fw[0], i + 3);
+        mma(fa[1], fw[1]);
+      }
+      if (i + 2 < nkb) {
+        load(fa[1], fw[1], i + 4);
+        mma(fa[2], fw[2]);
+      }
+    }
+  }
+  // the C/D layout of the 16 x 16 MFMA: a lane holds column r16, rows 4 g .. 4 g + 3
+#pragma unroll
+  for (int t = 0; t < MAX_TILES; ++t)
+    if (t < ntl) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[(wave * MAX_TILES + t) * TSZ + (4 * g + j) * TLD + r16] = acc[t][j];
+    }
+  if (tid == 0) bad_lds = 0;
+  __syncthreads();
+
+  // ---- epilogue: thread (row group rg, column c) owns rows row0 + 16 t + rg
+  const int c = tid & 15, rg = tid >> 4;
+  const int col = slice * 16 + c;
+  const bool colok = col < N;
+  const int cc = colok ? col : N - 1;
+  float v[MAX_TILES];
+  bool ok[MAX_TILES];
+#pragma unroll
+  for (int t = 0; t < MAX_TILES; ++t) {
+    ok[t] = t < ntl && row0 + t * 16 + rg < M;
+    float s = 0.f;
+    if (t < ntl) {
+      const float* ps = part + t * TSZ + rg * TLD + c;
+      s = ((ps[0] + ps[MAX_TILES * TSZ]) + ps[2 * MAX_TILES * TSZ]) + ps[3 * MAX_TILES * TSZ];
+    }
+    v[t] = s;
+  }
+  if constexpr (MODE == 1) {
+    const float b = n.bias ? n.bias[cc] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t)
+      if (ok[t] && colok) n.out[(size_t)(row0 + t * 16 + rg) * n.ld_out + col] = v[t] + b;
+    return;
+  }
+
+  // what the parts post: NW words per column; word w of part q, column c at mailbox[((q * 16 + c) * 3 + w]
+  constexpr int NW = MODE == 0 ? 2 : 3;
+  unsigned long long* mb = a.mailbox + ((size_t)(blockIdx.z * gridDim.x + slice) * 4) * 16 * 3;
+  auto exchange = [&](const float (&mine)[NW]) {
+    if (rg == 0) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        __hip_atomic_store(mb + ((size_t)r * 16 + c) * 3 + w, tc_pack(mine[w], a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (rg < a.R && min(a.tiles_per_part, T16 - rg * a.tiles_per_part) > 0) {     // wave 0: row group q polls part q
+      unsigned long long wv[NW];
+      const unsigned long long* src = mb + ((size_t)rg * 16 + c) * 3;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) wv[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        int spins = 0;
+        while ((unsigned)(wv[w] >> 32) != a.tag) {
+          if (++spins > a.spin_limit) { bad_lds = 1; wv[w] = tc_pack(__builtin_nanf(""), a.tag); break; }
+          __builtin_amdgcn_s_sleep(1);
+          wv[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        xs[(rg * 3 + w) * 16 + c] = __uint_as_float((unsigned)wv[w]);
+      }
+    }
+    __syncthreads();
+    if (bad_lds && tid == 0) __hip_atomic_fetch_add(a.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  const float inv_m = 1.f / (float)M;
+
+  if constexpr (MODE == 0) {
+    const float b = n.bias[cc];
+    const int n_mine = min(ntl * 16, M - row0);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t) { v[t] += b; s += ok[t] ? v[t] : 0.f; }
+    const float mean_l = tc_reduce(s, red, rg, c) / (float)n_mine;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t) { const float d = v[t] - mean_l; q += ok[t] ? d * d : 0.f; }
+    const float m2_l = tc_reduce(q, red, rg, c);
+    const float mine[2] = {mean_l, m2_l};
+    exchange(mine);
+    // the parts in part order (pairwise update of mean and centred sum of squares)
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int p = 0; p < a.R; ++p) {
+      const int np = min(a.tiles_per_part * 16, M - p * a.tiles_per_part * 16);
+      if (np <= 0) break;
+      const float mp = xs[(p * 3 + 0) * 16 + c], qp = xs[(p * 3 + 1) * 16 + c];
+      const float tot = cnt + (float)np, d = mp - mean;
+      mean += d * ((float)np / tot);
+      m2 += qp + d * d * (cnt * (float)np / tot);
+      cnt = tot;
+    }
+    const float var = m2 * inv_m;                                   // biased: what normalises the batch
+    const float rstd = 1.f / sqrtf(var + a.eps);
+    if (colok) {
+      const float gm = n.gamma[col], bt = n.beta[col], slope = n.slope[0];
+#pragma unroll
+      for (int t = 0; t < MAX_TILES; ++t)
+        if (ok[t]) {
+          const size_t row = (size_t)(row0 + t * 16 + rg);
+          n.z[row * n.ldz + col] = v[t];
+          const float y = gm * ((v[t] - mean) * rstd) + bt;
+          n.out[row * n.ld_out + col] = y > 0.f ? y : slope * y;
+        }
+      if (r == 0 && rg == 0) {
+        n.mean[col] = mean;
+        n.rstd[col] = rstd;
+        if (n.running_mean) {
+          const float unbiased = M > 1 ? var * (float)M / (float)(M - 1) : var;
+          n.running_mean[col] = (1.f - a.momentum) * n.running_mean[col] + a.momentum * mean;
+          n.running_var[col] = (1.f - a.momentum) * n.running_var[col] + a.momentum * unbiased;
+        }
+      }
+    }
+    if (slice == 0 && r == 0 && tid == 0 && n.num_batches) n.num_batches[0] += 1;
+    return;
+  }
+
+  if constexpr (MODE == 2) {
+    const float mean = n.mean[cc], rstd = n.rstd[cc];
+    const float gm = n.gamma[cc], bt = n.beta[cc], slope = n.slope[0];
+    float xh[MAX_TILES], dy[MAX_TILES];
+    float s_b = 0.f, s_g = 0.f, s_a = 0.f;
+#pragma unroll
+    for (int t = 0; t < MAX_TILES; ++t) {
+      const float z = ok[t] ? n.z_in[(size_t)(row0 + t * 16 + rg) * n.ldz + cc] : mean;
+      const float da = ok[t] ? v[t] : 0.f;
+      xh[t] = (z - mean) * rstd;
+      const float y = gm * xh[t] + bt;
+      dy[t] = y > 0.f ? da : slope * da;
+      s_b += dy[t];
+      s_g += dy[t] * xh[t];
+      s_a += y > 0.f ? 0.f : da * y;
+    }
+    float mine[3];
+    mine[0] = tc_reduce(s_b, red, rg, c);
+    mine[1] = tc_reduce(s_g, red, rg, c);
+    mine[2] = tc_reduce(colok ? s_a : 0.f, red, rg, c);
+    exchange(mine);
+    float dbeta = 0.f, dgamma = 0.f, dslope_c = 0.f;
+    for (int p = 0; p < a.R; ++p) {
+      if (M - p * a.tiles_per_part * 16 <= 0) break;
+      dbeta += xs[(p * 3 + 0) * 16 + c];
+      dgamma += xs[(p * 3 + 1) * 16 + c];
+      dslope_c += xs[(p * 3 + 2) * 16 + c];
+    }
+    if (colok) {
+      const float k = gm * rstd * inv_m;
+#pragma unroll
+      for (int t = 0; t < MAX_TILES; ++t)
+        if (ok[t]) n.out[(size_t)(row0 + t * 16 + rg) * n.ld_out + col] = k * ((float)M * dy[t] - dbeta - xh[t] * dgamma);
+      if (r == 0 && rg == 0) {
+        n.dgamma[col] = dgamma + (a.accumulate ? n.dgamma[col] : 0.f);
+        n.dbeta[col] = dbeta + (a.accumulate ? n.dbeta[col] : 0.f);
+      }
+    }
+    // slope: part 0's workgroup of a slice adds its columns, the slice that arrives last adds the slices in index order
+    if (r == 0) {
+      if (rg == 0) red[c] = dslope_c;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        __hip_atomic_store(n.dslope_partial + slice, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const int n_slices = (N + 15) >> 4;
+        if (atomicAdd(n.counter, 1) == n_slices - 1) {
+          __threadfence();
+          float total = 0.f;
+          for (int i = 0; i < n_slices; ++i) total += __hip_atomic_load(n.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          n.dslope[0] = total + (a.accumulate ? n.dslope[0] : 0.f);
+          n.counter[0] = 0;
+        }
+      }
+    }
+  }
+}
+
+size_t cols_mailbox_words(int n_max) { return (size_t)2 * ((n_max + 15) / 16) * 4 * 16 * 3; }
+
+bool cols_launchable(int n_max, int n_nets) {
+  static int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device: workgroups of the heaviest instantiation
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 8) return false;
+  if (resident[dev] == 0) {
+    int b0 = 0, b2 = 0;
+    if (coresident_blocks(reinterpret_cast<const void*>(cols_kernel<0>), tc::NT, 0, &b0) != hipSuccess) return false;
+    if (coresident_blocks(reinterpret_cast<const void*>(cols_kernel<2>), tc::NT, 0, &b2) != hipSuccess) return false;
+    resident[dev] = b0 < b2 ? b0 : b2;
+  }
+  return (long)((n_max + 15) / 16) * 4 * n_nets <= resident[dev];
+}
+
+hipError_t launch_cols(ColsArgs a, int mode, hipStream_t stream) {
+  if (a.n_nets < 1 || a.n_nets > 2 || a.M < 1 || a.M > COLS_MAX_ROWS) return hipErrorInvalidValue;
+  const int T16 = (a.M + 15) / 16;
+  a.R = T16 < 4 ? T16 : 4;
+  a.tiles_per_part = (T16 + a.R - 1) / a.R;
+  a.spin_limit = options().spin_limit > 0 ? options().spin_limit : 1 << 20;
+  a.timeouts = poll_timeout_word();
+  if (!a.timeouts) return hipErrorOutOfMemory;
+  int n_max = 0;
+  for (int i = 0; i < a.n_nets; ++i) n_max = a.net[i].N > n_max ? a.net[i].N : n_max;
+  const dim3 grid((n_max + 15) / 16, a.R, a.n_nets);
+  if (mode == 0) hipLaunchKernelGGL(cols_kernel<0>, grid, dim3(tc::NT), 0, stream, a);
+  else if (mode == 1) hipLaunchKernelGGL(cols_kernel<1>, grid, dim3(tc::NT), 0, stream, a);
+  else hipLaunchKernelGGL(cols_kernel<2>, grid, dim3(tc::NT), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace empose

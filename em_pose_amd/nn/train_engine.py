@@ -227,6 +227,31 @@ class LgdTrainEngine(object):
         _layers.BN_STATS_GENERATION[0] += 1
         return save
 
+    def _mlp_fwd_pair(self, views, x, ldx, outs, ld_outs, M):
+        """Both update networks of an iteration in one call (empose_mlp_train_fwd_pair: at the reference's training batch
+        every layer of both is one launch); returns their save buffers."""
+        ps = [v.params() for v in views]
+        saves = [self.new(self.lib.empose_mlp_train_save_floats(C.byref(p), M)) for p in ps]
+        nbytes = self.lib.empose_mlp_train_pair_workspace_bytes(C.byref(ps[0]), C.byref(ps[1]), M)
+        ws = self._hold(self.ws(nbytes))
+        _lib.check(self.lib.empose_mlp_train_fwd_pair(C.byref(ps[0]), C.byref(ps[1]), M, x, ldx, outs[0], ld_outs[0],
+                                                      outs[1], ld_outs[1], saves[0].data_ptr(), saves[1].data_ptr(),
+                                                      ws.data_ptr(), nbytes, self.stream))
+        from em_pose_amd.nn import layers as _layers
+        _layers.BN_STATS_GENERATION[0] += 2
+        return saves
+
+    def _mlp_bwd_deferred_pair(self, views, x, ldx, d_outs, ld_douts, saves, grads, accumulate, M, stashes):
+        ps = [v.params() for v in views]
+        gs = [v.grads(g) for v, g in zip(views, grads)]
+        nbytes = self.lib.empose_mlp_train_pair_workspace_bytes(C.byref(ps[0]), C.byref(ps[1]), M)
+        ws = self._hold(self.ws(nbytes))
+        _lib.check(self.lib.empose_mlp_train_bwd_deferred_pair(
+            C.byref(ps[0]), C.byref(ps[1]), M, x, ldx, d_outs[0], ld_douts[0], d_outs[1], ld_douts[1],
+            saves[0].data_ptr(), saves[1].data_ptr(), C.byref(gs[0]), C.byref(gs[1]), int(accumulate),
+            stashes[0].data_ptr(), stashes[1].data_ptr(), ws.data_ptr(), nbytes, self.stream))
+        return stashes
+
     def _mlp_bwd(self, view, x, ldx, d_out, ld_dout, save, grads, accumulate, M):
         p = view.params()
         g = view.grads(grads)
@@ -413,13 +438,14 @@ class LgdTrainEngine(object):
                 # network input rows [x0 | pose_i | shape_i | g_pose | g_shape] (the gradients are already there)
                 _lib.check(lib.empose_lgd_assemble_inputs(T, d_in, x0.data_ptr(), d_in, pose_hist[i].data_ptr(),
                                                           shape_hist[i].data_ptr(), Xi.data_ptr(), d_x, self.stream))
-                side_fwd = 'fwd' in self.side_parts
+                side_fwd = self._use_side and 'fwd' in self.side_parts
                 if side_fwd:
                     self._fork()                               # the two networks side by side
-                sp = self._mlp_fwd(views[0], Xi.data_ptr(), d_x, dp.data_ptr(), 66, T)
-                ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T, side=0 if side_fwd else None)
-                if side_fwd:
+                    sp = self._mlp_fwd(views[0], Xi.data_ptr(), d_x, dp.data_ptr(), 66, T)
+                    ss = self._mlp_fwd(views[1], Xi.data_ptr(), d_x, tmp10.data_ptr(), 10, T, side=0)
                     self._join()
+                else:                                          # one stream: both networks per call (paired launches)
+                    sp, ss = self._mlp_fwd_pair(views, Xi.data_ptr(), d_x, (dp.data_ptr(), tmp10.data_ptr()), (66, 10), T)
                 saves.append((sp, ss))
                 # pose_{i+1} = pose_i + s dp, shape_{i+1} = shape_i + s (window mean of) ds
                 _lib.check(lib.empose_lgd_additive_update(B, F, s, int(bool(net.shape_avg)), pose_hist[i].data_ptr(),
@@ -512,12 +538,18 @@ class LgdTrainEngine(object):
                     # weight gradients once over all N applications (one A^T B per layer instead of N).  Nothing below
                     # reads what these two calls write until the weight-gradient products: the shape network's backward
                     # of every iteration trails on the side stream, in order, without a join
-                    side_bwd = 'bwd' in self.side_parts
+                    side_bwd = self._use_side and 'bwd' in self.side_parts
                     side_pose = 1 if (side_bwd and 'bwd3' in self.side_parts) else None   # third stream: the pose net too
                     if side_bwd:
                         self._fork(0)
                     if side_pose is not None:
                         self._fork(1)
+                    if not side_bwd:                           # one stream: both networks per call (paired launches)
+                        self._mlp_bwd_deferred_pair(views, X[i - 1].data_ptr(), d_x, (dp_ptr, ds_ptr), (68, 12), (sp, ss),
+                                                    grads, acc, T, (st_p, st_s))
+                        pend[0].append((X[i - 1].data_ptr(), sp, st_p))
+                        pend[1].append((X[i - 1].data_ptr(), ss, st_s))
+                        continue
                     pend[0].append((X[i - 1].data_ptr(), sp,
                                     self._mlp_bwd_deferred(views[0], X[i - 1].data_ptr(), d_x, dp_ptr, 68, sp,
                                                            grads[0], acc, T, stash=st_p, side=side_pose)))

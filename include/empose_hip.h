@@ -69,7 +69,11 @@ const char* empose_arch(void);
  * products with fp32 accumulation, fp32-equivalent and 2.7 times the fp32 instruction's rate -- when every hidden width
  * is a multiple of 64: 1 [default]; 0 = the fp32 MFMA instruction; 2 = a variant whose waves share the operand split
  * through LDS, measured slower), "lstm_x3" (the same arithmetic for the LSTM steps of batches above 256 rows, inference,
- * uni-directional stacks with a hidden size of whole 32s: 1 [default]; 0 = the fp32 MFMA instruction),
+ * uni-directional stacks with a hidden size of whole 32s: 1 [default]; 0 = the fp32 MFMA instruction), "rows_x3" (the
+ * same arithmetic for the row-block products with fused prologue / epilogue: the blend products of the frame-per-lane
+ * SMPL path and the stacked init heads; 0 = the fp32 MFMA instruction), "train_cols" (training at up to 512 rows: a
+ * layer's product + BatchNorm + PReLU as one launch, forward and backward, both update networks side by side -- see
+ * empose_mlp_train_fwd_pair; 0 = a product and a BatchNorm launch per layer and network),
  * "mesh_skin_mfma" (split-bf16 full-mesh variant only: the bone blend as a second matrix-core contraction; 0 [default,
  * measured faster] = vector skinning), "spin_limit" (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
@@ -393,6 +397,26 @@ size_t empose_mlp_train_stash_floats(const empose_mlp_params* p, int M);
 int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float* x, int ldx, const float* d_out,
                                   int ld_dout, const float* save, const empose_mlp_grads* grads, int accumulate,
                                   float* dz_stash, void* workspace, size_t workspace_bytes, empose_stream_t stream);
+/* Both update networks of one LGD iteration (they read the same rows x; reference nn/models.py:584-587 applies
+ * `pose_net` and `shape_net` to the same detached input) in one call.  Up to 512 rows -- the reference's training batch of
+ * 12 windows x 32 frames (scripts/train.py:125-152) -- every layer of BOTH networks is ONE launch, forward (product +
+ * bias + train-mode BatchNorm + PReLU) and backward (dA = dZ W + the BatchNorm / PReLU reverse of the layer below):
+ * a workgroup per 16 columns x quarter of the rows, whose column statistics meet through a mailbox of tagged words inside
+ * the workspace (csrc/train_cols.hip; option "train_cols", 0 = a product and a BatchNorm launch per layer and network).
+ * Networks the paired launches do not cover (different depth / hidden width / BatchNorm constants, more rows, missing
+ * weight_t in the backward) run one after the other through the single-network entry points: same results either way.
+ * Reads and writes save layout 1, like empose_mlp_train_fwd / _bwd at these sizes (which use the same launches for one
+ * network).  A poll of the mailbox that gives up is reported like the cooperative LSTM kernels' (empose_async_status).
+ * workspace: empose_mlp_train_pair_workspace_bytes. */
+size_t empose_mlp_train_pair_workspace_bytes(const empose_mlp_params* p0, const empose_mlp_params* p1, int M);
+int empose_mlp_train_fwd_pair(const empose_mlp_params* p0, const empose_mlp_params* p1, int M, const float* x, int ldx,
+                              float* out0, int ld_out0, float* out1, int ld_out1, float* save0, float* save1,
+                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
+int empose_mlp_train_bwd_deferred_pair(const empose_mlp_params* p0, const empose_mlp_params* p1, int M, const float* x,
+                                       int ldx, const float* d_out0, int ld_dout0, const float* d_out1, int ld_dout1,
+                                       const float* save0, const float* save1, const empose_mlp_grads* grads0,
+                                       const empose_mlp_grads* grads1, int accumulate, float* dz_stash0, float* dz_stash1,
+                                       void* workspace, size_t workspace_bytes, empose_stream_t stream);
 size_t empose_mlp_train_wgrad_workspace_bytes(const empose_mlp_params* p, int n_app, int M);
 int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const float* const* x, int ldx,
                            const float* const* save, const float* const* dz_stash, const empose_mlp_grads* grads,

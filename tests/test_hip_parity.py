@@ -772,7 +772,8 @@ def test_linear_train_function_vs_torch_autograd(M, K, N):
                                        None) != 0
 
 
-@pytest.mark.parametrize('fused', [False, True, 'epi'], ids=['bn_kernels', 'bn_in_gemms', 'bn_epilogue_finish'])
+@pytest.mark.parametrize('fused', [False, True, 'epi', 'cols'],
+                         ids=['bn_kernels', 'bn_in_gemms', 'bn_epilogue_finish', 'one_launch_layers'])
 @pytest.mark.parametrize('name', ['train_lgdrnn12_n2', 'train_lgd6_n2'])
 def test_training_step_matches_reference_gradients(name, fused):
     """forward (train mode) + backward: losses and EVERY parameter gradient against the reference's own training
@@ -782,6 +783,7 @@ def test_training_step_matches_reference_gradients(name, fused):
     from em_pose_amd.data.data import SyntheticBatch
     _set_option(b'train_fused', 2 if fused is True else 0)
     _set_option(b'train_epi', 2 if fused == 'epi' else 0)   # round 4: statistics in the GEMM epilogues + one finish launch
+    _set_option(b'train_cols', 1 if fused == 'cols' else 0)   # round 5: product + BatchNorm of both networks as one launch
     case = H.load_case(name)
     meta, w, rec = case['meta'], case['in'], case['run']
     net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])

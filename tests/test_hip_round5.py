@@ -52,6 +52,7 @@ def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
     elif variant == 'bn_kernels_one_stream':
         _lib.check(lib.empose_set_option(b'train_epi', 0))
         _lib.check(lib.empose_set_option(b'train_fused', 0))
+        _lib.check(lib.empose_set_option(b'train_cols', 0))      # (default: the one-launch layers of train_cols.hip, paired)
     try:
         net = create_model(lgd_config(nm, True, N), SMPLLayer(H.small_model()))
         net.vertex_ids = [int(v) for v in fp['meta/vertex_ids']]
@@ -269,3 +270,132 @@ def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F,
     print('lstm %s vs float64: fp32 MFMA %.2e, three-piece bf16 %.2e' % ((B, F, In, Hd, L), err[0], err[1]))
     assert err[1] <= 1.5 * err[0] + 2e-7 and err[1] < 1e-5
     g.release()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# One-launch train-mode layers (csrc/train_cols.hip)
+def _mlp_pair(in_dim, hidden, seed):
+    from em_pose_amd.nn.layers import MLP
+    torch.manual_seed(seed)
+    nets = [MLP(in_dim, 66, hidden, num_layers=2), MLP(in_dim, 10, hidden, num_layers=2)]
+    g = torch.Generator().manual_seed(seed + 1)
+    for net in nets:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                with torch.no_grad():
+                    m.bias.copy_(0.3 * torch.randn(m.bias.shape, generator=g))
+                    m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                    m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+            if isinstance(m, torch.nn.PReLU):
+                with torch.no_grad():
+                    m.weight.fill_(0.1 + 0.3 * float(torch.rand(1, generator=g)))
+    return [n.to(DEV).train() for n in nets]
+
+
+def _run_mlp_train(nets, x, d_outs, M, pair, deferred=True, saves_from=None):
+    """forward + reverse sweep of both networks through the C ABI; returns everything they write.  `saves_from`: the
+    reverse sweep reads these saved activations instead of its own forward's (same PReLU branch decisions for two
+    reverse paths under comparison: an activation within rounding of zero flips one element's branch otherwise)."""
+    import ctypes as C
+    from em_pose_amd.nn.train_engine import _MlpView
+    lib = _lib.lib()
+    stream = _lib.current_stream()
+    views = [_MlpView(n) for n in nets]
+    for v in views:
+        v.fix_layout(lib, M)
+        v.prepare_backward(lib, stream)
+    ps = [v.params() for v in views]
+    ldx = x.shape[1]
+    outs = [torch.zeros(M, 66, device=DEV), torch.zeros(M, 10, device=DEV)]
+    saves = [torch.zeros(lib.empose_mlp_train_save_floats(C.byref(p), M), device=DEV) for p in ps]
+    nbytes = max(lib.empose_mlp_train_pair_workspace_bytes(C.byref(ps[0]), C.byref(ps[1]), M), 16)
+    ws = torch.empty(nbytes // 4 + 4, device=DEV)
+    grads = [[torch.zeros_like(p) for p in v.parameter_list()] for v in views]
+    gs = [v.grads(g) for v, g in zip(views, grads)]
+    stashes = [torch.zeros(lib.empose_mlp_train_stash_floats(C.byref(p), M), device=DEV) for p in ps]
+    lds = [d.shape[1] for d in d_outs]
+    if pair:
+        _lib.check(lib.empose_mlp_train_fwd_pair(C.byref(ps[0]), C.byref(ps[1]), M, _lib.dptr(x), ldx, _lib.dptr(outs[0]), 66,
+                                                 _lib.dptr(outs[1]), 10, _lib.dptr(saves[0]), _lib.dptr(saves[1]),
+                                                 _lib.dptr(ws), nbytes, stream))
+        if saves_from is not None:
+            fwd_saves = [t.clone() for t in saves]
+            for t, src in zip(saves, saves_from):
+                t.copy_(src)
+        _lib.check(lib.empose_mlp_train_bwd_deferred_pair(
+            C.byref(ps[0]), C.byref(ps[1]), M, _lib.dptr(x), ldx, _lib.dptr(d_outs[0]), lds[0], _lib.dptr(d_outs[1]), lds[1],
+            _lib.dptr(saves[0]), _lib.dptr(saves[1]), C.byref(gs[0]), C.byref(gs[1]), 0, _lib.dptr(stashes[0]),
+            _lib.dptr(stashes[1]), _lib.dptr(ws), nbytes, stream))
+    else:
+        for i in (0, 1):
+            _lib.check(lib.empose_mlp_train_fwd(C.byref(ps[i]), M, _lib.dptr(x), ldx, _lib.dptr(outs[i]), outs[i].shape[1],
+                                                _lib.dptr(saves[i]), _lib.dptr(ws), nbytes, stream))
+        if saves_from is not None:
+            fwd_saves = [t.clone() for t in saves]
+            for t, src in zip(saves, saves_from):
+                t.copy_(src)
+        for i in (0, 1):
+            if deferred:
+                _lib.check(lib.empose_mlp_train_bwd_deferred(C.byref(ps[i]), M, _lib.dptr(x), ldx, _lib.dptr(d_outs[i]), lds[i],
+                                                             _lib.dptr(saves[i]), C.byref(gs[i]), 0, _lib.dptr(stashes[i]),
+                                                             _lib.dptr(ws), nbytes, stream))
+            else:
+                _lib.check(lib.empose_mlp_train_bwd(C.byref(ps[i]), M, _lib.dptr(x), ldx, _lib.dptr(d_outs[i]), lds[i],
+                                                    _lib.dptr(saves[i]), C.byref(gs[i]), 0, _lib.dptr(ws), nbytes, stream))
+    torch.cuda.synchronize()
+    _lib.check(lib.empose_async_status())
+    res = {'out': outs, 'save': saves if saves_from is None else fwd_saves, 'stash': stashes, 'grads': grads}
+    res['bn'] = [[t.clone() for k, t in n.state_dict().items() if 'running_' in k or 'num_batches' in k] for n in nets]
+    return res
+
+
+@pytest.mark.parametrize('M,in_dim,hidden', [(384, 296, 512), (512, 296, 512), (100, 296, 512), (17, 152, 64),
+                                             (48, 296, 32), (1, 152, 64)])
+def test_one_launch_train_layers_equal_the_layer_by_layer_path(M, in_dim, hidden):
+    """Training at up to 512 rows (the reference's 12 windows x 32 frames = 384): a layer's product + bias + train-mode
+    BatchNorm + PReLU of BOTH update networks as one launch, forward and backward, its column statistics exchanged between
+    the four row parts through tagged words (csrc/train_cols.hip, reference nn/layers.py:13-77 in training mode) -- against
+    the product + BatchNorm launches of each network (option train_cols = 0): outputs, saved z / a / mean / rstd, running
+    statistics, the layer cotangents and the BatchNorm / PReLU gradients, to rounding (another summation order; the batch
+    variance by a pairwise update of the parts' centred sums).  The paired call and the two single-network calls run the
+    same launches: bit-identical."""
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(M + hidden)
+    x = torch.randn(M, in_dim, generator=g).to(DEV)
+    d_outs = [torch.zeros(M, 68), torch.zeros(M, 12)]
+    d_outs[0][:, :66] = torch.randn(M, 66, generator=g)
+    d_outs[1][:, :10] = torch.randn(M, 10, generator=g)
+    d_outs = [d.to(DEV) for d in d_outs]
+    res = {}
+    for key, cols, pair, deferred in (('passes', 0, False, True), ('single', 1, False, True), ('pair', 1, True, True),
+                                      ('passes_now', 0, False, False), ('single_now', 1, False, False)):
+        nets = _mlp_pair(in_dim, hidden, 5)
+        _lib.check(lib.empose_set_option(b'train_cols', cols))
+        try:
+            res[key] = _run_mlp_train(nets, x, d_outs, M, pair, deferred,
+                                      saves_from=None if key == 'passes' else res['passes']['save'])
+        finally:
+            _lib.check(lib.empose_set_option(b'train_cols', 1))
+    def flat(r, deferred=True):
+        out = list(r['out']) + list(r['save']) + [t for b in r['bn'] for t in b]
+        out += [t for gl in r['grads'] for t in gl]
+        return out + (list(r['stash']) if deferred else [])
+    for a, b in zip(flat(res['single']), flat(res['pair'])):
+        assert torch.equal(a, b)
+    if M == 1:       # one row: var = 0, rstd = 1 / sqrt(eps) amplifies rounding by 316 -- finite and paired == single is the check
+        assert all(torch.isfinite(t).all() for t in flat(res['single']))
+        return
+    worst = 0.0
+    for (want, got, deferred) in ((res['passes'], res['single'], True), (res['passes_now'], res['single_now'], False)):
+        for idx, (a, b) in enumerate(zip(flat(want, deferred), flat(got, deferred))):
+            assert torch.isfinite(b.float()).all()
+            scale = max(1.0, float(a.abs().max()))
+            err = float((a.double() - b.double()).abs().max()) / scale
+            worst = max(worst, err)
+            # (a bias in front of a train-mode BatchNorm has a mathematically zero gradient: both values are round-off of
+            # sums of M terms)
+            assert err < (1e-4 if a.ndim == 1 and a.numel() == hidden else 2e-5), (err, idx, a.shape, deferred)
+    # the deferred sweeps left the weight gradients alone; the immediate ones formed them
+    n_w = sum(float(t.abs().sum()) for t in res['single']['grads'][0][0:1])
+    assert n_w == 0.0 and float(res['single_now']['grads'][0][0].abs().sum()) > 0.0
+    print('one-launch layers M=%d %d->%d: worst relative difference to the layer-by-layer path %.2e' % (M, in_dim, hidden, worst))
