@@ -1104,6 +1104,15 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
   const int n = blockIdx.x * 4 + wave;
   const int M = p.M, N = p.N;
   constexpr int WMAX = 8;   // a segment's K <= 64 lanes x 4 x 8 = 2048
+  // lane m finishes row m: what the cell's reverse reads besides dh is fetched now, under the product (same arithmetic
+  // as lstm_cell_bwd_elem: rows past their length read valid addresses, their values are not used)
+  LstmCellBwdPre pre{};
+  const bool fin = n < N && lane < M;
+  float res = 0.f;
+  if (fin) {
+    pre = lstm_cell_bwd_load(cell, lane * cell.H + n);
+    if (p.resid) res = p.resid[(size_t)lane * p.ldr + n];
+  }
   float acc[MB];
 #pragma unroll
   for (int m = 0; m < MB; ++m) acc[m] = 0.f;
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
     }
     {
       const float* __restrict__ A = sg.A;
-      constexpr int SB = 8;
+      constexpr int SB = 12;    // 12 rows x 2048 floats are two rounds of 12 loads per thread
       int m = (int)threadIdx.x / k4n, c = (int)threadIdx.x - m * k4n;   // k4n >= 256: a step of 256 wraps at most once
       for (int i0 = threadIdx.x; i0 < MB * k4n; i0 += 256 * SB) {
         f32x4 v[SB];
@@ -1161,11 +1170,7 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == m) out = v;
   }
-  if (lane < M) {
-    float y = out;
-    if (p.resid) y += p.resid[(size_t)lane * p.ldr + n];
-    lstm_cell_bwd_elem(cell, lane * cell.H + n, y);
-  }
+  if (fin) lstm_cell_bwd_finish(cell, lane * cell.H + n, pre, out + res);
 }
 
 template <int MB>

@@ -160,7 +160,7 @@ struct ColsArgs {
   int accumulate;
   unsigned tag;                      // unique among the launches that share the mailbox since it was zeroed; > 0
   unsigned long long* mailbox;       // cols_mailbox_words(widest N) words
-  int R, tiles_per_part, spin_limit; unsigned* timeouts;   // set by launch_cols
+  int R, tiles_per_part, s_max, slices_per_group, plain, spin_limit; unsigned* timeouts;   // set by launch_cols
 };
 constexpr int COLS_MAX_ROWS = 512;
 size_t cols_mailbox_words(int n_max);

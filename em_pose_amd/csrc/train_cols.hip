@@ -6,8 +6,8 @@
 // split-K product, then a BatchNorm kernel that walks all rows of 32 columns), each near the floor of a launch.  Here a
 // layer's product and its BatchNorm meet in one kernel, on the whole chip:
 //   * a workgroup owns 16 output columns x one quarter of the rows (R = 4 row parts of up to 8 tiles of 16 rows);
-//     hidden width 512 and two networks: 32 x 4 x 2 = 256 workgroups;
-//   * its four waves split K (16-k blocks w, w + 4, ...), every wave keeps all row tiles of the part in registers
+//     hidden width 512 and two networks: 32 x 4 x 2 = 256 workgroups, mapped so that an XCD serves one network;
+//   * its eight waves split K (a contiguous range of 16-k blocks each), every wave keeps all row tiles of the part in registers
 //     (v_mfma_f32_16x16x4_f32, fp32 operands straight from the row-major arrays: a lane reads 16 bytes of a row and feeds
 //     one float to each of four MFMAs -- the k order inside a block is permuted the same way on both operands);
 //     the partial sums meet in LDS and are added in wave order;
@@ -28,36 +28,51 @@
 namespace empose {
 
 namespace tc {
-constexpr int NT = 256, MAX_TILES = 8;
+constexpr int NT = 512, NW8 = NT / 64, MAX_TILES = 8, RG = NT / 16, VT = MAX_TILES * 16 / RG;
+constexpr int CH = 4;                                     // 16-k blocks a wave has in flight (all loads issued before the products)
 constexpr int TLD = 17, TSZ = 16 * TLD;                   // padded 16 x 16 tile of partial sums
-constexpr int PART_FLOATS = 4 * MAX_TILES * TSZ;          // [wave][tile][row][col]
+constexpr int PART_FLOATS = NW8 * MAX_TILES * TSZ;        // [wave][tile][row][col]
 }  // namespace tc
 
 __device__ __forceinline__ unsigned long long tc_pack(float v, unsigned tag) {
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
 
-// sum over the 16 row groups of a column (every thread of the column gets the same sum, added in group order)
+// sum over the row groups of a column (every thread of the column gets the same sum, added in group order)
 __device__ __forceinline__ float tc_reduce(float v, float* red, int rg, int c) {
   red[rg * 16 + c] = v;
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) s += red[g * 16 + c];
+  for (int g = 0; g < tc::RG; ++g) s += red[g * 16 + c];
   __syncthreads();
   return s;
 }
 
-// MODE 0: forward with BatchNorm + PReLU; 1: forward, plain product + bias (the output layer); 2: backward
+// MODE 0: forward (a.plain: product + bias only, the output layer; else with BatchNorm + PReLU); 2: backward
+#ifdef TC_LAB_TIMES      // (scripts/dev/train_cols_lab.hip: shader-clock stamps of thread 0 of every workgroup)
+__device__ long long* tc_lab_times;
+#define TC_STAMP(i) do { if (threadIdx.x == 0) tc_lab_times[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define TC_STAMP(i) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   using namespace tc;
+  TC_STAMP(0);
   __shared__ float part[PART_FLOATS];
-  __shared__ float red[256];
+  __shared__ float red[RG * 16];
   __shared__ float xs[4 * 3 * 16];     // [part][word][col]: what the parts posted
   __shared__ int bad_lds;
-  const ColsNet& n = a.net[blockIdx.z];
-  const int slice = blockIdx.x, r = blockIdx.y;
+  // Workgroup -> (network, column slice, row part), XCD-aware: consecutive workgroup ids go round the 8 XCDs, so id & 7 is
+  // the XCD; one XCD takes ONE network and 1 / groups of its column slices with all their row parts -- its L2 then holds
+  // that network's rows once and only its own slices' weights (1.0 MB instead of 1.8 at two networks of width 512), and
+  // the parts that exchange statistics sit behind the same L2.
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int groups = 8 / a.n_nets, net_i = xcd / groups;
+  const int slice = (xcd % groups) * a.slices_per_group + j % a.slices_per_group, r = j / a.slices_per_group;
+  const ColsNet& n = a.net[net_i];
   const int N = n.N, K = n.K, M = a.M;
   if (slice * 16 >= N) return;
   const int T16 = (M + 15) >> 4;
@@ -69,47 +84,53 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
 
-  // ---- the product: wave w's 16-k blocks of all row tiles of this part
+  // ---- the product: wave w's contiguous range of 16-k blocks, all row tiles of this part.  A layer at this size is a
+  // latency chain, not a throughput problem: a wave issues the loads of CH blocks (all of its K at width 512) before the
+  // first product, so the whole operand of the workgroup is in flight at once.
   f32x4 acc[MAX_TILES];
 #pragma unroll
   for (int t = 0; t < MAX_TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     const int KB = (K + 15) >> 4;
-    const int nkb = KB > wave ? (KB - wave + 3) >> 2 : 0;
-    const float* wrow = n.W + (size_t)min(slice * 16 + r16, N - 1) * n.ldw + 4 * g;
+    const int per = (KB + NW8 - 1) / NW8;
+    const int kb0 = wave * per, kb1 = min(KB, kb0 + per);
+    const float* wrow = n.W + (size_t)min(slice * 16 + r16, N - 1) * n.ldw;
     int aoff[MAX_TILES];
 #pragma unroll
-    for (int t = 0; t < MAX_TILES; ++t) aoff[t] = min(row0 + t * 16 + r16, M - 1) * n.lda + 4 * g;
-    f32x4 fa[3][MAX_TILES], fw[3];
-    auto load = [&](f32x4 (&A)[MAX_TILES], f32x4& W, int i) {
-      if (i >= nkb) return;
-      const int k0 = (wave + 4 * i) * 16;
-      const bool in = k0 + 4 * g < K;                 // K % 4 == 0: a lane's four floats are inside or outside together
-#pragma unroll
-      for (int t = 0; t < MAX_TILES; ++t)
-        if (t < ntl) A[t] = in ? *reinterpret_cast<const f32x4*>(n.A + aoff[t] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-      W = in ? *reinterpret_cast<const f32x4*>(wrow + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto mma = [&](const f32x4 (&A)[MAX_TILES], const f32x4& W) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int t = 0; t < MAX_TILES; ++t) aoff[t] = min(row0 + t * 16 + r16, M - 1) * n.lda;
+#pragma unroll 1
+    for (int kb = kb0; kb < kb1; kb += CH) {
+      f32x4 fa[CH][MAX_TILES], fw[CH];
+      auto load = [&](int q) {
+        // K % 4 == 0: a lane's four floats are inside or outside together.  Outside (the last block of a ragged K, blocks
+        // past the wave's range) the lane reads the first four floats of the same rows instead -- no branch around a load,
+        // nothing read past a row's K -- and its weights count as zero (the row's own values times zero: what the row's
+        // sum holds anyway if they are not finite)
+        const bool in = kb + q < kb1 && (kb + q) * 16 + 4 * g < K;
+        const int k0 = in ? (kb + q) * 16 + 4 * g : 0;
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t)
-          if (t < ntl) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t][s], W[s], acc[t], 0, 0, 0);
-    };
-    load(fa[0], fw[0], 0);
-    load(fa[1], fw[1], 1);
-    for (int i = 0; i < nkb; i += 3) {
-      load(fa[2], fw[2], i + 2);
-      mma(fa[0], fw[0]);
-      if (i + 1 < nkb) {
-        load(fa[0], fw[0], i + 3);
-        mma(fa[1], fw[1]);
-      }
-      if (i + 2 < nkb) {
-        load(fa[1], fw[1], i + 4);
-        mma(fa[2], fw[2]);
-      }
+          if (t < ntl) fa[q][t] = *reinterpret_cast<const f32x4*>(n.A + aoff[t] + k0);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k0);
+        fw[q] = in ? wv : f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      auto mma = [&](int q) {
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI)
+#pragma unroll
+          for (int t = 0; t < MAX_TILES; ++t)
+            if (t < ntl) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q][t][sI], fw[q][sI], acc[t], 0, 0, 0);
+      };
+      // loads two blocks ahead of the products: the memory pipeline of the CU stays full (issuing all of a wave's loads at
+      // once stalls it for as long as the data takes to arrive, with the matrix cores idle: scripts/dev/train_cols_lab.hip)
+      load(0); load(1);
+      __builtin_amdgcn_sched_barrier(0);
+      load(2); mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(3); mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      TC_STAMP(1);
+      mma(2); mma(3);
     }
   }
   // the C/D layout of the 16 x 16 MFMA: a lane holds column r16, rows 4 g .. 4 g + 3
@@ -120,36 +141,40 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
       for (int j = 0; j < 4; ++j) part[(wave * MAX_TILES + t) * TSZ + (4 * g + j) * TLD + r16] = acc[t][j];
     }
   if (tid == 0) bad_lds = 0;
+  TC_STAMP(2);
   __syncthreads();
+  TC_STAMP(3);
 
-  // ---- epilogue: thread (row group rg, column c) owns rows row0 + 16 t + rg
+  // ---- epilogue: thread (row group rg of 32, column c) owns rows row0 + 32 t + rg
   const int c = tid & 15, rg = tid >> 4;
   const int col = slice * 16 + c;
   const bool colok = col < N;
   const int cc = colok ? col : N - 1;
-  float v[MAX_TILES];
-  bool ok[MAX_TILES];
+  float v[VT];
+  bool ok[VT];
 #pragma unroll
-  for (int t = 0; t < MAX_TILES; ++t) {
-    ok[t] = t < ntl && row0 + t * 16 + rg < M;
-    float s = 0.f;
-    if (t < ntl) {
-      const float* ps = part + t * TSZ + rg * TLD + c;
-      s = ((ps[0] + ps[MAX_TILES * TSZ]) + ps[2 * MAX_TILES * TSZ]) + ps[3 * MAX_TILES * TSZ];
+  for (int t = 0; t < VT; ++t) {
+    const int lr = t * RG + rg, tile = lr >> 4;       // row inside the part, its 16-row tile
+    ok[t] = tile < ntl && row0 + lr < M;
+    float sum = 0.f;
+    if (tile < ntl) {
+      const float* ps = part + tile * TSZ + (lr & 15) * TLD + c;
+#pragma unroll
+      for (int w = 0; w < NW8; ++w) sum += ps[w * MAX_TILES * TSZ];     // wave order
     }
-    v[t] = s;
+    v[t] = sum;
   }
-  if constexpr (MODE == 1) {
-    const float b = n.bias ? n.bias[cc] : 0.f;
+  if (MODE == 0 && a.plain) {      // the output layer: product + bias, nothing to exchange
+    const float b = n.bias[cc];
 #pragma unroll
-    for (int t = 0; t < MAX_TILES; ++t)
-      if (ok[t] && colok) n.out[(size_t)(row0 + t * 16 + rg) * n.ld_out + col] = v[t] + b;
+    for (int t = 0; t < VT; ++t)
+      if (ok[t] && colok) n.out[(size_t)(row0 + t * RG + rg) * n.ld_out + col] = v[t] + b;
     return;
   }
 
   // what the parts post: NW words per column; word w of part q, column c at mailbox[((q * 16 + c) * 3 + w]
   constexpr int NW = MODE == 0 ? 2 : 3;
-  unsigned long long* mb = a.mailbox + ((size_t)(blockIdx.z * gridDim.x + slice) * 4) * 16 * 3;
+  unsigned long long* mb = a.mailbox + ((size_t)(net_i * a.s_max + slice) * 4) * 16 * 3;
   auto exchange = [&](const float (&mine)[NW]) {
     if (rg == 0) {
 #pragma unroll
@@ -182,14 +207,21 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
     const int n_mine = min(ntl * 16, M - row0);
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAX_TILES; ++t) { v[t] += b; s += ok[t] ? v[t] : 0.f; }
+    for (int t = 0; t < VT; ++t) { v[t] += b; s += ok[t] ? v[t] : 0.f; }
     const float mean_l = tc_reduce(s, red, rg, c) / (float)n_mine;
     float q = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAX_TILES; ++t) { const float d = v[t] - mean_l; q += ok[t] ? d * d : 0.f; }
+    for (int t = 0; t < VT; ++t) { const float d = v[t] - mean_l; q += ok[t] ? d * d : 0.f; }
     const float m2_l = tc_reduce(q, red, rg, c);
+    if (colok) {                          // (the pre-BatchNorm rows do not wait for the other parts)
+#pragma unroll
+      for (int t = 0; t < VT; ++t)
+        if (ok[t]) n.z[(size_t)(row0 + t * RG + rg) * n.ldz + col] = v[t];
+    }
     const float mine[2] = {mean_l, m2_l};
+    TC_STAMP(4);
     exchange(mine);
+    TC_STAMP(5);
     // the parts in part order (pairwise update of mean and centred sum of squares)
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
     for (int p = 0; p < a.R; ++p) {
@@ -206,10 +238,9 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
     if (colok) {
       const float gm = n.gamma[col], bt = n.beta[col], slope = n.slope[0];
 #pragma unroll
-      for (int t = 0; t < MAX_TILES; ++t)
+      for (int t = 0; t < VT; ++t)
         if (ok[t]) {
-          const size_t row = (size_t)(row0 + t * 16 + rg);
-          n.z[row * n.ldz + col] = v[t];
+          const size_t row = (size_t)(row0 + t * RG + rg);
           const float y = gm * ((v[t] - mean) * rstd) + bt;
           n.out[row * n.ld_out + col] = y > 0.f ? y : slope * y;
         }
@@ -224,17 +255,18 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
       }
     }
     if (slice == 0 && r == 0 && tid == 0 && n.num_batches) n.num_batches[0] += 1;
+    TC_STAMP(6);
     return;
   }
 
   if constexpr (MODE == 2) {
     const float mean = n.mean[cc], rstd = n.rstd[cc];
     const float gm = n.gamma[cc], bt = n.beta[cc], slope = n.slope[0];
-    float xh[MAX_TILES], dy[MAX_TILES];
+    float xh[VT], dy[VT];
     float s_b = 0.f, s_g = 0.f, s_a = 0.f;
 #pragma unroll
-    for (int t = 0; t < MAX_TILES; ++t) {
-      const float z = ok[t] ? n.z_in[(size_t)(row0 + t * 16 + rg) * n.ldz + cc] : mean;
+    for (int t = 0; t < VT; ++t) {
+      const float z = ok[t] ? n.z_in[(size_t)(row0 + t * RG + rg) * n.ldz + cc] : mean;
       const float da = ok[t] ? v[t] : 0.f;
       xh[t] = (z - mean) * rstd;
       const float y = gm * xh[t] + bt;
@@ -258,8 +290,8 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
     if (colok) {
       const float k = gm * rstd * inv_m;
 #pragma unroll
-      for (int t = 0; t < MAX_TILES; ++t)
-        if (ok[t]) n.out[(size_t)(row0 + t * 16 + rg) * n.ld_out + col] = k * ((float)M * dy[t] - dbeta - xh[t] * dgamma);
+      for (int t = 0; t < VT; ++t)
+        if (ok[t]) n.out[(size_t)(row0 + t * RG + rg) * n.ld_out + col] = k * ((float)M * dy[t] - dbeta - xh[t] * dgamma);
       if (r == 0 && rg == 0) {
         n.dgamma[col] = dgamma + (a.accumulate ? n.dgamma[col] : 0.f);
         n.dbeta[col] = dbeta + (a.accumulate ? n.dbeta[col] : 0.f);
@@ -299,7 +331,8 @@ bool cols_launchable(int n_max, int n_nets) {
     if (coresident_blocks(reinterpret_cast<const void*>(cols_kernel<2>), tc::NT, 0, &b2) != hipSuccess) return false;
     resident[dev] = b0 < b2 ? b0 : b2;
   }
-  return (long)((n_max + 15) / 16) * 4 * n_nets <= resident[dev];
+  const int groups = 8 / n_nets, s_max = (n_max + 15) / 16;
+  return (long)8 * ((s_max + groups - 1) / groups) * 4 <= resident[dev];
 }
 
 hipError_t launch_cols(ColsArgs a, int mode, hipStream_t stream) {
@@ -312,9 +345,12 @@ hipError_t launch_cols(ColsArgs a, int mode, hipStream_t stream) {
   if (!a.timeouts) return hipErrorOutOfMemory;
   int n_max = 0;
   for (int i = 0; i < a.n_nets; ++i) n_max = a.net[i].N > n_max ? a.net[i].N : n_max;
-  const dim3 grid((n_max + 15) / 16, a.R, a.n_nets);
-  if (mode == 0) hipLaunchKernelGGL(cols_kernel<0>, grid, dim3(tc::NT), 0, stream, a);
-  else if (mode == 1) hipLaunchKernelGGL(cols_kernel<1>, grid, dim3(tc::NT), 0, stream, a);
+  a.s_max = (n_max + 15) / 16;
+  const int groups = 8 / a.n_nets;
+  a.slices_per_group = (a.s_max + groups - 1) / groups;
+  const dim3 grid(8 * a.slices_per_group * a.R);
+  a.plain = mode == 1;
+  if (mode <= 1) hipLaunchKernelGGL(cols_kernel<0>, grid, dim3(tc::NT), 0, stream, a);
   else hipLaunchKernelGGL(cols_kernel<2>, grid, dim3(tc::NT), 0, stream, a);
   return hipGetLastError();
 }

@@ -40,7 +40,9 @@ def test_poll_timeout_of_the_whole_sequence_lstm_is_reported_not_silent():
     with torch.no_grad():
         want, _ = R.lstm_forward(sd, 'lstm.', x, lens, None, L, False)
     timed_out = 0
-    for attempt in range(4):
+    for attempt in range(12):      # (whether a first re-check finds the word depends on the clocks of the moment: 4 were too few once)
+        if timed_out >= 2:
+            break
         _lib.check(lib.empose_set_option(b'spin_limit', 1))
         g.init_state = None
         got = g(x.to(DEV), lens.to(DEV))          # returns normally: the failure happens later, on the device
