@@ -1724,12 +1724,11 @@ struct MlpTrainWs {
   float* wt;         // transposed weight [hidden][max(hidden, out_pad)]
   float* atb; size_t atb_floats; float* bn; float* slope_partial; int* counter;
   float* part; float* coef;   // fused path: per-row-block partial sums, BatchNorm-reverse coefficients [3][H]
-  // one-launch layers (train_cols.hip): mailbox words, then the two networks' arrival counters -- zeroed together once
-  // per call; slope partial sums of the second network of a pair
-  unsigned long long* mbox; size_t mbox_bytes; int* counter2; float* slope_partial2;
+  // one-launch layers (train_cols.hip): mailbox words, zeroed once per call
+  unsigned long long* mbox; size_t mbox_bytes;
 };
 size_t cols_zero_bytes(const empose_mlp_params* p) {
-  return cols_mailbox_words(p->hidden > p->out_dim ? p->hidden : p->out_dim) * sizeof(unsigned long long) + 64;
+  return cols_mailbox_words(p->hidden > p->out_dim ? p->hidden : p->out_dim) * sizeof(unsigned long long);
 }
 // every A^T B product of one MLP over M rows: (H, in_dim), (H, H), (out_dim, H)
 size_t mlp_atb_floats(const empose_mlp_params* p, int M) {
@@ -1743,13 +1742,12 @@ MlpTrainWs carve_mlp_train(Carver& c, const empose_mlp_params* p, int M) {
   w.atb_floats = mlp_atb_floats(p, M);
   w.atb = c.f(w.atb_floats + 64);
   w.bn = c.f(bn_prelu_workspace_floats(M, H) + 64);
-  w.slope_partial = c.f((size_t)(H + 15) / 16 + 8);   // (per 16 columns on the one-launch layers, per 32 otherwise)
+  w.slope_partial = c.f((size_t)(H + 31) / 32 + 8);
   w.counter = reinterpret_cast<int*>(c.f(64));
   w.part = c.f(bn_fused_partial_floats(M, H) + 64);
   w.coef = c.f((size_t)3 * H + 64);
   w.mbox_bytes = cols_zero_bytes(p);
   w.mbox = reinterpret_cast<unsigned long long*>(c.f(w.mbox_bytes / sizeof(float)));
-  w.slope_partial2 = c.f((size_t)(H + 15) / 16 + 8);
   return w;
 }
 // The BatchNorm / PReLU passes folded into the GEMMs (train_fused.hip).  Opt-in: gradient parity with the reference is
@@ -1790,9 +1788,6 @@ bool mlp_cols_pairable(const empose_mlp_params* a, const empose_mlp_params* b, i
   return a->n_layers == b->n_layers && a->hidden == b->hidden && a->bn_eps == b->bn_eps &&
          a->bn_momentum == b->bn_momentum && mlp_train_cols(a, M) && mlp_train_cols(b, M) &&
          b->out_dim <= (a->hidden > a->out_dim ? a->hidden : a->out_dim);
-}
-int* cols_counter(const MlpTrainWs& w, int i) {
-  return reinterpret_cast<int*>(reinterpret_cast<char*>(w.mbox) + w.mbox_bytes - 64) + 8 * i;
 }
 
 int mlp_fwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* x, int ldx, float* const* outs,
@@ -2000,7 +1995,6 @@ int mlp_bwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* 
       c.z_in = sv; c.ldz = H; c.mean = const_cast<float*>(sv + (size_t)2 * M * H); c.rstd = c.mean + H;
       c.out = dz_of(i, l - 1); c.ld_out = H;
       c.dgamma = grs[i]->bn_weight[l - 1]; c.dbeta = grs[i]->bn_bias[l - 1]; c.dslope = grs[i]->prelu[l - 1];
-      c.dslope_partial = i == 0 ? w.slope_partial : w.slope_partial2; c.counter = cols_counter(w, i);
     }
     hipError_t e = launch_cols(a, 2, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "one-launch layer backward: %s", hipGetErrorString(e));

@@ -151,7 +151,7 @@ struct ColsNet {
   const float* z_in; float* z; int ldz;   // pre-BatchNorm rows: written by the forward, read (z_in) by the backward
   float* out; int ld_out;            // forward: the activations (mode 1: the plain product); backward: dZ of the N columns
   float* mean; float* rstd;          // [N]: written by the forward, read by the backward
-  float* dgamma; float* dbeta; float* dslope; float* dslope_partial; int* counter;   // backward (counter: zero, re-arms)
+  float* dgamma; float* dbeta; float* dslope;   // backward
 };
 struct ColsArgs {
   ColsNet net[2];

@@ -66,8 +66,16 @@ __global__ __launch_bounds__(256) void lstm_split_rows_kernel(const float* __res
   for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4_t*>(o + pc * lx::FRAG) = q.p[pc];
 }
 
+#ifdef LX_LAB_TIMES      // (scripts/dev/lstm_x3_lab.hip: shader-clock stamps of thread 0 of every workgroup)
+__device__ long long* lx_lab_times;
+#define LX_STAMP(i) do { if (threadIdx.x == 0) lx_lab_times[(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (i)] = clock64(); } while (0)
+#else
+#define LX_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
   using namespace lx;
+  LX_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float part[];
   const int H = a.H, B = a.B, F = a.F;
   const int jb = blockIdx.x, JB = H / BU, j0 = jb * BU;
@@ -76,7 +84,9 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   const int KS_h = H / 16;
-  // the finishing thread's element group: row f_row, units j0 + 8 f_ug .. + 7 (all four gates)
+  // the finishing thread's element group: row f_row, units j0 + 8 f_ug .. + 7 (all four gates).  (Four lanes per row --
+  // whole 128-byte lines of c / h / y per row -- measured the same: the finish is its 128 LDS reads and 40 transcendental
+  // functions per thread, 5.1 k of the 39 k clocks a unit takes, scripts/dev/lstm_x3_lab.hip with -DLX_LAB_TIMES)
   const int f_row = tid & 63, f_ug = tid >> 6;
   const int g_row = m0 + f_row, g_rowc = g_row < B ? g_row : B - 1;
   const int g_unit = j0 + f_ug * 8;
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
 #endif
     if (i < n_w) mma(fa[0], fw[0]);
     if (i + 1 < n_w) mma(fa[1], fw[1]);
+    LX_STAMP(1 + 5 * (u - u_beg));
 
     // ---- partial sums -> LDS as [wave][gate][unit][row]: 16-byte pieces of four consecutive rows (the C/D layout has rows
     // 8 q + 4 lh .. + 3 of a column in one lane); the row stride of 68 floats spreads the 32 units of a store over the banks
@@ -199,7 +210,9 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
             *reinterpret_cast<f32x4*>(pw + (q * BU + l31) * PLD + r * 32 + 8 * v + 4 * lh) =
                 f32x4{acc[r][q][4 * v], acc[r][q][4 * v + 1], acc[r][q][4 * v + 2], acc[r][q][4 * v + 3]};
     }
+    LX_STAMP(2 + 5 * (u - u_beg));
     __syncthreads();
+    LX_STAMP(3 + 5 * (u - u_beg));
 
 #ifdef LX_LAB_NOFINISH   // (lab ablation: the exchange, but no cell arithmetic and no stores)
     if (part[tid] == 123.456f) U.c[tid] = part[tid + 1] + e_c[0][0] + e_hp[0][0] + e_bias[0][0];
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
       hv[e] = live ? h_new : (a.seq_lengths ? h_old : 0.f);
       yv[e] = live ? h_new : 0.f;
     }
+    LX_STAMP(4 + 5 * (u - u_beg));
     if (g_row < B) {
       const size_t hc = (size_t)g_row * H + g_unit;
       *reinterpret_cast<f32x4*>(U.c + hc) = f32x4{cv[0], cv[1], cv[2], cv[3]};
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4_t*>(o + pc * FRAG) = q.p[pc];
     }
+    LX_STAMP(5 + 5 * (u - u_beg));
   }
 }
 

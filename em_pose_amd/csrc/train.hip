@@ -629,33 +629,38 @@ hipError_t launch_lgd_assemble(int T, int d_in, const float* x0, int ld0, const 
 
 // pose_next = pose + step * d_pose;  shape_next = shape + step * (shape_avg ? window mean of d_shape : d_shape).
 // One workgroup per window of F frames (reference models.py:529-535, 588-600).
+// (grid (B, 1 + LGD_POSE_PARTS): y = 0 the window's shape columns -- the only part that needs the whole window --, y >= 1 a
+// slice of its F x 66 pose entries; one workgroup per window was a serial walk of ten loads deep, 12-18 us per launch at the
+// reference's 12 windows.  Same arithmetic per element.)
+constexpr int LGD_POSE_PARTS = 4;
 __global__ __launch_bounds__(256) void lgd_update_kernel(int F, float step, int shape_avg, const float* pose,
                                                          const float* d_pose, const float* shape, const float* d_shape,
                                                          float* pose_next, float* shape_next) {
   __shared__ float mean[10];
   const size_t t0 = (size_t)blockIdx.x * F;
+  if (blockIdx.y > 0) {
+    const int n = F * 66, per = (n + LGD_POSE_PARTS - 1) / LGD_POSE_PARTS;
+    const int lo = (blockIdx.y - 1) * per, hi = min(n, lo + per);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) pose_next[t0 * 66 + i] = step * d_pose[t0 * 66 + i] + pose[t0 * 66 + i];
+    return;
+  }
   if (shape_avg && threadIdx.x < 10) {
     float s = 0.f;
     for (int f = 0; f < F; ++f) s += d_shape[(t0 + f) * 10 + threadIdx.x];
     mean[threadIdx.x] = s / (float)F;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < F * 76; i += 256) {
-    const int f = i / 76, c = i - f * 76;
-    const size_t t = t0 + f;
-    if (c < 66) pose_next[t * 66 + c] = step * d_pose[t * 66 + c] + pose[t * 66 + c];
-    else {
-      const int k = c - 66;
-      const float d = shape_avg ? mean[k] : d_shape[t * 10 + k];
-      shape_next[t * 10 + k] = step * d + shape[t * 10 + k];
-    }
+  for (int i = threadIdx.x; i < F * 10; i += 256) {
+    const int k = i % 10;
+    const float d = shape_avg ? mean[k] : d_shape[t0 * 10 + i];
+    shape_next[t0 * 10 + i] = step * d + shape[t0 * 10 + i];
   }
 }
 hipError_t launch_lgd_update(int B, int F, float step, int shape_avg, const float* pose, const float* d_pose,
                              const float* shape, const float* d_shape, float* pose_next, float* shape_next,
                              hipStream_t stream) {
-  hipLaunchKernelGGL(lgd_update_kernel, dim3(B), dim3(256), 0, stream, F, step, shape_avg, pose, d_pose, shape, d_shape,
-                     pose_next, shape_next);
+  hipLaunchKernelGGL(lgd_update_kernel, dim3(B, 1 + LGD_POSE_PARTS), dim3(256), 0, stream, F, step, shape_avg, pose, d_pose,
+                     shape, d_shape, pose_next, shape_next);
   return hipGetLastError();
 }
 
@@ -673,10 +678,12 @@ __global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, 
                                                             float* dspad) {
   extern __shared__ float sds[];   // [F][10]
   const size_t t0 = (size_t)blockIdx.x * F;
-  for (int i = threadIdx.x; i < F * 76; i += 256) {
-    const int f = i / 76, c = i - f * 76;
-    const size_t t = t0 + f;
-    if (c < 66) {
+  if (blockIdx.y > 0) {            // a slice of the window's F x 66 pose entries (grid as lgd_update_kernel)
+    const int n = F * 66, per = (n + LGD_POSE_PARTS - 1) / LGD_POSE_PARTS;
+    const int lo = (blockIdx.y - 1) * per, hi = min(n, lo + per);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      const int f = i / 66, c = i - f * 66;
+      const size_t t = t0 + f;
       float v = d_pose[t * 66 + c];
       if (!first) v = v + Dp[t * 66 + c];
       v = vp[t * 66 + c] + v;
@@ -686,15 +693,18 @@ __global__ __launch_bounds__(256) void lgd_cotangent_kernel(int F, float inv_T, 
         dpad[t * 68 + c] = step * v;
         if (c >= 64) dpad[t * 68 + c + 2] = 0.f;   // the two padding columns
       }
-    } else {
-      const int k = c - 66;
-      float v = d_shape[t * 10 + k];
-      if (!first) v = v + Ds[t * 10 + k];
-      v = vs[t * 10 + k] + v;
-      if (g_beta) v = inv_T * g_beta[t * ld_gb + k] + v;
-      Ds[t * 10 + k] = v;
-      sds[f * 10 + k] = v;
     }
+    return;
+  }
+  for (int i = threadIdx.x; i < F * 10; i += 256) {
+    const int f = i / 10, k = i - f * 10;
+    const size_t t = t0 + f;
+    float v = d_shape[t * 10 + k];
+    if (!first) v = v + Ds[t * 10 + k];
+    v = vs[t * 10 + k] + v;
+    if (g_beta) v = inv_T * g_beta[t * ld_gb + k] + v;
+    Ds[t * 10 + k] = v;
+    sds[f * 10 + k] = v;
   }
   if (!dspad) return;
   __syncthreads();
@@ -716,7 +726,7 @@ hipError_t launch_lgd_cotangent(int B, int F, int first, const float* d_pose, co
                                 const float* vs, const float* g_theta, int ld_g, const float* g_beta, int ld_gb, float* Dp,
                                 float* Ds, float step, int shape_avg, float* dpad, float* dspad, hipStream_t stream) {
   const float inv_T = 1.f / (float)((long)B * F);
-  hipLaunchKernelGGL(lgd_cotangent_kernel, dim3(B), dim3(256), (size_t)F * 10 * sizeof(float), stream, F, inv_T, first,
+  hipLaunchKernelGGL(lgd_cotangent_kernel, dim3(B, 1 + LGD_POSE_PARTS), dim3(256), (size_t)F * 10 * sizeof(float), stream, F, inv_T, first,
                      d_pose, d_shape, vp, vs, g_theta, ld_g, g_beta, ld_gb, Dp, Ds, step, shape_avg, dpad, dspad);
   return hipGetLastError();
 }

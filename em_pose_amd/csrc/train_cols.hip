@@ -62,7 +62,7 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   using namespace tc;
   TC_STAMP(0);
   __shared__ float part[PART_FLOATS];
-  __shared__ float red[RG * 16];
+  __shared__ float red[3 * RG * 16];
   __shared__ float xs[4 * 3 * 16];     // [part][word][col]: what the parts posted
   __shared__ int bad_lds;
   // Workgroup -> (network, column slice, row part), XCD-aware: consecutive workgroup ids go round the 8 XCDs, so id & 7 is
@@ -83,6 +83,22 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g = lane >> 4;
+
+  // the epilogue's element group: thread (row group rg of 32, column c) owns rows row0 + 32 t + rg.  What the reverse reads
+  // besides the product -- the saved pre-BatchNorm rows and the layer's constants -- is fetched now, under the product.
+  const int c = tid & 15, rg = tid >> 4;
+  const int col = slice * 16 + c;
+  const bool colok = col < N;
+  const int cc = colok ? col : N - 1;
+  bool ok[VT];
+#pragma unroll
+  for (int t = 0; t < VT; ++t) ok[t] = ((t * RG + rg) >> 4) < ntl && row0 + t * RG + rg < M;
+  float zin[VT], e_mean = 0.f, e_rstd = 0.f, e_gm = 0.f, e_bt = 0.f, e_slope = 0.f;
+  if constexpr (MODE == 2) {
+    e_mean = n.mean[cc]; e_rstd = n.rstd[cc]; e_gm = n.gamma[cc]; e_bt = n.beta[cc]; e_slope = n.slope[0];
+#pragma unroll
+    for (int t = 0; t < VT; ++t) zin[t] = n.z_in[(size_t)min(row0 + t * RG + rg, M - 1) * n.ldz + cc];
+  }
 
   // ---- the product: wave w's contiguous range of 16-k blocks, all row tiles of this part.  A layer at this size is a
   // latency chain, not a throughput problem: a wave issues the loads of CH blocks (all of its K at width 512) before the
@@ -145,17 +161,11 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   __syncthreads();
   TC_STAMP(3);
 
-  // ---- epilogue: thread (row group rg of 32, column c) owns rows row0 + 32 t + rg
-  const int c = tid & 15, rg = tid >> 4;
-  const int col = slice * 16 + c;
-  const bool colok = col < N;
-  const int cc = colok ? col : N - 1;
+  // ---- epilogue
   float v[VT];
-  bool ok[VT];
 #pragma unroll
   for (int t = 0; t < VT; ++t) {
     const int lr = t * RG + rg, tile = lr >> 4;       // row inside the part, its 16-row tile
-    ok[t] = tile < ntl && row0 + lr < M;
     float sum = 0.f;
     if (tile < ntl) {
       const float* ps = part + tile * TSZ + (lr & 15) * TLD + c;
@@ -260,13 +270,12 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
   }
 
   if constexpr (MODE == 2) {
-    const float mean = n.mean[cc], rstd = n.rstd[cc];
-    const float gm = n.gamma[cc], bt = n.beta[cc], slope = n.slope[0];
+    const float mean = e_mean, rstd = e_rstd, gm = e_gm, bt = e_bt, slope = e_slope;
     float xh[VT], dy[VT];
     float s_b = 0.f, s_g = 0.f, s_a = 0.f;
 #pragma unroll
     for (int t = 0; t < VT; ++t) {
-      const float z = ok[t] ? n.z_in[(size_t)(row0 + t * RG + rg) * n.ldz + cc] : mean;
+      const float z = ok[t] ? zin[t] : mean;
       const float da = ok[t] ? v[t] : 0.f;
       xh[t] = (z - mean) * rstd;
       const float y = gm * xh[t] + bt;
@@ -275,10 +284,19 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
       s_g += dy[t] * xh[t];
       s_a += y > 0.f ? 0.f : da * y;
     }
-    float mine[3];
-    mine[0] = tc_reduce(s_b, red, rg, c);
-    mine[1] = tc_reduce(s_g, red, rg, c);
-    mine[2] = tc_reduce(colok ? s_a : 0.f, red, rg, c);
+    // the three column sums over the row groups in one pass through LDS (each in group order, as tc_reduce adds them)
+    float mine[3] = {0.f, 0.f, 0.f};
+    red[rg * 16 + c] = s_b;
+    red[RG * 16 + rg * 16 + c] = s_g;
+    red[2 * RG * 16 + rg * 16 + c] = colok ? s_a : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int gI = 0; gI < RG; ++gI) {
+      mine[0] += red[gI * 16 + c];
+      mine[1] += red[RG * 16 + gI * 16 + c];
+      mine[2] += red[2 * RG * 16 + gI * 16 + c];
+    }
+    __syncthreads();
     exchange(mine);
     float dbeta = 0.f, dgamma = 0.f, dslope_c = 0.f;
     for (int p = 0; p < a.R; ++p) {
@@ -297,29 +315,44 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
         n.dbeta[col] = dbeta + (a.accumulate ? n.dbeta[col] : 0.f);
       }
     }
-    // slope: part 0's workgroup of a slice adds its columns, the slice that arrives last adds the slices in index order
+    // slope: part 0's workgroup of a slice adds its columns and posts the sum like the statistics (a tagged word per slice
+    // behind the statistics' words); slice 0's workgroup waits for all of them and adds them in slice order.  (A last-arriver
+    // counter needs a release fence in every workgroup -- an L2 write-back on this chip, 5 us per launch.)
     if (r == 0) {
       if (rg == 0) red[c] = dslope_c;
       __syncthreads();
+      unsigned long long* sw = a.mailbox + (size_t)a.n_nets * a.s_max * 4 * 16 * 3 + (size_t)net_i * a.s_max;
       if (tid == 0) {
         float t = 0.f;
         for (int i = 0; i < 16; ++i) t += red[i];
-        __hip_atomic_store(n.dslope_partial + slice, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        __hip_atomic_store(sw + slice, tc_pack(t, a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (slice == 0) {
         const int n_slices = (N + 15) >> 4;
-        if (atomicAdd(n.counter, 1) == n_slices - 1) {
-          __threadfence();
+        for (int i = tid; i < n_slices; i += NT) {
+          unsigned long long wv = __hip_atomic_load(sw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((unsigned)(wv >> 32) != a.tag) {
+            if (++spins > a.spin_limit) { bad_lds = 2; wv = tc_pack(__builtin_nanf(""), a.tag); break; }
+            __builtin_amdgcn_s_sleep(1);
+            wv = __hip_atomic_load(sw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          part[i] = __uint_as_float((unsigned)wv);       // (the partial sums of the product are long consumed)
+        }
+        __syncthreads();
+        if (tid == 0) {
+          if (bad_lds == 2) __hip_atomic_fetch_add(a.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           float total = 0.f;
-          for (int i = 0; i < n_slices; ++i) total += __hip_atomic_load(n.dslope_partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int i = 0; i < n_slices; ++i) total += part[i];
           n.dslope[0] = total + (a.accumulate ? n.dslope[0] : 0.f);
-          n.counter[0] = 0;
         }
       }
     }
   }
 }
 
-size_t cols_mailbox_words(int n_max) { return (size_t)2 * ((n_max + 15) / 16) * 4 * 16 * 3; }
+// per network and column slice: 4 parts x 16 columns x 3 statistics words, then one slope word
+size_t cols_mailbox_words(int n_max) { return (size_t)2 * ((n_max + 15) / 16) * (4 * 16 * 3 + 1); }
 
 bool cols_launchable(int n_max, int n_nets) {
   static int resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device: workgroups of the heaviest instantiation

@@ -59,7 +59,28 @@ int main(int argc, char** argv) {
     }
     printf("%-44s B=%d: %.1f us/launch (%s)\n", name, B, best * 1e3, hipGetErrorString(hipGetLastError()));
   };
+#ifdef LX_LAB_TIMES
+  long long* times; (void)hipMalloc(&times, 512 * 16 * 8); (void)hipMemset(times, 0, 512 * 16 * 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(lx_lab_times), &times, sizeof(times));
+#endif
   time_it("both units, one workgroup walks both", a);
+#ifdef LX_LAB_TIMES
+  {
+    std::vector<long long> t(512 * 16);
+    (void)hipMemcpy(t.data(), times, t.size() * 8, hipMemcpyDeviceToHost);
+    const char* names[11] = {"", "u0 products", "u0 sums in LDS", "u0 barrier", "u0 cell math", "u0 stored", "u1 products",
+                             "u1 sums in LDS", "u1 barrier", "u1 cell math", "u1 stored"};
+    double mean[11] = {0}; int cnt = 0;
+    for (int b = 0; b < 256; ++b) {
+      if (!t[b * 16 + 10]) continue;
+      ++cnt;
+      for (int i = 1; i <= 10; ++i) mean[i] += (double)(t[b * 16 + i] - t[b * 16]);
+    }
+    printf("  mean over %d workgroups, shader clocks since the workgroup's start:\n   ", cnt);
+    for (int i = 1; i <= 10; ++i) printf(" %s %.0f |", names[i], mean[i] / cnt);
+    printf("\n");
+  }
+#endif
   LstmX3Args b = a; b.units_per_block = 1;
   time_it("both units, a workgroup each", b);
   LstmX3Args c = a; c.n_units = 1; c.units_per_block = 1;
