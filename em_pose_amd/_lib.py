@@ -180,6 +180,7 @@ SIGNATURES = {
     'empose_mlp_train_bwd_deferred': (C.c_int, [C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                C.c_void_p, C.POINTER(MlpGrads), C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_size_t, C.c_void_p]),
+    'empose_mlp_train_uses_weight_t': (C.c_int, [C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_pair_workspace_bytes': (C.c_size_t, [C.POINTER(MlpParams), C.POINTER(MlpParams), C.c_int]),
     'empose_mlp_train_fwd_pair': (C.c_int, [C.POINTER(MlpParams), C.POINTER(MlpParams), C.c_int, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -1821,6 +1821,11 @@ int mlp_fwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* 
 }
 }  // namespace
 
+int empose_mlp_train_uses_weight_t(const empose_mlp_params* p, int M) {
+  if (!p || M <= 0) return fail(EMPOSE_EINVAL, "null parameters / no rows");
+  return mlp_train_cols(p, M) ? 0 : 1;
+}
+
 int empose_mlp_train_save_layout(const empose_mlp_params* p, int M) {
   if (!p || M <= 0) return fail(EMPOSE_EINVAL, "null parameters / no rows");
   if (p->save_layout < 0 || p->save_layout > 3) return fail(EMPOSE_EINVAL, "save_layout must be 0 .. 3");
@@ -1980,17 +1985,12 @@ int mlp_bwd_cols(const empose_mlp_params* const* ps, int n, int M, const float* 
     for (int i = 0; i < n; ++i) {
       const empose_mlp_params* p = ps[i];
       const int H = p->hidden, op = (p->out_dim + 3) & ~3, kdim = last ? op : H;
-      const float* wt = p->weight_t[l];
-      if (!wt) {   // (single network: the pair entry point requires the transposed copies)
-        if (last) HIP_TRY(hipMemsetAsync(w.wt, 0, (size_t)H * op * sizeof(float), stream));
-        hipError_t e = launch_transpose(p->weight[l], H, w.wt, kdim, last ? p->out_dim : H, H, stream);
-        if (e != hipSuccess) return fail(EMPOSE_EHIP, "transpose: %s", hipGetErrorString(e));
-        wt = w.wt;
-      }
       const float* sv = layer_save(i, l - 1);
       ColsNet& c = a.net[i];
       c.A = last ? d_outs[i] : dz_of(i, l); c.lda = last ? ld_douts[i] : H;
-      c.W = wt; c.ldw = kdim; c.N = H; c.K = kdim;
+      c.N = H; c.K = kdim;
+      if (p->weight_t[l]) { c.W = p->weight_t[l]; c.ldw = kdim; }
+      else { c.W = p->weight[l]; c.ldw = H; c.w_kmajor = 1; c.Kw = last ? p->out_dim : H; }   // the layer's own W, read by rows
       c.gamma = p->bn_weight[l - 1]; c.beta = p->bn_bias[l - 1]; c.slope = p->prelu[l - 1];
       c.z_in = sv; c.ldz = H; c.mean = const_cast<float*>(sv + (size_t)2 * M * H); c.rstd = c.mean + H;
       c.out = dz_of(i, l - 1); c.ld_out = H;
@@ -2217,8 +2217,6 @@ int empose_mlp_train_bwd_deferred_pair(const empose_mlp_params* p0, const empose
   if (workspace_bytes < empose_mlp_train_pair_workspace_bytes(p0, p1, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
   bool pair = M > 0 && x && d_out0 && d_out1 && save0 && save1 && gr0 && gr1 && workspace && mlp_cols_pairable(p0, p1, M) &&
               ld_dout0 % 4 == 0 && ld_dout1 % 4 == 0 && ld_dout0 >= ((p0->out_dim + 3) & ~3) && ld_dout1 >= ((p1->out_dim + 3) & ~3);
-  for (int l = 1; l < p0->n_layers && pair; ++l)
-    if (!p0->weight_t[l] || !p1->weight_t[l]) pair = false;          // (one scratch transpose buffer: one network at a time)
   for (int l = 0; l < p0->n_layers - 1 && pair; ++l)
     if (!gr0->bn_weight[l] || !gr0->bn_bias[l] || !gr0->prelu[l] || !gr1->bn_weight[l] || !gr1->bn_bias[l] || !gr1->prelu[l])
       pair = false;

@@ -1173,11 +1173,117 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
   if (fin) lstm_cell_bwd_finish(cell, lane * cell.H + n, pre, out + res);
 }
 
+// Round 5: the same product with the K range split over the four waves and BOTH operands in registers.  The kernel above
+// stages the M rows of A in LDS (98 KB per segment at 12 rows x 2048) and every wave re-reads all of them for its one
+// column: a 12-window BPTT step spent its time waiting for that staging and on LDS reads (4 per 16 multiply-adds).  Here
+// wave w owns the quarter [w K / 4, (w + 1) K / 4) of every segment for all four columns of the workgroup: a lane loads
+// its 16-byte pieces of the M rows and of the 4 weight rows once (all loads of a segment in flight together), 4 M
+// accumulators per lane; the sums over the 64 lanes are a reduce-scatter (each step halves what a lane carries: 51 lane
+// exchanges for 48 sums instead of 288), the four waves' sums meet in LDS and are added in wave order.  Needs K % 16 == 0.
+template <int N, int OFF>
+struct LaneReduceScatter {   // v[0 .. N) summed over lanes; on return lane holds sums base .. base + count - 1 of the original N
+  static __device__ __forceinline__ void run(float (&v)[64], int lane, int& base, int& count) {
+    if constexpr (OFF == 0) {
+      count = N;
+    } else if constexpr (N % 2 == 0) {
+      const bool up = (lane & OFF) != 0;
+#pragma unroll
+      for (int i = 0; i < N / 2; ++i) {
+        const float send = up ? v[i] : v[i + N / 2];
+        const float keep = up ? v[i + N / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, OFF, 64);
+      }
+      base += up ? N / 2 : 0;
+      LaneReduceScatter<N / 2, OFF / 2>::run(v, lane, base, count);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], OFF, 64);
+      LaneReduceScatter<N, OFF / 2>::run(v, lane, base, count);
+    }
+  }
+};
+
+template <int MB>
+__global__ __launch_bounds__(256) void rec_fewrows_reg_kernel(RecBatch b, LstmCellBwdArgs cell0, LstmCellBwdArgs cell1) {
+  __shared__ float wsum[4][4 * MB + 4];
+  const RecProb& p = b.p[blockIdx.y];
+  const LstmCellBwdArgs& cell = blockIdx.y == 0 ? cell0 : cell1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * 4;
+  const int M = p.M, N = p.N;
+  // thread (column c, row m) finishes element (m, n0 + c): what the cell's reverse reads besides dh is fetched now
+  const int f_c = tid / MB, f_m = tid - f_c * MB;
+  const bool fin = tid < 4 * MB && f_m < M && n0 + f_c < N;
+  LstmCellBwdPre pre{};
+  float res = 0.f;
+  if (fin) {
+    pre = lstm_cell_bwd_load(cell, f_m * cell.H + n0 + f_c);
+    if (p.resid) res = p.resid[(size_t)f_m * p.ldr + n0 + f_c];
+  }
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 4 * MB; ++i) v[i] = 0.f;
+  for (int g = 0; g < p.nseg; ++g) {
+    const RecSeg& sg = p.seg[g];
+    const int Kq = sg.K >> 2;                      // this wave's quarter: Kq <= 512 floats, a multiple of 4
+    const int kbase = wave * Kq;
+    f32x4 a[MB][2], w[4][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kl = j * 256 + lane * 4;
+      const bool in = kl < Kq;
+      const int k = kbase + (in ? kl : 0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sg.W + (size_t)min(n0 + c, N - 1) * sg.ldw + k);
+        w[c][j] = in ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sg.A + (size_t)min(m, M - 1) * sg.lda + k);
+        a[m][j] = (in && m < M) ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          float t = v[c * MB + m];
+          t = __builtin_fmaf(a[m][j][0], w[c][j][0], t);
+          t = __builtin_fmaf(a[m][j][1], w[c][j][1], t);
+          t = __builtin_fmaf(a[m][j][2], w[c][j][2], t);
+          t = __builtin_fmaf(a[m][j][3], w[c][j][3], t);
+          v[c * MB + m] = t;
+        }
+  }
+  int base = 0, count = 0;
+  LaneReduceScatter<4 * MB, 32>::run(v, lane, base, count);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)          // (count <= 3 for the instantiated row counts; lanes that hold the same sums write the same)
+    if (i < count) wsum[wave][base + i] = v[i];
+  __syncthreads();
+  if (fin) {
+    const float out = ((wsum[0][tid] + wsum[1][tid]) + wsum[2][tid]) + wsum[3][tid];
+    lstm_cell_bwd_finish(cell, f_m * cell.H + n0 + f_c, pre, out + res);
+  }
+}
+
 template <int MB>
 static hipError_t launch_rec_fewrows_cfg(const RecBatch& b, const LstmCellBwdArgs* cells, int maxN, int maxK,
                                          hipStream_t stream) {
   const size_t lds = (size_t)MB * maxK * sizeof(float);   // arow[MB][K of the widest segment]
   if (lds > FEWROWS_MAX_LDS) return hipErrorInvalidValue;
+  bool k16 = true;
+  for (int i = 0; i < b.count; ++i)
+    for (int g = 0; g < b.p[i].nseg; ++g) k16 = k16 && b.p[i].seg[g].K % 16 == 0;
+  if (k16) {      // both operands in registers, K split over the waves
+    hipLaunchKernelGGL(rec_fewrows_reg_kernel<MB>, dim3((maxN + 3) / 4, b.count), dim3(256), 0, stream, b, cells[0],
+                       cells[b.count > 1 ? 1 : 0]);
+    return hipGetLastError();
+  }
   if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(rec_fewrows_kernel<MB>), lds)) return e;
   hipLaunchKernelGGL(rec_fewrows_kernel<MB>, dim3((maxN + 3) / 4, b.count), dim3(256), lds, stream, b, cells[0],
                      cells[b.count > 1 ? 1 : 0]);

@@ -143,7 +143,8 @@ struct BnPreluArgs {
 // the row parts through a mailbox of tagged words.
 struct ColsNet {
   const float* A; int lda;           // operand rows [M][K]: the layer input (forward) / the cotangent dZ_l (backward)
-  const float* W; int ldw;           // [N][K]: W_l (forward) / W_l^T (backward: rows = columns of the layer below)
+  const float* W; int ldw;           // [N][K]: W_l (forward) / W_l^T (backward: rows = columns of the layer below);
+  int w_kmajor, Kw;                  // backward: W is W_l itself, [Kw][N] with Kw <= K rows -- no transposed copy needed
   const float* bias;                 // forward: [N]
   int N, K;                          // K % 4 == 0, lda % 4 == 0, ldw % 4 == 0
   const float* gamma; const float* beta; const float* slope;       // BatchNorm / PReLU of the N columns

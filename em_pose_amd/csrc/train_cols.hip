@@ -110,7 +110,8 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
     const int KB = (K + 15) >> 4;
     const int per = (KB + NW8 - 1) / NW8;
     const int kb0 = wave * per, kb1 = min(KB, kb0 + per);
-    const float* wrow = n.W + (size_t)min(slice * 16 + r16, N - 1) * n.ldw;
+    const int wcol = min(slice * 16 + r16, N - 1);
+    const float* wrow = n.W + (size_t)wcol * n.ldw;
     int aoff[MAX_TILES];
 #pragma unroll
     for (int t = 0; t < MAX_TILES; ++t) aoff[t] = min(row0 + t * 16 + r16, M - 1) * n.lda;
@@ -127,7 +128,16 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
 #pragma unroll
         for (int t = 0; t < MAX_TILES; ++t)
           if (t < ntl) fa[q][t] = *reinterpret_cast<const f32x4*>(n.A + aoff[t] + k0);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + k0);
+        f32x4 wv;
+        if (MODE == 2 && n.w_kmajor) {   // the layer's own W [k][columns] (no transposed copy): four 64-byte row pieces
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {          // (W has Kw <= K rows: the cotangent's zero padding columns have none)
+            const float wk = n.W[(size_t)min(k0 + e, n.Kw - 1) * n.ldw + wcol];
+            wv[e] = k0 + e < n.Kw ? wk : 0.f;
+          }
+        } else {
+          wv = *reinterpret_cast<const f32x4*>(wrow + k0);
+        }
         fw[q] = in ? wv : f32x4{0.f, 0.f, 0.f, 0.f};
       };
       auto mma = [&](int q) {

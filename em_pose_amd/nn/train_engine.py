@@ -36,6 +36,8 @@ def _ptr(t):
 class _MlpView(object):
     """Device-pointer view of one MLP (reference layers.py:46-77) for empose_mlp_train_*."""
 
+    always_transpose = False     # A/B (scripts/train.py --weight_t): transposed weight copies even where the backward reads W itself
+
     def __init__(self, mlp):
         self.mlp = mlp
         self.specs = mlp.dense_specs()
@@ -87,9 +89,18 @@ class _MlpView(object):
                 p.weight_t[l] = t.data_ptr()
         return p
 
-    def prepare_backward(self, lib, stream):
+    def prepare_backward(self, lib, stream, M=None):
         """W^T of layers 1.. (what dX = dY . W needs on the K-contiguous GEMM): once per step instead of once per
-        application of the network -- the weights do not change inside a step."""
+        application of the network -- the weights do not change inside a step.  Not at all when the backward of M rows
+        reads W itself (the one-launch layers of small batches)."""
+        self.weight_t = None
+        if M is not None and not _MlpView.always_transpose:
+            p = self.params()
+            uses = lib.empose_mlp_train_uses_weight_t(C.byref(p), int(M))
+            if uses < 0:
+                _lib.check(uses)
+            if uses == 0:
+                return
         self.weight_t = [None]
         for lin, _, _ in self.specs[1:]:
             n_out, n_in = lin.weight.shape
@@ -509,7 +520,7 @@ class LgdTrainEngine(object):
             X = ctx['X']
             deferred = self.batched_wgrad and 1 <= N <= 8   # (row counts off the 32-row grid: per application inside)
             for v in views:
-                v.prepare_backward(lib, self.stream)
+                v.prepare_backward(lib, self.stream, T)
             pend = ([], [])
             for i in range(N, -1, -1):
                 _lib.check(lib.empose_smpl_sensors_vjp(

@@ -353,7 +353,8 @@ typedef struct {
   /* Optional, backward only: the weights of layers 1 .. n_layers-1 transposed, [in_l][out_l] with the leading dimension
    * of the last layer padded to a multiple of 4 and its padding columns ZERO (empose_transpose_f32 into a zeroed buffer).
    * With NULL entries the backward transposes the weights itself on every call; a caller that applies the network
-   * several times per step (the LGD loop) transposes once per step instead. */
+   * several times per step (the LGD loop) transposes once per step instead.  empose_mlp_train_uses_weight_t() says
+   * whether the backward of M rows reads them at all (the one-launch layers of up to 512 rows read W itself). */
   const float* weight_t[EMPOSE_MAX_DENSE];
   /* How `save` is laid out: 0 = whatever the options "train_fused" / "train_epi" select AT THE TIME OF EACH CALL (every
    * call of a step must then see the same options); 1 / 2 / 3 = the layout empose_mlp_train_save_layout() reported when
@@ -372,6 +373,8 @@ typedef struct {                /* gradient outputs, shapes of the parameters */
 /* 1 (BatchNorm kernels) / 2 (BatchNorm folded into the GEMMs) / 3 (statistics in the GEMM epilogues): the layout the
  * current options select for M rows; store it in empose_mlp_params::save_layout for the calls of the step. */
 int empose_mlp_train_save_layout(const empose_mlp_params* p, int M);
+/* 1: the backward of M rows reads `weight_t` (or transposes on every call when it is NULL); 0: it does not. */
+int empose_mlp_train_uses_weight_t(const empose_mlp_params* p, int M);
 size_t empose_mlp_train_save_floats(const empose_mlp_params* p, int M);
 size_t empose_mlp_train_workspace_bytes(const empose_mlp_params* p, int M);
 /* x [M][ldx] -> out [M][ld_out] (out_dim columns written). */
@@ -403,8 +406,8 @@ int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float
  * bias + train-mode BatchNorm + PReLU) and backward (dA = dZ W + the BatchNorm / PReLU reverse of the layer below):
  * a workgroup per 16 columns x quarter of the rows, whose column statistics meet through a mailbox of tagged words inside
  * the workspace (csrc/train_cols.hip; option "train_cols", 0 = a product and a BatchNorm launch per layer and network).
- * Networks the paired launches do not cover (different depth / hidden width / BatchNorm constants, more rows, missing
- * weight_t in the backward) run one after the other through the single-network entry points: same results either way.
+ * Networks the paired launches do not cover (different depth / hidden width / BatchNorm constants, more rows) run one
+ * after the other through the single-network entry points: same results either way.
  * Reads and writes save layout 1, like empose_mlp_train_fwd / _bwd at these sizes (which use the same launches for one
  * network).  A poll of the mailbox that gives up is reported like the cooperative LSTM kernels' (empose_async_status).
  * workspace: empose_mlp_train_pair_workspace_bytes. */

@@ -209,6 +209,8 @@ def main():
                    help='A/B: the training engine on one stream (default: shape network, weight gradients on a side stream)')
     p.add_argument('--streams', default=None, help="A/B: which parts of the step use the engine's side stream, e.g. 'bwd,wgrad' "
                                                    "(default: fwd,bwd,bwd3,wgrad)")
+    p.add_argument('--weight_t', action='store_true',
+                   help='A/B: transposed weight copies every step even where the reverse sweep reads W itself (<= 512 rows)')
     p.add_argument('--side_min_frames', type=int, default=None,
                    help="A/B: frames per step from which the engine's side streams are used (default 2048; 0 = always)")
     p.add_argument('--bucket_mb', type=int, default=8, help='size of a flat gradient bucket')
@@ -260,6 +262,9 @@ def main():
     if args.single_stream:
         from em_pose_amd.nn.train_engine import LgdTrainEngine
         LgdTrainEngine.two_streams = False
+    if args.weight_t:
+        from em_pose_amd.nn.train_engine import _MlpView
+        _MlpView.always_transpose = True
     if args.side_min_frames is not None:
         from em_pose_amd.nn.train_engine import LgdTrainEngine
         LgdTrainEngine.two_streams_min_frames = args.side_min_frames

@@ -303,7 +303,9 @@ def _run_mlp_train(nets, x, d_outs, M, pair, deferred=True, saves_from=None):
     views = [_MlpView(n) for n in nets]
     for v in views:
         v.fix_layout(lib, M)
-        v.prepare_backward(lib, stream)
+        # (paired call: as the engine prepares it -- no transposed copies when the reverse reads W itself; the single-network
+        # calls get the copies: the same operand values through the other load path, so the two stay bit-identical)
+        v.prepare_backward(lib, stream, M if pair else None)
     ps = [v.params() for v in views]
     ldx = x.shape[1]
     outs = [torch.zeros(M, 66, device=DEV), torch.zeros(M, 10, device=DEV)]
