@@ -970,6 +970,7 @@ int empose_set_option(const char* name, int value) {
       {"lstm_x3", &o.lstm_x3},
       {"rows_x3", &o.rows_x3},
       {"train_cols", &o.train_cols},
+      {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
@@ -1004,6 +1005,7 @@ int empose_get_option(const char* name) {
       {"lstm_x3", o.lstm_x3},
       {"rows_x3", o.rows_x3},
       {"train_cols", o.train_cols},
+      {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) return e.v;

@@ -15,6 +15,7 @@
 
 #include "gemm_epilogue.h"
 #include "lstm_cell_bwd.h"
+#include "lane_reduce.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -1180,29 +1181,6 @@ __global__ __launch_bounds__(256) void rec_fewrows_kernel(RecBatch b, LstmCellBw
 // its 16-byte pieces of the M rows and of the 4 weight rows once (all loads of a segment in flight together), 4 M
 // accumulators per lane; the sums over the 64 lanes are a reduce-scatter (each step halves what a lane carries: 51 lane
 // exchanges for 48 sums instead of 288), the four waves' sums meet in LDS and are added in wave order.  Needs K % 16 == 0.
-template <int N, int OFF>
-struct LaneReduceScatter {   // v[0 .. N) summed over lanes; on return lane holds sums base .. base + count - 1 of the original N
-  static __device__ __forceinline__ void run(float (&v)[64], int lane, int& base, int& count) {
-    if constexpr (OFF == 0) {
-      count = N;
-    } else if constexpr (N % 2 == 0) {
-      const bool up = (lane & OFF) != 0;
-#pragma unroll
-      for (int i = 0; i < N / 2; ++i) {
-        const float send = up ? v[i] : v[i + N / 2];
-        const float keep = up ? v[i + N / 2] : v[i];
-        v[i] = keep + __shfl_xor(send, OFF, 64);
-      }
-      base += up ? N / 2 : 0;
-      LaneReduceScatter<N / 2, OFF / 2>::run(v, lane, base, count);
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], OFF, 64);
-      LaneReduceScatter<N, OFF / 2>::run(v, lane, base, count);
-    }
-  }
-};
-
 template <int MB>
 __global__ __launch_bounds__(256) void rec_fewrows_reg_kernel(RecBatch b, LstmCellBwdArgs cell0, LstmCellBwdArgs cell1) {
   __shared__ float wsum[4][4 * MB + 4];
@@ -1260,7 +1238,7 @@ __global__ __launch_bounds__(256) void rec_fewrows_reg_kernel(RecBatch b, LstmCe
         }
   }
   int base = 0, count = 0;
-  LaneReduceScatter<4 * MB, 32>::run(v, lane, base, count);
+  LaneReduceScatter<4 * MB, 32, 64>::run(v, lane, base, count);
 #pragma unroll
   for (int i = 0; i < 4; ++i)          // (count <= 3 for the instantiated row counts; lanes that hold the same sums write the same)
     if (i < count) wsum[wave][base + i] = v[i];

@@ -39,6 +39,8 @@ struct Options {
                           // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int train_cols = 1;     // training at <= 512 rows: a layer's product + BatchNorm + PReLU as one launch, both update networks
                           // side by side (train_cols.hip); 0: a product and a BatchNorm launch per layer and network
+  int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
+                          // instead of the whole-sequence kernel / lstm_small_kernel (0: those; they share their bits)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
                           // (mlp_fused_x3.hip: fp32-equivalent accuracy, measured equal to the fp32 instruction's against
                           // float64); 0: the fp32 MFMA instruction (mlp_fused.hip); 2: the variant whose waves share the
@@ -346,6 +348,7 @@ size_t lstm_seq_counter_uints(int B);
 hipError_t launch_lstm_seq(const LstmWaveArgs& a, float* const* h_third, unsigned* counters, hipStream_t stream, bool* done);
 // Whole sequence of a stacked uni-directional LSTM in one cooperative launch (B <= 16); *done = false: not covered.
 constexpr int LSTM_PERSIST_B = 16;   // largest batch of the whole-sequence kernel
+constexpr int LSTM_FEWROWS_MIN_B = 4;   // from here to 16 rows a step launch of lstm_fewrows_kernel beats it (option lstm_fewrows)
 size_t lstm_persist_xch_floats(int n_units, int B, int H);   // its exchange buffer (8-byte aligned)
 hipError_t launch_lstm_persist(const LstmWaveArgs& a, float* xch, hipStream_t stream, bool* done);
 

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "lane_reduce.h"
 
 namespace empose {
 
@@ -942,6 +943,111 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(LstmWaveArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A few rows (4 .. 16: the reference's training batch of 12 windows, the batched evaluation driver's chunk of recordings),
+// round 5.  lstm_small_kernel above costs 2.2 us per row and step (34 us per step at 12 rows: a row's 16-byte pieces are
+// loaded inside the k loop, 6 lane exchanges per gate sum); the whole-sequence kernel below polls B x H exchange words per
+// layer and step in every workgroup (16 us per step at 12 rows).  Here a step is one launch in which a workgroup owns TWO
+// hidden units (8 gate columns) and ALL its 256 threads split the unit's K = [input | recurrent] (1024 floats at 2 x 512:
+// one 16-byte piece per thread): a thread loads its piece of the B rows and of the 8 weight rows once, 8 B accumulators;
+// the sums over a wave's lanes are a reduce-scatter (lane_reduce.h), the four waves' sums meet in LDS and are added in
+// wave order; thread (unit, row) applies the cell.  Same state handling and saves as lstm_small_kernel; another summation
+// order (option "lstm_fewrows" = 0 selects the kernels above, whose bits the whole-sequence kernel shares).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MB, int NU>   // rows handled (B <= MB), hidden units per workgroup
+__global__ __launch_bounds__(256) void lstm_fewrows_kernel(LstmWaveArgs a) {
+  constexpr int C = 4 * NU, NV = C * MB;
+  __shared__ float wsum[4][NV + 4];
+  const int n_seg = a.z_cnt[blockIdx.y];
+  if (n_seg == 0) return;
+  const int seg_beg = a.z_beg[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, B = a.B, F = a.F;
+  const int u0 = blockIdx.x * NU;
+  const LstmUnitArgs& L = a.unit[a.seg[seg_beg].unit];
+  const int t = a.seg[seg_beg].k;
+  const int* __restrict__ lens = a.seq_lengths;
+  // thread (unit f_u, row f_m) finishes a cell: its state and bias are fetched now, under the product
+  const int f_u = tid / MB, f_m = tid - f_u * MB;
+  const bool fin = tid < NU * MB && f_m < B && u0 + f_u < H;
+  const int unit = u0 + (f_u < NU ? f_u : 0);
+  float e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_c = 0.f, e_hp = 0.f;
+  int e_len = F;
+  if (fin) {
+    const size_t hc = (size_t)f_m * H + unit;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e_bias[q] = L.bias[q * H + unit];
+    e_c = L.c[hc];
+    e_hp = L.h[t & 1][hc];
+    e_len = lens ? lens[f_m] : F;
+  }
+
+  float v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = 0.f;
+  {
+    const LstmSeg s0 = a.seg[seg_beg], s1 = a.seg[seg_beg + 1];
+    const int n0 = s0.K >> 2, n1 = n_seg > 1 ? s1.K >> 2 : 0;       // 16-byte pieces of the two operand segments
+    for (int p = tid; p < n0 + n1; p += 256) {
+      const bool first = p < n0;
+      const int k4 = (first ? p : p - n0) * 4;
+      const float* __restrict__ wb = (first ? s0.w : s1.w) + k4;
+      const float* __restrict__ ab = (first ? s0.a : s1.a) + k4;
+      const int ldw = first ? s0.ldw : s1.ldw, lda = first ? s0.lda : s1.lda;
+      const int tstride = first ? s0.tstride : s1.tstride, sk = first ? s0.k : s1.k;
+      f32x4 w[C], x[MB];
+#pragma unroll
+      for (int ul = 0; ul < NU; ++ul)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          w[ul * 4 + q] = *reinterpret_cast<const f32x4*>(wb + (size_t)(q * H + min(u0 + ul, H - 1)) * ldw);
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const int mr = m < B ? m : B - 1;
+        const int tr = (lens ? lens[mr] : F) - 1 - sk;
+        x[m] = *reinterpret_cast<const f32x4*>(ab + (size_t)mr * lda + (size_t)(tr > 0 ? tr : 0) * tstride);
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) v[c * MB + m] = dot4_acc(v[c * MB + m], w[c], x[m]);
+    }
+  }
+  int base = 0, count = 0;
+  LaneReduceScatter<NV, 32, NV>::run(v, lane, base, count);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)      // (count <= 3 for the instantiated sizes; lanes that hold the same sums write the same)
+    if (i < count) wsum[wave][base + i] = v[i];
+  __syncthreads();
+  if (!fin) return;
+  float gs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = (f_u * 4 + q) * MB + f_m;
+    gs[q] = ((wsum[0][o] + wsum[1][o]) + wsum[2][o]) + wsum[3][o];
+  }
+  const int row = f_m;
+  const bool rev = L.reverse != 0;
+  const size_t hc = (size_t)row * H + unit;
+  const bool live = t < e_len;
+  const int t_out = (rev && live) ? e_len - 1 - t : t;   // a finished reverse row zero-fills the padded slot t
+  const float g_i = fsigmoid(gs[0] + e_bias[0]), g_f = fsigmoid(gs[1] + e_bias[1]);
+  const float g_g = ftanh(gs[2] + e_bias[2]), g_o = fsigmoid(gs[3] + e_bias[3]);
+  const float c_new = g_f * e_c + g_i * g_g;
+  const float h_new = g_o * ftanh(c_new);
+  if (live) L.c[hc] = c_new;
+  L.h[(t + 1) & 1][hc] = live ? h_new : e_hp;
+  if (L.y) L.y[((size_t)row * F + t_out) * L.y_ld + L.y_col + unit] = live ? h_new : 0.f;
+  if (L.sv_gates) {   // training forward: what back-propagation through time reads
+    const size_t rt = (size_t)row * F + t;
+    float* sg = L.sv_gates + rt * 4 * H + unit;
+    sg[0] = g_i; sg[H] = g_f; sg[2 * H] = g_g; sg[3 * H] = g_o;
+    L.sv_c[rt * H + unit] = live ? c_new : e_c;
+    if (t + 1 < F) L.sv_hprev[(rt + 1) * H + unit] = live ? h_new : e_hp;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Small batches, whole sequence in ONE launch (the streaming driver: B = 1, F = 256 is 257 dependent wavefront steps).
 // The per-step launches above pay a dispatch per step (~6 us back to back) to stream 13.8 MB of weights that never
 // change.  Here a wave owns one hidden unit of one layer for the whole sequence and keeps that unit's four gate rows in
@@ -1218,6 +1324,8 @@ size_t lstm_persist_xch_floats(int n_units, int B, int H) { return (size_t)2 * n
 hipError_t launch_lstm_persist(const LstmWaveArgs& w, float* xch, hipStream_t stream, bool* done) {
   *done = false;
   if (w.B > LSTM_PERSIST_B || w.H % 4 != 0 || w.H > 512 || w.n_units < 1 || w.n_units > 4) return hipSuccess;
+  // from 4 rows on a step launch of lstm_fewrows_kernel is faster than polling B x H exchange words per layer and step
+  if (options().lstm_fewrows != 0 && w.B >= LSTM_FEWROWS_MIN_B) return hipSuccess;
   // (a block's four waves cover all layers: 4, 2 or 1 units of each)
   int k0max = 0;
   for (int u = 0; u < w.n_units; ++u) {
@@ -1256,6 +1364,18 @@ hipError_t launch_lstm_wave(const LstmWaveArgs& a_in, hipStream_t stream) {
   LstmWaveArgs a = a_in;
   if (a.B <= LSTM_SMALL_B) {   // weight-streaming matrix-vector kernel, one z slice per unit
     lstm_build_chain(a, 1);
+    if (options().lstm_fewrows != 0 && a.B >= LSTM_FEWROWS_MIN_B && a.H % 2 == 0) {   // all threads split K, reduce-scatter
+      bool ok = true;
+      for (int z = 0; z < a.n_units; ++z)
+        for (int i = 0; i < a.z_cnt[z]; ++i) ok = ok && a.seg[a.z_beg[z] + i].K % 4 == 0 && a.z_cnt[z] <= 2;
+      if (ok) {
+        if (a.B <= 4) hipLaunchKernelGGL((lstm_fewrows_kernel<4, 2>), dim3(a.H / 2, a.n_units), dim3(256), 0, stream, a);
+        else if (a.B <= 8) hipLaunchKernelGGL((lstm_fewrows_kernel<8, 2>), dim3(a.H / 2, a.n_units), dim3(256), 0, stream, a);
+        else if (a.B <= 12) hipLaunchKernelGGL((lstm_fewrows_kernel<12, 2>), dim3(a.H / 2, a.n_units), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_fewrows_kernel<16, 1>), dim3(a.H, a.n_units), dim3(256), 0, stream, a);
+        return hipGetLastError();
+      }
+    }
     dim3 grid((a.H + 3) / 4, a.n_units);
     if (a.B <= 4) hipLaunchKernelGGL(lstm_small_kernel<4>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(lstm_small_kernel<LSTM_SMALL_B>, grid, dim3(256), 0, stream, a);
