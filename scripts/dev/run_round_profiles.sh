@@ -16,16 +16,16 @@ python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
 python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
 python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
-python scripts/train.py --steps 20 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json
-python scripts/train.py --steps 20 --graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph.json
-python scripts/train.py --steps 20 --graph --side_min_frames 0 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_graph_side_streams.json
-( for bs in 12 64 256; do for g in "" "--graph" "--single_stream"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt
+python scripts/train.py --steps 30 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json          # default: replayed as a HIP graph
+python scripts/train.py --steps 30 --no_graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_eager.json
+( for o in "train_cols=0" "lstm_fewrows=0" "train_cols=0 --option lstm_fewrows=0"; do echo -n "$o: "; python scripts/train.py --steps 30 --json --option $o 2>/dev/null | tail -1; done ) > gpurun_out/${TAG}_train_step_bs12_ablations.txt
+( for bs in 12 64 256; do for g in "--no_graph" "--graph" "--single_stream --no_graph"; do echo -n "bs_train $bs $g: "; python scripts/train.py --steps 20 --bs_train $bs $g --json 2>/dev/null | tail -1; done; done ) > gpurun_out/${TAG}_train_batch_scaling.txt
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --bs_train 256 --json > $OUT.log 2>&1 )
 cp $OUT/t_kernel_stats.csv gpurun_out/${TAG}_train_kernel_stats_bs256.csv
 rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --json > $OUT.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --no_graph --json > $OUT.log 2>&1 )
 cp $OUT/t_kernel_stats.csv gpurun_out/${TAG}_train_kernel_stats_bs12.csv
 rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vb -- python $R/bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
@@ -41,4 +41,7 @@ python scripts/dev/bench_lstm_small.py > gpurun_out/${TAG}_lstm_small_batch_per_
 python scripts/dev/bench_lstm_mid.py > gpurun_out/${TAG}_lstm_medium_batch_per_step.txt 2>&1
 python scripts/dev/prof_seq.py > gpurun_out/${TAG}_streaming_forward_b1_f256.txt 2>&1
 [ -x scripts/dev/bin/fused_x3_lab ] && scripts/dev/bin/fused_x3_lab 32768 > gpurun_out/${TAG}_fused_mlp_x3_lab.txt 2>&1
+[ -x scripts/dev/bin/lstm_x3_lab_times ] && ( scripts/dev/bin/lstm_x3_lab_times 1024; for v in NOLOAD NOPART NOFINISH; do echo "== without: $v"; scripts/dev/bin/lstm_x3_lab_$v 1024; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_lstm_x3_lab.txt
+[ -x scripts/dev/bin/train_cols_lab_times ] && ( scripts/dev/bin/train_cols_lab 384; scripts/dev/bin/train_cols_lab_times 384 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_train_cols_lab.txt
+bash scripts/dev/train_trace.sh 12 2>&1 | grep -v Segm > gpurun_out/${TAG}_train_step_bs12_trace.txt
 ls -la gpurun_out | grep $TAG

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$PWD; BS=${1:-12}
 OUT=$R/gpurun_out/train_trace_$BS; rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --bs_train $BS --json > $OUT.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --bs_train $BS --no_graph --json > $OUT.log 2>&1 )
 python - <<PY
 import csv, glob
 f = glob.glob('$OUT/**/t_kernel_trace.csv', recursive=True)[0]

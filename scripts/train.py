@@ -196,7 +196,10 @@ def main():
     p.add_argument('--lr', type=float, default=0.0005)
     p.add_argument('--seed', type=int, default=1615200973)
     p.add_argument('--graph', action='store_true',
-                   help='capture forward + backward in a HIP graph and replay it (static shapes, full-length windows)')
+                   help='capture forward + backward in a HIP graph and replay it (static shapes, full-length windows): the '
+                        'default of the synthetic step benchmark on one stream')
+    p.add_argument('--no_graph', action='store_true', help='synthetic step benchmark: eager launches (the step is then bound by '
+                                                          'the host: ~250 launches at 12 windows)')
     p.add_argument('--json', action='store_true')
     # training on AMASS sequences (the loop of reference scripts/train.py:125-230 with checkpoints and validation)
     p.add_argument('--amass_dir', default=None, help='directory tree of AMASS *.npz sequences; switches from the '
@@ -302,6 +305,11 @@ def main():
     batches = [make_batch(s) for s in range(4)]  # data preparation is not part of the measured step
     net.train()
     buckets = make_buckets(net, params, world, args)
+    # Fixed shapes, one rank, one stream: the step replays as a HIP graph unless asked otherwise (the
+    # eager step at the reference's 12 windows is bound by the host's ~250 launches, 3.1 ms against 2.4 ms of kernels).
+    if not args.graph and not args.no_graph and world == 1 and not args.force_dist and args.streams is None \
+            and args.side_min_frames is None and B * F < 2048:
+        args.graph = True
     graphed = None
     if args.graph:
         from em_pose_amd.helpers.graphed import GraphedTrainStep
