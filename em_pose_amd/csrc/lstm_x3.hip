@@ -128,13 +128,17 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
     // ones, W from the matching matrix; everything is a wave-uniform base plus lane * 16 bytes.
     u32x4_t fa[3][2][3], fw[3][4][3];
     const int n_w = (KS - wave + 3) / 4;
-    auto load = [&](u32x4_t (&A)[2][3], u32x4_t (&W)[4][3], int i) {
+    // (the unit's operand pointers in scalar registers for the whole K loop: read from the kernel arguments inside it they
+    // cost a scalar load and a wait -- a bubble in the matrix pipe -- per fragment set)
+    const unsigned short* const p_in = U.a3_in; const unsigned short* const p_rec = U.a3_rec;
+    const unsigned short* const p_wih = U.w3_ih; const unsigned short* const p_whh = U.w3_hh;
+    auto load = [&, p_in, p_rec, p_wih, p_whh](u32x4_t (&A)[2][3], u32x4_t (&W)[4][3], int i) {
       int g = wave + 4 * i;
       g = g < KS ? g : KS - 1;                      // (past the wave's last step: fetched, never multiplied)
       const bool in = g < KS_in;
       const int ks = in ? g : g - KS_in, ksn = in ? KS_in : KS_h;
-      lx_gptr_t ab = (lx_gptr_t)(in ? U.a3_in : U.a3_rec) + (((size_t)rt0 * ksn + ks) * 3) * FRAG + lane * 8;
-      lx_gptr_t wb = (lx_gptr_t)(in ? U.w3_ih : U.w3_hh) + ((((size_t)ks * JB + jb) * 4) * 3) * FRAG + lane * 8;
+      lx_gptr_t ab = (lx_gptr_t)(in ? p_in : p_rec) + (((size_t)rt0 * ksn + ks) * 3) * FRAG + lane * 8;
+      lx_gptr_t wb = (lx_gptr_t)(in ? p_wih : p_whh) + ((((size_t)ks * JB + jb) * 4) * 3) * FRAG + lane * 8;
       const size_t rt_stride = (size_t)ksn * 3 * FRAG;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
