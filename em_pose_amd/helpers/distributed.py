@@ -116,6 +116,13 @@ def local_device_index(local_rank, what='this script'):
     n = torch.cuda.device_count()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if os.environ.get(SHARE_DEVICES_ENV) == '1' and n > 0:
+        if world > n:
+            # Kernels whose workgroups wait for each other need the device to themselves: every workgroup of a launch must be
+            # resident at once.  The one-launch training layers fill the chip (256 workgroups at width 512); two processes
+            # launching them on ONE device starve each other until the polls give up (EMPOSE_ETIMEOUT, outputs NaN).  Ranks
+            # that share a device therefore take the layer-by-layer path.
+            from em_pose_amd import _lib
+            _lib.check(_lib.lib().empose_set_option(b'train_cols', 0))
         return local_rank % n
     if n <= local_rank:
         raise SystemExit('{} --gpus {} needs {} GPUs, found {}'.format(what, world, world, n))
