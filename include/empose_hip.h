@@ -73,7 +73,9 @@ const char* empose_arch(void);
  * same arithmetic for the row-block products with fused prologue / epilogue: the blend products of the frame-per-lane
  * SMPL path and the stacked init heads; 0 = the fp32 MFMA instruction), "train_cols" (training at up to 512 rows: a
  * layer's product + BatchNorm + PReLU as one launch, forward and backward, both update networks side by side -- see
- * empose_mlp_train_fwd_pair; 0 = a product and a BatchNorm launch per layer and network),
+ * empose_mlp_train_fwd_pair; 0 = a product and a BatchNorm launch per layer and network), "lstm_fewrows" (LSTM steps of 4 to
+ * 16 rows -- the reference's training batch, chunks of recordings -- as launches whose workgroups own two hidden units and
+ * split K over all their threads; 0 = the whole-sequence kernel / the small-batch step kernel, which share their bits),
  * "mesh_skin_mfma" (split-bf16 full-mesh variant only: the bone blend as a second matrix-core contraction; 0 [default,
  * measured faster] = vector skinning), "spin_limit" (see empose_async_status).
  * empose_get_option returns -1 for an unknown name.  New in this library (no counterpart in the reference). */
