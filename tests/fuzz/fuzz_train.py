@@ -24,8 +24,9 @@ import numpy as np
 import torch
 
 
-def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print):
-    """Returns {'n', 'worst' (gradient error / tolerance), 'flips', 'stats'}; AssertionError on a mismatch."""
+def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print, keep_going=False):
+    """Returns {'n', 'worst' (gradient error / tolerance), 'flips', 'stats', 'refused'}; AssertionError on a mismatch
+    (`keep_going`, for soaks: the mismatch is recorded in 'refused' and the run continues with the next case)."""
     try:
         import helpers as H
     except ImportError:
@@ -55,17 +56,27 @@ def run(seed=0, seconds=None, n_cases=None, per_iteration=False, log=print):
                                           torch.from_numpy(o_r), torch.from_numpy(o_t))
         return p.numpy(), o.numpy()
 
-    stats, flips = {}, set()
+    stats, flips, refused = {}, set(), []
     t_end, n, worst = time.time() + (seconds if seconds is not None else 1e9), 0, 0.0
     try:
         while time.time() < t_end and (n_cases is None or n < n_cases):
-            n, worst = _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, seed)
+            try:
+                n, worst = _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, seed)
+            except AssertionError as e:
+                if not keep_going:
+                    raise
+                refused.append((n, str(e)))
+                n += 1
     finally:
         _layers.FORCE_LARGE_LINEAR[0], LgdTrainEngine.batched_wgrad = force_large0, batched0
         _lib.check(_lib.lib().empose_set_option(b'train_fused', 0))
         _lib.check(_lib.lib().empose_set_option(b'train_epi', 1))
     assert len(flips) <= max(3, n // 6), 'too many to be kink flips'
-    return {'n': n, 'worst': worst, 'flips': len(flips), 'stats': stats}
+    return {'n': n, 'worst': worst, 'flips': len(flips), 'stats': stats, 'refused': refused}
+
+
+FORCE = {}     # dev: overrides of a case's drawn configuration (after the draws: the sequence of cases stays what it is),
+               # keys rnn / n_markers / N / B / F / hidden / fused / epi / cols
 
 
 def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, seed):
@@ -83,9 +94,17 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
     # the train-mode layer with BatchNorm / PReLU inside the GEMMs in half of the cases
     rnn_hidden = 256 if (rnn and rng.integers(0, 8) == 0) else hidden
     fused = int(rng.choice([0, 2]))
+    rnn, n_markers, N, B, F = [FORCE.get(k, v) for k, v in (('rnn', rnn), ('n_markers', n_markers), ('N', N), ('B', B), ('F', F))]
+    hidden, fused = FORCE.get('hidden', hidden), FORCE.get('fused', fused)
+    if 'hidden' in FORCE:
+        rnn_hidden = hidden
     _lib.check(_lib.lib().empose_set_option(b'train_fused', fused))
     # round 4: of the cases without it, half with the statistics in the GEMM epilogues + one finish launch per layer
-    _lib.check(_lib.lib().empose_set_option(b'train_epi', 2 if (fused == 0 and n % 2 == 0) else 0))
+    _lib.check(_lib.lib().empose_set_option(b'train_epi', FORCE.get('epi', 2 if (fused == 0 and n % 2 == 0) else 0)))
+    # (round 5: what is left -- a quarter of the cases -- runs the one-launch layers of train_cols.hip, the library's default
+    # at these row counts)
+    if 'cols' in FORCE:
+        _lib.check(_lib.lib().empose_set_option(b'train_cols', FORCE['cols']))
     cfg = lgd_config(n_markers, rnn, N, hidden=hidden, rnn_hidden=rnn_hidden)
     net = create_model(cfg, SMPLLayer(model))
     net.vertex_ids = vids
@@ -105,6 +124,16 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
     ulp = {k: (1.0 + 1.2e-7 * np.sign(rng.standard_normal(w[k].shape))).astype(np.float32) for k in ('marker_pos', 'marker_oris')}
     for mode in ('engine', 'autograd', 'engine_perturbed'):
         net.load_state_dict(state0)
+        if mode == 'engine_perturbed':
+            # Round 5: the weights move by one unit in the last place too.  The engine's one-launch layers and the autograd
+            # path's layer-by-layer kernels are different implementations in a quarter of the cases: what separates two fp32
+            # implementations of a train-mode step is rounding at every layer, and an input-only perturbation understates
+            # that six-fold (measured on the reference's own step: tests/golden/make_golden.py, make_train_fingerprints).
+            gp = torch.Generator().manual_seed(1000003 * seed + n)
+            with torch.no_grad():
+                for q in net.parameters():
+                    if q.dtype == torch.float32 and q.requires_grad:
+                        q.mul_((1.0 + 1.2e-7 * torch.sign(torch.randn(q.shape, generator=gp))).to(q.device))
         net.use_train_engine = mode != 'autograd'
         wi = dict(w)
         if mode == 'engine_perturbed':
@@ -118,7 +147,9 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
         total, vals = net.backward(batch, out)
         res[mode] = (float(total.detach()) if torch.is_tensor(total) else float(total),
                      {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None},
-                     {k: v.detach().clone() for k, v in out.items()})
+                     {k: v.detach().clone() for k, v in out.items()},
+                     [h.detach().clone().reshape(B, F, -1) for h in getattr(net, 'pose_hat_history', [])],
+                     [h.detach().clone().reshape(B, F, -1) for h in getattr(net, 'shape_hat_history', [])])
     sens_g = {k: float((res['engine_perturbed'][1][k] - v).abs().max()) for k, v in res['engine'][1].items()}
     sens_o = {k: float((res['engine_perturbed'][2][k] - v).abs().max()) for k, v in res['engine'][2].items()}
     res = {True: res['engine'], False: res['autograd']}
@@ -139,7 +170,36 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
         # is out of tolerance in the row(s) of the flipped channel(s) only (at most two), its bias / BatchNorm gradients
         # at those channels only; the layers above it (towards the input) may move densely (the BatchNorm backward
         # spreads one channel over all rows), the layers below it, the other network, the LSTM and the heads not at all.
-        why = _kink_flip_pattern(bad, {k: (res[True][1][k] - res[False][1][k]).abs() for k in bad}, tols)
+        diffs = {k: (res[True][1][k] - res[False][1][k]).abs() for k in bad}
+        why = _kink_flip_pattern(bad, diffs, tols)
+        if why is not None:
+            # What else has a kink: the L1 terms of the loss (reference loss.py:13-21).  Their cotangent is sign(estimate -
+            # target); an estimate within rounding of its target (the synthetic targets hold exact zeros) takes different
+            # signs in the two paths, and everything UPSTREAM of that history entry moves by that element's share: the
+            # networks of the initial estimate, and for an entry i >= 1 the update network of that quantity.  Found by the
+            # round-5 soak (seed 6605 cases 726, 914; the same cases on the round-4 build).  Accepted by footprint: the
+            # sign flip is shown on the estimates themselves, the tensors out of tolerance are confined to what lies
+            # upstream of it, and whatever else is out of tolerance has the PReLU footprint on its own.
+            gt_p = torch.as_tensor(w['poses']).reshape(B, F, -1).to(dev)
+            gt_s = torch.as_tensor(w['shapes']).reshape(B, 1, -1).to(dev)
+            live = (torch.arange(F, device=dev)[None, :] < lens[:, None])[..., None]
+            upstream = set()
+            for which, gt, idx, iter_net in (('pose', gt_p, 3, 'pose_net_iter.'), ('shape', gt_s, 4, 'shape_net_iter.')):
+                for i, (ha, hb) in enumerate(zip(res[True][idx], res[False][idx])):
+                    a, b = ha[..., :gt.shape[-1]] - gt[..., :ha.shape[-1]], hb[..., :gt.shape[-1]] - gt[..., :hb.shape[-1]]
+                    nflip = int(((torch.sign(a) != torch.sign(b)) & live).sum())
+                    if nflip:
+                        print('  L1 kink: %s estimate %d has %d entr%s on the other side of its target in the two paths'
+                              % (which, i, nflip, 'y' if nflip == 1 else 'ies'))
+                        upstream.add('init')
+                        if i >= 1:
+                            upstream.add(iter_net)
+            if upstream:
+                is_up = lambda k: ('_init' in k.split('.')[0] or k.startswith('rnn')) or any(k.startswith(u) for u in upstream)
+                rest = [k for k in bad if not is_up(k)]
+                why = _kink_flip_pattern(rest, {k: diffs[k] for k in rest}, tols) if rest else None
+                if why is None:
+                    stats.setdefault('L1 kink cases', []).append(float(n))
         if why is not None:
             print('TRAIN MISMATCH', seed, n, dict(rnn=rnn, n_markers=n_markers, N=N, B=B, F=F, hidden=hidden, lens=lens.tolist()), why)
             for kk, vv in res[False][1].items():
@@ -189,7 +249,15 @@ def _kink_flip_pattern(bad, diffs, tols):
         return 'out of tolerance outside the update / init MLPs: ' + ', '.join(k for k in bad if where[k] is None)
     nets = {v[0] for v in where.values()}
     if len(nets) != 1:
-        return 'out of tolerance in more than one network: ' + ', '.join(sorted(nets))
+        # (round 5: the engine's one-launch layers and the autograd path's layer-by-layer kernels are DIFFERENT forward
+        # kernels in a quarter of the cases, so two networks of a step may each have a flip: every network's tensors
+        # must then show the footprint on their own)
+        for net in sorted(nets):
+            sub = [k for k in bad if where[k][0] == net]
+            why = _kink_flip_pattern(sub, {k: diffs[k] for k in sub}, tols)
+            if why is not None:
+                return '%d networks out of tolerance, and in %s: %s' % (len(nets), net, why)
+        return None
     last = max(v[1] for v in where.values())
     if last == 99:
         return 'the output layer (no PReLU behind it) is out of tolerance'
@@ -208,9 +276,10 @@ def _kink_flip_pattern(bad, diffs, tols):
 if __name__ == '__main__':
     arg = sys.argv[2] if len(sys.argv) > 2 else '60'
     r = run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, n_cases=int(arg[2:]) if arg.startswith('n=') else None,
-            seconds=None if arg.startswith('n=') else float(arg), per_iteration='per_iteration' in sys.argv[3:])
-    print('train: %d random configurations, worst gradient error / tolerance %.2f; %d configurations with a PReLU kink flip'
-          % (r['n'], r['worst'], r['flips']))
+            seconds=None if arg.startswith('n=') else float(arg), per_iteration='per_iteration' in sys.argv[3:],
+            keep_going='keep_going' in sys.argv[3:])
+    print('train: %d random configurations, worst gradient error / tolerance %.2f; %d configurations with a PReLU kink flip; '
+          '%d refused %s' % (r['n'], r['worst'], r['flips'], len(r['refused']), r['refused']))
     for k, v in r['stats'].items():
         v = np.sort(np.array(v))
         print('  %s: median %.1e, 99%% %.1e, max %.1e' % (k, np.median(v), v[int(0.99 * (len(v) - 1))], v[-1]))
