@@ -29,7 +29,7 @@ namespace empose {
 
 namespace tc {
 constexpr int NT = 512, NW8 = NT / 64, MAX_TILES = 8, RG = NT / 16, VT = MAX_TILES * 16 / RG;
-constexpr int CH = 4;                                     // 16-k blocks a wave has in flight (all loads issued before the products)
+constexpr int CH = 4;                                     // 16-k blocks of a wave per round (its whole K at width 512): loads two blocks ahead of the products
 constexpr int TLD = 17, TSZ = 16 * TLD;                   // padded 16 x 16 tile of partial sums
 constexpr int PART_FLOATS = NW8 * MAX_TILES * TSZ;        // [wave][tile][row][col]
 }  // namespace tc
@@ -100,9 +100,9 @@ __global__ __launch_bounds__(tc::NT) void cols_kernel(ColsArgs a) {
     for (int t = 0; t < VT; ++t) zin[t] = n.z_in[(size_t)min(row0 + t * RG + rg, M - 1) * n.ldz + cc];
   }
 
-  // ---- the product: wave w's contiguous range of 16-k blocks, all row tiles of this part.  A layer at this size is a
-  // latency chain, not a throughput problem: a wave issues the loads of CH blocks (all of its K at width 512) before the
-  // first product, so the whole operand of the workgroup is in flight at once.
+  // ---- the product: wave w's contiguous range of 16-k blocks, all row tiles of this part.  A layer at this size is bound
+  // by getting the operands into the CU (L2 -> CU at ~25 bytes per clock), not by the matrix cores: the loads run two
+  // blocks ahead of the products so that the memory pipeline stays full.
   f32x4 acc[MAX_TILES];
 #pragma unroll
   for (int t = 0; t < MAX_TILES; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
