@@ -317,8 +317,17 @@ class GradientBuckets(object):
 
 def attach_gradient_buckets(net, buckets):
     """The training engine of `net` writes gradients into `buckets` and stages each parameter group as the reverse sweep
-    finishes it (None detaches)."""
+    finishes it (None detaches).
+
+    With buckets the collectives of finished groups run on a side stream BESIDE the rest of the sweep.  The one-launch
+    training layers (csrc/train_cols.hip) need every workgroup of a launch resident at once; a collective kernel that holds
+    compute units while it waits for a slower rank would leave such a launch half resident, spinning on its mailbox until
+    the polls give up (EMPOSE_ETIMEOUT).  No deadlock -- the collectives do not depend on it -- but how long the wait lasts
+    is the other ranks' business, so the overlapped sweep takes the layer-by-layer path (option "train_cols" = 0)."""
     net._grad_sink = buckets
+    if buckets is not None:
+        from em_pose_amd import _lib
+        _lib.check(_lib.lib().empose_set_option(b'train_cols', 0))
 
 
 _ONE_SHOT_BUCKETS = {}

@@ -414,7 +414,8 @@ int empose_mlp_train_bwd_deferred(const empose_mlp_params* p, int M, const float
  * network).  A poll of the mailbox that gives up is reported like the cooperative LSTM kernels' (empose_async_status).
  * Like those kernels the paired launches need every workgroup of a launch resident at once -- the device to themselves:
  * processes that SHARE one GPU must set "train_cols" to 0 (em_pose_amd/helpers/distributed.py does when ranks wrap around
- * the devices), or their launches starve each other until the polls give up.
+ * the devices), or their launches starve each other until the polls give up; the same holds beside collective kernels that
+ * wait for other ranks on another stream (the helper's gradient buckets switch it off for the overlapped sweep).
  * workspace: empose_mlp_train_pair_workspace_bytes. */
 size_t empose_mlp_train_pair_workspace_bytes(const empose_mlp_params* p0, const empose_mlp_params* p1, int M);
 int empose_mlp_train_fwd_pair(const empose_mlp_params* p0, const empose_mlp_params* p1, int M, const float* x, int ldx,

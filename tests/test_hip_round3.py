@@ -352,14 +352,19 @@ def test_rccl_single_rank_collectives_on_device_tensors():
         batch.joints_gt = torch.randn(4, 8, 66, generator=gen).to(dev)
         bn_state = {k: v.clone() for k, v in net.state_dict().items() if 'running_' in k or 'num_batches' in k}
         own = [q for n, q in net.named_parameters() if not n.startswith('smpl.')]
+        # (round 5: with buckets attached the sweep takes the layer-by-layer training layers -- the one-launch ones need the
+        # device to themselves, helpers/distributed.py -- so the bit-for-bit reference below is taken on that path too)
+        _lib.check(_lib.lib().empose_set_option(b'train_cols', 0))
         net.zero_grad()
         net.backward(batch, net(batch))
         plain = [q.grad.clone() for q in own]
+        _lib.check(_lib.lib().empose_set_option(b'train_cols', 1))
         order = LgdTrainEngine.gradient_order(net)
         assert {id(q) for q in order} == {id(q) for q in own}
         nb = GradientBuckets(order, bucket_bytes=16 << 10, force=True)
         assert nb.n_buckets >= 3
         attach_gradient_buckets(net, nb)
+        assert _lib.lib().empose_get_option(b'train_cols') == 0
         ptrs = None
         for _ in range(2):
             net.load_state_dict(bn_state, strict=False)
