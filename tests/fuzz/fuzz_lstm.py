@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-BATCHES = (1, 2, 3, 5, 8, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700)
+BATCHES = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700)   # (4, 12: the other two sizes of lstm_fewrows_kernel)
 
 
 def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4):
