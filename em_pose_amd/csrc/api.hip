@@ -594,7 +594,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   // model, stream or thread it belongs to -- until empose_async_status() has reported and cleared it.  (Clearing it here
   // let the one call that happened to come next swallow the report while the call that produced the NaNs returned OK.)
   if (const unsigned n = poll_timeouts_peek())
-    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative LSTM kernel launched by an earlier call timed out waiting for "
+    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative kernel (whole-sequence LSTM / one-launch training layer) launched by an earlier call timed out waiting for "
                 "another workgroup's exchange word; that call's outputs are NaN (the state it carried too); "
                 "empose_async_status() reports and clears this", n);
   // the wavefront kernel addresses its operands with 32-bit byte offsets from a per-segment base
@@ -979,7 +979,7 @@ int empose_set_option(const char* name, int value) {
 
 int empose_async_status(void) {
   if (const unsigned n = poll_timeouts_take())
-    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative LSTM kernel timed out waiting for another workgroup's exchange "
+    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative kernel (whole-sequence LSTM / one-launch training layer) timed out waiting for another workgroup's exchange "
                 "word; the outputs of that call are NaN", n);
   return EMPOSE_OK;
 }

@@ -496,3 +496,41 @@ def test_lstm_training_forward_of_a_few_rows_and_its_reverse_equal_the_small_bat
     for a, b in zip(got, want):
         scale = max(1.0, float(b.abs().max()))
         assert float((a.double().cpu() - b).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.provokes_poll_timeout
+def test_mailbox_poll_of_the_one_launch_layers_gives_up_loudly():
+    """spin_limit = 1: a row part that does not find the other parts' statistics at its first re-check gives up -- the call
+    returns normally (the failure happens on the device), the outputs are poisoned with NaN, empose_async_status() reports
+    EMPOSE_ETIMEOUT exactly then; with the normal limit the same call gives finite numbers again.  Nothing hangs."""
+    lib = _lib.lib()
+    M, in_dim, hidden = 384, 296, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, in_dim, generator=g).to(DEV)
+    d_outs = [torch.zeros(M, 68, device=DEV), torch.zeros(M, 12, device=DEV)]
+    d_outs[0][:, :66] = torch.randn(M, 66, generator=g).to(DEV)
+    d_outs[1][:, :10] = torch.randn(M, 10, generator=g).to(DEV)
+    assert lib.empose_async_status() == 0
+    timed_out = 0
+    for attempt in range(12):
+        nets = _mlp_pair(in_dim, hidden, 5)
+        _lib.check(lib.empose_set_option(b'spin_limit', 1))
+        try:
+            res = _run_mlp_train(nets, x, d_outs, M, pair=True)
+            status = 0
+        except _lib.EmposeError as e:          # (_run_mlp_train checks the status after synchronising)
+            assert 'error -4' in str(e) and 'timed out' in str(e)
+            status = -4
+        finally:
+            _lib.check(lib.empose_set_option(b'spin_limit', 0))
+        if status == -4:
+            timed_out += 1
+            assert lib.empose_async_status() == 0          # reported once
+        else:
+            assert all(torch.isfinite(t).all() for t in res['out'])
+        if timed_out >= 2:
+            break
+    assert timed_out >= 1, 'spin_limit = 1 never made a mailbox poll give up: the test does not exercise the path'
+    nets = _mlp_pair(in_dim, hidden, 5)
+    res = _run_mlp_train(nets, x, d_outs, M, pair=True)       # back to normal
+    assert all(torch.isfinite(t).all() for t in res['out'] + res['stash'])
