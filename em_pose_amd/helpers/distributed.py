@@ -323,7 +323,8 @@ def attach_gradient_buckets(net, buckets):
     training layers (csrc/train_cols.hip) need every workgroup of a launch resident at once; a collective kernel that holds
     compute units while it waits for a slower rank would leave such a launch half resident, spinning on its mailbox until
     the polls give up (EMPOSE_ETIMEOUT).  No deadlock -- the collectives do not depend on it -- but how long the wait lasts
-    is the other ranks' business, so the overlapped sweep takes the layer-by-layer path (option "train_cols" = 0)."""
+    is the other ranks' business, so the overlapped sweep takes the layer-by-layer path (option "train_cols" = 0; options
+    are process-wide, and detaching the buckets does not switch it back on)."""
     net._grad_sink = buckets
     if buckets is not None:
         from em_pose_amd import _lib
