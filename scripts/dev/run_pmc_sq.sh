@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ / GRBM counter pass (own run, kernel-trace only) over the bench workload: effective clock (GRBM_GUI_ACTIVE / wall),
-# wave-cycle buckets and matrix-core busy cycles per kernel.  BENCH_ARGS="--workload vertices" selects another workload.
+# wave-cycle buckets and matrix-core busy cycles per kernel.  BENCH_ARGS="--workload vertices" selects another workload,
+# PMC_CMD="python $PWD/scripts/train.py --steps 3 --no_graph --json" another command (the training step).
 set -u
 TAG=${1:-r1}
 export TMPDIR=/tmp
@@ -9,7 +10,7 @@ mkdir -p gpurun_out
 OUT=$R/gpurun_out/pmc_sq_$TAG
 rm -rf $OUT
 ( cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
-    --kernel-trace --output-format csv -d $OUT -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile ${BENCH_ARGS:-} > $OUT.log 2>&1 )
+    --kernel-trace --output-format csv -d $OUT -o pmc -- ${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile ${BENCH_ARGS:-}} > $OUT.log 2>&1 )
 tail -3 $OUT.log
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys
