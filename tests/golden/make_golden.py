@@ -412,9 +412,28 @@ def make_train_fingerprints(vids):
             batch.joints_gt = torch.from_numpy(w['joints_gt'])
             net.train()
             net.zero_grad()
+            # (round 6) every PReLU application of the step: its input z (the BatchNorm output) and the cotangent its
+            # output receives, summed over ALL reverse passes that cross it (the N in-forward `backward` calls of
+            # models.py:576 deposit through the networks of earlier iterations, then `backward` proper).  An element with z
+            # within rounding of zero may take the other branch in another fp32 implementation; the k elements nearest to
+            # zero of every application are kept so that a test can PROVE such a flip instead of guessing it.
+            prelu_calls = {}
+
+            def _watch(name):
+                def hook(mod, inp, outp):
+                    z = inp[0].detach().clone()
+                    cot = torch.zeros_like(z)
+                    outp.register_hook(lambda g, cot=cot: (cot.add_(g), None)[1])
+                    prelu_calls.setdefault(name, []).append((z, cot))
+                return hook
+            watches = [m.register_forward_hook(_watch(name)) for name, m in net.named_modules()
+                       if isinstance(m, torch.nn.PReLU)]
             out = net(batch)
             total, loss_vals = net.backward(batch, out)
-            rec = {'out': {k: v.detach().numpy().copy() for k, v in out.items()},
+            for h in watches:
+                h.remove()
+            rec = {'prelu': prelu_calls,
+                   'out': {k: v.detach().numpy().copy() for k, v in out.items()},
                    'loss': dict(loss_vals, total=float(total.detach())),
                    'grad': {k: TH.tensor_fingerprint(k, p_.grad) for k, p_ in net.named_parameters()
                             if not k.startswith('smpl.') and p_.grad is not None},
@@ -444,11 +463,72 @@ def make_train_fingerprints(vids):
                 data['grad/{}/{}'.format(k, f)] = np.asarray(fp[f])
             for f in ('l2', 'proj', 'sample'):
                 data['sens/{}/{}'.format(k, f)] = scatter(lambda r: r['grad'][k][f])
+        # PReLU applications: per module and call the K_NEAR elements nearest to zero (row, column, z, summed cotangent,
+        # normalised BatchNorm input x^ = (z - beta) / gamma of that element) and `z_noise`: how far ANY element of that
+        # application's z moves between the five fp32 realisations of the reference's own step
+        K_NEAR = 48
+        sd0 = TH.seeded_state_dict(net.state_dict(), seed)
+        for name, calls in base['prelu'].items():
+            bn = TH.batch_norm_of_prelu(name)
+            gamma, beta = sd0[bn + '.weight'].double(), sd0[bn + '.bias'].double()
+            for c, (z, cot) in enumerate(calls):
+                noise = max(float((r['prelu'][name][c][0] - z).abs().max()) for r in runs[1:])
+                flat = z.abs().reshape(-1)
+                pick = torch.argsort(flat)[:K_NEAR]
+                rows, cols = pick // z.shape[1], pick % z.shape[1]
+                zz = z.reshape(-1)[pick].double()
+                key = 'prelu/{}/{}/'.format(name, c)
+                data[key + 'row'], data[key + 'col'] = rows.numpy().astype(np.int32), cols.numpy().astype(np.int32)
+                data[key + 'z'], data[key + 'cot'] = zz.numpy(), cot.reshape(-1)[pick].double().numpy()
+                data[key + 'xhat'] = ((zz - beta[cols]) / gamma[cols]).numpy()
+                data[key + 'z_noise'] = np.asarray(noise)
         data['meta/n_markers'], data['meta/N'], data['meta/rnn'] = np.asarray(nm), np.asarray(N), np.asarray(1)
         data['meta/seed'], data['meta/vertex_ids'], data['meta/hidden'] = np.asarray(seed), np.asarray(vids), np.asarray(512)
         path = os.path.join(HERE, tag + '.npz')
         np.savez_compressed(path, **data)
         print('wrote', path, '%.0f KB' % (os.path.getsize(path) / 1024))
+
+
+def make_inner_windows(vids):
+    """Case J: the INNER windowing of `BaseModel.window_generator` (reference models.py:146-163) -- the
+    `window_size=k` argument of `forward`, valid for a batch of ONE sequence (its fresh `seq_lengths` has shape (1,)).
+    LGD-RNN-12, N=4, one sequence of 72 frames fed as two calls: frames 0..40 as `net(batch, window_size=16)` (inner
+    windows of 16, 16 and a ragged 8 frames, LSTM state carried from one inner window to the next, the shape mean taken
+    per INNER window, models.py:501,529-535) and frames 40..72 as `net(batch, window_size=12, is_new_sequence=False)`
+    (12, 12, 8; state carried over from the first call).  A few sensors are missing.  Recorded: outputs, the merged
+    N+1 histories (models.py:611-629), the gradient features of every inner window, the LSTM state after each call."""
+    net, smpl = make_net(lgd_flags(12, True, 4, 32, 32), 1615200974, vids)
+    w = synthetic.make_windows(1, 72, 1615200974, sensors_from_reference(net, smpl))
+    masks = np.ones((1, 72, 12), dtype=np.float32)
+    masks[0, 14:18, 3] = 0.0          # straddles the first inner boundary
+    masks[0, 39, 0] = 0.0
+    masks[0, 50, [5, 9]] = 0.0
+    recs = {}
+    for tag, (sf, ef), ws, new in (('call0', (0, 40), 16, True), ('call1', (40, 72), 12, False)):
+        batch = real_batch(w, torch.tensor([ef - sf]), masks=masks, sf=sf, ef=ef)
+        feats = []
+        h = net.pose_net_iter.register_forward_pre_hook(lambda m, inp: feats.append(inp[0].detach().clone()))
+        out = net(batch, window_size=ws, is_new_sequence=new)
+        h.remove()
+        d_in, N = net.input_size, net.N
+        rec = {'out_' + k: v.detach().numpy() for k, v in out.items()}
+        for name in ('pose', 'shape', 'joints', 'markers', 'markers_ori'):
+            hist = getattr(net, name + '_hat_history')
+            assert len(hist) == N + 1
+            rec['hist_' + name] = np.stack([t.detach().numpy().reshape(1, ef - sf, -1) for t in hist])
+        n_win = len(feats) // N
+        assert n_win == 3 and len(feats) == n_win * N
+        # the hook fires window-major (inner window 0: iterations 0..N-1, then inner window 1, ...): regroup per iteration
+        per_iter = [torch.cat([feats[k * N + n] for k in range(n_win)], dim=0) for n in range(N)]
+        assert all(t.shape[0] == ef - sf for t in per_iter)
+        rec['g_pose'] = np.stack([f[:, d_in + 76:d_in + 142].numpy() for f in per_iter])
+        rec['g_shape'] = np.stack([f[:, d_in + 142:].numpy() for f in per_iter])
+        rec['rnn_h'] = net.rnn.final_state[0].detach().numpy()
+        rec['rnn_c'] = net.rnn.final_state[1].detach().numpy()
+        rec['window_size'] = np.asarray(ws)
+        recs[tag] = rec
+    w2 = dict(w, marker_masks=masks)
+    save_case('lgdrnn12_n4_inner_windows', net, w2, recs, {'n_markers': 12, 'N': 4, 'rnn': 1, 'vertex_ids': vids})
 
 
 def _write_recording(path, seq_id, n_frames, seed, sensors_fn, missing_rate, forced_missing=()):
@@ -622,6 +702,9 @@ def main():
     if '--only-train-sensitivity' in sys.argv:
         sys.argv.remove('--only-train-sensitivity')
         return train_sensitivity(vids)
+    if '--only-inner-windows' in sys.argv:
+        sys.argv.remove('--only-inner-windows')
+        return make_inner_windows(vids)
     if '--only-baselines' in sys.argv:
         sys.argv.remove('--only-baselines')
         return make_baselines(vids)
@@ -790,6 +873,7 @@ def main():
     make_baselines(vids)
     train_sensitivity(vids)
     make_lmdb_schema()
+    make_inner_windows(vids)
     make_train_fingerprints(vids)
     # the entry-point fixture needs its own environment (the asset tree's directories), hence its own process
     import subprocess

@@ -118,8 +118,84 @@ def tensor_fingerprint(name, t):
     a function of the tensor's NAME (the same in the reference's module and in this repository's)."""
     import zlib
     x = torch.as_tensor(t).detach().to('cpu', torch.float64).reshape(-1)
-    g = torch.Generator().manual_seed(770000 + zlib.crc32(name.encode()) % 100000)
-    z = torch.randn(N_PROJ, x.numel(), generator=g, dtype=torch.float64)
-    idx = torch.randperm(x.numel(), generator=g)[:N_SAMPLE]
+    z, idx = fingerprint_basis(name, x.numel())
     return {'max': float(x.abs().max()), 'l2': float(x.norm()), 'n': int(x.numel()), 'proj': (z @ x).numpy(),
             'sample': x[idx].numpy()}
+
+
+def fingerprint_basis(name, numel):
+    """The N_PROJ Gaussian directions (N_PROJ, numel) and the N_SAMPLE entry indices `tensor_fingerprint` uses for a tensor
+    of that name and size."""
+    import zlib
+    g = torch.Generator().manual_seed(770000 + zlib.crc32(name.encode()) % 100000)
+    z = torch.randn(N_PROJ, numel, generator=g, dtype=torch.float64)
+    idx = torch.randperm(numel, generator=g)[:N_SAMPLE]
+    return z, idx
+
+
+def batch_norm_of_prelu(name):
+    """Module name of the BatchNorm1d in front of a PReLU of an MLP (reference nn/layers.py:13-77): `X.activation_fn` ->
+    `X.batch_norm`; `X.hidden_layers.j.layers.2` -> `.layers.1`; `.layers.6` -> `.layers.5`."""
+    if name.endswith('.activation_fn'):
+        return name[:-len('activation_fn')] + 'batch_norm'
+    head, i = name.rsplit('.', 1)
+    assert int(i) in (2, 6), name
+    return '{}.{}'.format(head, int(i) - 1)
+
+
+def prelu_of_batch_norm(name):
+    if name.endswith('.batch_norm'):
+        return name[:-len('batch_norm')] + 'activation_fn'
+    head, i = name.rsplit('.', 1)
+    assert int(i) in (1, 5), name
+    return '{}.{}'.format(head, int(i) + 1)
+
+
+def explain_by_prelu_flips(fp, name, mine_full, want, tol_e, tol_p, tol_l, slope):
+    """PROOF that what separates a BatchNorm parameter gradient from the reference's fingerprint is a PReLU branch flip.
+
+    `fp` is a tests/golden/train_fp_*.npz fixture: for every PReLU application of the reference's step it holds the
+    elements nearest to zero -- (row, column, z, summed cotangent of the PReLU output, normalised BatchNorm input x^) --
+    and `z_noise`, how far the reference's own five fp32 realisations move that application's z.  An element with
+    |z| <= z_noise may legitimately sit on the other side of zero in another fp32 implementation; if it does, the gradient
+    of the BatchNorm bias in front of that PReLU moves at THAT column by exactly  -sign(z) (1 - slope) cot  (its weight:
+    times x^), nowhere else.  Accepted only if one or two such recorded elements reproduce the observed difference: every
+    sampled entry, all N_PROJ projections and the norm must be within their ORDINARY tolerances once the predicted
+    difference is subtracted.  Returns the list of (call, row, column, z, predicted difference) or None."""
+    import itertools
+    kind = name.rsplit('.', 1)[1]
+    if kind not in ('weight', 'bias'):
+        return None
+    try:
+        prelu = prelu_of_batch_norm(name.rsplit('.', 1)[0])
+    except (AssertionError, ValueError):
+        return None
+    cands = []
+    c = 0
+    while 'prelu/{}/{}/z'.format(prelu, c) in fp:
+        key = 'prelu/{}/{}/'.format(prelu, c)
+        noise = float(fp[key + 'z_noise'])
+        for row, col, z, cot, xhat in zip(fp[key + 'row'], fp[key + 'col'], fp[key + 'z'], fp[key + 'cot'], fp[key + 'xhat']):
+            if abs(z) <= noise and cot != 0.0:
+                pred = -np.sign(z) * (1.0 - slope) * cot * (xhat if kind == 'weight' else 1.0)
+                cands.append((c, int(row), int(col), float(z), float(pred)))
+        c += 1
+    n = int(want['n'])
+    Z, idx = fingerprint_basis(name, n)
+    Z, idx = Z.numpy(), idx.numpy()
+    mine_full = np.asarray(mine_full, dtype=np.float64).reshape(-1)
+    ds, dp = mine_full[idx] - want['sample'], Z @ mine_full - want['proj']
+    for size in (1, 2):
+        for sub in itertools.combinations(cands, size):
+            d = np.zeros(n)
+            for _, _, col, _, pred in sub:
+                d[col] += pred
+            if np.abs(ds - d[idx]).max() > tol_e or np.abs(dp - Z @ d).max() > tol_p:
+                continue
+            # the reference's norm with the flips applied: ||want + d||^2 = ||want||^2 + sum_c (2 want_c d_c + d_c^2),
+            # want_c = mine_c - d_c up to the tolerance just checked
+            cols = np.nonzero(d)[0]
+            l2 = np.sqrt(max(float(want['l2']) ** 2 + float(np.sum(2.0 * (mine_full[cols] - d[cols]) * d[cols] + d[cols] ** 2)), 0.0))
+            if abs(np.linalg.norm(mine_full) - l2) <= tol_l + 2.0 * tol_e * size:
+                return list(sub)
+    return None

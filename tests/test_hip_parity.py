@@ -383,6 +383,52 @@ def test_golden_ragged_and_masked():
     _run_case('lgdrnn12_n3_ragged_masked', [('run', (None, None))], sl_key='seq_lengths')
 
 
+def test_golden_inner_windows_of_one_sequence():
+    """SURVEY 8 a3, `forward(batch, window_size=k)` (reference models.py:146-163, 501): one 72-frame sequence fed to the
+    reference as `net(batch, window_size=16)` over frames 0..40 (inner windows 16 / 16 / ragged 8, LSTM state handed from
+    one inner window to the next, shape mean per inner window) and `net(batch, window_size=12, is_new_sequence=False)`
+    over frames 40..72, with missing sensors.  The same two calls through this module's `forward` on the GPU: outputs,
+    the merged N+1 histories, the gradient features of every inner window and the carried LSTM state."""
+    from em_pose_amd.data.data import RealBatch
+    case = H.load_case('lgdrnn12_n4_inner_windows')
+    meta, w = case['meta'], case['in']
+    N = int(meta['N'])
+    net = build_net(cfg_of(meta), H.small_model(), meta['vertex_ids'], case['sd'])
+    net.keep_gradient_trace = True
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for tag, (sf, ef), new in (('call0', (0, 40), True), ('call1', (40, 72), False)):
+        rec = case[tag]
+        n = ef - sf
+        b = RealBatch([0], torch.tensor([n]), t(w['poses'][:, sf:ef]), t(w['shapes']), torch.zeros(1, n, 3),
+                      t(w['marker_pos'][:, sf:ef]), t(w['marker_oris'][:, sf:ef]), t(w['marker_masks'][:, sf:ef]),
+                      t(w['offset_t']), t(w['offset_r'])).to_gpu(torch.device(DEV))
+        out = net(b, window_size=int(rec['window_size']), is_new_sequence=new)
+        torch.cuda.synchronize()
+        for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+            assert out[k].shape == rec['out_' + k].shape
+            np.testing.assert_allclose(out[k].cpu().numpy(), rec['out_' + k], atol=ATOL, err_msg=tag + k)
+        for name in ('pose', 'shape', 'joints', 'markers', 'markers_ori'):
+            hist = getattr(net, name + '_hat_history')
+            assert len(hist) == N + 1
+            got = np.stack([h.cpu().numpy().reshape(1, n, -1) for h in hist])
+            np.testing.assert_allclose(got, rec['hist_' + name], atol=ATOL, err_msg=tag + name)
+        assert net.markers_hat_history[0].shape == (1, n * 12, 3)
+        assert len(net.gradient_trace) == 3          # one trace per inner window
+        gp = np.concatenate([tr['g_pose'].cpu().numpy().reshape(N, -1, 66) for tr in net.gradient_trace], axis=1)
+        gs = np.concatenate([tr['g_shape'].cpu().numpy().reshape(N, -1, 10) for tr in net.gradient_trace], axis=1)
+        np.testing.assert_allclose(gp, rec['g_pose'], atol=1e-5 * np.abs(rec['g_pose']).max(), rtol=0)
+        np.testing.assert_allclose(gs, rec['g_shape'], atol=1e-5 * np.abs(rec['g_shape']).max(), rtol=0)
+        np.testing.assert_allclose(net.rnn.final_state[0].cpu().numpy(), rec['rnn_h'], atol=2e-5)
+        np.testing.assert_allclose(net.rnn.final_state[1].cpu().numpy(), rec['rnn_c'], atol=2e-5)
+    # the reference's restriction stands: a fresh one-entry `seq_lengths` per inner window only fits a batch of one
+    b2 = RealBatch([0, 1], torch.tensor([40, 40]), t(np.repeat(w['poses'][:, :40], 2, 0)), t(np.repeat(w['shapes'], 2, 0)),
+                   torch.zeros(2, 40, 3), t(np.repeat(w['marker_pos'][:, :40], 2, 0)),
+                   t(np.repeat(w['marker_oris'][:, :40], 2, 0)), torch.ones(2, 40, 12),
+                   t(np.repeat(w['offset_t'], 2, 0)), t(np.repeat(w['offset_r'], 2, 0))).to_gpu(torch.device(DEV))
+    with pytest.raises((AssertionError, ValueError, _lib.EmposeError)):
+        net(b2, window_size=16)
+
+
 def test_module_forward_mirrors_reference_interface():
     """forward(batch) through the batch container: dict keys/shapes, history shapes, state carry (models.py:485-632)."""
     from em_pose_amd.data.data import RealBatch

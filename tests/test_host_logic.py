@@ -381,3 +381,47 @@ def test_metrics_engine_accepts_a_precomputed_valid_mask():
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k])
     assert sa['angle'].shape[0] == 14
+
+
+def test_prelu_flip_proof_accepts_a_recorded_element_and_nothing_else():
+    """tests/helpers.py::explain_by_prelu_flips (what the full-width training test accepts a BatchNorm gradient entry
+    beyond tolerance by): a difference that IS a flip of a recorded near-zero element is explained -- as one element, and
+    as two in different columns --, the same magnitude at a column without a recorded element, a recorded element at half
+    its predicted magnitude, and a dense difference are not."""
+    import os
+    from tests import helpers as TH
+    z = np.load(os.path.join(TH.GOLDEN, 'train_fp_lgdrnn12_n4_h512.npz'))
+    fp = {k: z[k] for k in z.files if k.startswith('prelu/pose_net_iter.hidden_layers.1.layers.2/')}
+    name, slope = 'pose_net_iter.hidden_layers.1.layers.1.bias', 0.3
+    rng = np.random.default_rng(0)
+    ref = rng.normal(size=512) * 1e-2
+    want = TH.tensor_fingerprint(name, ref)
+    tol_e, tol_p, tol_l = 1e-6, 1e-6 * np.sqrt(512), 1e-6
+    cands = []
+    for c in range(4):
+        key = 'prelu/pose_net_iter.hidden_layers.1.layers.2/%d/' % c
+        for col, zz, cot in zip(fp[key + 'col'], fp[key + 'z'], fp[key + 'cot']):
+            if abs(zz) <= float(fp[key + 'z_noise']) and abs(cot) * (1 - slope) > 20 * tol_e:
+                cands.append((int(col), -np.sign(zz) * (1 - slope) * cot))
+    assert len(cands) >= 2
+    noise = rng.normal(size=512) * 1e-7
+    one = ref + noise
+    one[cands[0][0]] += cands[0][1]
+    got = TH.explain_by_prelu_flips(fp, name, one, want, tol_e, tol_p, tol_l, slope)
+    assert got is not None and len(got) == 1 and got[0][2] == cands[0][0]
+    other = next(c for c in cands if c[0] != cands[0][0])
+    two = one.copy()
+    two[other[0]] += other[1]
+    got = TH.explain_by_prelu_flips(fp, name, two, want, tol_e, tol_p, tol_l, slope)
+    assert got is not None and sorted(g[2] for g in got) == sorted([cands[0][0], other[0]])
+    taken = {int(c) for k in fp if k.endswith('/col') for c in fp[k]}
+    free = next(c for c in range(512) if c not in taken)
+    wrong_col = ref + noise
+    wrong_col[free] += cands[0][1]
+    assert TH.explain_by_prelu_flips(fp, name, wrong_col, want, tol_e, tol_p, tol_l, slope) is None
+    half = ref + noise
+    half[cands[0][0]] += 0.5 * cands[0][1]
+    assert TH.explain_by_prelu_flips(fp, name, half, want, tol_e, tol_p, tol_l, slope) is None
+    assert TH.explain_by_prelu_flips(fp, name, ref + 30 * tol_e, want, tol_e, tol_p, tol_l, slope) is None
+    # a Linear weight or a PReLU slope is never explained this way
+    assert TH.explain_by_prelu_flips(fp, 'pose_net_iter.hidden_layers.1.layers.2.weight', one[:1], want, 1, 1, 1, slope) is None

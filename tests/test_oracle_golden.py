@@ -67,6 +67,33 @@ def test_ragged_masked():
     np.testing.assert_allclose(hist['rnn_state'][0].numpy(), case['run']['rnn_h'], atol=TOL)
 
 
+def test_inner_windows():
+    """`forward(batch, window_size=k)` on one sequence (reference models.py:146-163): inner windows of 16, 16, 8 frames,
+    then a second call with 12, 12, 8 frames continuing the LSTM state.  The oracle runs one `ief_forward` per inner
+    window with the state handed on; concatenated along time it equals what the reference's single call returned."""
+    case = H.load_case('lgdrnn12_n4_inner_windows')
+    state = None
+    for tag, (sf, ef) in (('call0', (0, 40)), ('call1', (40, 72))):
+        rec = case[tag]
+        ws = int(rec['window_size'])
+        outs, hists = [], []
+        for a in range(sf, ef, ws):
+            out, hist = H.run_oracle(case, tag, H.oracle_inputs(case['in'], sf=a, ef=min(a + ws, ef)), state=state)
+            state = hist['rnn_state']
+            outs.append(out)
+            hists.append(hist)
+        out = {k: torch.cat([o[k] for o in outs], dim=1) for k in outs[0]}
+        hist = {}
+        for name in ('pose', 'shape', 'joints', 'markers', 'markers_ori'):
+            hist[name] = [torch.cat([h[name][n].reshape(1, min(ws, ef - sf - i * ws), -1) for i, h in enumerate(hists)],
+                                    dim=1) for n in range(len(hists[0][name]))]
+        for name in ('g_pose', 'g_shape'):
+            hist[name] = [torch.cat([h[name][n] for h in hists], dim=0) for n in range(len(hists[0][name]))]
+        _check(rec, out, hist)
+        np.testing.assert_allclose(state[0].numpy(), rec['rnn_h'], atol=TOL)
+        np.testing.assert_allclose(state[1].numpy(), rec['rnn_c'], atol=TOL)
+
+
 def test_components():
     z = np.load(os.path.join(H.GOLDEN, 'components.npz'))
     gt, hat = torch.from_numpy(z['rl_gt']), torch.from_numpy(z['rl_hat'])
