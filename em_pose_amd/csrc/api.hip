@@ -583,6 +583,18 @@ void fill_unit(LstmUnitArgs& ua, const Lstm& r, const LstmWs& ws, int u) {
   ua.y = nullptr; ua.y_ld = 0; ua.y_col = 0;
 }
 
+// A poll of a cooperative kernel launched by an EARLIER call gave up (that call's outputs are NaN): reported by every entry
+// point that launches or consumes such kernels -- the recurrences and, round 6, the training layers (empose_mlp_train_*,
+// empose_lstm_train_*) -- without synchronising (the counter is a host-mapped word), and STICKY until
+// empose_async_status() has reported and cleared it.
+int earlier_poll_timeouts() {
+  if (const unsigned n = poll_timeouts_peek())
+    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative kernel (whole-sequence LSTM / one-launch training layer) launched by an earlier call timed out waiting for "
+                "another workgroup's exchange word; that call's outputs are NaN (the state it carried too); "
+                "empose_async_status() reports and clears this", n);
+  return EMPOSE_OK;
+}
+
 // State layout of h0/c0/h_n/c_n: [num_layers * dirs][B][H], unit u = layer * dirs + direction (PyTorch's order).
 int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* seq_lengths, const float* h0,
              const float* c0, float* y, float* h_n, float* c_n, const LstmWs& ws, hipStream_t stream) {
@@ -593,10 +605,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
   // STICKY: the count is only looked at here; it stays set -- and every recurrence of the process keeps failing, whichever
   // model, stream or thread it belongs to -- until empose_async_status() has reported and cleared it.  (Clearing it here
   // let the one call that happened to come next swallow the report while the call that produced the NaNs returned OK.)
-  if (const unsigned n = poll_timeouts_peek())
-    return fail(EMPOSE_ETIMEOUT, "%u poll(s) of a cooperative kernel (whole-sequence LSTM / one-launch training layer) launched by an earlier call timed out waiting for "
-                "another workgroup's exchange word; that call's outputs are NaN (the state it carried too); "
-                "empose_async_status() reports and clears this", n);
+  TRY(earlier_poll_timeouts());
   // the wavefront kernel addresses its operands with 32-bit byte offsets from a per-segment base
   if ((size_t)B * F * (size_t)(ldx > 2 * H ? ldx : 2 * H) * sizeof(float) >= ((size_t)1 << 32))
     return fail(EMPOSE_EINVAL, "LSTM batch of %d x %d frames is too large for one call; split the batch", B, F);
@@ -970,6 +979,7 @@ int empose_set_option(const char* name, int value) {
       {"lstm_x3", &o.lstm_x3},
       {"rows_x3", &o.rows_x3},
       {"train_cols", &o.train_cols},
+      {"cols_coop", &o.cols_coop},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
@@ -1005,6 +1015,7 @@ int empose_get_option(const char* name) {
       {"lstm_x3", o.lstm_x3},
       {"rows_x3", o.rows_x3},
       {"train_cols", o.train_cols},
+      {"cols_coop", o.cols_coop},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
@@ -1849,6 +1860,7 @@ size_t empose_mlp_train_workspace_bytes(const empose_mlp_params* p, int M) {
 int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int ldx, float* out, int ld_out,
                          float* save, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p));
+  TRY(earlier_poll_timeouts());
   if (!x || !out || !save || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   if (M <= 0 || ldx < p->in_dim || ldx % 4 != 0 || ld_out < p->out_dim) return fail(EMPOSE_EINVAL, "bad sizes");
   if (workspace_bytes < empose_mlp_train_workspace_bytes(p, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
@@ -2009,6 +2021,7 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
                        const float* save, const empose_mlp_grads* gr, int accumulate, float* stash, void* workspace,
                        size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p));
+  TRY(earlier_poll_timeouts());
   if (!x || !d_out || !save || !gr || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   const int H = p->hidden, L = p->n_layers, op = (p->out_dim + 3) & ~3;
   if (M <= 0 || ldx < p->in_dim || ld_dout < op || ld_dout % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
@@ -2193,6 +2206,7 @@ int empose_mlp_train_fwd_pair(const empose_mlp_params* p0, const empose_mlp_para
                               void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p0));
   TRY(check_mlp_params(p1));
+  TRY(earlier_poll_timeouts());
   if (workspace_bytes < empose_mlp_train_pair_workspace_bytes(p0, p1, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
   if (M > 0 && x && out0 && out1 && save0 && save1 && workspace && ldx % 4 == 0 && ldx >= p0->in_dim && ldx >= p1->in_dim &&
       ld_out0 >= p0->out_dim && ld_out1 >= p1->out_dim && mlp_cols_pairable(p0, p1, M)) {
@@ -2215,6 +2229,7 @@ int empose_mlp_train_bwd_deferred_pair(const empose_mlp_params* p0, const empose
                                        void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p0));
   TRY(check_mlp_params(p1));
+  TRY(earlier_poll_timeouts());
   if (!dz_stash0 || !dz_stash1) return fail(EMPOSE_EINVAL, "null stash");
   if (workspace_bytes < empose_mlp_train_pair_workspace_bytes(p0, p1, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
   bool pair = M > 0 && x && d_out0 && d_out1 && save0 && save1 && gr0 && gr1 && workspace && mlp_cols_pairable(p0, p1, M) &&
@@ -2250,6 +2265,7 @@ int empose_mlp_train_wgrad(const empose_mlp_params* p, int n_app, int M, const f
                            const float* const* save, const float* const* dz_stash, const empose_mlp_grads* gr,
                            int accumulate, void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_mlp_params(p));
+  TRY(earlier_poll_timeouts());
   if (!x || !save || !dz_stash || !gr || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   if (n_app < 1 || n_app > ATB_MAX_SEG || M <= 0 || ldx < p->in_dim) return fail(EMPOSE_EINVAL, "bad sizes");
   if (workspace_bytes < empose_mlp_train_wgrad_workspace_bytes(p, n_app, M)) return fail(EMPOSE_ENOMEM, "workspace too small");
@@ -2397,6 +2413,7 @@ int empose_lstm_train_fwd(const empose_lstm_params* p, int B, int F, const float
                           const float* h0, const float* c0, float* y, float* h_n, float* c_n, float* save,
                           void* workspace, size_t workspace_bytes, empose_stream_t stream_) {
   TRY(check_lstm_params(p));
+  TRY(earlier_poll_timeouts());
   if (!x || !y || !save || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   if (B <= 0 || F <= 0 || ldx < p->input_size || ldx % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
   if (workspace_bytes < empose_lstm_train_workspace_bytes(p, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");
@@ -2457,6 +2474,7 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
                           const empose_lstm_grads* grads, void* workspace, size_t workspace_bytes,
                           empose_stream_t stream_) {
   TRY(check_lstm_params(p));
+  TRY(earlier_poll_timeouts());
   if (!x || !save || !dy || !grads || !workspace) return fail(EMPOSE_EINVAL, "null argument");
   if (B <= 0 || F <= 0 || ldx < p->input_size || ldx % 4 != 0) return fail(EMPOSE_EINVAL, "bad sizes");
   if (workspace_bytes < empose_lstm_train_workspace_bytes(p, B, F)) return fail(EMPOSE_ENOMEM, "workspace too small");

@@ -39,6 +39,8 @@ struct Options {
                           // bf16 pieces per operand (lstm_x3.hip); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int train_cols = 1;     // training at <= 512 rows: a layer's product + BatchNorm + PReLU as one launch, both update networks
                           // side by side (train_cols.hip); 0: a product and a BatchNorm launch per layer and network
+  int cols_coop = 1;      // those one-launch layers, eager: launched with hipLaunchCooperativeKernel (all workgroups resident by
+                          // the runtime's guarantee); 0: the ordinary launch (residency argued from the occupancy query)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
                           // instead of the whole-sequence kernel / lstm_small_kernel (0: those; they share their bits)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
       const int ks = in ? g : g - KS_in, ksn = in ? KS_in : KS_h;
       lx_gptr_t ab = (lx_gptr_t)(in ? p_in : p_rec) + (((size_t)rt0 * ksn + ks) * 3) * FRAG + lane * 8;
       lx_gptr_t wb = (lx_gptr_t)(in ? p_wih : p_whh) + ((((size_t)ks * JB + jb) * 4) * 3) * FRAG + lane * 8;
-      const size_t rt_stride = (size_t)ksn * 3 * FRAG;
+      // (an odd number of 32-row tiles: the last workgroup's second tile does not exist in the piece planes -- it reads its
+      // first tile again instead of one tile past the plane; those rows are >= B and never stored)
+      const size_t rt_stride = rt0 + 1 < (B + 31) / 32 ? (size_t)ksn * 3 * FRAG : 0;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll

@@ -789,6 +789,16 @@ static FusedMlpArgs rows_t_args(const float* A, int lda, const float* Wp, float*
   return a;
 }
 
+// Kernels that issue v_mfma_f32_32x32x16_bf16 run ONE wave per SIMD (scripts/dev/bf16_hazard_repro.md: with two, single
+// accumulator elements come out wrong).  Their workgroups are four waves, so one workgroup per CU is the rule, enforced BY
+// CONSTRUCTION here: the dynamic LDS request is raised above half a CU's LDS, so a second workgroup never fits -- whatever
+// the kernel's own footprint (33 KB for the init heads of a 128-wide LSTM) and register count would have allowed (round 6;
+// before, only the 512-wide layouts were safe, by their size).
+static size_t x3_exclusive_lds(size_t lds) {
+  const size_t half = LDS_BYTES_PER_CU / 2 + 1024;
+  return lds > half ? lds : half;
+}
+
 template <class Kern, class Extra>
 static hipError_t launch_rows_t_fused(Kern kern, size_t lds, const FusedMlpArgs& a, const Extra& x, hipStream_t stream) {
   if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return e;
@@ -803,8 +813,8 @@ hipError_t launch_blend_feat_gemm(const FeatArgs& fa, const float* Wp, float* C_
   const FusedMlpArgs a = rows_t_args(nullptr, 0, Wp, C_t, ldc_t, fa.T, N, BLEND_FEAT_K);
   const size_t lds = blend_feat_lds().bytes();   // the A block + the tile's window means
   if (x3) {
-    if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5, true>, lds, a, fa, stream);
-    return launch_rows_t_fused(blend_feat_gemm_kernel<4, true>, lds, a, fa, stream);
+    if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5, true>, x3_exclusive_lds(lds), a, fa, stream);
+    return launch_rows_t_fused(blend_feat_gemm_kernel<4, true>, x3_exclusive_lds(lds), a, fa, stream);
   }
   if (N > 256) return launch_rows_t_fused(blend_feat_gemm_kernel<5>, lds, a, fa, stream);
   return launch_rows_t_fused(blend_feat_gemm_kernel<4>, lds, a, fa, stream);
@@ -814,7 +824,7 @@ hipError_t launch_blend_t_gemm_rod(const float* A_t, int lda_t, const float* Wp,
                                    hipStream_t stream) {
   if (K % 4 != 0) return hipErrorInvalidValue;
   const FusedMlpArgs a = rows_t_args(A_t, lda_t, Wp, nullptr, 0, ra.T, BLEND_T_N, K);
-  if (x3) return launch_rows_t_fused(blend_t_gemm_rod_kernel<4, true>, blend_t_rod_lds(K).bytes(), a, ra, stream);
+  if (x3) return launch_rows_t_fused(blend_t_gemm_rod_kernel<4, true>, x3_exclusive_lds(blend_t_rod_lds(K).bytes()), a, ra, stream);
   return launch_rows_t_fused(blend_t_gemm_rod_kernel<4>, blend_t_rod_lds(K).bytes(), a, ra, stream);
 }
 
@@ -829,8 +839,9 @@ hipError_t launch_heads_rows(const float* y, int ldy, const float* Wp, const flo
   // row block is smaller than the 96 x 64 result) -- rows_lds, the layout the kernel indexes with
   const size_t lds = rows_lds(K, 64, false, n_pose + n_shape).bytes();
   if (x3) {
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel<true>), lds)) return e;
-    hipLaunchKernelGGL(heads_rows_kernel<true>, dim3((M + 63) / 64), dim3(fm::NT), lds, stream, a, h);
+    const size_t lds1 = x3_exclusive_lds(lds);
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel<true>), lds1)) return e;
+    hipLaunchKernelGGL(heads_rows_kernel<true>, dim3((M + 63) / 64), dim3(fm::NT), lds1, stream, a, h);
     return hipGetLastError();
   }
   if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(heads_rows_kernel<false>), lds)) return e;

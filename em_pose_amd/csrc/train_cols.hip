@@ -393,6 +393,21 @@ hipError_t launch_cols(ColsArgs a, int mode, hipStream_t stream) {
   a.slices_per_group = (a.s_max + groups - 1) / groups;
   const dim3 grid(8 * a.slices_per_group * a.R);
   a.plain = mode == 1;
+  // The workgroups of a launch wait for each other's exchange words, so ALL of them must be resident.  Eager launches ask
+  // the runtime for exactly that guarantee (hipLaunchCooperativeKernel: the dispatch does not start until the whole grid
+  // fits, whatever else this or another stream has on the device) -- round 6; before, residency was only ARGUED from the
+  // occupancy query and a kernel of another stream could starve a late workgroup into a poll timeout.  A stream that is
+  // being CAPTURED takes the ordinary launch (a cooperative node is not something the graph of this runtime records): the
+  // replay is then safe only alone on the device, which is what the caller of a capture asserts (nn/train_engine.py
+  // refuses to capture with side streams forked; option "cols_coop" = 0 forces the ordinary launch for A/B timing).
+  const void* fn = mode <= 1 ? reinterpret_cast<const void*>(cols_kernel<0>) : reinterpret_cast<const void*>(cols_kernel<2>);
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
+  if (capturing == hipStreamCaptureStatusNone && options().cols_coop) {
+    void* params[] = {&a};
+    if (hipLaunchCooperativeKernel(fn, grid, dim3(tc::NT), params, 0u, stream) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();      // no cooperative launch in this context: fall back to the argued residency
+  }
   if (mode <= 1) hipLaunchKernelGGL(cols_kernel<0>, grid, dim3(tc::NT), 0, stream, a);
   else hipLaunchKernelGGL(cols_kernel<2>, grid, dim3(tc::NT), 0, stream, a);
   return hipGetLastError();

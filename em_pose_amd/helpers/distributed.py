@@ -121,8 +121,11 @@ def local_device_index(local_rank, what='this script'):
             # resident at once.  The one-launch training layers fill the chip (256 workgroups at width 512); two processes
             # launching them on ONE device starve each other until the polls give up (EMPOSE_ETIMEOUT, outputs NaN).  Ranks
             # that share a device therefore take the layer-by-layer path.
+            import logging
             from em_pose_amd import _lib
             _lib.check(_lib.lib().empose_set_option(b'train_cols', 0))
+            logging.getLogger('em_pose_amd.distributed').info(
+                '%d ranks share %d device(s): option train_cols -> 0 for this process', world, n)
         return local_rank % n
     if n <= local_rank:
         raise SystemExit('{} --gpus {} needs {} GPUs, found {}'.format(what, world, world, n))
@@ -323,12 +326,25 @@ def attach_gradient_buckets(net, buckets):
     training layers (csrc/train_cols.hip) need every workgroup of a launch resident at once; a collective kernel that holds
     compute units while it waits for a slower rank would leave such a launch half resident, spinning on its mailbox until
     the polls give up (EMPOSE_ETIMEOUT).  No deadlock -- the collectives do not depend on it -- but how long the wait lasts
-    is the other ranks' business, so the overlapped sweep takes the layer-by-layer path (option "train_cols" = 0; options
-    are process-wide, and detaching the buckets does not switch it back on)."""
-    net._grad_sink = buckets
+    is the other ranks' business, so the overlapped sweep takes the layer-by-layer path (option "train_cols" = 0).  Options
+    are process-wide: the value found is remembered on `net` and put back when the buckets are detached (None), and the
+    change is logged.  (Eager launches of those layers are cooperative launches since round 6 -- the runtime guarantees
+    residency -- but a captured step replays ordinary launches, and the engine captures whenever shapes repeat.)"""
+    import logging
+    from em_pose_amd import _lib
+    lib = _lib.lib()
+    log = logging.getLogger('em_pose_amd.distributed')
     if buckets is not None:
-        from em_pose_amd import _lib
-        _lib.check(_lib.lib().empose_set_option(b'train_cols', 0))
+        if getattr(net, '_grad_sink', None) is None:
+            net._train_cols_before = int(lib.empose_get_option(b'train_cols'))
+        _lib.check(lib.empose_set_option(b'train_cols', 0))
+        if net._train_cols_before != 0:
+            log.info('gradient buckets attached: option train_cols %d -> 0 until they are detached', net._train_cols_before)
+    elif getattr(net, '_grad_sink', None) is not None and hasattr(net, '_train_cols_before'):
+        _lib.check(lib.empose_set_option(b'train_cols', net._train_cols_before))
+        log.info('gradient buckets detached: option train_cols back to %d', net._train_cols_before)
+        del net._train_cols_before
+    net._grad_sink = buckets
 
 
 _ONE_SHOT_BUCKETS = {}

@@ -67,6 +67,7 @@ def train_on_amass(args, dev, rank, world):
     `scripts/evaluate_real.py --model_id <id>` / `eval.helpers.load_model` find them)."""
     import glob
     from torch.utils.data import DataLoader, Subset
+    from em_pose_amd import _lib
     from em_pose_amd.data.data import AMASSBatch
     from em_pose_amd.data.datasets import AMASSNpzDataset, LMDBDataset
     from em_pose_amd.data.transforms import ExtractWindow, ToTensor, get_end_to_end_preprocess_fn
@@ -144,14 +145,39 @@ def train_on_amass(args, dev, rank, world):
         print('Model created with {} trainable parameters'.format(count_parameters(net)))
         print('Saving checkpoints to {}'.format(checkpoint))
     me = MetricsEngine(smpl)
-    step, best, done = 0, float('inf'), False
+    step, best, done, skipped = 0, float('inf'), False, 0
     for epoch in range(args.n_epochs):
         for i, abatch in enumerate(train_loader):
             t0 = time.perf_counter()
             net.train()
             opt.zero_grad()
             batch = fn_train(abatch.to_gpu(dev))
-            loss, vals = net.backward(batch, net(batch))
+            try:
+                loss, vals = net.backward(batch, net(batch))
+                poisoned = _lib.lib().empose_async_status() != 0
+            except _lib.EmposeError:
+                # (an entry point of the same step already saw the word: EMPOSE_ETIMEOUT; anything else is not ours to hide)
+                if _lib.lib().empose_async_status() == 0:
+                    raise
+                poisoned = True
+            # `vals` are host floats: the step's kernels have finished, so the word the cooperative kernels (whole-sequence
+            # LSTM, one-launch training layers) count their abandoned polls in is final and reading it costs nothing.  A
+            # step whose poll gave up carries NaN gradients: it is NOT applied.  Every rank decides the same way (the
+            # collective below must be entered by all or by none), so the flags are reduced first.
+            if world > 1:
+                flag = torch.tensor([float(poisoned)], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+                poisoned = bool(flag.item())
+            if poisoned:
+                skipped += 1
+                print('[TRAIN {:0>5d} | {:0>3d}] rank {}: step dropped, a cooperative kernel gave up on a poll ({}); '
+                      'gradients discarded'.format(i + 1, epoch + 1, rank, _lib.lib().empose_last_error().decode()))
+                if skipped >= 3:
+                    raise SystemExit('three steps dropped: is another process using this GPU?  --option train_cols=0 '
+                                     '--option lstm_persist=0 run without cooperative kernels')
+                if buckets is not None:
+                    buckets.finish()       # the collectives the backward already started are drained; their sums are dropped
+                continue
             average_gradients(buckets, params)
             opt.step()
             if rank == 0:

@@ -16,6 +16,55 @@ recorded from the reference itself).
 import sys
 import time
 
+def _bn_names(net, layer):
+    """Parameter-name stem of the BatchNorm of hidden layer `layer` of an MLP (inverse of `_layer_of`)."""
+    if layer == 0:
+        return net + 'batch_norm'
+    j, second = (layer - 1) // 2, (layer - 1) % 2
+    return '%shidden_layers.%d.layers.%d' % (net, j, 5 if second else 1)
+
+
+def _kink_flip_relation(bad, signed, tols, state):
+    """None if, in every network with tensors out of tolerance, the BatchNorm gradients of its most downstream such layer
+    differ the way PReLU flips at z ~ 0 make them differ.  The flipped channels c are where that layer's Linear weight
+    gradient (row c) or BatchNorm gradients (entry c) are out of tolerance; there d(bias)[c] must STAND OUT of the rounding
+    noise of the other channels (it may well lie inside the tolerance, which is set by the tensor's scale: the five cases of
+    the first round-6 soak that an out-of-tolerance requirement refused) and d(weight)[c] = x^_c d(bias)[c] with
+    x^_c = -beta_c / gamma_c must hold to 2 % -- flips in one channel superpose, the layers downstream of the most
+    downstream flip do not move at all, so nothing else contributes there."""
+    where = {k: _layer_of(k) for k in bad}
+    for net in sorted({v[0] for v in where.values() if v is not None}):
+        last = max(v[1] for v in where.values() if v is not None and v[0] == net)
+        stem = _bn_names(net, last)
+        kw, kb = stem + '.weight', stem + '.bias'
+        if kw not in signed or kb not in signed:
+            return 'no BatchNorm behind layer %d of %s' % (last, net)
+        channels = set()
+        for k in bad:
+            if where[k] is None or where[k][0] != net or where[k][1] != last or where[k][2] == 'prelu':
+                continue
+            d = signed[k].abs()
+            channels.update((d.reshape(d.shape[0], -1) > tols[k]).any(dim=1).nonzero().flatten().tolist())
+        if not channels:
+            return 'layer %d of %s: no channel out of tolerance' % (last, net)
+        gamma, beta = state[kw].double(), state[kb].double()
+        xhat = -(beta / gamma).to(signed[kw].device)
+        dw, db = signed[kw].double(), signed[kb].double()
+        others = torch.ones_like(db, dtype=torch.bool)
+        others[sorted(channels)] = False
+        noise_b = float(db[others].abs().median()) if bool(others.any()) else 0.0
+        noise_w = float(dw[others].abs().median()) if bool(others.any()) else 0.0
+        for c in sorted(channels):
+            if abs(float(db[c])) < 10.0 * noise_b or abs(float(db[c])) == 0.0:
+                return ('layer %d of %s, channel %d: d(bias) = %.2e does not stand out of the other channels\' %.2e -- no '
+                        'flip is visible there' % (last, net, c, float(db[c]), noise_b))
+            want = float(xhat[c] * db[c])
+            if abs(float(dw[c]) - want) > 0.02 * (abs(float(dw[c])) + abs(want)) + 10.0 * (noise_w + abs(float(xhat[c])) * noise_b):
+                return ('layer %d of %s, channel %d: d(weight) = %.3e, x^ d(bias) = %.3e (a flip at z ~ 0 makes them equal)'
+                        % (last, net, c, float(dw[c]), want))
+    return None
+
+
 if __name__ == '__main__':
     sys.path.insert(0, '.')
     sys.path.insert(0, 'tests')
@@ -172,6 +221,12 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
         # spreads one channel over all rows), the layers below it, the other network, the LSTM and the heads not at all.
         diffs = {k: (res[True][1][k] - res[False][1][k]).abs() for k in bad}
         why = _kink_flip_pattern(bad, diffs, tols)
+        if why is None:
+            # round 6: the footprint is necessary, not sufficient.  A flip sits at an element with z = gamma x^ + beta ~ 0,
+            # i.e. x^ = -beta / gamma of its channel, and moves that channel's BatchNorm gradients by d(bias) = delta and
+            # d(weight) = delta x^: the two differences of the most downstream layer must stand in exactly that ratio,
+            # channel by channel, with x^ computed from the PARAMETERS -- a relation no other kind of error satisfies.
+            why = _kink_flip_relation(bad, {k: res[True][1][k] - res[False][1][k] for k in res[False][1]}, tols, state0)
         if why is not None:
             # What else has a kink: the L1 terms of the loss (reference loss.py:13-21).  Their cotangent is sign(estimate -
             # target); an estimate within rounding of its target (the synthetic targets hold exact zeros) takes different
@@ -198,6 +253,8 @@ def _one(n, worst, rng, dev, model, bm, vids, tables, sensors, stats, flips, see
                 is_up = lambda k: ('_init' in k.split('.')[0] or k.startswith('rnn')) or any(k.startswith(u) for u in upstream)
                 rest = [k for k in bad if not is_up(k)]
                 why = _kink_flip_pattern(rest, {k: diffs[k] for k in rest}, tols) if rest else None
+                if why is None and rest:
+                    why = _kink_flip_relation(rest, {k: res[True][1][k] - res[False][1][k] for k in res[False][1]}, tols, state0)
                 if why is None:
                     stats.setdefault('L1 kink cases', []).append(float(n))
         if why is not None:

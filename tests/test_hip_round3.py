@@ -379,6 +379,7 @@ def test_rccl_single_rank_collectives_on_device_tensors():
             assert ptrs is None or ptrs == now
             ptrs = now
         attach_gradient_buckets(net, None)
+        assert _lib.lib().empose_get_option(b'train_cols') == 1      # detaching puts the option back
         # metric accumulators through the group
         me = MetricsEngine(None)
         j = torch.randn(2, 5, 66, device=dev)
@@ -447,6 +448,9 @@ def test_frame_per_lane_smpl_path(which, n_markers, T, F, big_model):
         tile_fwd = _sensors_call(handle, T, F, theta, beta, off_r, off_t)
         again = _sensors_call(handle, T, F, theta, beta, off_r, off_t, tgt, scale)
     assert all(np.isfinite(x).all() for x in tile)
+    # launch after launch the same bits (the blend products of this path run on the three-piece bf16 MFMA by default)
+    for a_, b_ in zip(tile, again):
+        assert np.array_equal(a_, b_)
     # against the float64 blueprint: the tolerances of test_smpl_sensors_fwd_bwd (tuned on 96 frames), or -- the worst
     # element of thousands of frames lies further out for either kernel -- 3 x what the general kernel shows here (two fp32 roundings of the same
     # ill-conditioned elements land on opposite sides)

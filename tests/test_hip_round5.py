@@ -97,7 +97,10 @@ def test_full_width_training_step_matches_reference_fingerprints(tag, variant):
         # layer) only ~2.1 -- the same four-fold margin in standard deviations needs the ratio of the two as a factor
         n_e = min(mine['n'], H.N_SAMPLE)
         few = float(np.sqrt(np.log(10.0 * H.N_SAMPLE) / np.log(10.0 * n_e)))
-        few_p = float(np.sqrt(np.log(10.0 * H.N_SAMPLE) / np.log(10.0 * H.N_PROJ)))
+        # (a one-element tensor's norm and its N_PROJ projections are that one element again, times constants: the same
+        # single draw per pair of realisations, so the same factor -- round 6; the 8-projection factor understated it and the
+        # footprint rule that used to wave single slopes through is gone)
+        few_p = few if mine['n'] == 1 else float(np.sqrt(np.log(10.0 * H.N_SAMPLE) / np.log(10.0 * H.N_PROJ)))
         tol_e = max(1e-4 * scale, 4.0 * few * sens['sample'])
         tol_p = max(1e-4 * scale * np.sqrt(mine['n']), 4.0 * few_p * sens['proj'])
         tol_l = max(1e-4 * float(want['l2']), 4.0 * few_p * sens['l2'])

@@ -1,0 +1,126 @@
+"""
+Round 6 GPU tests (run with `-m gpu` on an MI355X).
+
+  * kernels on the three-piece bf16 MFMA run one workgroup per CU by construction: repeat launches are bit-identical at a
+    narrow LSTM width, where their own LDS footprint would have let two or three workgroups share a CU
+  * the one-launch training layers beside a long kernel on another stream: correct gradients, no poll timeout (VERDICT r5
+    item 8: eager launches are cooperative launches)
+"""
+import numpy as np
+import pytest
+import torch
+
+from em_pose_amd import _lib, synthetic
+from em_pose_amd.bodymodels.smpl import SMPLLayer
+from em_pose_amd.helpers.configuration import CONSTANTS as CONST
+from em_pose_amd.helpers.configuration import lgd_config
+from em_pose_amd.nn.models import create_model
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def big_model():
+    return synthetic.make_model()
+
+
+class _Option(object):
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = _lib.lib().empose_get_option(self.name)
+        _lib.check(_lib.lib().empose_set_option(self.name, self.value))
+
+    def __exit__(self, *exc):
+        _lib.lib().empose_set_option(self.name, self.old)
+        return False
+
+
+@pytest.mark.parametrize('rnn_hidden', [128, 256])
+def test_three_piece_bf16_row_kernels_repeat_bit_identically_at_narrow_widths(big_model, rnn_hidden):
+    """LGD-RNN-12, N = 2, with a 128- / 256-wide LSTM, 160 windows x 32 frames, frame-per-lane SMPL path forced: the init
+    heads (heads_rows_kernel<true>, 33 / 67 KB of LDS of its own) and both blend products (blend_feat / blend_t, X3) run on
+    v_mfma_f32_32x32x16_bf16.  Two waves of one SIMD issuing that instruction leave sporadic wrong accumulator elements
+    (scripts/dev/bf16_hazard_repro.md), so their launches request more than half a CU's LDS: one workgroup per CU whatever
+    the width.  Six forwards, the same bits every time, and right (eight sampled windows against the oracle)."""
+    torch.manual_seed(rnn_hidden)
+    net = create_model(lgd_config(12, True, 2, rnn_hidden=rnn_hidden), SMPLLayer(big_model)).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    bm = R.BodyModelTensors(big_model)
+    tables = R.sensor_tables(big_model['f'], CONST.VERTEX_IDS)
+
+    def fn(poses, betas, o_r, o_t):
+        with torch.no_grad():
+            p, o, _ = R.estimated_markers(bm, tables, CONST.VERTEX_IDS, torch.from_numpy(poses),
+                                          torch.from_numpy(betas), torch.from_numpy(o_r), torch.from_numpy(o_t))
+        return p.numpy(), o.numpy()
+    B, F = 160, 32
+    pool = synthetic.make_windows(32, F, 99, fn)
+    order = np.random.default_rng(3).permutation(B) % 32
+    keys = ('marker_pos', 'marker_oris', 'offset_t', 'offset_r')
+    batch = {k: np.ascontiguousarray(pool[k][order]) for k in keys}
+    pick = [0, 1, 63, 64, 65, 127, 128, B - 1]
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith('smpl.')}
+    inp = {k: torch.from_numpy(batch[k][pick]) for k in keys}
+    inp['marker_masks'] = None
+    inp['seq_lengths'] = torch.full((len(pick),), F, dtype=torch.int64)
+    want, _ = R.ief_forward(sd, bm, tables, CONST.VERTEX_IDS, inp, n_markers=12, N=2, rnn_init=True)
+    net = net.to(DEV)
+    dev_in = [torch.from_numpy(batch[k]).to(DEV) for k in keys]
+    runs = []
+    with _Option(b'smpl_tile', 2), _Option(b'rows_x3', 1):
+        for _ in range(6):
+            res = net.forward_tensors(*dev_in)
+            torch.cuda.synchronize()
+            runs.append({k: res[k].cpu().numpy().copy() for k in ('pose', 'shape', 'joints')})
+    for r in runs[1:]:
+        for k in r:
+            assert np.array_equal(r[k], runs[0][k]), k
+    pose = runs[0]['pose'][pick]
+    np.testing.assert_allclose(pose[:, :, 3:], want['pose_hat'].numpy(), atol=1e-4)
+    np.testing.assert_allclose(pose[:, :, :3], want['root_ori_hat'].numpy(), atol=1e-4)
+    np.testing.assert_allclose(runs[0]['shape'][pick], want['shape_hat'].numpy(), atol=1e-4)
+    np.testing.assert_allclose(runs[0]['joints'][pick], want['joints_hat'].numpy(), atol=1e-4)
+
+
+def test_one_launch_training_layers_beside_a_long_kernel_on_another_stream():
+    """The workgroups of a one-launch training layer (csrc/train_cols.hip) wait for each other's exchange words: all of
+    them must be resident.  Eager launches are cooperative launches (hipLaunchCooperativeKernel), so the runtime -- not an
+    occupancy argument -- guarantees it, whatever else is on the device.  Here a second stream keeps every CU busy with long
+    element-wise kernels while the paired layers of a 12-window step (384 rows, both update networks) run forward and
+    backward: the results are those of the same call alone on the device, bit for bit, and no poll gave up."""
+    from tests.test_hip_round5 import _mlp_pair, _run_mlp_train
+    lib = _lib.lib()
+    assert lib.empose_get_option(b'cols_coop') == 1 and lib.empose_get_option(b'train_cols') == 1
+    M, in_dim, hidden = 384, 296, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, in_dim, generator=g).to(DEV)
+    d_outs = [torch.zeros(M, 68, device=DEV), torch.zeros(M, 12, device=DEV)]
+    d_outs[0][:, :66] = torch.randn(M, 66, generator=g).to(DEV)
+    d_outs[1][:, :10] = torch.randn(M, 10, generator=g).to(DEV)
+    assert lib.empose_async_status() == 0
+    alone = _run_mlp_train(_mlp_pair(in_dim, hidden, 5), x, d_outs, M, pair=True)
+    side = torch.cuda.Stream()
+    big = torch.randn(1 << 28, device=DEV)          # 1 GiB: each pass over it occupies the whole chip for ~0.3 ms
+    torch.cuda.synchronize()
+    for rep in range(3):
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            for _ in range(60):
+                big.mul_(1.0000001).add_(1e-9)
+            done.record()
+        nets = _mlp_pair(in_dim, hidden, 5)
+        res = _run_mlp_train(nets, x, d_outs, M, pair=True)      # (synchronises and checks empose_async_status)
+        for a, b in zip(res['out'] + res['grads'][0] + res['grads'][1], alone['out'] + alone['grads'][0] + alone['grads'][1]):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a, b)
+        side.synchronize()
+    assert lib.empose_async_status() == 0
