@@ -247,7 +247,8 @@ def test_three_piece_bf16_update_nets_are_as_accurate_as_the_fp32_mfma_ones(scal
     assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-4 * max(1.0, out_scale)
 
 
-@pytest.mark.parametrize('B,F,In,Hd,L', [(1024, 8, 144, 512, 2), (300, 7, 72, 512, 2), (333, 5, 200, 192, 3)])
+@pytest.mark.parametrize('B,F,In,Hd,L', [(1024, 8, 144, 512, 2), (300, 7, 72, 512, 2), (333, 5, 200, 192, 3), (257, 4, 144, 64, 1),
+                                         (1000, 3, 36, 128, 4)])
 def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F, In, Hd, L):
     """lstm_x3.hip (the wavefront step of batches above 256 rows: weights and hidden states as three bf16 pieces in
     fragment order, six bf16 MFMA products per fp32 product, K split over the waves) against a float64 LSTM
@@ -270,10 +271,10 @@ def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F,
     g = layer.to(DEV)
     err = {}
     lib = _lib.lib()
-    for x3 in (0, 1):
+    for x3 in (0, 1, 2):       # 2 (the default, round 6): lstm_rows_x3.hip, row-split waves; 1: lstm_x3.hip, K-split waves
         _lib.check(lib.empose_set_option(b'lstm_x3', x3))
         worst, first = 0.0, None
-        for rep in range(2 if x3 else 1):
+        for rep in range(3 if x3 else 1):
             outs = []
             for carried in (False, True):
                 g.init_state = (h0.to(DEV), c0.to(DEV)) if carried else None
@@ -290,8 +291,10 @@ def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F,
                 for a_, b_ in zip(first, outs):
                     assert np.array_equal(a_, b_)
         err[x3] = worst
-    print('lstm %s vs float64: fp32 MFMA %.2e, three-piece bf16 %.2e' % ((B, F, In, Hd, L), err[0], err[1]))
+    print('lstm %s vs float64: fp32 MFMA %.2e, three-piece bf16 %.2e (K-split waves) %.2e (row-split waves)'
+          % ((B, F, In, Hd, L), err[0], err[1], err[2]))
     assert err[1] <= 1.5 * err[0] + 2e-7 and err[1] < 1e-5
+    assert err[2] <= 1.5 * err[0] + 2e-7 and err[2] < 1e-5
     g.release()
 
 
