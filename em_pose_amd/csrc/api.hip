@@ -683,7 +683,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
         }
         xa.units_per_block = tiles >= 192 ? xa.n_units : 1;
         prof_mark(P_LSTM_STEP, stream);
-        e = options().lstm_x3 == 1 ? launch_lstm_chain_x3(xa, stream) : launch_lstm_rows_x3(xa, stream);
+        e = options().lstm_x3 == 2 ? launch_lstm_rows_x3(xa, stream) : launch_lstm_chain_x3(xa, stream);
         if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step (bf16 pieces): %s", hipGetErrorString(e));
       }
       done = true;

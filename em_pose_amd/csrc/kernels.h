@@ -35,9 +35,10 @@ struct Options {
   int spin_limit = 0;     // polls of the cooperative LSTM kernels give up after this many spins (0: their own limits)
   int rows_x3 = 1;        // the row-block products with fused prologue / epilogue (blend GEMMs of the frame-per-lane SMPL path, init
                           // heads) on the same three-piece bf16 arithmetic; 0: the fp32 MFMA instruction
-  int lstm_x3 = 2;        // large-batch LSTM steps (inference, uni-directional): fp32 products as six bf16-MFMA products of three
-                          // bf16 pieces per operand; 2: lstm_rows_x3.hip (row-split waves, weights through LDS, cell update in
-                          // registers), 1: lstm_x3.hip (K-split waves); 0: the fp32 MFMA instruction (lstm_chain_kernel)
+  int lstm_x3 = 1;        // large-batch LSTM steps (inference, uni-directional): fp32 products as six bf16-MFMA products of three
+                          // bf16 pieces per operand; 1: lstm_x3.hip (K-split waves); 2: lstm_rows_x3.hip (row-split waves, weights
+                          // through LDS, cell update in registers -- round 6, measured 10 % SLOWER: 47.5 against 42.9 us per
+                          // launch, profiles/r06_lstm_rows_lab.txt, so opt-in); 0: the fp32 MFMA instruction (lstm_chain_kernel)
   int train_cols = 1;     // training at <= 512 rows: a layer's product + BatchNorm + PReLU as one launch, both update networks
                           // side by side (train_cols.hip); 0: a product and a BatchNorm launch per layer and network
   int cols_coop = 1;      // those one-launch layers, eager: launched with hipLaunchCooperativeKernel (all workgroups resident by
@@ -345,7 +346,7 @@ struct LstmX3Args {
 };
 hipError_t launch_lstm_chain_x3(const LstmX3Args& a, hipStream_t stream);
 // the same step with the waves splitting ROWS, the weight block of a k-step shared through LDS and the cell update in
-// registers (lstm_rows_x3.hip; option lstm_x3 = 2, the default): one unit per workgroup, `units_per_block` unused
+// registers (lstm_rows_x3.hip; option lstm_x3 = 2): one unit per workgroup, `units_per_block` unused
 hipError_t launch_lstm_rows_x3(const LstmX3Args& a, hipStream_t stream);
 hipError_t launch_lstm_split_rows(const float* src, long row_stride, long z_stride, int n_z, int B, int K, int KS,
                                   unsigned short* dst, long dst_z_stride, hipStream_t stream);

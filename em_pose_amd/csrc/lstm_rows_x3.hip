@@ -17,7 +17,7 @@
 //   * A wave holds all four gates of its (row, unit) cells in the same lane and accumulator index, so the cell update runs
 //     in registers: no exchange, no barrier; c, h and y leave as 128-byte row segments, and the new hidden state's three
 //     pieces leave in A-fragment order after a 4 KB transpose through the wave's own LDS.
-// One raw s_barrier per k-step hands the LDS stage over (lgkmcnt only: the global loads in flight stay in flight).
+// One raw s_barrier per TWO k-steps hands the LDS stage over (lgkmcnt only: the global loads in flight stay in flight).
 // One workgroup per CU by its LDS request (one wave per SIMD: scripts/dev/bf16_hazard_repro.md).
 // The two units of a launch (layer 0: K = input + H, layer 1: K = 2 H) go to different workgroups (blockIdx.z).
 #include "bf16x3.h"
@@ -31,9 +31,10 @@ constexpr int FRAG = 512;                                // bf16 elements of one
 constexpr int WBLK = 12 * FRAG;                          // elements of one k-step's weight block (4 gates x 3 pieces)
 constexpr int WBUF_BYTES = WBLK * 2;                     // 12,288
 constexpr int TP = 33;                                   // row stride of the transpose tile (floats)
-constexpr size_t LDS_BYTES = 84 * 1024;                  // > half of a CU's 160 KB: never two workgroups on a CU
+constexpr int NBUF = 8;                                   // LDS stage buffers (a k-step's weight block each)
+constexpr size_t LDS_BYTES = NBUF * WBUF_BYTES;           // 96 KB > half of a CU's 160 KB: never two workgroups on a CU
 constexpr int SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
-static_assert(2 * WBUF_BYTES <= (int)LDS_BYTES && 4 * 32 * TP * 4 <= 2 * WBUF_BYTES, "LDS layout");
+static_assert(LDS_BYTES > 80 * 1024 && 4 * 32 * TP * 4 <= 2 * WBUF_BYTES, "LDS layout");
 }  // namespace lr
 
 typedef const __attribute__((address_space(1))) u32x4_t* lr_gvec_t;
@@ -44,17 +45,31 @@ typedef const __attribute__((address_space(1))) unsigned short* lr_gptr_t;
 __device__ __forceinline__ float lr_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float lr_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+__device__ unsigned short lr_zero_frags[3 * lr::FRAG];   // zero-initialised: the A fragments of the padding k-steps
+
 __global__ __launch_bounds__(lr::NT) void lstm_rows_x3_kernel(LstmX3Args a) {
   using namespace lr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = a.H, B = a.B, F = a.F;
-  const int jb = blockIdx.x, JB = H / BU, j0 = jb * BU;
+  const int JB = H / BU;
+  int jb = blockIdx.x, rb = blockIdx.y, uz = blockIdx.z;
+#ifndef LR_LAB_NOXCD
+  // Workgroups go to the 8 XCDs round-robin by their linear index.  When the grid is 16 unit blocks x 8 row blocks (the
+  // headline shape) the 32 workgroups of an XCD are remapped to 4 unit blocks x 4 row blocks x both units: its L2 then
+  // streams 5.2 + 5.2 MB of weights and A planes per launch instead of 2.6 + 10.3 MB.
+  if (JB == 16 && gridDim.y == 8) {
+    const int lin = blockIdx.x + 16 * (blockIdx.y + 8 * blockIdx.z);
+    const int xcd = lin & 7, s = lin >> 3;
+    if ((int)gridDim.z == 2) { jb = 4 * (xcd & 3) + (s & 3); rb = 4 * (xcd >> 2) + ((s >> 2) & 3); uz = s >> 4; }
+  }
+#endif
+  const int j0 = jb * BU;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const LstmX3Unit& U = a.unit[blockIdx.z];
+  const LstmX3Unit& U = a.unit[uz];
   const int RT = (B + 31) / 32;
-  const int rt_own = blockIdx.y * 4 + wave;
+  const int rt_own = rb * 4 + wave;
   const bool tile_live = rt_own < RT;                 // (a row tile past the batch: fetches the last one, stores nothing)
   const int rt = tile_live ? rt_own : RT - 1;
   const int KS_h = H / 16, KS_in = U.ks_in, KS = KS_in + KS_h;
@@ -101,21 +116,23 @@ __global__ __launch_bounds__(lr::NT) void lstm_rows_x3_kernel(LstmX3Args a) {
     // The K loop runs whole groups of six steps (its register sets rotate with periods 3, 3 and 2; exits in mid-group cost
     // the compiler 170 spilled registers): the steps past the unit's last one multiply ZERO A fragments -- at most five
     // k-steps of 41 / 64 added, 1.6 / 3 % -- against the last step's weights again.
-    // (the zeroing happens where the fragments are USED -- `step` -- so that no wait for the load is needed here)
-    g = g < KS ? g : KS - 1;
+    // (they are FETCHED as zeros, from lr_zero_frags: masking loaded values made the compiler wait for the load a step early)
+    const bool dead = g >= KS;
+    g = dead ? KS - 1 : g;
     const bool in = g < KS_in;
     const int ks = in ? g : g - KS_in, ksn = in ? KS_in : KS_h;
-    lr_gptr_t ab = (lr_gptr_t)(in ? p_in : p_rec) + (((size_t)rt * ksn + ks) * 3) * FRAG + lane * 8;
+    lr_gptr_t ab = dead ? (lr_gptr_t)lr_zero_frags + lane * 8
+                        : (lr_gptr_t)(in ? p_in : p_rec) + (((size_t)rt * ksn + ks) * 3) * FRAG + lane * 8;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) A[pc] = *(lr_gvec_t)(ab + pc * FRAG);
   };
   auto lds_write = [&](const u32x4_t (&S)[3], int g) {
-    unsigned char* b = smem + (g & 1) * WBUF_BYTES + tid * 16;
+    unsigned char* b = smem + (g & (NBUF - 1)) * WBUF_BYTES + tid * 16;
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4_t*>(b + p * (NT * 16)) = S[p];
   };
   auto lds_read = [&](u32x4_t (&W)[12], int g) {
-    const unsigned char* b = smem + (g & 1) * WBUF_BYTES + lane * 16;
+    const unsigned char* b = smem + (g & (NBUF - 1)) * WBUF_BYTES + lane * 16;
 #pragma unroll
     for (int f = 0; f < 12; ++f) W[f] = *reinterpret_cast<const u32x4_t*>(b + f * 1024);
   };
@@ -128,24 +145,26 @@ __global__ __launch_bounds__(lr::NT) void lstm_rows_x3_kernel(LstmX3Args a) {
                                                          __builtin_bit_cast(bf16x8_t, W[q * 3 + X3_PB[p]]), acc[q], 0, 0, 0);
   };
   auto handover = [&]() {
+#ifndef LR_LAB_NOBARRIER   // (scripts/dev/lstm_rows_lab.sh: timing ablations, results are then wrong)
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): this wave's LDS writes and reads of the stage are done
     __builtin_amdgcn_s_barrier();
+#endif
   };
   // One k-step i: the products of step i (operands in registers) with, spread between them, the global loads of the weight
-  // pieces of step i + 4 and the A fragments of step i + 2, the LDS write of the pieces of step i + 2 (loaded two steps ago)
-  // and the LDS reads of the fragments of step i + 1 (written one step ago).
-  auto step = [&](int i, u32x4_t (&S_new)[3], const u32x4_t (&S_ready)[3], u32x4_t (&A_new)[3], const u32x4_t (&A_cur)[3],
-                  u32x4_t (&W_next)[12], const u32x4_t (&W_cur)[12]) {
-    gload_w(S_new, i + 4);
+  // pieces of step i + 6 and the A fragments of step i + 2, the LDS write of the pieces of step i + 4 (loaded two steps ago)
+  // and the LDS reads of the fragments of step i + 1.  The stage is handed over every SECOND step: a block is written at
+  // step k - 4 and read at step k - 1 (a hand-over lies between), its buffer is rewritten at step k + 4 (eight buffers).
+  auto step = [&](int i, bool sync, u32x4_t (&S_new)[3], const u32x4_t (&S_ready)[3], u32x4_t (&A_new)[3],
+                  const u32x4_t (&A_cur)[3], u32x4_t (&W_next)[12], const u32x4_t (&W_cur)[12]) {
+#ifndef LR_LAB_NOGLOAD
+    gload_w(S_new, i + 6);
     gload_a(A_new, i + 2);
-    lds_write(S_ready, i + 2);
+#endif
+#ifndef LR_LAB_NOLDS
+    lds_write(S_ready, i + 4);
     lds_read(W_next, i + 1);
-    const unsigned keep = i < KS ? 0xffffffffu : 0u;
-    u32x4_t A_use[3];
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-      A_use[pc] = u32x4_t{A_cur[pc][0] & keep, A_cur[pc][1] & keep, A_cur[pc][2] & keep, A_cur[pc][3] & keep};
-    mma(A_use, W_cur);
+#endif
+    mma(A_cur, W_cur);
 #pragma unroll
     for (int q = 0; q < 24; ++q) {
       LR_SGB(SG_MFMA, 1);
@@ -153,32 +172,42 @@ __global__ __launch_bounds__(lr::NT) void lstm_rows_x3_kernel(LstmX3Args a) {
       else if (q < 9) LR_SGB(SG_DS_WR, 1);
       else if (q < 21) LR_SGB(SG_DS_RD, 1);
     }
-    handover();
+    if (sync) handover();
   };
 
-  // ---- prologue: steps 0 and 1 in LDS, 2 and 3 in flight, the fragments of step 0 in registers
+  // ---- prologue: steps 0 .. 3 in LDS, 4 and 5 in flight, the fragments of step 0 in registers
   gload_w(sreg[0], 0);
   gload_w(sreg[1], 1);
+  gload_w(sreg[2], 2);
   gload_a(areg[0], 0);
   gload_a(areg[1], 1);
-  gload_w(sreg[2], 2);
   lds_write(sreg[0], 0);
   lds_write(sreg[1], 1);
+  lds_write(sreg[2], 2);
   gload_w(sreg[0], 3);
+  lds_write(sreg[0], 3);
+  gload_w(sreg[1], 4);
+  gload_w(sreg[2], 5);
   handover();
   lds_read(wreg[0], 0);
-  handover();
 
+#if defined(LR_LAB_KS)      // (lab: a fixed number of k-steps: what a launch costs besides its K loop)
+  const int KS_loop = LR_LAB_KS;
+#elif defined(LR_LAB_BALANCED)   // (lab: every workgroup runs the mean of the two units' k-steps: the floor a balanced split would have)
+  const int KS_loop = 54;
+#else
+  const int KS_loop = KS;
+#endif
   // (sets rotate with periods 3, 3 and 2: six steps per trip)
-  for (int i = 0; i < KS; i += 6) {
-    step(i, sreg[1], sreg[2], areg[2], areg[0], wreg[1], wreg[0]);
-    step(i + 1, sreg[2], sreg[0], areg[0], areg[1], wreg[0], wreg[1]);
-    step(i + 2, sreg[0], sreg[1], areg[1], areg[2], wreg[1], wreg[0]);
-    step(i + 3, sreg[1], sreg[2], areg[2], areg[0], wreg[0], wreg[1]);
-    step(i + 4, sreg[2], sreg[0], areg[0], areg[1], wreg[1], wreg[0]);
-    step(i + 5, sreg[0], sreg[1], areg[1], areg[2], wreg[0], wreg[1]);
+  for (int i = 0; i < KS_loop; i += 6) {
+    step(i, false, sreg[0], sreg[1], areg[2], areg[0], wreg[1], wreg[0]);
+    step(i + 1, true, sreg[1], sreg[2], areg[0], areg[1], wreg[0], wreg[1]);
+    step(i + 2, false, sreg[2], sreg[0], areg[1], areg[2], wreg[1], wreg[0]);
+    step(i + 3, true, sreg[0], sreg[1], areg[2], areg[0], wreg[0], wreg[1]);
+    step(i + 4, false, sreg[1], sreg[2], areg[0], areg[1], wreg[1], wreg[0]);
+    step(i + 5, true, sreg[2], sreg[0], areg[1], areg[2], wreg[0], wreg[1]);
   }
-  // (every step ends in a hand-over: no wave still reads or writes the stage buffers, which now hold the transpose tiles)
+  // (every trip ends in a hand-over: no wave still reads or writes the stage buffers, which now hold the transpose tiles)
 
   // ---- the cell update, in registers: lane = (unit, 16 rows), accumulator q = gate q (PyTorch's order i, f, g, o)
   float hv[16];

@@ -13,6 +13,8 @@ net.vertex_ids = synthetic.small_vertex_ids(160)
 h = net._ensure_handle(dev); lib = _lib.lib()
 if len(sys.argv) > 1:
     _lib.check(lib.empose_set_option(b'lstm_seq', int(sys.argv[1])))
+if os.environ.get('EMPOSE_LSTM_X3'):
+    _lib.check(lib.empose_set_option(b'lstm_x3', int(os.environ['EMPOSE_LSTM_X3'])))
 B, F = 1024, 32
 x = torch.randn(B, F, 144, device=dev); y = torch.empty(B, F, 512, device=dev)
 nb = lib.empose_lstm_workspace_bytes(h, B, F); ws = torch.empty(nb, dtype=torch.uint8, device=dev)

@@ -271,7 +271,7 @@ def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F,
     g = layer.to(DEV)
     err = {}
     lib = _lib.lib()
-    for x3 in (0, 1, 2):       # 2 (the default, round 6): lstm_rows_x3.hip, row-split waves; 1: lstm_x3.hip, K-split waves
+    for x3 in (0, 1, 2):       # 1 (the default): lstm_x3.hip, K-split waves; 2 (round 6, opt-in): lstm_rows_x3.hip, row-split waves
         _lib.check(lib.empose_set_option(b'lstm_x3', x3))
         worst, first = 0.0, None
         for rep in range(3 if x3 else 1):
