@@ -145,6 +145,7 @@ struct empose_mesh {
   float* skin_w4 = nullptr;
   int* parents = nullptr;
   unsigned short* wc_bf16 = nullptr;   // split-bf16 pieces of wc in fragment order (only when the handle asked for them)
+  unsigned short* wc_x3 = nullptr;     // three bf16 pieces of wc in fragment order (mesh_x3.hip), kb <= 4
   unsigned short* skin_bf16 = nullptr; // dense skin weights per 32-vertex tile, bf16 hi + lo, B-fragment order (ditto)
 };
 
@@ -980,6 +981,7 @@ int empose_set_option(const char* name, int value) {
       {"rows_x3", &o.rows_x3},
       {"train_cols", &o.train_cols},
       {"cols_coop", &o.cols_coop},
+      {"mesh_x3", &o.mesh_x3},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
@@ -1016,6 +1018,7 @@ int empose_get_option(const char* name) {
       {"rows_x3", o.rows_x3},
       {"train_cols", o.train_cols},
       {"cols_coop", o.cols_coop},
+      {"mesh_x3", o.mesh_x3},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
@@ -2730,6 +2733,36 @@ static float host_bf16_f32(unsigned short h) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+// Tables of mesh_rows_x3_kernel (mesh_x3.hip): per 32-vertex tile, k-step of 16, coordinate plane c and piece p one
+// fragment of 1 KB -- lane (v = lane & 31, half = lane >> 5) owns the eight values k = kstep * 16 + half * 8 .. + 7 of
+// row (tile * 32 + v) * 3 + c, as piece p of their three-piece bf16 split (bf16x3.h); k >= 200 and vertices past V are zero.
+static int pack_mesh_tiles_x3(empose_mesh* m, const empose_mesh_desc* d) {
+  const int V = d->n_vertices, NT = (V + 31) / 32, K = 200, KS = 13;
+  const size_t tile_shorts = MESH_X3_TILE_BYTES / 2;
+  std::vector<unsigned short> buf((size_t)NT * tile_shorts, 0);
+  for (int t = 0; t < NT; ++t)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int v = t * 32 + (lane & 31), half = lane >> 5;
+      if (v >= V) continue;
+      for (int c = 0; c < 3; ++c) {
+        const float* row = d->wc + ((size_t)v * 3 + c) * K;
+        for (int ks = 0; ks < KS; ++ks)
+          for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + half * 8 + e;
+            if (k >= K) continue;
+            const float x = row[k];
+            const unsigned short p0 = host_bf16_rne(x);
+            const float r1 = x - host_bf16_f32(p0);
+            const unsigned short p1 = host_bf16_rne(r1);
+            const unsigned short p2 = host_bf16_rne(r1 - host_bf16_f32(p1));
+            unsigned short* dst = &buf[(size_t)t * tile_shorts + ((size_t)((ks * 3 + c) * 3) * 64 + lane) * 8 + e];
+            dst[0] = p0; dst[64 * 8] = p1; dst[2 * 64 * 8] = p2;
+          }
+      }
+    }
+  return upload(m->allocs, buf.data(), buf.size(), &m->wc_x3);
+}
+
 static int pack_mesh_tiles_bf16(empose_mesh* m, const empose_mesh_desc* d) {
   const int V = d->n_vertices, NT = (V + 31) / 32, K = 200, KS = 14;
   const size_t tile_shorts = MESH_BF16_TILE_BYTES / 2;
@@ -2810,6 +2843,7 @@ int empose_mesh_create(const empose_mesh_desc* d, empose_mesh_t** out) {
       (rc = upload(m->allocs, d->skin_idx, (size_t)d->n_vertices * d->kb, &m->skin_idx)) ||
       (rc = upload(m->allocs, d->skin_w, (size_t)d->n_vertices * d->kb, &m->skin_w)) ||
       (rc = upload(m->allocs, d->parents, (size_t)nj, &m->parents)) || (rc = pack_mesh_tiles(m, d)) ||
+      (d->kb <= 4 && (rc = pack_mesh_tiles_x3(m, d))) ||
       (d->with_bf16x3 && (rc = pack_mesh_tiles_bf16(m, d)))) {
     empose_mesh_destroy(m);
     return rc;
@@ -2875,10 +2909,16 @@ static int run_mesh(const empose_mesh_t* mesh, int T, const float* poses, const 
     sa.feat = w.feat; sa.wc = mesh->wc; sa.xf = w.xf; sa.skin_idx = mesh->skin_idx; sa.skin_w = mesh->skin_w;
     sa.kb = mesh->kb; sa.trans = tr; sa.vertices = vertices + (size_t)t0 * mesh->V * 3; sa.T = n; sa.V = mesh->V;
     sa.wc_frag = mesh->wc_frag; sa.skin_idx4 = mesh->skin_idx4; sa.skin_w4 = mesh->skin_w4;
-    sa.wc_bf16 = mesh->wc_bf16; sa.skin_bf16 = mesh->skin_bf16;
-    e = !bf16x3 ? launch_mesh_rows(sa, stream)
-                : (options().mesh_skin_mfma && mesh->skin_bf16 ? launch_mesh_rows_bf16s(sa, stream)
-                                                              : launch_mesh_rows_bf16(sa, stream));
+    sa.wc_bf16 = mesh->wc_bf16; sa.skin_bf16 = mesh->skin_bf16; sa.wc_x3 = mesh->wc_x3;
+    // default: the three-piece bf16 contraction (fp32-equivalent); `bf16x3`: the explicitly selected two-piece variant
+    if (bf16x3)
+      e = options().mesh_skin_mfma && mesh->skin_bf16 ? launch_mesh_rows_bf16s(sa, stream) : launch_mesh_rows_bf16(sa, stream);
+    else if (options().mesh_x3 != 0 && mesh->wc_x3 && mesh->kb <= 4) {
+      sa.stagger = options().mesh_x3 == 1;
+      e = launch_mesh_rows_x3(sa, options().mesh_x3 == 3, stream);
+    }
+    else
+      e = launch_mesh_rows(sa, stream);
     if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused mesh kernel: %s", hipGetErrorString(e));
   }
   return EMPOSE_OK;

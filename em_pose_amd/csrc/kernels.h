@@ -43,6 +43,10 @@ struct Options {
                           // side by side (train_cols.hip); 0: a product and a BatchNorm launch per layer and network
   int cols_coop = 1;      // those one-launch layers, eager: launched with hipLaunchCooperativeKernel (all workgroups resident by
                           // the runtime's guarantee); 0: the ordinary launch (residency argued from the occupancy query)
+  int mesh_x3 = 1;        // full-mesh vertices: blend shapes as six bf16-MFMA products of three bf16 pieces per operand
+                          // (mesh_x3.hip): 1 stores staggered into the next tile's products, 2 stores at the end of the tile,
+                          // 3 skinning software-pipelined under the next tile's products; 0: the fp32 MFMA instruction
+                          // (mesh_rows_kernel)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
                           // instead of the whole-sequence kernel / lstm_small_kernel (0: those; they share their bits)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
@@ -676,6 +680,8 @@ struct MeshSkinArgs {
   const int* skin_idx4; const float* skin_w4;   // [tiles * 32][4]
   const void* wc_bf16 = nullptr;   // bf16 pieces of wc in fragment order per tile (api.hip pack_mesh_tiles_bf16), or nullptr
   const void* skin_bf16 = nullptr; // dense skin weights per 32-vertex tile as bf16 pieces in fragment order (pack_mesh_skin_bf16)
+  const void* wc_x3 = nullptr;     // THREE bf16 pieces of wc in fragment order per tile (api.hip pack_mesh_tiles_x3)
+  int stagger = 1;                 // mesh_rows_x3_kernel: a tile's stores ride in the next tile's K loop, at a per-wave k-step
 };
 hipError_t launch_mesh_rows(const MeshSkinArgs& a, hipStream_t stream);
 // The same evaluation with the blend-shape contraction in split bf16 (mesh.hip); needs MeshSkinArgs::wc_bf16.
@@ -684,6 +690,13 @@ constexpr int MESH_BF16_TILE_BYTES = 14 * 3 * 2 * 1024;
 // ... and with the bone blend as a second contraction on the matrix cores (needs MeshSkinArgs::skin_bf16 too).
 hipError_t launch_mesh_rows_bf16s(const MeshSkinArgs& a, hipStream_t stream);
 constexpr int MESH_SKIN_BF16_TILE_BYTES = 2 * 2 * 1024;
+// The blend-shape contraction on three bf16 pieces per operand -- fp32-equivalent, the default arithmetic of the full-mesh
+// evaluation since round 6 (mesh_x3.hip; option mesh_x3: 1 = products, skinning, stores one after the other with the stores
+// staggered into the next tile's K loop, 2 = the same with the stores at the end of their tile, 3 = the skinning
+// software-pipelined under the next tile's K loop (measured no faster), 0 = the fp32 MFMA kernel).  Four bones per vertex
+// (kb <= 4); needs MeshSkinArgs::wc_x3.
+hipError_t launch_mesh_rows_x3(const MeshSkinArgs& a, bool overlap, hipStream_t stream);
+constexpr int MESH_X3_TILE_BYTES = 13 * 9 * 1024;
 
 struct VirtualSensorArgs {
   const float* vertices;   // [T][V][3]

@@ -124,3 +124,68 @@ def test_one_launch_training_layers_beside_a_long_kernel_on_another_stream():
             assert torch.equal(a, b)
         side.synchronize()
     assert lib.empose_async_status() == 0
+
+
+@pytest.mark.parametrize('n', [200, 4096 + 17, 16384])
+def test_full_mesh_three_piece_bf16_is_as_accurate_as_the_fp32_mfma_kernel(big_model, n):
+    """mesh_x3.hip (round 6, the default full-mesh path): the blend-shape contraction of all 200 columns as six bf16 MFMA
+    products of three bf16 pieces per operand, fp32 accumulate.  Claim: fp32-EQUIVALENT -- against a float64 evaluation of
+    the same body model (V = 6890: 215 whole vertex tiles + one of 10 vertices; frame counts off the 64-frame block) its
+    error is no larger than that of the kernel on the fp32 MFMA instruction (option mesh_x3 = 0) -- with a tile's stores
+    staggered into the next tile's K loop (1, the default), at the end of their tile (2), and with the skinning
+    software-pipelined under the next tile's products (3): the three agree bit for bit; repeated launches are bit-identical
+    (one wave per SIMD, and no store while the wave has MFMAs in flight); joints do not depend on the option."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(n)
+    pose = rng.normal(0, 0.5, size=(n, 63)).astype(np.float32)
+    root = rng.normal(0, 0.5, size=(n, 3)).astype(np.float32)
+    betas = rng.normal(0, 1.5, size=(n, 10)).astype(np.float32)
+    trans = rng.normal(0, 1, size=(n, 3)).astype(np.float32)
+    bm64 = R.BodyModelTensors(big_model, dtype=torch.float64)
+    pick = np.unique(np.concatenate([np.arange(0, n, max(1, n // 96)), [n - 1, n - 2, 63, 64, 65]]))
+    pick = pick[pick < n]
+    v64, j64 = R.smpl_fk(bm64, torch.from_numpy(pose[pick]).double(), torch.from_numpy(betas[pick]).double(),
+                         torch.from_numpy(root[pick]).double(), torch.from_numpy(trans[pick]).double())
+    smpl = SMPLLayer(big_model).to(DEV)
+    kw = dict(poses_body=torch.from_numpy(pose).to(DEV), betas=torch.from_numpy(betas).to(DEV),
+              poses_root=torch.from_numpy(root).to(DEV), trans=torch.from_numpy(trans).to(DEV))
+    err, out = {}, {}
+    for opt in (0, 1, 2, 3):
+        with _Option(b'mesh_x3', opt):
+            v, j = smpl(**kw)
+            torch.cuda.synchronize()
+            for _ in range(3 if opt else 1):
+                v2, _ = smpl(**kw)
+                assert torch.equal(v, v2)
+        out[opt] = (v.cpu(), j.cpu())
+        err[opt] = float((out[opt][0][pick].double() - v64).abs().max())
+    print('full mesh, %d frames vs float64: fp32 MFMA %.2e, three-piece bf16 %.2e (staggered stores) %.2e (stores at the end '
+          'of the tile) %.2e (skinning under the products)' % (n, err[0], err[1], err[2], err[3]))
+    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][0], out[3][0])
+    assert all(torch.equal(out[0][1], out[o][1]) for o in (1, 2, 3))
+    assert err[1] <= 1.5 * err[0] + 1e-7 and err[1] < 2e-5
+    assert float((out[1][0] - out[0][0]).abs().max()) < 1e-5
+
+
+def test_full_mesh_three_piece_bf16_on_a_small_mesh_and_few_frames():
+    """The same kernel where the grid splits the mesh's tiles over workgroups (few frames), on the 160-vertex model, with
+    and without a translation, against the oracle (2e-5, the bar of test_full_mesh_vertices_vs_oracle)."""
+    from tests import helpers as H
+    model = H.small_model()
+    bm = R.BodyModelTensors(model)
+    smpl = SMPLLayer(model).to(DEV)
+    rng = np.random.default_rng(4)
+    for n, with_trans in ((1, True), (3, False), (65, True), (700, False)):
+        pose = rng.normal(0, 0.4, size=(n, 63)).astype(np.float32)
+        root = rng.normal(0, 0.5, size=(n, 3)).astype(np.float32)
+        betas = rng.normal(0, 1, size=(n, 10)).astype(np.float32)
+        trans = rng.normal(0, 1, size=(n, 3)).astype(np.float32) if with_trans else None
+        v_ref, j_ref = R.smpl_fk(bm, torch.from_numpy(pose), torch.from_numpy(betas), torch.from_numpy(root),
+                                 torch.from_numpy(trans) if with_trans else None)
+        for opt in (1, 2, 3):
+            with _Option(b'mesh_x3', opt):
+                v, j = smpl(poses_body=torch.from_numpy(pose).to(DEV), betas=torch.from_numpy(betas).to(DEV),
+                            poses_root=torch.from_numpy(root).to(DEV),
+                            trans=torch.from_numpy(trans).to(DEV) if with_trans else None)
+            np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
+            np.testing.assert_allclose(j.cpu().numpy(), j_ref.numpy(), atol=2e-5)
