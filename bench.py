@@ -88,6 +88,24 @@ def flops_per_frame(net):
     return fl
 
 
+def arithmetic_label(x3_options, mlp_x3_on, rnn):
+    """Which products of the headline ran as three-piece bf16 (fp32-equivalent) and which on the fp32 MFMA instruction,
+    from the library's options at the time of the timed region."""
+    on, off = [], []
+    (on if mlp_x3_on else off).append('update MLPs (mlp_fused%s.hip)' % ('_x3' if mlp_x3_on else ''))
+    if rnn:
+        (on if x3_options[b'lstm_x3'] else off).append('LSTM steps (lstm%s.hip)' % ('_x3' if x3_options[b'lstm_x3'] else ''))
+    (on if x3_options[b'rows_x3'] else off).append('init heads and SMPL blend GEMMs (rows kernels of mlp_fused.hip)')
+    txt = 'fp32 operands and fp32 accumulation'
+    if on:
+        txt += ('; every fp32 product of the %s is formed from three bf16 pieces per operand (8+8+8 mantissa bits) as six bf16 '
+                'matrix-core products: fp32-equivalent, error against float64 measured equal to the fp32 MFMA '
+                'instruction\'s (tests/test_hip_round5.py)' % ', the '.join(on))
+    if off:
+        txt += '; %s on the fp32 MFMA instruction' % ', '.join(off)
+    return txt
+
+
 def baseline_config_label(net, n_markers, F, B):
     """Which entry of BASELINE.json `configs` the command-line shape is (the headline is configs[2])."""
     if n_markers == 12 and net.N == 4 and F == 32:
@@ -187,7 +205,7 @@ def pmc_traffic_live(argv_tail, kernel_name, timeout_s=240):
         try:
             cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'pmc', '--',
                    sys.executable, os.path.abspath(__file__)] + argv_tail + \
-                  ['--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--no_profile']
+                  ['--steps', '2', '--warmup', '1', '--no_cpu_baseline', '--no_profile', '--no_secondary']
             r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=timeout_s)
             vals = []
@@ -235,58 +253,190 @@ def pmc_traffic(T, hidden, kernel_name):
     return hit[0]['hbm_bytes_per_launch_corrected'], 'profiles/' + os.path.basename(files[-1])
 
 
-def run_vertices(args, dev):
-    """Secondary workload (SURVEY.md 8d): stand-alone full-mesh SMPL-H evaluation `smpl_vertices_fwd`
-    (SMPLLayer.forward -> empose_mesh_vertices_fwd), the only piece of the path whose algorithmic traffic is large:
-    83 842 B/frame (82 680 B of vertices written)."""
-    from em_pose_amd import synthetic
-    from em_pose_amd.bodymodels.smpl import SMPLLayer
-    smpl = SMPLLayer(synthetic.make_model(), arithmetic=args.arith).to(dev)
-    T = args.batch * args.frames
+def vertices_numbers(smpl, dev, T, steps, warmup):
+    """Stand-alone full-mesh SMPL-H evaluation `smpl_vertices_fwd` (SMPLLayer.forward -> empose_mesh_vertices_fwd) on T
+    frames: wall-clock frames/s, device ms per call, and the two roofline fractions on SURVEY.md 8(d)'s per-frame figures."""
     g = torch.Generator().manual_seed(3)
     pose = (torch.randn(T, 63, generator=g) * 0.3).to(dev)
     root = (torch.randn(T, 3, generator=g) * 0.3).to(dev)
     betas = torch.randn(T, 10, generator=g).to(dev)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         v, j = smpl(poses_body=pose, betas=betas, poses_root=root)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
+    for _ in range(steps):
         v, j = smpl(poses_body=pose, betas=betas, poses_root=root)
     e1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / args.steps
+    dev_ms = e0.elapsed_time(e1) / steps
     V = smpl.n_vertices
     bytes_frame = 66 * 4 + 10 * 4 + V * 3 * 4 + 66 * 4
     flops_frame = 2.0 * 200 * (V * 3 + 66) + V * 3 * (4 * 8 + 8)
-    fps = T * args.steps / wall
-    hbm = bytes_frame * T / (dev_ms * 1e-3) / 1e9
-    tfl = flops_frame * T / (dev_ms * 1e-3) / 1e12
-    split = args.arith == 'bf16x3'
-    # In the split-bf16 variant the algorithmic flops are unchanged (what the reference computes); the matrix cores
-    # execute 3x (pose) / 6x (shape) as many bf16 MACs, priced against the fp32 peak they would no longer be the bound.
-    bound = 'mfma' if (not split and tfl / PEAK_FP32_MFMA_TFLOPS > hbm / PEAK_HBM_GBS) else 'hbm'
+    return {'fps': T * steps / wall, 'wall_ms': 1000.0 * wall / steps, 'dev_ms': dev_ms, 'V': V,
+            'bytes_frame': bytes_frame, 'flops_frame': flops_frame,
+            'hbm': bytes_frame * T / (dev_ms * 1e-3) / 1e9, 'tfl': flops_frame * T / (dev_ms * 1e-3) / 1e12,
+            'tfl_contraction': 2.0 * 200 * (V * 3 + 66) * T / (dev_ms * 1e-3) / 1e12}
+
+
+def vertices_arithmetic(arith):
+    """(label, kernel name, True when the contraction runs as bf16 piece products) of the full-mesh path now selected."""
+    from em_pose_amd import _lib
+    if arith == 'bf16x3':
+        return ('two-piece split bf16 on the pose columns (3 products), three pieces on the shape columns: NOT fp32-equivalent, '
+                'explicitly selected', 'mesh_rows_bf16_kernel', True)
+    opt = _lib.lib().empose_get_option(b'mesh_x3')
+    if opt != 0:
+        return ('fp32 operands and fp32 accumulation; every fp32 product of the blend-shape contraction is formed from three '
+                'bf16 pieces per operand as six bf16 matrix-core products (mesh_x3.hip): fp32-equivalent, error against float64 '
+                'measured equal to the fp32 MFMA kernel\'s (tests/test_hip_round6.py); chain and skinning fp32 vector '
+                'arithmetic', 'mesh_rows_x3_kernel', True)
+    return 'fp32 MFMA instruction (mesh_rows_kernel), fp32 vector skinning', 'mesh_rows_kernel', False
+
+
+def run_vertices(args, dev):
+    """Secondary workload (SURVEY.md 8d): stand-alone full-mesh SMPL-H evaluation `smpl_vertices_fwd`
+    (SMPLLayer.forward -> empose_mesh_vertices_fwd), the only piece of the path whose algorithmic traffic is large:
+    83 842 B/frame (82 680 B of vertices written).  Its roofline is the HBM one (north_star: >= 40 % asked for THIS kernel)."""
+    from em_pose_amd import synthetic
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    smpl = SMPLLayer(synthetic.make_model(), arithmetic=args.arith).to(dev)
+    T = args.batch * args.frames
+    n = vertices_numbers(smpl, dev, T, args.steps, args.warmup)
+    label, kname, pieces = vertices_arithmetic(args.arith)
+    traffic, traffic_src = None, 'skipped (--no_traffic)'
+    if not args.no_traffic:
+        tail = ['--workload', 'vertices', '--arith', args.arith, '--batch', str(args.batch), '--frames', str(args.frames),
+                '--no_traffic'] + [a for kv in args.option for a in ('--option', kv)]
+        traffic, traffic_src = pmc_traffic_live(tail, kname)
     print(json.dumps({
-        'metric': 'frames/sec SMPL-H full-mesh vertices (smpl_vertices_fwd%s)' % (', split-bf16 variant' if split else ''),
-        'value': fps, 'unit': 'frames/sec',
-        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * wall / args.steps,
+        'metric': 'frames/sec SMPL-H full-mesh vertices (smpl_vertices_fwd%s)' % (', two-piece split-bf16 variant'
+                                                                                 if args.arith == 'bf16x3' else ''),
+        'value': n['fps'], 'unit': 'frames/sec',
+        'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': n['wall_ms'],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16x3 (fp32 operands split into bf16 pieces, fp32 accumulate; chain + skinning f32)' if split else 'f32',
-        'data': 'synthetic',
+        'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'SMPLLayer.forward: %d frames per step, V=%d vertices + 52 joints, synthetic SMPL-H-shaped '
-                               'model' % (T, V), 'frames_per_step': T, 'arithmetic': args.arith},
-        'roofline': {'bound': bound, 'achieved': tfl if bound == 'mfma' else hbm,
-                     'peak': PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS,
-                     'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
-                     'frac': tfl / PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else hbm / PEAK_HBM_GBS, 'traffic': None,
-                     'kernel': 'update_feat + rest-joint gemm + mesh_chain + %s (device time of the call)'
-                               % ('mesh_rows_bf16_kernel' if split else 'mesh_rows_kernel'),
-                     'device_ms_per_step': dev_ms, 'hbm_GBs_on_algorithmic_bytes': hbm,
-                     'hbm_frac': hbm / PEAK_HBM_GBS, 'fp32_mfma_TFLOPs': tfl, 'mfma_frac': tfl / PEAK_FP32_MFMA_TFLOPS,
-                     'algorithmic_bytes_per_frame': bytes_frame, 'flops_per_frame': flops_frame}}))
+                               'model' % (T, n['V']), 'frames_per_step': T, 'arithmetic': label},
+        'roofline': {'bound': 'hbm', 'achieved': n['hbm'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                     'frac': n['hbm'] / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                     'traffic_raw_counters': getattr(pmc_traffic_live, 'raw', None) if traffic is not None else None,
+                     'kernel': 'update_feat + rest-joint gemm + mesh_chain + %s (device time of the call; the last one is '
+                               '> 95 %% of it)' % kname,
+                     'device_ms_per_step': n['dev_ms'], 'hbm_GBs_on_algorithmic_bytes': n['hbm'],
+                     'hbm_frac': n['hbm'] / PEAK_HBM_GBS, 'algorithmic_TFLOPs': n['tfl'],
+                     'executed_bf16_matrix_TFLOPs': n['tfl_contraction'] * X3_PRODUCTS if pieces and args.arith != 'bf16x3' else None,
+                     'mfma_frac_of_its_roof': (n['tfl_contraction'] * X3_PRODUCTS / PEAK_BF16_MFMA_TFLOPS)
+                     if pieces and args.arith != 'bf16x3' else n['tfl_contraction'] / PEAK_FP32_MFMA_TFLOPS,
+                     'algorithmic_bytes_per_frame': n['bytes_frame'], 'flops_per_frame': n['flops_frame'],
+                     'what_binds': 'not HBM: the six bf16 products of the blend shapes (0.5 ms of 1.06 at 16384 frames), the '
+                                   'LDS-bound gather of four bone transforms per vertex and frame (0.35 ms) and the '
+                                   'staggered stores; profiles/r06_mesh_x3_lab.txt'}}))
+
+
+def _json_tail(cmd, timeout_s):
+    """Last stdout line of a child command as JSON, or {'error': ...}."""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip().startswith('{')]
+        return json.loads(lines[-1]) if lines else {'error': 'no JSON line (exit code %d)' % r.returncode}
+    except Exception as e:    # noqa: BLE001 (a secondary number must never take the headline down)
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
+def secondary_workloads(args, dev, model):
+    """The other BASELINE configs and the full-mesh workload, measured after the headline on the same GPU, so that they are
+    visible to whoever reads the ONE result line.  Never `value`; each entry says what it ran.
+      configs[1]: LGD-12 without the RNN, N = 4, 256 windows, in this process (frames/s + dominant-kernel fraction)
+      vertices:   smpl_vertices_fwd at 16384 frames, in this process (frames/s + HBM fraction on 83 842 B/frame)
+      configs[3]: scripts/evaluate_real.py --synthetic (36 sequences with the README's lengths, 54 030 frames, LGD-RNN-6
+                  N = 2, 256-frame chunks with carried state), batched and sequential drivers, child processes
+      configs[4]: scripts/train.py synthetic step (LGD-RNN-12, N = 4, forward + backward + Adam) at 12 and 256 windows of
+                  32 frames, child processes; training roofline = 3 x the forward's dense flops / step time / fp32 MFMA peak"""
+    from em_pose_amd import _lib
+    from em_pose_amd.bodymodels.smpl import SMPLLayer
+    lib = _lib.lib()
+    sec = {}
+    t_all = time.perf_counter()
+    # ---- configs[1]
+    try:
+        net, _ = build_net(12, False, 4)
+        net = net.to(dev)
+        B, F = 256, 32
+        _, inputs = make_inputs(net, dev, B, F, seed=2000)
+        for _ in range(3):
+            net.forward_tensors(*inputs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            out = net.forward_tensors(*inputs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(out['pose']).all()
+        entry = {'workload': 'BASELINE configs[1]: LGD (no RNN) 12-sensor, N=4, 2x512 MLP, batch 256 windows x 32 frames',
+                 'frames_per_sec': B * F * 20 / dt, 'ms_per_step': 1000.0 * dt / 20}
+        _lib.check(lib.empose_profile_enable_only(b'mlp_fused'))
+        for _ in range(10):
+            net.forward_tensors(*inputs)
+        solo = _lib.profile_read()
+        lib.empose_profile_enable(0)
+        if 'mlp_fused' in solo:
+            avg_ms = solo['mlp_fused'][0] / solo['mlp_fused'][1]
+            flops = sum(2.0 * (B * F) * lin.in_features * lin.out_features
+                        for mlp in (net.pose_net_iter, net.shape_net_iter) for lin, _, _ in mlp.dense_specs())
+            x3 = lib.empose_get_option(b'mlp_x3') != 0
+            peak = PEAK_BF16_MFMA_TFLOPS / X3_PRODUCTS if x3 else PEAK_FP32_MFMA_TFLOPS
+            entry['roofline'] = {'bound': 'mfma', 'kernel': 'mlp_fused_x3_kernel' if x3 else 'mlp_fused_kernel',
+                                 'avg_launch_ms': avg_ms, 'achieved': flops / (avg_ms * 1e-3) / 1e12, 'peak': peak,
+                                 'unit': 'TFLOP/s', 'frac': flops / (avg_ms * 1e-3) / 1e12 / peak}
+        sec['configs1_lgd12_b256'] = entry
+        del net, inputs
+    except Exception as e:    # noqa: BLE001
+        sec['configs1_lgd12_b256'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    # ---- vertices
+    try:
+        smpl = SMPLLayer(model).to(dev)
+        n = vertices_numbers(smpl, dev, 16384, 10, 3)
+        label, kname, _ = vertices_arithmetic('f32')
+        sec['vertices_t16384'] = {'workload': 'smpl_vertices_fwd (SMPLLayer.forward), 16384 frames, V=%d' % n['V'],
+                                  'frames_per_sec': n['fps'], 'device_ms_per_step': n['dev_ms'], 'kernel': kname,
+                                  'roofline': {'bound': 'hbm', 'achieved': n['hbm'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                               'frac': n['hbm'] / PEAK_HBM_GBS,
+                                               'algorithmic_bytes_per_frame': n['bytes_frame']},
+                                  'arithmetic': label}
+        del smpl
+    except Exception as e:    # noqa: BLE001
+        sec['vertices_t16384'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    # ---- configs[3] stand-in and configs[4], as child processes (their own entry points)
+    py = sys.executable
+    for key, extra in (('batched', []), ('sequential', ['--sequential'])):
+        r = _json_tail([py, os.path.join(ROOT, 'scripts', 'evaluate_real.py'), '--synthetic', '--repeat', '3', '--json'] + extra, 120)
+        sec['configs3_evaluate_real_synthetic_' + key] = r if 'error' in r else {
+            'workload': 'BASELINE configs[3] stand-in: scripts/evaluate_real.py --synthetic%s (36 sequences, 54 030 frames, '
+                        'LGD-RNN-6 N=2, 256-frame chunks, carried state), 1 GPU' % (' --sequential' if extra else ''),
+            'frames_per_sec': r.get('frames_per_sec'), 'seconds_per_pass': r.get('seconds'), 'frames': r.get('frames')}
+    fwd_flops = 26.47e6       # dense MFLOP per frame of LGD-RNN-12 N=4 (SURVEY.md 8d); fwd + dX + dW = 3 x
+    for key, extra, windows in (('12_windows', ['--steps', '20'], 12), ('256_windows', ['--steps', '8', '--bs_train', '256'], 256)):
+        r = _json_tail([py, os.path.join(ROOT, 'scripts', 'train.py'), '--json'] + extra, 180)
+        if 'error' in r:
+            sec['configs4_train_step_' + key] = r
+            continue
+        ms = r.get('median_step_ms')
+        tfl = 3.0 * fwd_flops * windows * 32 / (ms * 1e-3) / 1e12 if ms else None
+        sec['configs4_train_step_' + key] = {
+            'workload': 'BASELINE configs[4] per-GPU step: scripts/train.py synthetic, LGD-RNN-12 N=4, %d windows x 32 frames, '
+                        'forward + backward + Adam, 1 GPU%s' % (windows, ', replayed as a HIP graph' if r.get('hip_graph') else ''),
+            'median_step_ms': ms, 'frames_per_sec': r.get('frames_per_sec'), 'steps_per_sec': r.get('steps_per_sec'),
+            'roofline': {'bound': 'mfma', 'achieved': tfl, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tfl / PEAK_FP32_MFMA_TFLOPS if tfl else None,
+                         'flops': '3 x 26.47 MFLOP/frame (forward dense flops + the same again for dX and for dW); the GEMMs of '
+                                  'the training kernels run on the fp32 MFMA instruction'}}
+    sec['seconds_spent'] = time.perf_counter() - t_all
+    return sec
 
 
 def main():
@@ -308,6 +458,8 @@ def main():
     ap.add_argument('--no_profile', action='store_true')
     ap.add_argument('--no_fp32_line', action='store_true',
                     help='skip the second timed region on the fp32 MFMA instruction (option mlp_x3=0)')
+    ap.add_argument('--no_secondary', action='store_true',
+                    help='skip the `secondary` object (the other BASELINE configs + the full-mesh workload, ~1 min)')
     ap.add_argument('--no_traffic', action='store_true',
                     help='skip the two rocprofv3 --pmc child passes that measure roofline.traffic (~25 s each)')
     ap.add_argument('--force_dist', action='store_true', help='init the process group even for one rank (self-test)')
@@ -392,9 +544,11 @@ def main():
     # MLPs as three-piece bf16 products: reported beside the headline, never as `value`.
     lib0 = _lib.lib()
     x3_on = lib0.empose_get_option(b'mlp_x3') != 0 and net.config.m_hidden_size % 64 == 0 and B * F >= 64 * 128
+    x3_options = {k: lib0.empose_get_option(k) for k in (b'mlp_x3', b'lstm_x3', b'rows_x3')}
     fp32_line = None
     if x3_on and not args.no_fp32_line:
-        _lib.check(lib0.empose_set_option(b'mlp_x3', 0))
+        for k in x3_options:          # the whole path on the fp32 MFMA instruction: update MLPs, LSTM steps, heads, blend GEMMs
+            _lib.check(lib0.empose_set_option(k, 0))
         for _ in range(max(args.warmup, 1)):
             out32 = net.forward_tensors(*inputs)
         barrier()
@@ -403,7 +557,8 @@ def main():
             out32 = net.forward_tensors(*inputs)
         torch.cuda.synchronize()
         e32 = time.perf_counter() - t1
-        _lib.check(lib0.empose_set_option(b'mlp_x3', 1))
+        for k, v in x3_options.items():     # back to what the headline ran with (a user's --option survives)
+            _lib.check(lib0.empose_set_option(k, v))
         if dist is not None:
             t = torch.tensor([e32], dtype=torch.float64, device=D.collective_device(dev))
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -411,8 +566,8 @@ def main():
         fp32_line = {'value': frames_total * args.steps / e32, 'ms_per_step': 1000.0 * e32 / args.steps,
                      'max_abs_diff_to_headline_outputs': float(max((out32[k] - out[k]).abs().max() for k in
                                                                    ('pose', 'shape', 'joints'))),
-                     'what': 'option mlp_x3=0: the update MLPs on v_mfma_f32_32x32x2_f32 (mlp_fused.hip), everything else '
-                             'unchanged; same inputs, same timed region'}
+                     'what': 'options mlp_x3 = lstm_x3 = rows_x3 = 0: update MLPs (mlp_fused.hip), LSTM steps, init heads '
+                             'and blend GEMMs on the fp32 MFMA instruction; same inputs, same timed region'}
         barrier()
 
     result = None
@@ -438,11 +593,7 @@ def main():
 
                        'dense_mflop_per_frame': fpf / 1e6,
                        'whole_path_tflops': value * fpf / 1e12,
-                       'arithmetic': ('fp32 operands and fp32 accumulation; the update MLPs form every fp32 product from '
-                                      'three bf16 pieces per operand (8+8+8 mantissa bits) as six bf16 matrix-core products '
-                                      '(mlp_fused_x3.hip): fp32-equivalent, error against float64 measured equal to the fp32 '
-                                      'MFMA instruction\'s (tests/test_hip_round5.py); LSTM, heads and SMPL GEMMs on the fp32 '
-                                      'MFMA instruction') if x3_on else 'fp32 MFMA instruction throughout'},
+                       'arithmetic': arithmetic_label(x3_options, x3_on, net.rnn_init)},
         }
         if fp32_line is not None:
             result['fp32_mfma_path'] = fp32_line
@@ -522,6 +673,11 @@ def main():
         result['breakdown_ms_per_step']['sum_of_kernels'] = total / psteps
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(net, model, w, hip_out=out)
+    if rank == 0 and world == 1 and not args.no_secondary and not args.no_rnn and (B, F, args.n_markers) == (1024, 32, 12):
+        # (only beside the headline configuration; `value` / `metric` / `config` above are untouched by it)
+        del inputs, out
+        torch.cuda.empty_cache()
+        result['secondary'] = secondary_workloads(args, dev, model)
     if rank == 0:
         print(json.dumps(result), file=results_out, flush=True)
     if dist is not None:

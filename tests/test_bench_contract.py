@@ -193,6 +193,33 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
 
 
 @pytest.mark.gpu
+def test_bench_secondary_object_carries_the_other_configs():
+    """The headline line of `bench.py` (BASELINE configs[2] shape) carries a `secondary` object: configs[1], the full-mesh
+    workload, the configs[3] stand-in under both drivers and the configs[4] step at 12 and 256 windows -- each with what it
+    ran, its rate and a roofline fraction where one applies; `value` / `metric` / `config` are the headline's own."""
+    r = _run(['--steps', '5', '--warmup', '2', '--no_cpu_baseline', '--no_traffic', '--no_fp32_line'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['metric'] == 'frames/sec LGD-RNN N=4 12-sensor ws=32; MPJPE vs ref (mm)'
+    assert d['value'] == pytest.approx(1024 * 32 / (d['ms_per_step'] * 1e-3), rel=1e-6)
+    sec = d['secondary']
+    keys = ('configs1_lgd12_b256', 'vertices_t16384', 'configs3_evaluate_real_synthetic_batched',
+            'configs3_evaluate_real_synthetic_sequential', 'configs4_train_step_12_windows', 'configs4_train_step_256_windows')
+    for k in keys:
+        assert k in sec and 'error' not in sec[k], (k, sec.get(k))
+        assert 'workload' in sec[k] and sec[k]['frames_per_sec'] > 0
+    for k in ('configs1_lgd12_b256', 'vertices_t16384', 'configs4_train_step_12_windows', 'configs4_train_step_256_windows'):
+        rf = sec[k]['roofline']
+        assert rf['bound'] in ('hbm', 'mfma') and 0.0 < rf['frac'] < 1.0
+        assert rf['frac'] == pytest.approx(rf['achieved'] / rf['peak'], rel=1e-9)
+    assert sec['vertices_t16384']['roofline']['bound'] == 'hbm'
+    assert sec['configs3_evaluate_real_synthetic_batched']['frames'] == 54030
+    assert sec['seconds_spent'] < 240
+
+
+@pytest.mark.gpu
 def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
