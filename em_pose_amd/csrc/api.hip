@@ -92,6 +92,9 @@ struct Lstm {   // unit u = layer * dirs + direction
   // the same matrices as three bf16 pieces per weight in the fragment order of lstm_x3.hip (uni-directional stacks only)
   unsigned short* w3_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned short* w3_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // ... and in the fragment order of lstm_mid_x3.hip (8-unit blocks, the four gates of a unit in one 32-column tile)
+  unsigned short* w3m_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned short* w3m_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -454,6 +457,15 @@ bool lstm_x3_covers(const Lstm& r, int B) {
     if (!r.w3_ih[l] || !r.w3_hh[l]) return false;
   return true;
 }
+// medium batches (the batched evaluation driver's chunks): lstm_mid_x3.hip
+bool lstm_x3_mid_covers(const Lstm& r, int B) {
+  if (options().lstm_x3 == 0 || options().lstm_mid_x3 == 0 || r.dirs != 1 || r.num_layers > 4) return false;
+  if (B <= LSTM_PERSIST_B || B >= LSTM_SEQ_MIN_B) return false;
+  if (r.H % 32 != 0 || r.input_size % 4 != 0) return false;
+  for (int l = 0; l < r.num_layers; ++l)
+    if (!r.w3m_ih[l] || !r.w3m_hh[l]) return false;
+  return true;
+}
 LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
   const int H = r.H, U = r.num_layers * r.dirs;
@@ -470,7 +482,7 @@ LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   const bool seq = r.dirs == 1 && B >= LSTM_SEQ_MIN_B && r.num_layers <= 4;
   for (int u = 0; u < 8; ++u) w.h3[u] = (seq && u < U) ? c.f((size_t)B * H) : nullptr;
   w.seq_cnt = seq ? reinterpret_cast<unsigned*>(c.f(lstm_seq_counter_uints(B))) : nullptr;
-  const bool x3 = lstm_x3_covers(r, B);
+  const bool x3 = lstm_x3_covers(r, B) || lstm_x3_mid_covers(r, B);
   w.x3_t_stride = lstm_x3_plane_elems(B, r.input_size);
   w.x3 = x3 ? reinterpret_cast<unsigned short*>(c.f((w.x3_t_stride * F + 1) / 2)) : nullptr;
   for (int u = 0; u < 8; ++u)
@@ -658,7 +670,8 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
       seq_done = done;
     }
     // Large batches, inference: the steps on the bf16 matrix path with three bf16 pieces per operand (lstm_x3.hip)
-    if (!done && ws.x3 && !a.unit[0].sv_gates && lstm_x3_covers(r, B)) {
+    const bool mid3 = lstm_x3_mid_covers(r, B);
+    if (!done && ws.x3 && !a.unit[0].sv_gates && (lstm_x3_covers(r, B) || mid3)) {
       prof_mark(P_COPY, stream);
       const int KS_in = (r.input_size + 15) / 16, KS_h = H / 16;
       hipError_t e = launch_lstm_split_rows(x, (long)F * ldx, ldx, F, B, r.input_size, KS_in, ws.x3, (long)ws.x3_t_stride, stream);
@@ -675,7 +688,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
           const int t = s - l;
           if (t < 0 || t >= F) continue;
           LstmX3Unit& xu = xa.unit[xa.n_units++];
-          xu.w3_ih = r.w3_ih[l]; xu.w3_hh = r.w3_hh[l]; xu.bias = r.bias[l];
+          xu.w3_ih = mid3 ? r.w3m_ih[l] : r.w3_ih[l]; xu.w3_hh = mid3 ? r.w3m_hh[l] : r.w3_hh[l]; xu.bias = r.bias[l];
           xu.a3_in = l == 0 ? ws.x3 + (size_t)t * ws.x3_t_stride : ws.a3[l - 1][(t + 1) & 1];
           xu.ks_in = l == 0 ? KS_in : KS_h;
           xu.a3_rec = ws.a3[l][t & 1]; xu.a3_out = ws.a3[l][(t + 1) & 1];
@@ -684,7 +697,8 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
         }
         xa.units_per_block = tiles >= 192 ? xa.n_units : 1;
         prof_mark(P_LSTM_STEP, stream);
-        e = options().lstm_x3 == 2 ? launch_lstm_rows_x3(xa, stream) : launch_lstm_chain_x3(xa, stream);
+        e = mid3 ? launch_lstm_mid_x3(xa, stream)
+                 : options().lstm_x3 == 2 ? launch_lstm_rows_x3(xa, stream) : launch_lstm_chain_x3(xa, stream);
         if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step (bf16 pieces): %s", hipGetErrorString(e));
       }
       done = true;
@@ -732,14 +746,18 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
 // An LSTM weight matrix [4H][K] (gate-major rows) as three bf16 pieces per weight in the fragment order of lstm_x3.hip:
 // [k-step of 16][32-unit block][gate][piece] -> one wave fragment of 512 bf16, lane (n = lane & 31, half = lane >> 5) owns
 // W[gate * H + block * 32 + n][ks * 16 + half * 8 .. + 7]; k past K is zero.
-int pack_lstm_x3(std::vector<void*>& allocs, const float* w, int H, int K, unsigned short** out) {
-  const int KS = (K + 15) / 16, JB = H / 32;
-  std::vector<unsigned short> buf((size_t)KS * JB * 4 * 3 * 512, 0);
+// `mid`: the order of lstm_mid_x3.hip instead -- [k-step of 16][8-unit block][piece] -> one fragment whose column
+// n = lane & 31 is gate n >> 3 of unit block * 8 + (n & 7).
+int pack_lstm_x3(std::vector<void*>& allocs, const float* w, int H, int K, unsigned short** out, bool mid = false) {
+  const int KS = (K + 15) / 16, JB = mid ? H / 8 : H / 32, NQ = mid ? 1 : 4;
+  std::vector<unsigned short> buf((size_t)KS * JB * NQ * 3 * 512, 0);
   for (int ks = 0; ks < KS; ++ks)
     for (int jb = 0; jb < JB; ++jb)
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < NQ; ++q)
         for (int lane = 0; lane < 64; ++lane) {
-          const float* row = w + (size_t)(q * H + jb * 32 + (lane & 31)) * K;
+          const int n = lane & 31;
+          const float* row = mid ? w + (size_t)((n >> 3) * H + jb * 8 + (n & 7)) * K
+                                 : w + (size_t)(q * H + jb * 32 + n) * K;
           for (int e = 0; e < 8; ++e) {
             const int k = ks * 16 + (lane >> 5) * 8 + e;
             if (k >= K) continue;
@@ -747,7 +765,7 @@ int pack_lstm_x3(std::vector<void*>& allocs, const float* w, int H, int K, unsig
             const float r1 = row[k] - bf16_value(h);
             const unsigned short m = bf16_round(r1);
             const unsigned short l = bf16_round(r1 - bf16_value(m));
-            const size_t at = ((((size_t)ks * JB + jb) * 4 + q) * 3) * 512 + (size_t)lane * 8 + e;
+            const size_t at = ((((size_t)ks * JB + jb) * NQ + q) * 3) * 512 + (size_t)lane * 8 + e;
             buf[at] = h; buf[at + 512] = m; buf[at + 1024] = l;
           }
         }
@@ -777,6 +795,8 @@ int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, c
       if (dirs == 1 && r.hidden_size % 32 == 0) {
         TRY(pack_lstm_x3(allocs, w_ih[u], r.hidden_size, k_in, &out->w3_ih[u]));
         TRY(pack_lstm_x3(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3_hh[u]));
+        TRY(pack_lstm_x3(allocs, w_ih[u], r.hidden_size, k_in, &out->w3m_ih[u], true));
+        TRY(pack_lstm_x3(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3m_hh[u], true));
       }
     }
   return EMPOSE_OK;
@@ -982,6 +1002,7 @@ int empose_set_option(const char* name, int value) {
       {"train_cols", &o.train_cols},
       {"cols_coop", &o.cols_coop},
       {"mesh_x3", &o.mesh_x3},
+      {"lstm_mid_x3", &o.lstm_mid_x3},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
@@ -1019,6 +1040,7 @@ int empose_get_option(const char* name) {
       {"train_cols", o.train_cols},
       {"cols_coop", o.cols_coop},
       {"mesh_x3", o.mesh_x3},
+      {"lstm_mid_x3", o.lstm_mid_x3},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)

@@ -47,6 +47,8 @@ struct Options {
                           // (mesh_x3.hip): 1 stores staggered into the next tile's products, 2 stores at the end of the tile,
                           // 3 skinning software-pipelined under the next tile's products; 0: the fp32 MFMA instruction
                           // (mesh_rows_kernel)
+  int lstm_mid_x3 = 1;    // LSTM steps of 17 .. 256 rows (inference, uni-directional) on three bf16 pieces, 64 x 8-unit tiles
+                          // (lstm_mid_x3.hip); 0: lstm_mid_kernel (fp32 MFMA, operands through LDS)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
                           // instead of the whole-sequence kernel / lstm_small_kernel (0: those; they share their bits)
   int mlp_x3 = 1;         // fused update MLPs: fp32 products as six bf16-MFMA products of three bf16 pieces per operand
@@ -352,6 +354,9 @@ hipError_t launch_lstm_chain_x3(const LstmX3Args& a, hipStream_t stream);
 // the same step with the waves splitting ROWS, the weight block of a k-step shared through LDS and the cell update in
 // registers (lstm_rows_x3.hip; option lstm_x3 = 2): one unit per workgroup, `units_per_block` unused
 hipError_t launch_lstm_rows_x3(const LstmX3Args& a, hipStream_t stream);
+// the step of MEDIUM batches (17 .. 256 rows): 64 rows x 8 units per workgroup, weights in the 8-unit-block order
+// (api.hip pack_lstm_x3 with mid = true), K split over the waves (lstm_mid_x3.hip; option lstm_mid_x3)
+hipError_t launch_lstm_mid_x3(const LstmX3Args& a, hipStream_t stream);
 hipError_t launch_lstm_split_rows(const float* src, long row_stride, long z_stride, int n_z, int B, int K, int KS,
                                   unsigned short* dst, long dst_z_stride, hipStream_t stream);
 constexpr int LSTM_SEQ_MIN_B = 257;   // below: lstm_mid_kernel / the small-batch kernels

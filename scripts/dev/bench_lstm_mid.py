@@ -4,7 +4,11 @@ this sweep run with either kernel forced)."""
 import sys, time
 sys.path.insert(0, '.')
 import torch
+from em_pose_amd import _lib
 from em_pose_amd.nn.layers import RNNLayer
+for kv in sys.argv[1:]:          # NAME=INT kernel-variant switches, e.g. lstm_mid_x3=0
+    k, _, v = kv.partition('=')
+    _lib.check(_lib.lib().empose_set_option(k.encode(), int(v)))
 dev = 'cuda:0'
 layer = RNNLayer(60, 512, 2).eval().to(dev)
 F = 64

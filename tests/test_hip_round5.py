@@ -248,7 +248,10 @@ def test_three_piece_bf16_update_nets_are_as_accurate_as_the_fp32_mfma_ones(scal
 
 
 @pytest.mark.parametrize('B,F,In,Hd,L', [(1024, 8, 144, 512, 2), (300, 7, 72, 512, 2), (333, 5, 200, 192, 3), (257, 4, 144, 64, 1),
-                                         (1000, 3, 36, 128, 4)])
+                                         (1000, 3, 36, 128, 4),
+                                         # round 6, 17 .. 256 rows: lstm_mid_x3.hip (one / two row tiles, several row blocks)
+                                         (36, 9, 72, 512, 2), (17, 5, 144, 512, 2), (32, 4, 144, 256, 2), (33, 3, 72, 64, 1),
+                                         (100, 4, 144, 128, 3), (256, 3, 36, 512, 2)])
 def test_three_piece_bf16_lstm_steps_are_as_accurate_as_the_fp32_mfma_ones(B, F, In, Hd, L):
     """lstm_x3.hip (the wavefront step of batches above 256 rows: weights and hidden states as three bf16 pieces in
     fragment order, six bf16 MFMA products per fp32 product, K split over the waves) against a float64 LSTM
