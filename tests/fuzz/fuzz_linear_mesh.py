@@ -79,6 +79,10 @@ def run_mesh(seed=0, seconds=None, n_cases=None, log=print, dev='cuda:0', tol=3e
         betas, trans = torch.randn(T, 10, generator=g), torch.randn(T, 3, generator=g)
         use_tr = bool(rng.integers(0, 2))
         conv = ('smplx', 'so3')[int(rng.integers(0, 2))]
+        # round 6: the default ('f32') path is the three-piece bf16 kernel (mesh_x3.hip) in one of its three forms, or the
+        # fp32 MFMA kernel (option mesh_x3 = 0)
+        from em_pose_amd import _lib
+        _lib.check(_lib.lib().empose_set_option(b'mesh_x3', int(rng.integers(0, 4))))
         for arith in ('f32', 'bf16x3'):
             bm, smpl = layers[(conv, arith)]
             v_ref, j_ref = R.smpl_fk(bm, pose, betas, root, trans if use_tr else None)

@@ -14,7 +14,8 @@ import numpy as np
 import torch
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-BATCHES = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700)   # (4, 12: the other two sizes of lstm_fewrows_kernel)
+BATCHES = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 36, 64, 100, 128, 256, 257, 300, 700)   # (17 .. 256: lstm_mid_x3.hip since round 6)
+BATCHES_R5 = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700)   # (4, 12: the other two sizes of lstm_fewrows_kernel)
 
 
 def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4):
