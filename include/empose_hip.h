@@ -586,7 +586,8 @@ typedef struct {
   const int* parents;     /* [n_joints], topologically ordered, parents[0] < 0 */
   int n_joints;           /* posed joints returned: 22 (body) ... 52 (all of SMPL-H, as `body.Jtr`); 0 means 22 */
   int rodrigues;          /* EMPOSE_RODRIGUES_* */
-  int with_bf16x3;        /* also pack the split-bf16 coefficient tables (empose_mesh_vertices_fwd_bf16x3), +25 MB */
+  int with_bf16x3;        /* also pack the TWO-piece split-bf16 tables of empose_mesh_vertices_fwd_bf16x3 (+18 MB); the
+                           * three-piece tables of the default path (25 MB) are always packed when kb <= 4 */
 } empose_mesh_desc;
 
 int empose_mesh_create(const empose_mesh_desc* desc, empose_mesh_t** out);
@@ -595,7 +596,11 @@ size_t empose_mesh_workspace_bytes(const empose_mesh_t* mesh, int T);
 int empose_mesh_n_joints(const empose_mesh_t* mesh);
 /* Replaces SMPLLayer.forward/fk (reference bodymodels/smpl.py:81-147): poses [T][66] (root first), betas [T][10],
  * trans [T][3] or NULL -> vertices [T][V][3], joints [T][n_joints][3] (n_joints = 52 reproduces `body.Jtr`; the 30 hand
- * joints have zero pose, reference smpl.py:99, so they ride rigidly on the wrists' frames). */
+ * joints have zero pose, reference smpl.py:99, so they ride rigidly on the wrists' frames).
+ * Arithmetic (round 6): fp32 operands and fp32 accumulation; for body models with at most four bones per vertex the
+ * blend-shape contraction forms every fp32 product from three bf16 pieces per operand on the bf16 matrix cores
+ * (csrc/mesh_x3.hip: fp32-equivalent, measured against float64 in tests/test_hip_round6.py); option "mesh_x3" = 0 selects
+ * the kernel on the fp32 MFMA instruction, which models with more bones per vertex always take. */
 int empose_mesh_vertices_fwd(const empose_mesh_t* mesh, int T, const float* poses, const float* betas,
                              const float* trans, float* vertices, float* joints,
                              void* workspace, size_t workspace_bytes, empose_stream_t stream);
