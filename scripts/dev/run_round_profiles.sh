@@ -8,12 +8,14 @@ mkdir -p gpurun_out
 if [ -z "${SKIP_TESTS:-}" ]; then
   python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|error|fuzz slice|vs float64|fingerprints" | tail -60 > gpurun_out/${TAG}_gpu_tests.log
 fi
-python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json
+python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024.json       # incl. `secondary`
 python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json   # with its own parity sample (cpu_baseline)
 python bench.py --gpus 1 --force_dist --steps 20 --warmup 3 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024_spawned_rank_nccl.json
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
-python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json
-python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
+python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json   # three-piece kernel, live PMC traffic
+python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 --no_traffic --option mesh_x3=0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_fp32_mfma_t16384.json
+python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
+python scripts/dev/time_mesh.py 16384 0,1,2,3 2>&1 | grep mesh_x3= > gpurun_out/${TAG}_mesh_variants_t16384.txt
 python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
 python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 30 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json          # default: replayed as a HIP graph
@@ -28,20 +30,14 @@ rm -rf $OUT
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $R/scripts/train.py --steps 10 --no_graph --json > $OUT.log 2>&1 )
 cp $OUT/t_kernel_stats.csv gpurun_out/${TAG}_train_kernel_stats_bs12.csv
 rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vb -- python $R/bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
-cp $OUT/vb_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_bf16x3_t16384.csv
-rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_traffic --no_fp32_line > $OUT.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o lgd -- python $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_traffic --no_fp32_line --no_secondary > $OUT.log 2>&1 )
 cp $OUT/lgd_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_lgdrnn12_b1024.csv
 rm -rf $OUT
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o v -- python $R/bench.py --workload vertices --batch 512 --frames 32 --steps 5 --warmup 1 > $OUT.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o v -- python $R/bench.py --workload vertices --batch 512 --frames 32 --steps 5 --warmup 1 --no_traffic > $OUT.log 2>&1 )
 cp $OUT/v_kernel_stats.csv gpurun_out/${TAG}_rocprofv3_kernel_stats_bench_vertices_t16384.csv
 rm -rf $OUT
 python scripts/dev/bench_lstm_small.py > gpurun_out/${TAG}_lstm_small_batch_per_step.txt 2>&1
 python scripts/dev/bench_lstm_mid.py > gpurun_out/${TAG}_lstm_medium_batch_per_step.txt 2>&1
 python scripts/dev/prof_seq.py > gpurun_out/${TAG}_streaming_forward_b1_f256.txt 2>&1
-[ -x scripts/dev/bin/fused_x3_lab ] && scripts/dev/bin/fused_x3_lab 32768 > gpurun_out/${TAG}_fused_mlp_x3_lab.txt 2>&1
-[ -x scripts/dev/bin/lstm_x3_lab_times ] && ( scripts/dev/bin/lstm_x3_lab_times 1024; for v in NOLOAD NOPART NOFINISH; do echo "== without: $v"; scripts/dev/bin/lstm_x3_lab_$v 1024; done ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_lstm_x3_lab.txt
-[ -x scripts/dev/bin/train_cols_lab_times ] && ( scripts/dev/bin/train_cols_lab 384; scripts/dev/bin/train_cols_lab_times 384 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_train_cols_lab.txt
 bash scripts/dev/train_trace.sh 12 2>&1 | grep -v Segm > gpurun_out/${TAG}_train_step_bs12_trace.txt
 ls -la gpurun_out | grep $TAG
