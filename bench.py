@@ -399,7 +399,7 @@ def secondary_workloads(args, dev, model):
     # ---- vertices
     try:
         smpl = SMPLLayer(model).to(dev)
-        n = vertices_numbers(smpl, dev, 16384, 10, 3)
+        n = vertices_numbers(smpl, dev, 16384, 40, 8)    # (the clocks settle over the first few calls of a 1 ms workload)
         label, kname, _ = vertices_arithmetic('f32')
         sec['vertices_t16384'] = {'workload': 'smpl_vertices_fwd (SMPLLayer.forward), 16384 frames, V=%d' % n['V'],
                                   'frames_per_sec': n['fps'], 'device_ms_per_step': n['dev_ms'], 'kernel': kname,

@@ -741,48 +741,71 @@ hipError_t launch_chain_sensors(const ChainArgs& a, hipStream_t stream) {
 // Full mesh (final vertices): chain to relative transforms, then dense skinning of all V vertices.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void mesh_chain_kernel(MeshChainArgs a) {
-  // one thread per (frame, joint, row): walks parents up to the root.  Joints >= NB (the 30 hand joints of SMPL-H) have
-  // zero pose on this path (reference smpl.py:99), i.e. identity rotation under either Rodrigues convention: they only
-  // translate along their parent's frame and get no skinning transform of their own (weights folded into the wrists).
+  // one thread per (frame, joint): walks from the root down to its joint with the running transform (3 x 3 | t) in
+  // registers.  (Round 6: a thread per (frame, joint, ROW) before -- three times the threads, each repeating the walk and
+  // the ancestor look-ups for one row: 119 us per 16384 frames, a tenth of the full-mesh evaluation.)  Joints >= NB (the 30
+  // hand joints of SMPL-H) have zero pose on this path (reference smpl.py:99), i.e. identity rotation under either
+  // Rodrigues convention: they only translate along their parent's frame and get no skinning transform of their own
+  // (weights folded into the wrists).
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int nj = a.n_joints;
-  if (idx >= a.T * nj * 3) return;
-  const int t = idx / (nj * 3), jr = idx % (nj * 3), j = jr / 3, r = jr % 3;
+  // (the parent table in LDS: the walks below are chains of dependent look-ups, ~80 per thread)
+  __shared__ int parents_s[MESH_MAX_JOINTS];
+  for (int i = threadIdx.x; i < nj; i += blockDim.x) parents_s[i] = a.parents[i];
+  __syncthreads();
+  if (idx >= a.T * nj) return;
+  const int t = idx / nj, j = idx % nj;
   const float* R = a.rot + (size_t)t * NB * 9;
   const float* J = a.out + (size_t)t * a.ncp + a.j_off;
   // the joints from the root down to j, without a per-thread array of the path (a dynamically indexed array lives in
   // scratch memory): the ancestor k levels above j is found by walking up k times -- chains are at most a dozen joints long
   int n = 0;
-  for (int q = j; q >= 0; q = a.parents[q]) ++n;
-  float row0 = R[r * 3 + 0], row1 = R[r * 3 + 1], row2 = R[r * 3 + 2];
-  float tr = J[r];
+  for (int q = j; q >= 0; q = parents_s[q]) ++n;
+  float G[3][3], tr[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    G[r][0] = R[r * 3 + 0]; G[r][1] = R[r * 3 + 1]; G[r][2] = R[r * 3 + 2];
+    tr[r] = J[r];
+  }
   int prev = 0;
   for (int k = n - 2; k >= 0; --k) {
     int q = j;
-    for (int up = 0; up < k; ++up) q = a.parents[q];
+    for (int up = 0; up < k; ++up) q = parents_s[q];
     const float* Jq = J + q * 3;
     const float* Jp = J + prev * 3;
-    tr = row0 * (Jq[0] - Jp[0]) + row1 * (Jq[1] - Jp[1]) + row2 * (Jq[2] - Jp[2]) + tr;
+    const float dx = Jq[0] - Jp[0], dy = Jq[1] - Jp[1], dz = Jq[2] - Jp[2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) tr[r] = G[r][0] * dx + G[r][1] * dy + G[r][2] * dz + tr[r];
     if (q < NB) {
       const float* Rq = R + q * 9;
-      const float n0 = row0 * Rq[0] + row1 * Rq[3] + row2 * Rq[6];
-      const float n1 = row0 * Rq[1] + row1 * Rq[4] + row2 * Rq[7];
-      const float n2 = row0 * Rq[2] + row1 * Rq[5] + row2 * Rq[8];
-      row0 = n0; row1 = n1; row2 = n2;
+      float Rv[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Rv[e] = Rq[e];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float n0 = G[r][0] * Rv[0] + G[r][1] * Rv[3] + G[r][2] * Rv[6];
+        const float n1 = G[r][0] * Rv[1] + G[r][1] * Rv[4] + G[r][2] * Rv[7];
+        const float n2 = G[r][0] * Rv[2] + G[r][1] * Rv[5] + G[r][2] * Rv[8];
+        G[r][0] = n0; G[r][1] = n1; G[r][2] = n2;
+      }
     }
     prev = q;
   }
   if (j < NB) {
     const float* Jj = J + j * 3;
     // relative transform, row r: (G^R[r][0..2], A^t[r]) -- one 16-byte read per (bone, row) in the skinning epilogue
-    *reinterpret_cast<float4*>(a.xf + (((size_t)t * NB + j) * 3 + r) * 4) =
-        make_float4(row0, row1, row2, tr - (row0 * Jj[0] + row1 * Jj[1] + row2 * Jj[2]));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      *reinterpret_cast<float4*>(a.xf + (((size_t)t * NB + j) * 3 + r) * 4) =
+          make_float4(G[r][0], G[r][1], G[r][2], tr[r] - (G[r][0] * Jj[0] + G[r][1] * Jj[1] + G[r][2] * Jj[2]));
   }
-  a.joints[(size_t)t * nj * 3 + j * 3 + r] = tr + (a.trans ? a.trans[(size_t)t * 3 + r] : 0.f);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    a.joints[(size_t)t * nj * 3 + j * 3 + r] = tr[r] + (a.trans ? a.trans[(size_t)t * 3 + r] : 0.f);
 }
 
 hipError_t launch_mesh_chain(const MeshChainArgs& a, hipStream_t stream) {
-  const long n = (long)a.T * a.n_joints * 3;
+  const long n = (long)a.T * a.n_joints;
   hipLaunchKernelGGL(mesh_chain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -12,8 +12,8 @@ python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}_
 python bench.py --steps 20 --warmup 3 --no_rnn --batch 256 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgd12_b256_config1.json   # with its own parity sample (cpu_baseline)
 python bench.py --gpus 1 --force_dist --steps 20 --warmup 3 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn12_b1024_spawned_rank_nccl.json
 python bench.py --steps 20 --warmup 3 --n_markers 6 --no_cpu_baseline --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_lgdrnn6_b1024.json
-python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json   # three-piece kernel, live PMC traffic
-python bench.py --workload vertices --batch 512 --frames 32 --steps 10 --warmup 2 --no_traffic --option mesh_x3=0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_fp32_mfma_t16384.json
+python bench.py --workload vertices --batch 512 --frames 32 --steps 40 --warmup 8 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_t16384.json   # three-piece kernel, live PMC traffic
+python bench.py --workload vertices --batch 512 --frames 32 --steps 40 --warmup 8 --no_traffic --option mesh_x3=0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_fp32_mfma_t16384.json
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
 python scripts/dev/time_mesh.py 16384 0,1,2,3 2>&1 | grep mesh_x3= > gpurun_out/${TAG}_mesh_variants_t16384.txt
 python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
