@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libempose_hip.so')
+# (EMPOSE_LIB_PATH: a lab build of the library, scripts/dev/*_lab.sh -- development only; the default is the in-tree build)
+LIB_PATH = os.environ.get('EMPOSE_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libempose_hip.so')
 
 MAX_DENSE = 8
 RODRIGUES = {'smplx': 0, 'so3': 1}   # EMPOSE_RODRIGUES_* (include/empose_hip.h)
@@ -85,7 +86,8 @@ class MlpParams(C.Structure):    # empose_mlp_params: DEVICE pointers
                 ('bn_running_mean', C.c_void_p * MAX_DENSE), ('bn_running_var', C.c_void_p * MAX_DENSE),
                 ('bn_num_batches', C.c_void_p * MAX_DENSE), ('prelu', C.c_void_p * MAX_DENSE),
                 ('bn_eps', C.c_float), ('bn_momentum', C.c_float), ('weight_t', C.c_void_p * MAX_DENSE),
-                ('save_layout', C.c_int)]
+                ('save_layout', C.c_int),
+                ('weight_x3', C.c_void_p * MAX_DENSE), ('weight_t_x3', C.c_void_p * MAX_DENSE)]
 
 
 class MlpGrads(C.Structure):     # empose_mlp_grads
@@ -121,6 +123,8 @@ SIGNATURES = {
     'empose_get_option': (C.c_int, [C.c_char_p]),
     'empose_reset_options': (C.c_int, []),
     'empose_async_status': (C.c_int, []),
+    'empose_pack_weight_x3_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'empose_pack_weight_x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'empose_model_create': (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     'empose_model_destroy': (None, [C.c_void_p]),
     'empose_lgd_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -1003,11 +1003,25 @@ int empose_set_option(const char* name, int value) {
       {"cols_coop", &o.cols_coop},
       {"mesh_x3", &o.mesh_x3},
       {"lstm_mid_x3", &o.lstm_mid_x3},
+      {"train_x3", &o.train_x3},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
   for (const auto& e : tab)
     if (std::strcmp(name, e.n) == 0) { *e.v = value; return EMPOSE_OK; }
   return fail(EMPOSE_EINVAL, "unknown option '%s'", name);
+}
+
+size_t empose_pack_weight_x3_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return pack_x3_elems(N, K) * sizeof(unsigned short);
+}
+
+int empose_pack_weight_x3(const float* W, int ldw, int N, int K, void* out, empose_stream_t stream_) {
+  if (!W || !out) return fail(EMPOSE_EINVAL, "null argument");
+  if (N <= 0 || K <= 0 || K % 4 != 0 || ldw < K) return fail(EMPOSE_EINVAL, "bad sizes");
+  hipError_t e = launch_pack_x3(W, ldw, N, K, static_cast<unsigned short*>(out), static_cast<hipStream_t>(stream_));
+  if (e != hipSuccess) return fail(EMPOSE_EHIP, "weight pack: %s", hipGetErrorString(e));
+  return EMPOSE_OK;
 }
 
 int empose_async_status(void) {
@@ -1041,6 +1055,7 @@ int empose_get_option(const char* name) {
       {"cols_coop", o.cols_coop},
       {"mesh_x3", o.mesh_x3},
       {"lstm_mid_x3", o.lstm_mid_x3},
+      {"train_x3", o.train_x3},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};
   for (const auto& e : tab)
@@ -1907,7 +1922,8 @@ int empose_mlp_train_fwd(const empose_mlp_params* p, int M, const float* x, int 
       g.C = last ? out : sv; g.ldc = last ? ld_out : H;
       g.M = M; g.N = last ? p->out_dim : H; g.K = l == 0 ? p->in_dim : H; g.bias = p->bias[l];
       g.part = w.part;
-      hipError_t e = launch_gemm_train(g, 0, last ? 0 : 1, stream);
+      const bool x3 = !last && options().train_x3 != 0 && p->weight_x3[l] && gemm_train_x3_applicable(g.M, g.N, g.K);
+      hipError_t e = x3 ? launch_gemm_train_x3(g, p->weight_x3[l], 1, stream) : launch_gemm_train(g, 0, last ? 0 : 1, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "mlp forward gemm (statistics epilogue): %s", hipGetErrorString(e));
       if (last) break;
       BnFinishFwdArgs c{};
@@ -2116,7 +2132,8 @@ int mlp_train_bwd_impl(const empose_mlp_params* p, int M, const float* x, int ld
       g.C = dz_of(l - 1); g.ldc = H; g.M = M; g.N = H; g.K = kdim; g.bias = nullptr;
       g.part = w.part; g.e_y = layer_save(l - 1); g.ld_ey = H;
       g.e_mean = stats_of(l - 1); g.e_rstd = g.e_mean + H; g.e_s = g.e_rstd + H; g.e_t = g.e_s + H; g.e_slope = p->prelu[l - 1];
-      hipError_t e = launch_gemm_train(g, 0, 2, stream);
+      const bool x3 = options().train_x3 != 0 && p->weight_t[l] && p->weight_t_x3[l] && gemm_train_x3_applicable(g.M, g.N, g.K);
+      hipError_t e = x3 ? launch_gemm_train_x3(g, p->weight_t_x3[l], 2, stream) : launch_gemm_train(g, 0, 2, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "fused dX gemm: %s", hipGetErrorString(e));
       if (epi) {
         BnFinishBwdArgs f{};

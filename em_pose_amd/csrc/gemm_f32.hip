@@ -13,6 +13,8 @@
 #include "kernels.h"
 #include <cstdint>
 
+#include "bf16x3.h"
+
 #include "gemm_epilogue.h"
 #include "lstm_cell_bwd.h"
 #include "lane_reduce.h"
@@ -1354,6 +1356,165 @@ hipError_t launch_gemm_train(const TrainGemmArgs& t, int amode, int emode, hipSt
   // per 8192 x 512 x 512 launch than the plain tile even with the transform switched off at run time)
   if (amode == 0) return emode == 1 ? launch_cfg<CfgS12, 4>(b, stream) : launch_cfg<CfgS12, 0>(b, stream);
   return launch_cfg<CfgS12, 2>(b, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The train-mode layer products of LARGE batches on three bf16 pieces per operand (bf16x3.h; round 6): y = a W^T + b with the
+// statistics epilogue, and dA = dY W with the dyh epilogue -- what launch_gemm_train runs on the fp32 MFMA instruction
+// (CfgS12, ROLE 2 / 3).  Structure of the fused inference MLP (mlp_fused_x3.hip): a workgroup stages its 64 rows of A
+// (all of K <= 512, fp32) in LDS once; its four waves take 64 rows x 64 columns each (2 x 2 tiles), read 8 consecutive fp32
+// of a k-step per row tile from LDS and split them into pieces in registers, and stream the weight pieces -- split ONCE per
+// optimiser step by pack_x3_kernel, fragment order [k-step][32-column tile][piece] -> 1 KB -- from L2 into a register ring;
+// the accumulators then go through the SAME train_epilogue as the fp32 kernels (same C/D layout).  One workgroup per CU
+// (132 KB of LDS), stores only after the K loop (bf16_hazard_repro.md).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace gx {
+constexpr int BM = 64, BN = 256, NT = 256;
+constexpr int LDA = FUSED_MAX_WIDTH + 4;
+constexpr size_t LDS_BYTES = (size_t)BM * LDA * sizeof(float) + 64;
+constexpr int RING = 3;
+}  // namespace gx
+
+typedef const __attribute__((address_space(1))) u32x4_t* gx_gvec_t;
+typedef const __attribute__((address_space(1))) unsigned short* gx_gptr_t;
+
+// W [N][ldw] (K columns used) -> pieces in fragment order: [k-step of 16][32-column tile][piece][lane][8], lane
+// (n = lane & 31, half = lane >> 5) owns W[tile * 32 + n][ks * 16 + half * 8 .. + 7]; rows >= N and columns >= K are zero.
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ W, int ldw, int N, int K,
+                                                      unsigned short* __restrict__ out) {
+  const int KS = (K + 15) / 16, NT32 = (N + 31) / 32;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)KS * NT32 * 64) return;
+  const int lane = (int)(i & 63), tile = (int)((i >> 6) % NT32), ks = (int)((i >> 6) / NT32);
+  const int n = tile * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (n < N && k0 + e < K) ? W[(size_t)n * ldw + k0 + e] : 0.f;
+  const Pieces q = split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  unsigned short* o = out + (((size_t)ks * NT32 + tile) * 3) * 512 + lane * 8;
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4_t*>(o + pc * 512) = q.p[pc];
+}
+
+size_t pack_x3_elems(int N, int K) { return (size_t)((K + 15) / 16) * ((N + 31) / 32) * 3 * 512; }
+
+hipError_t launch_pack_x3(const float* W, int ldw, int N, int K, unsigned short* out, hipStream_t stream) {
+  const long n = (long)((K + 15) / 16) * ((N + 31) / 32) * 64;
+  hipLaunchKernelGGL(pack_x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, W, ldw, N, K, out);
+  return hipGetLastError();
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(gx::NT) void gemm_train_x3_kernel(GemmProb p, const unsigned short* __restrict__ wfrag) {
+  X3_EXCLUSIVE_SIMD();
+  using namespace gx;
+  extern __shared__ __attribute__((aligned(16))) float act[];
+  const int M = p.M, N = p.N, K = p.K;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = (K + 15) / 16, NT32 = (N + 31) / 32;
+  {   // the block's rows of A, columns [0, 16 KS) (zero past K; rows past M repeat row M - 1 and are never stored)
+    const int c4n = KS * 4;
+    for (int i = tid; i < BM * c4n; i += NT) {
+      const int r = i / c4n, c = (i % c4n) * 4;
+      const int row = m0 + r < M ? m0 + r : M - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < K) v = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + c);   // K % 4 == 0
+      *reinterpret_cast<f32x4*>(act + r * LDA + c) = v;
+    }
+  }
+  __syncthreads();
+  // the wave's two column tiles (a tile past the matrix reads the last one; the epilogue drops its columns)
+  int ct[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int t = n0 / 32 + wave * 2 + j; ct[j] = t < NT32 ? t : NT32 - 1; }
+  gx_gptr_t wb = (gx_gptr_t)wfrag + lane * 8;
+  const float* a_rd = act + l31 * LDA + lh * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4_t fb[RING][2][3];
+  Pieces ap[2][2];
+  auto bload = [&](u32x4_t (&b)[2][3], int ks) {
+    const int kc = ks < KS ? ks : KS - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) b[j][pc] = *(gx_gvec_t)(wb + (((size_t)kc * NT32 + ct[j]) * 3 + pc) * 512);
+  };
+  auto asplit = [&](Pieces (&a)[2], int ks) {
+    const int kc = ks < KS ? ks : KS - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * LDA + kc * 16);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(a_rd + i * 32 * LDA + kc * 16 + 4);
+      a[i] = split8(lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]);
+    }
+  };
+  auto mma = [&](const Pieces (&a)[2], const u32x4_t (&b)[2][3]) {
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i].p[X3_PA[t]]),
+                                                              __builtin_bit_cast(bf16x8_t, b[j][X3_PB[t]]), acc[i][j], 0, 0, 0);
+  };
+  bload(fb[0], 0);
+  bload(fb[1], 1);
+  asplit(ap[0], 0);
+  // k-steps in groups of six (the ring rotates with period 3, the A pieces with period 2), then the tail below
+  int ks = 0;
+  for (; ks + 6 <= KS; ks += 6) {
+    bload(fb[2], ks + 2); asplit(ap[1], ks + 1); mma(ap[0], fb[0]);
+    bload(fb[0], ks + 3); asplit(ap[0], ks + 2); mma(ap[1], fb[1]);
+    bload(fb[1], ks + 4); asplit(ap[1], ks + 3); mma(ap[0], fb[2]);
+    bload(fb[2], ks + 5); asplit(ap[0], ks + 4); mma(ap[1], fb[0]);
+    bload(fb[0], ks + 6); asplit(ap[1], ks + 5); mma(ap[0], fb[1]);
+    bload(fb[1], ks + 7); asplit(ap[0], ks + 6); mma(ap[1], fb[2]);
+  }
+  // tail (at most five steps): the same rotation, each step guarded by a wave-uniform test
+  if (ks < KS) { bload(fb[2], ks + 2); asplit(ap[1], ks + 1); mma(ap[0], fb[0]); }
+  if (ks + 1 < KS) { bload(fb[0], ks + 3); asplit(ap[0], ks + 2); mma(ap[1], fb[1]); }
+  if (ks + 2 < KS) { bload(fb[1], ks + 4); asplit(ap[1], ks + 3); mma(ap[0], fb[2]); }
+  if (ks + 3 < KS) { bload(fb[2], ks + 5); asplit(ap[0], ks + 4); mma(ap[1], fb[0]); }
+  if (ks + 4 < KS) { asplit(ap[1], ks + 5); mma(ap[0], fb[1]); }
+
+  train_epilogue<2, 2, BWD>(p, acc, m0, n0 + wave * 64, l31, lh);
+}
+
+bool gemm_train_x3_applicable(int M, int N, int K) {
+  return M >= 1024 && N % 64 == 0 && N >= 256 && K % 4 == 0 && K >= 16 && K <= FUSED_MAX_WIDTH;
+}
+
+hipError_t launch_gemm_train_x3(const TrainGemmArgs& t, const unsigned short* wfrag, int emode, hipStream_t stream) {
+  if (emode > 2 || !wfrag || !gemm_train_x3_applicable(t.M, t.N, t.K)) return hipErrorInvalidValue;
+  GemmProb g{};
+  g.A = t.A; g.lda = t.lda; g.W = nullptr; g.ldw = 0; g.C = t.C; g.ldc = t.ldc; g.M = t.M; g.N = t.N; g.K = t.K;
+  g.scale = nullptr; g.shift = t.bias; g.resid = nullptr; g.ldr = 0; g.act = 0; g.slope = 0.f;
+  if (emode >= 1) g.stat_part = t.part;
+  if (emode == 2) {
+    g.e_y = t.e_y; g.ld_ey = t.ld_ey; g.e_s = t.e_s; g.e_t = t.e_t; g.e_mean = t.e_mean; g.e_rstd = t.e_rstd;
+    g.e_slope = t.e_slope;
+  }
+  const dim3 grid((unsigned)(((t.M + gx::BM - 1) / gx::BM) * ((t.N + gx::BN - 1) / gx::BN)));
+  if (emode == 2) {
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_train_x3_kernel<true>), gx::LDS_BYTES)) return e;
+    hipLaunchKernelGGL(gemm_train_x3_kernel<true>, grid, dim3(gx::NT), gx::LDS_BYTES, stream, g, wfrag);
+  } else {
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(gemm_train_x3_kernel<false>), gx::LDS_BYTES)) return e;
+    hipLaunchKernelGGL(gemm_train_x3_kernel<false>, grid, dim3(gx::NT), gx::LDS_BYTES, stream, g, wfrag);
+  }
+  return hipGetLastError();
 }
 
 // Name (as a profiler prints it) of the kernel `launch_gemm` runs for `count` problems of this shape.

@@ -47,6 +47,9 @@ struct Options {
                           // (mesh_x3.hip): 1 stores staggered into the next tile's products, 2 stores at the end of the tile,
                           // 3 skinning software-pipelined under the next tile's products; 0: the fp32 MFMA instruction
                           // (mesh_rows_kernel)
+  int train_x3 = 1;       // training at more than 1024 rows: the layer products y = a W^T and dA = dY W of the update networks on
+                          // three bf16 pieces (gemm_train_x3_kernel) when the caller supplies the packed weights
+                          // (empose_mlp_params::weight_x3 / weight_t_x3); 0: the fp32 MFMA tile
   int lstm_mid_x3 = 1;    // LSTM steps of 17 .. 256 rows (inference, uni-directional) on three bf16 pieces, 64 x 8-unit tiles
                           // (lstm_mid_x3.hip); 0: lstm_mid_kernel (fp32 MFMA, operands through LDS)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
@@ -204,6 +207,12 @@ struct TrainGemmArgs {       // C[M][N] = A'[M][K] . W[N][K]^T (+ bias), 64 x 12
   const float* e_slope;
 };
 hipError_t launch_gemm_train(const TrainGemmArgs& p, int amode, int emode, hipStream_t stream);
+// The same products (amode 0) on three bf16 pieces per operand for large batches (gemm_f32.hip, gemm_train_x3_kernel):
+// `wfrag` = the weight matrix W [N][K] as pieces in fragment order, made by launch_pack_x3 once per optimiser step.
+bool gemm_train_x3_applicable(int M, int N, int K);
+hipError_t launch_gemm_train_x3(const TrainGemmArgs& p, const unsigned short* wfrag, int emode, hipStream_t stream);
+size_t pack_x3_elems(int N, int K);
+hipError_t launch_pack_x3(const float* W, int ldw, int N, int K, unsigned short* out, hipStream_t stream);
 struct BnFusedFwdArgs {
   int M, C; const float* part;                        // [ceil(M / 32)][2][C]
   const float* gamma; const float* beta; float eps, momentum;

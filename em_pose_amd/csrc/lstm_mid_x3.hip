@@ -40,6 +40,7 @@ __device__ __forceinline__ float lm3_tanh(float x) { return 1.f - 2.f * __builti
 
 template <int RTS>   // row tiles of 32 a workgroup multiplies: 1 (launches of at most 32 rows) or 2
 __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace lm3;
   extern __shared__ __attribute__((aligned(16))) float part[];
   float* hx = part + PART_FLOATS;

@@ -48,6 +48,7 @@ __device__ __forceinline__ float lr_tanh(float x) { return 1.f - 2.f * __builtin
 __device__ unsigned short lr_zero_frags[3 * lr::FRAG];   // zero-initialised: the A fragments of the padding k-steps
 
 __global__ __launch_bounds__(lr::NT) void lstm_rows_x3_kernel(LstmX3Args a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace lr;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int H = a.H, B = a.B, F = a.F;

@@ -74,6 +74,7 @@ __device__ long long* lx_lab_times;
 #endif
 
 __global__ __launch_bounds__(lx::NT) void lstm_chain_x3_kernel(LstmX3Args a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace lx;
   LX_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float part[];

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include "bf16x3.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
 
@@ -284,6 +285,7 @@ __device__ __forceinline__ float bf16_f32(unsigned short h) { return __uint_as_f
 
 template <bool EXTRA>
 __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16_kernel(MeshSkinArgs a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace mb;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(lds);
@@ -518,6 +520,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 }  // namespace ms
 
 __global__ __launch_bounds__(mb::NW * 64) void mesh_rows_bf16s_kernel(MeshSkinArgs a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace ms;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(lds);

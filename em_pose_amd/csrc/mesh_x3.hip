@@ -42,6 +42,7 @@ static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES > 80 * 1024, "one workgroup p
 
 template <bool OVERLAP>
 __global__ __launch_bounds__(mx::NW * 64) void mesh_rows_x3_kernel(MeshSkinArgs a) {
+  X3_EXCLUSIVE_SIMD();
   using namespace mx;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned short* Ab = reinterpret_cast<unsigned short*>(lds);

@@ -657,6 +657,7 @@ constexpr int BLEND_FEAT_K = 200;   // feature columns (feat_rows.h); a tile of 
 __host__ __device__ constexpr RowsLds blend_feat_lds() { return rows_lds(BLEND_FEAT_K, 64, false, 0, 64 * 10); }
 template <int WN, bool X3 = false>
 __global__ __launch_bounds__(fm::NT) void blend_feat_gemm_kernel(FusedMlpArgs args, FeatArgs fa) {
+  if (X3) X3_EXCLUSIVE_SIMD();
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
   const FusedLayer& L = net.layer[0];
@@ -709,6 +710,7 @@ __host__ __device__ constexpr RowsLds blend_t_rod_lds(int K) {
 }
 template <int WN, bool X3 = false>
 __global__ __launch_bounds__(fm::NT) void blend_t_gemm_rod_kernel(FusedMlpArgs args, RodBwdTArgs ra) {
+  if (X3) X3_EXCLUSIVE_SIMD();
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
   const FusedLayer& L = net.layer[0];
@@ -758,6 +760,7 @@ struct HeadsArgs {
 };
 template <bool X3>
 __global__ __launch_bounds__(fm::NT) void heads_rows_kernel(FusedMlpArgs args, HeadsArgs h) {
+  if (X3) X3_EXCLUSIVE_SIMD();
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[0];
   const FusedLayer& L = net.layer[0];

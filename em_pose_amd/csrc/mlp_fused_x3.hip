@@ -445,6 +445,7 @@ __device__ __forceinline__ void x3c_layer(const FusedNet& net, const FusedLayer&
 }
 
 __global__ __launch_bounds__(fx::NT) void mlp_fused_x3c_kernel(FusedMlpArgs args) {
+  X3_EXCLUSIVE_SIMD();
   using namespace fx;
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[blockIdx.y];
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(fx::NT) void mlp_fused_x3c_kernel(FusedMlpArgs args
 }
 
 __global__ __launch_bounds__(fx::NT) void mlp_fused_x3_kernel(FusedMlpArgs args) {
+  X3_EXCLUSIVE_SIMD();
   using namespace fx;
   extern __shared__ __attribute__((aligned(16))) float act[];
   const FusedNet& net = args.net[blockIdx.y];

@@ -46,6 +46,8 @@ class _MlpView(object):
         self.hidden = self.specs[0][0].out_features
         self.out_dim = self.specs[-1][0].out_features
         self.weight_t = None
+        self.weight_x3 = None     # pack_forward_x3(): three-piece bf16 copies of the hidden layers' weights (large batches)
+        self.weight_t_x3 = None   # prepare_backward(): ... of their transposed copies
         self.save_layout = 0      # fix_layout(): how this step's forward lays out its saved activations
 
     def fix_layout(self, lib, M):
@@ -87,7 +89,30 @@ class _MlpView(object):
         for l, t in enumerate(self.weight_t or ()):   # transposed once per step (prepare_backward)
             if t is not None:
                 p.weight_t[l] = t.data_ptr()
+        for name in ('weight_x3', 'weight_t_x3'):     # packed once per step (pack_forward_x3 / prepare_backward)
+            for l, t in enumerate(getattr(self, name) or ()):
+                if t is not None:
+                    getattr(p, name)[l] = t.data_ptr()
         return p
+
+    X3_MIN_ROWS = 1024       # below, the library runs these layers on other kernels (one-launch layers, fp32 tiles)
+
+    def _pack_x3(self, lib, stream, W, ld, n_rows, n_cols):
+        nbytes = lib.empose_pack_weight_x3_bytes(int(n_rows), int(n_cols))
+        out = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=W.device)
+        _lib.check(lib.empose_pack_weight_x3(W.data_ptr(), int(ld), int(n_rows), int(n_cols), out.data_ptr(), stream))
+        return out
+
+    def pack_forward_x3(self, lib, stream, M):
+        """Three-piece bf16 copies (fragment order) of the hidden layers' weights for the forward products of this step:
+        once per step, like the transposed copies -- the weights do not change inside a step.  Large batches only."""
+        self.weight_x3 = None
+        if M < _MlpView.X3_MIN_ROWS or self.hidden % 64 != 0 or lib.empose_get_option(b'train_x3') == 0:
+            return
+        self.weight_x3 = []
+        for lin, bn, _ in self.specs:
+            n_out, n_in = lin.weight.shape
+            self.weight_x3.append(self._pack_x3(lib, stream, lin.weight, n_in, n_out, n_in) if bn is not None else None)
 
     def prepare_backward(self, lib, stream, M=None):
         """W^T of layers 1.. (what dX = dY . W needs on the K-contiguous GEMM): once per step instead of once per
@@ -109,6 +134,12 @@ class _MlpView(object):
             t = alloc(n_in, ld, dtype=torch.float32, device=lin.weight.device)
             _lib.check(lib.empose_transpose_f32(n_out, n_in, lin.weight.data_ptr(), n_in, t.data_ptr(), ld, stream))
             self.weight_t.append(t)
+        # ... and their three-piece bf16 copies for dA = dY . W on the bf16 matrix cores (the product against W^T
+        # [in][ld]: "N" = in features, "K" = ld = out features padded to a multiple of 4 with zero columns)
+        self.weight_t_x3 = None
+        if M is not None and M >= _MlpView.X3_MIN_ROWS and self.hidden % 64 == 0 and lib.empose_get_option(b'train_x3') != 0:
+            self.weight_t_x3 = [None] + [self._pack_x3(lib, stream, t, t.shape[1], t.shape[0], t.shape[1])
+                                         for t in self.weight_t[1:]]
 
     def parameter_list(self):
         out = []
@@ -420,6 +451,7 @@ class LgdTrainEngine(object):
                 ctx['init_views'] = (_MlpView(net.pose_net_init), _MlpView(net.shape_net_init))
                 for v in ctx['init_views']:
                     v.fix_layout(self.lib, T)
+                    v.pack_forward_x3(self.lib, self.stream, T)
                 ctx['init_saves'] = (self._mlp_fwd(ctx['init_views'][0], x0.data_ptr(), d_in, pose_hist[0].data_ptr(), 66, T),
                                      self._mlp_fwd(ctx['init_views'][1], x0.data_ptr(), d_in, tmp10.data_ptr(), 10, T))
             if net.shape_avg:
@@ -430,6 +462,7 @@ class LgdTrainEngine(object):
             views = (_MlpView(net.pose_net_iter), _MlpView(net.shape_net_iter))
             for v in views:
                 v.fix_layout(self.lib, T)
+                v.pack_forward_x3(self.lib, self.stream, T)
             X = self.new(max(N, 1), T, d_x)
             dp, ds = self.new(T, 66), self.new(T, 10)
             saves = []

@@ -363,7 +363,19 @@ typedef struct {
    * the forward ran -- the backward and weight-gradient calls of that step then read the buffer the way it was written
    * even if an option changed in between (an A/B script, another thread). */
   int save_layout;
+  /* Optional (round 6), large batches only: the weights of layers 0 .. n_layers-2 (weight_x3: W_l itself, [hidden][in_l])
+   * and of layers 1 .. n_layers-1 (weight_t_x3: the transposed copy `weight_t[l]`, [in_l][ld]) as three bf16 pieces per
+   * weight in matrix-core fragment order, made by empose_pack_weight_x3 once per optimiser step.  When present (and option
+   * "train_x3" != 0, M >= 1024, hidden % 64 == 0) the forward products y_l = a_{l-1} W_l^T and the reverse products
+   * dA_{l-1} = dY_l W_l form every fp32 product from three bf16 pieces per operand (fp32-equivalent; bf16x3.h) instead of
+   * running on the fp32 MFMA instruction.  NULL entries: the fp32 instruction. */
+  const unsigned short* weight_x3[EMPOSE_MAX_DENSE];
+  const unsigned short* weight_t_x3[EMPOSE_MAX_DENSE];
 } empose_mlp_params;
+/* A weight matrix W [N][ldw] (K columns used, K % 4 == 0) as three bf16 pieces per weight in fragment order; `out`:
+ * empose_pack_weight_x3_bytes(N, K) bytes of device memory, 16-byte aligned. */
+size_t empose_pack_weight_x3_bytes(int N, int K);
+int empose_pack_weight_x3(const float* W, int ldw, int N, int K, void* out, empose_stream_t stream);
 typedef struct {                /* gradient outputs, shapes of the parameters */
   float* weight[EMPOSE_MAX_DENSE];
   float* bias[EMPOSE_MAX_DENSE];

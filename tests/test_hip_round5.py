@@ -332,6 +332,7 @@ def _run_mlp_train(nets, x, d_outs, M, pair, deferred=True, saves_from=None):
     views = [_MlpView(n) for n in nets]
     for v in views:
         v.fix_layout(lib, M)
+        v.pack_forward_x3(lib, stream, M)     # (round 6: three-piece copies of the weights for large M, option train_x3)
         # (paired call: as the engine prepares it -- no transposed copies when the reverse reads W itself; the single-network
         # calls get the copies: the same operand values through the other load path, so the two stay bit-identical)
         v.prepare_backward(lib, stream, M if pair else None)

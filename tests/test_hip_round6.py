@@ -189,3 +189,109 @@ def test_full_mesh_three_piece_bf16_on_a_small_mesh_and_few_frames():
                             trans=torch.from_numpy(trans).to(DEV) if with_trans else None)
             np.testing.assert_allclose(v.cpu().numpy(), v_ref.numpy(), atol=2e-5)
             np.testing.assert_allclose(j.cpu().numpy(), j_ref.numpy(), atol=2e-5)
+
+
+def _dense_names(mlp):
+    """(linear, batch norm, activation) state_dict prefixes of an MLP's layers in order (reference nn/layers.py:13-77)."""
+    mods = dict(mlp.named_modules())
+    names = {id(m): n for n, m in mods.items()}
+    return [(names[id(lin)], None if bn is None else names[id(bn)], None if act is None else names[id(act)])
+            for lin, bn, act in mlp.dense_specs()]
+
+
+@pytest.mark.parametrize('M,in_dim', [(8192, 296), (2048 + 40, 224)])
+def test_training_layer_products_on_three_bf16_pieces(M, in_dim):
+    """Large training batches (round 6, gemm_train_x3_kernel): the forward products y = a W^T (statistics epilogue) and the
+    reverse products dA = dY W (dyh epilogue) of the two update networks on three bf16 pieces per operand, the weights packed
+    once per step (empose_pack_weight_x3), against the same calls on the fp32 MFMA tile (option train_x3 = 0) -- outputs,
+    saved activations, BatchNorm statistics, cotangent stashes, BatchNorm / PReLU gradients, weight gradients -- to rounding
+    (the reverse sweeps read ONE set of saved activations, so no PReLU branch differs), and the forward against a float64
+    evaluation: no less accurate than the fp32 instruction.  Repeated calls are bit-identical."""
+    from tests.test_hip_round5 import _mlp_pair, _run_mlp_train
+    lib = _lib.lib()
+    hidden = 512
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, in_dim, generator=g).to(DEV)
+    d_outs = [torch.zeros(M, 68, device=DEV), torch.zeros(M, 12, device=DEV)]
+    d_outs[0][:, :66] = torch.randn(M, 66, generator=g).to(DEV)
+    d_outs[1][:, :10] = torch.randn(M, 10, generator=g).to(DEV)
+    res = {}
+    for key, opt in (('fp32', 0), ('x3', 1), ('x3_again', 1)):
+        nets = _mlp_pair(in_dim, hidden, 5)
+        with _Option(b'train_x3', opt):
+            res[key] = _run_mlp_train(nets, x, d_outs, M, pair=False, deferred=False,
+                                      saves_from=None if key == 'fp32' else res['fp32']['save'])
+    def flat(r):
+        return list(r['out']) + list(r['save']) + [t for b in r['bn'] for t in b] + [t for gl in r['grads'] for t in gl]
+    for a, b in zip(flat(res['x3']), flat(res['x3_again'])):
+        assert torch.equal(a, b)
+    worst = 0.0
+    for idx, (a, b) in enumerate(zip(flat(res['fp32']), flat(res['x3']))):
+        assert torch.isfinite(b.float()).all()
+        scale = max(1.0, float(a.abs().max()))
+        err = float((a.double() - b.double()).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < (1e-4 if a.ndim == 1 and a.numel() == hidden else 2e-5), (err, idx, a.shape)
+    # the forward against float64 (train-mode BatchNorm over the batch, reference nn/layers.py:13-77)
+    errs = {}
+    for key in ('fp32', 'x3'):
+        worst64 = 0.0
+        for i, net in enumerate(_mlp_pair(in_dim, hidden, 5)):
+            sd = {k: v.detach().double() for k, v in net.state_dict().items()}
+            h = x.double()
+            for lin, bn, act in [(n_[0], n_[1], n_[2]) for n_ in _dense_names(net)]:
+                h = h @ sd[lin + '.weight'].T + sd[lin + '.bias']
+                if bn is not None:
+                    mean, var = h.mean(0), h.var(0, unbiased=False)
+                    h = (h - mean) / torch.sqrt(var + 1e-5) * sd[bn + '.weight'] + sd[bn + '.bias']
+                    h = torch.where(h > 0, h, sd[act + '.weight'] * h)
+            want = h
+            worst64 = max(worst64, float((res[key]['out'][i].double() - want).abs().max()) / max(1.0, float(want.abs().max())))
+        errs[key] = worst64
+    print('training layers M=%d in=%d: three pieces vs fp32 tile worst relative difference %.2e; forward vs float64: fp32 %.2e, '
+          'three pieces %.2e' % (M, in_dim, worst, errs['fp32'], errs['x3']))
+    assert errs['x3'] <= 1.5 * errs['fp32'] + 1e-7
+
+
+def test_three_piece_kernels_keep_their_bits_beside_a_storing_kernel_on_another_stream(big_model):
+    """A global store issued by ANY wave of a SIMD while v_mfma_f32_32x32x16_bf16 is in flight there corrupts an accumulator
+    element (scripts/dev/bf16_hazard_repro.md).  Every kernel built on that instruction therefore allocates all 512 registers
+    of its SIMD lane (X3_EXCLUSIVE_SIMD, csrc/bf16x3.h): no wave of any other kernel -- another stream of this process, as
+    the training engine's side streams and the streaming evaluation driver use them, or another process -- fits beside it.
+    Here a second stream runs element-wise kernels (stores, no LDS, few registers: they fit anywhere there is room) without
+    pause while the headline-shaped forward (update MLPs, LSTM steps, heads, blend GEMMs on three pieces) and the full-mesh
+    evaluation repeat on the first one: every repetition has the bits of the run alone on the device.  A guard, not the
+    reproducer: found in round 6 when the three-piece training GEMMs met the engine's side streams -- two runs of the same
+    64-window step differed in the eighth digit; `scripts/dev/x3_shared_simd_lab.sh` shows five runs / five results without
+    the macro and five / one with it, and tests/test_bench_contract.py::test_training_with_buckets_rccl_and_side_streams_
+    equals_the_plain_step holds the exact equality in the suite."""
+    torch.manual_seed(3)
+    net = create_model(lgd_config(12, True, 4), SMPLLayer(big_model)).eval().to(DEV)
+    B, F = 512, 32
+    g = torch.Generator().manual_seed(7)
+    inputs = [torch.randn(B, F, 36, generator=g).to(DEV), torch.randn(B, F, 108, generator=g).to(DEV),
+              (0.02 * torch.randn(B, 12, 3, generator=g)).to(DEV),
+              torch.eye(3).repeat(B, 12, 1, 1).to(DEV)]
+    smpl = SMPLLayer(big_model).to(DEV)
+    T = 4096
+    kw = dict(poses_body=(torch.randn(T, 63, generator=g) * 0.5).to(DEV), betas=torch.randn(T, 10, generator=g).to(DEV),
+              poses_root=(torch.randn(T, 3, generator=g) * 0.5).to(DEV))
+
+    def run():
+        res = net.forward_tensors(*inputs)
+        v, j = smpl(**kw)
+        torch.cuda.synchronize()
+        return [res[k].clone() for k in ('pose', 'shape', 'joints')] + [v.clone()]
+    alone = run()
+    assert all(torch.isfinite(t).all() for t in alone)
+    side = torch.cuda.Stream()
+    big = torch.randn(1 << 26, device=DEV)
+    stop = []
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(400):
+                big.mul_(1.0000001).add_(1e-9)
+        got = run()
+        for a, b in zip(got, alone):
+            assert torch.equal(a, b)
+        side.synchronize()
