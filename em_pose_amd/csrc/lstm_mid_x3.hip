@@ -38,7 +38,7 @@ typedef const __attribute__((address_space(1))) unsigned short* lm3_gptr_t;
 __device__ __forceinline__ float lm3_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float lm3_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-template <int RTS>   // row tiles of 32 a workgroup multiplies: 1 (launches of at most 32 rows) or 2
+template <int RTS, int D>   // row tiles of 32 a workgroup multiplies: 1 (launches of at most 32 rows) or 2; ring depth
 __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
   X3_EXCLUSIVE_SIMD();
   using namespace lm3;
@@ -78,8 +78,12 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
       for (int v = 0; v < 16; ++v) acc[r][h][v] = 0.f;
 
   // ---- the wave's k-steps: g = wave + 4 i
-  u32x4_t fa[3][RTS][3], fw[3][3];
+  u32x4_t fa[D][RTS][3], fw[D][3];
+#ifdef LM3_LAB_NOK      // (dev, scripts/dev/lstm_mid_lab.sh: one k-step per wave -- what a launch costs without its K loop)
+  const int n_w = 1;
+#else
   const int n_w = (KS - wave + 3) / 4;
+#endif
   const unsigned short* const p_in = U.a3_in; const unsigned short* const p_rec = U.a3_rec;
   const unsigned short* const p_wih = U.w3_ih; const unsigned short* const p_whh = U.w3_hh;
   auto load = [&, p_in, p_rec, p_wih, p_whh](u32x4_t (&A)[RTS][3], u32x4_t (&W)[3], int i) {
@@ -106,19 +110,19 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
         acc[r][p & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, A[r][X3_PA[p]]),
                                                                 __builtin_bit_cast(bf16x8_t, W[X3_PB[p]]), acc[r][p & 1], 0, 0, 0);
   };
-  load(fa[0], fw[0], 0);
-  load(fa[1], fw[1], 1);
-  int i = 0;
-  for (; i + 3 <= n_w; i += 3) {
-    load(fa[2], fw[2], i + 2);
-    mma(fa[0], fw[0]);
-    load(fa[0], fw[0], i + 3);
-    mma(fa[1], fw[1]);
-    load(fa[1], fw[1], i + 4);
-    mma(fa[2], fw[2]);
+  // A ring of D k-steps: the fragments of D steps are in flight before the first product.  A step's operands come from the
+  // memory side of the L2 (every launch streams its weight block; the A planes were written by the launch before), ~2 us
+  // away: with two steps in flight (rounds 6a-6g) the 16 steps of a wave were eight round trips, 7.4 us per launch at
+  // 32 rows; the ring costs registers only (24 per step and row tile) and the wave has all 512.
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(fa[d], fw[d], d);
+  for (int i0 = 0; i0 < n_w; i0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (i0 + d < n_w) mma(fa[d], fw[d]);                       // (uniform)
+      if (i0 + d + D < n_w) load(fa[d], fw[d], i0 + d + D);
+    }
   }
-  if (i < n_w) mma(fa[0], fw[0]);
-  if (i + 1 < n_w) mma(fa[1], fw[1]);
 
   // ---- partial sums -> LDS as [wave][column][row] (16-byte pieces of four consecutive rows of a column)
   {
@@ -170,15 +174,24 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
   }
 }
 
+#ifndef LM3_RING1
+#define LM3_RING1 8
+#endif
+#ifndef LM3_RING2
+#define LM3_RING2 6
+#endif
+
 hipError_t launch_lstm_mid_x3(const LstmX3Args& a, hipStream_t stream) {
   if (a.n_units == 0) return hipSuccess;
   dim3 grid(a.H / lm3::BU, (a.B + lm3::BM - 1) / lm3::BM, a.n_units);
   if (a.B <= 32) {
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(lstm_mid_x3_kernel<1>), lm3::LDS_BYTES)) return e;
-    hipLaunchKernelGGL(lstm_mid_x3_kernel<1>, grid, dim3(lm3::NT), lm3::LDS_BYTES, stream, a);
+    auto* fn = lstm_mid_x3_kernel<1, LM3_RING1>;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(fn), lm3::LDS_BYTES)) return e;
+    hipLaunchKernelGGL(fn, grid, dim3(lm3::NT), lm3::LDS_BYTES, stream, a);
   } else {
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(lstm_mid_x3_kernel<2>), lm3::LDS_BYTES)) return e;
-    hipLaunchKernelGGL(lstm_mid_x3_kernel<2>, grid, dim3(lm3::NT), lm3::LDS_BYTES, stream, a);
+    auto* fn = lstm_mid_x3_kernel<2, LM3_RING2>;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(fn), lm3::LDS_BYTES)) return e;
+    hipLaunchKernelGGL(fn, grid, dim3(lm3::NT), lm3::LDS_BYTES, stream, a);
   }
   return hipGetLastError();
 }

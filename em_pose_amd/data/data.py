@@ -120,6 +120,17 @@ class RealBatch(ABatch):
                          pad([s.marker_ori_real for s in samples]), pad([s.marker_masks for s in samples]),
                          torch.stack([s.offset_means for s in samples]), torch.stack([s.offset_r for s in samples]))
 
+    def pin_memory(self):
+        """The hook `torch.utils.data.DataLoader(pin_memory=True)` calls on a custom batch type: every host field into
+        page-locked memory, so that `.to(device, non_blocking=True)` of a field (or of a slice of it) neither stages nor
+        blocks.  A loader's job, once per batch; the evaluation drivers only benefit from it."""
+        for name in ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes', 'trans',
+                     'offset_t', 'offset_r'):
+            f = getattr(self, name)
+            if torch.is_tensor(f) and not f.is_cuda and not f.is_pinned():
+                setattr(self, name, f.contiguous().pin_memory())
+        return self
+
     def to_gpu(self, device=None):
         device = C.DEVICE if device is None else device
         names = ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes',

@@ -309,6 +309,12 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
     that still have frames, `seq_lengths` = frames left in this chunk, LSTM state carried per row).  Windows are
     independent of each other in the model, so this only changes how much work one launch carries:
     36 recordings need 14 launches of the loop instead of 211.
+
+    The metric rows of a chunk are scattered on the device to where they belong in ONE block in recording order; a
+    recording's rows go to the host (pinned memory, side stream) with the chunk it ends in, and its table row is worked
+    out while the device runs the chunks after it -- the host part of the metrics (a third of a pass when it ran after the
+    last chunk) is hidden behind the device, which is the bound of this driver (the LSTM's dependent steps).
+
     `host_times` (a dict, optional): seconds of host time per section of the pass (dev: where a slow pass spends it).
     """
     import time as _time
@@ -337,38 +343,76 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
         sl = [lengths[i] for i in order]
         n_chunks = (sl[0] + window_size - 1) // window_size
         dev = torch.device(device)
+        on_gpu = dev.type == 'cuda'
+        # (fields a loader has pinned -- RealBatch.pin_memory -- go up without staging and without blocking the host)
+        up = lambda t: t.to(device=device, dtype=C.DTYPE, non_blocking=True)
         fields = ('poses', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks')
-        packed = {k: pad_sequence([getattr(batches[i], k)[0].to(device=device, dtype=C.DTYPE) for i in order],
-                                  batch_first=True) for k in fields}
-        whole = {k: torch.cat([getattr(batches[i], k).to(device=device, dtype=C.DTYPE) for i in order])
-                 for k in ('shapes', 'offset_t', 'offset_r')}
+        packed = {k: pad_sequence([up(getattr(batches[i], k)[0]) for i in order], batch_first=True) for k in fields}
+        whole = {k: torch.cat([up(getattr(batches[i], k)) for i in order]) for k in ('shapes', 'offset_t', 'offset_r')}
         # the frames that count -- inside the recording and every sensor present -- from the host copies of the masks
         # (numpy: a torch CPU op on a 36 x 256 x 12 block wakes the whole intra-op thread pool)
         valid_all = np.zeros((n, sl[0]), dtype=bool)
         for j, i in enumerate(order):
             valid_all[j, :sl[j]] = (batches[i].marker_masks[0].numpy() != 0).all(axis=-1)
         # As in `evaluate_sequences`: chunk c + 1's packing and LSTM (current stream) beside chunk c's refinement
-        # iterations and metrics (side stream); nothing in the loop reads device results back.
+        # iterations and metrics (side stream); nothing in the loop waits for the device.
         side = None
-        if dev.type == 'cuda' and not net.training:
+        if on_gpu and not net.training:
             side = getattr(net, '_side_stream', None)
             if side is None or side.device != dev:
                 side = net._side_stream = torch.cuda.Stream(device=dev)
             net.iter_stream = side
-        me_chunks = MetricsEngine(smpl_model)   # every chunk's rows, in (chunk, row, frame) order; read back ONCE
-        counts = []                             # per chunk: valid frames of each of its rows
+        me_chunks = MetricsEngine(smpl_model)
+        placed = on_gpu and me_chunks.angle_glob and hasattr(smpl_model, 'fk_joints')   # (the device path of `compute`)
+        # Where every frame's row goes: recording i owns rows base[i] .. base[i + 1] of one block, its valid frames in
+        # frame order (what the sequential driver accumulates, recording after recording); frames that do not count go to
+        # a spare row past the end.
+        per_row = valid_all.sum(axis=1)
+        base = np.zeros(n + 1, dtype=np.int64)
+        base[1:][order] = per_row
+        base = np.concatenate([[0], np.cumsum(base[1:])])
+        total = int(base[-1])
+        if placed:
+            dest_all = np.where(valid_all, np.cumsum(valid_all, axis=1) - 1 + base[:-1][order][:, None], total)
+            dest_host = torch.from_numpy(np.ascontiguousarray(dest_all, dtype=np.int64)).pin_memory()
+            dest_dev = dest_host.to(device, non_blocking=True)
+            rows_dev = torch.empty(total + 1, 65, dtype=torch.float64, device=dev)
+            rows_host = torch.empty(max(total, 1), 65, dtype=torch.float64, pin_memory=True)
+            rows_np = rows_host.numpy()[:total]   # (the view keeps the pinned block alive; torch caches it afterwards)
+        counts = []                             # not placed: per chunk, the valid frames of each of its rows
+        arrived = []                            # placed: (event, recordings whose rows it brings), in chunk order
+        results = [None] * n                    # per recording: its table row
+
+        def table_row(i):
+            me = MetricsEngine(smpl_model)
+            r = rows_np[base[i]:base[i + 1]]
+            me.merge({'eucl': r[:, :22], 'eucl_pa': r[:, 22:44], 'angle': r[:, 44:]})
+            results[i] = (batches[i].ids[0], me.get_metrics())
+
+        def take_arrived(wait):
+            while arrived and (wait or arrived[0][0].query()):
+                ev, recs = arrived.pop(0)
+                ev.synchronize()
+                for i in recs:
+                    table_row(i)
+        # the lengths of every chunk's rows in ONE pinned block and one copy that does not block (a pageable copy would make
+        # the host wait for the stream; a pinned block per chunk asks the host allocator 14 times a pass, and a request it
+        # cannot serve from its cache waits for the device)
+        lens_all = np.clip(np.asarray(sl, dtype=np.int64)[None, :] - window_size * np.arange(n_chunks)[:, None], 0,
+                           window_size).astype(np.int32)
+        lens_all_dev = torch.from_numpy(lens_all)
+        if on_gpu:
+            lens_all_dev = lens_all_dev.pin_memory().to(device, non_blocking=True)
         state, first_shape, frames = None, None, 0
         lap('setup')
         for c in range(n_chunks):
             sf = c * window_size
             k = sum(1 for L in sl if L > sf)
+            k_next = sum(1 for L in sl if L > sf + window_size)
             lens = [min(window_size, L - sf) for L in sl[:k]]
             f = lens[0]
             cut = lambda name: packed[name][:k, sf:sf + f]
-            # (the lengths through pinned memory, not blocking: a pageable copy would make the host wait for the stream)
-            lens_dev = torch.tensor(lens, dtype=torch.int32)
-            if dev.type == 'cuda':
-                lens_dev = lens_dev.pin_memory().to(device, non_blocking=True)
+            lens_dev = lens_all_dev[c, :k]
             chunk = RealBatch([batches[i].ids[0] for i in order[:k]], lens_dev, cut('poses'),
                               whole['shapes'][:k], cut('trans'), cut('marker_pos_real'), cut('marker_ori_real'),
                               cut('marker_masks'), whole['offset_t'][:k], whole['offset_r'][:k]).to_gpu(device)
@@ -391,15 +435,38 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
                 me_chunks.compute(chunk.poses_body, chunk.shapes, out['pose_hat'], first_shape[:k], chunk.seq_lengths,
                                   chunk.poses_root, out['root_ori_hat'], frame_mask=chunk.marker_masks,
                                   valid=torch.from_numpy(np.ascontiguousarray(valid_np)))
-            counts.append(valid_np.sum(axis=1).tolist())
+                if placed:
+                    (rows, _, _), = me_chunks.take_device_rows()
+                    if side is not None:
+                        dest_dev.record_stream(side)
+                        rows_dev.record_stream(side)
+                    rows_dev.index_copy_(0, dest_dev[:k, sf:sf + f].reshape(-1), rows)
+                    ended = [order[j] for j in range(k_next, k)]   # the recordings whose last chunk this was
+                    for i in ended:
+                        if base[i + 1] > base[i]:
+                            rows_host[base[i]:base[i + 1]].copy_(rows_dev[base[i]:base[i + 1]], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    arrived.append((ev, ended))
+            if not placed:
+                counts.append(valid_np.sum(axis=1).tolist())
             frames += sum(lens)
             lap('metrics_enqueue')
+            take_arrived(wait=False)
+            lap('per_recording_metrics')
+        if placed:
+            take_arrived(wait=True)     # (the last event is the end of the side stream's work)
+            lap('wait_for_device')
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        if dev.type == 'cuda':
+        if on_gpu:
             torch.cuda.synchronize(dev)
             _check_async(dev)
         lap('wait_for_device')
+        if placed:
+            me_all = MetricsEngine(smpl_model)
+            me_all.merge({'eucl': rows_np[:, :22], 'eucl_pa': rows_np[:, 22:44], 'angle': rows_np[:, 44:]})
+            return me_all, results, frames
         st = me_chunks.state()    # one device-side gather of the valid rows, one copy to (cached) pinned host memory
         engines = [MetricsEngine(smpl_model) for _ in range(n)]
         at = 0

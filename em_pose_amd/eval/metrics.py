@@ -145,6 +145,13 @@ class MetricsEngine(object):
         # kept on the device until somebody reads the accumulators: no host round trip per chunk
         self._pending.append((rows, pose is not None, valid))
 
+    def take_device_rows(self):
+        """The rows of the `compute` calls since the last read, still on the device and no longer this engine's:
+        [(rows (m, 65) float64 = 22 Euclidean | 22 Procrustes | 21 angle columns, has_angle, valid), ...] in call order.
+        For a driver that places and reads the rows itself (eval/helpers.py::evaluate_sequences_batched)."""
+        pending, self._pending = self._pending, []
+        return pending
+
     def _flush(self):
         """Device rows of earlier `compute` calls -> the host accumulators, in call order: ONE gather of the rows that
         count on the device (the per-call tensors concatenated, the valid rows picked by an index built on the host) and

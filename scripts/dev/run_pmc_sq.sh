@@ -10,7 +10,7 @@ mkdir -p gpurun_out
 OUT=$R/gpurun_out/pmc_sq_$TAG
 rm -rf $OUT
 ( cd /tmp && timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
-    --kernel-trace --output-format csv -d $OUT -o pmc -- ${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile ${BENCH_ARGS:-}} > $OUT.log 2>&1 )
+    --kernel-trace --output-format csv -d $OUT -o pmc -- ${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_profile --no_secondary --no_traffic ${BENCH_ARGS:-}} > $OUT.log 2>&1 )
 tail -3 $OUT.log
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys

@@ -191,6 +191,8 @@ def main():
     net, smpl, lengths, load, name = (synthetic_setup if args.synthetic else real_setup)(args, device)
     mine = partition_sequences(lengths, world)[rank]
     batches = [load(i) for i in mine]  # data preparation is outside the timed region
+    if not on_cpu:   # what DataLoader(pin_memory=True) does with a batch: uploads neither stage nor block the host
+        batches = [b.pin_memory() for b in batches]
     net.keep_history = False
     from em_pose_amd.nn.models import IterativeErrorFeedback
     sequential = args.sequential or not isinstance(net, IterativeErrorFeedback)

@@ -1043,6 +1043,19 @@ def test_batched_streaming_equals_sequential():
             assert mb[k] == pytest.approx(ma[k], rel=1e-5, abs=1e-4), (ida, k)
     for k, v in a_all.get_metrics().items():
         assert b_all.get_metrics()[k] == pytest.approx(v, rel=1e-5, abs=1e-4)
+    # the overall engine holds the rows in recording order, as the sequential driver accumulates them
+    sa, sb = a_all.state(), b_all.state()
+    for key in sa:
+        assert sa[key].shape == sb[key].shape, key
+        np.testing.assert_allclose(sb[key], sa[key], rtol=1e-4, atol=1e-4, err_msg=key)
+    # page-locked fields (RealBatch.pin_memory, what a DataLoader with pin_memory=True hands over): same bits
+    c_all, c_seq, c_frames = evaluate_sequences_batched(net, [b.pin_memory() for b in batches], smpl, torch.device(DEV))
+    assert c_frames == b_frames and [i for i, _ in c_seq] == [i for i, _ in b_seq]
+    for (_, mb), (_, mc) in zip(b_seq, c_seq):
+        assert mb == mc
+    sc = c_all.state()
+    for key in sb:
+        assert np.array_equal(sb[key], sc[key]), key
 
 
 # ----------------------------------------------------------------------------------------------------------------------
