@@ -447,6 +447,9 @@ struct LstmWs {
   // lstm_x3.hip: the stored input of every time step and the hidden states (ping-pong) as bf16 piece planes, or nullptr
   unsigned short* x3; size_t x3_t_stride;
   unsigned short* a3[8][2];
+  // lstm_midseq_x3.hip: [F + 1] sets of hidden-state planes per layer and the progress counters, or nullptr
+  unsigned short* xa[8];
+  unsigned* midseq_flags;
 };
 // bf16 elements of one set of A planes: [32-row tiles][k-steps][3 pieces][512]
 size_t lstm_x3_plane_elems(int B, int K) { return (size_t)((B + 31) / 32) * ((K + 15) / 16) * 3 * 512; }
@@ -466,6 +469,18 @@ bool lstm_x3_mid_covers(const Lstm& r, int B) {
     if (!r.w3m_ih[l] || !r.w3m_hh[l]) return false;
   return true;
 }
+// medium batches, whole sequence in one launch: lstm_midseq_x3.hip (needs the 8-unit-block weight order too)
+constexpr int LSTM_MIDSEQ_MIN_B = 4, LSTM_MIDSEQ_MAX_B = 64;   // (up to 3 rows: lstm_persist_kernel)
+bool lstm_x3_midseq_covers(const Lstm& r, int B) {
+  if (options().lstm_x3 == 0 || options().lstm_mid_x3 == 0 || options().lstm_midseq == 0 || r.dirs != 1) return false;
+  if (B < LSTM_MIDSEQ_MIN_B || B > LSTM_MIDSEQ_MAX_B || r.num_layers > 4 || r.input_size % 4 != 0) return false;
+  int ks_in[4];
+  for (int l = 0; l < r.num_layers; ++l) {
+    if (!r.w3m_ih[l] || !r.w3m_hh[l]) return false;
+    ks_in[l] = l == 0 ? (r.input_size + 15) / 16 : r.H / 16;
+  }
+  return lstm_midseq_shape_ok(B, r.H, r.num_layers, ks_in);
+}
 LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   LstmWs w;
   const int H = r.H, U = r.num_layers * r.dirs;
@@ -482,12 +497,17 @@ LstmWs carve_lstm_of(Carver& c, const Lstm& r, int B, int F) {
   const bool seq = r.dirs == 1 && B >= LSTM_SEQ_MIN_B && r.num_layers <= 4;
   for (int u = 0; u < 8; ++u) w.h3[u] = (seq && u < U) ? c.f((size_t)B * H) : nullptr;
   w.seq_cnt = seq ? reinterpret_cast<unsigned*>(c.f(lstm_seq_counter_uints(B))) : nullptr;
-  const bool x3 = lstm_x3_covers(r, B) || lstm_x3_mid_covers(r, B);
+  const bool midseq = lstm_x3_midseq_covers(r, B);
+  const bool x3 = lstm_x3_covers(r, B) || lstm_x3_mid_covers(r, B) || midseq;
   w.x3_t_stride = lstm_x3_plane_elems(B, r.input_size);
   w.x3 = x3 ? reinterpret_cast<unsigned short*>(c.f((w.x3_t_stride * F + 1) / 2)) : nullptr;
   for (int u = 0; u < 8; ++u)
     for (int k = 0; k < 2; ++k)
       w.a3[u][k] = (x3 && u < U) ? reinterpret_cast<unsigned short*>(c.f((lstm_x3_plane_elems(B, H) + 1) / 2)) : nullptr;
+  for (int u = 0; u < 8; ++u)
+    w.xa[u] = (midseq && u < U) ? reinterpret_cast<unsigned short*>(c.f((lstm_x3_plane_elems(B, H) * (size_t)(F + 1) + 1) / 2))
+                                : nullptr;
+  w.midseq_flags = midseq ? reinterpret_cast<unsigned*>(c.f(lstm_midseq_flag_uints(U, H))) : nullptr;
   return w;
 }
 LstmWs carve_lstm(Carver& c, const empose_model* m, int B, int F) { return carve_lstm_of(c, m->rnn, B, F); }
@@ -668,6 +688,29 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
       hipError_t e = launch_lstm_seq(a, ws.h3, ws.seq_cnt, stream, &done);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel (large batch): %s", hipGetErrorString(e));
       seq_done = done;
+    }
+    // Medium batches, inference: the whole sequence in one cooperative launch on three bf16 pieces per operand, weights in
+    // registers (lstm_midseq_x3.hip); falls back to the step launches below when it cannot be launched here.
+    if (!done && ws.xa[0] && ws.x3 && F >= 4 && !a.unit[0].sv_gates && lstm_x3_midseq_covers(r, B)) {
+      prof_mark(P_COPY, stream);
+      const int KS_in = (r.input_size + 15) / 16, KS_h = H / 16;
+      hipError_t e = launch_lstm_split_rows(x, (long)F * ldx, ldx, F, B, r.input_size, KS_in, ws.x3, (long)ws.x3_t_stride, stream);
+      for (int l = 0; l < L && e == hipSuccess; ++l)
+        e = launch_lstm_split_rows(ws.h[l][0], H, 0, 1, B, H, KS_h, ws.xa[l], 0, stream);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm operand split: %s", hipGetErrorString(e));
+      LstmMidSeqArgs qa;
+      qa.n_units = L; qa.seq_lengths = seq_lengths; qa.B = B; qa.F = F; qa.H = H; qa.flags = ws.midseq_flags;
+      for (int l = 0; l < 4; ++l) {
+        const int ll = l < L ? l : 0;
+        LstmMidSeqUnit& qu = qa.unit[l];
+        qu.w3_ih = r.w3m_ih[ll]; qu.w3_hh = r.w3m_hh[ll]; qu.bias = r.bias[ll];
+        qu.in3 = ws.x3; qu.in_t_stride = ws.x3_t_stride; qu.ks_in = ll == 0 ? KS_in : KS_h;
+        qu.xa = ws.xa[ll]; qu.h0 = ws.h[ll][0]; qu.h_last = ws.h[ll][F & 1]; qu.c = ws.c[ll];
+        qu.y = ll == L - 1 ? y : nullptr; qu.y_ld = H; qu.y_col = 0;
+      }
+      prof_mark(P_LSTM_STEP, stream);
+      e = launch_lstm_midseq_x3(qa, stream, &done);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm sequence kernel (medium batch): %s", hipGetErrorString(e));
     }
     // Large batches, inference: the steps on the bf16 matrix path with three bf16 pieces per operand (lstm_x3.hip)
     const bool mid3 = lstm_x3_mid_covers(r, B);
@@ -1003,6 +1046,7 @@ int empose_set_option(const char* name, int value) {
       {"cols_coop", &o.cols_coop},
       {"mesh_x3", &o.mesh_x3},
       {"lstm_mid_x3", &o.lstm_mid_x3},
+      {"lstm_midseq", &o.lstm_midseq},
       {"train_x3", &o.train_x3},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
@@ -1055,6 +1099,7 @@ int empose_get_option(const char* name) {
       {"cols_coop", o.cols_coop},
       {"mesh_x3", o.mesh_x3},
       {"lstm_mid_x3", o.lstm_mid_x3},
+      {"lstm_midseq", o.lstm_midseq},
       {"train_x3", o.train_x3},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};

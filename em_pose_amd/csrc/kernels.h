@@ -50,6 +50,10 @@ struct Options {
   int train_x3 = 1;       // training at more than 1024 rows: the layer products y = a W^T and dA = dY W of the update networks on
                           // three bf16 pieces (gemm_train_x3_kernel) when the caller supplies the packed weights
                           // (empose_mlp_params::weight_x3 / weight_t_x3); 0: the fp32 MFMA tile
+  int lstm_midseq = 0;    // 1: medium batches (4 .. 64 rows, inference): the whole sequence in one cooperative launch with the
+                          // weight pieces in registers (lstm_midseq_x3.hip) -- built, same bits, measured SLOWER than a launch
+                          // per wavefront step (10.5 against 8.2 us per step at 32 rows: a hand-over between XCDs costs more
+                          // than a kernel boundary; profiles/r06i_lstm_midseq_lab.txt), so opt-in
   int lstm_mid_x3 = 1;    // LSTM steps of 17 .. 256 rows (inference, uni-directional) on three bf16 pieces, 64 x 8-unit tiles
                           // (lstm_mid_x3.hip); 0: lstm_mid_kernel (fp32 MFMA, operands through LDS)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
@@ -366,6 +370,29 @@ hipError_t launch_lstm_rows_x3(const LstmX3Args& a, hipStream_t stream);
 // the step of MEDIUM batches (17 .. 256 rows): 64 rows x 8 units per workgroup, weights in the 8-unit-block order
 // (api.hip pack_lstm_x3 with mid = true), K split over the waves (lstm_mid_x3.hip; option lstm_mid_x3)
 hipError_t launch_lstm_mid_x3(const LstmX3Args& a, hipStream_t stream);
+// The whole sequence of a medium batch (B <= 64) in one cooperative launch with the weight pieces in registers
+// (lstm_midseq_x3.hip; option lstm_midseq): same tiles, products and bits as the step launches of lstm_mid_x3.hip.
+struct LstmMidSeqUnit {
+  const unsigned short* w3_ih; const unsigned short* w3_hh;   // the 8-unit-block order of lstm_mid_x3.hip
+  const float* bias;                 // [4H] = b_ih + b_hh
+  const unsigned short* in3; size_t in_t_stride;   // layer 0: planes of the stored input, bf16 elements per time step
+  int ks_in;                         // k-steps of 16 of the unit's input
+  unsigned short* xa;                // [F + 1] sets of planes of the unit's hidden state: slot 0 = initial, slot t + 1 = h_t
+  const float* h0; float* h_last; float* c;   // [B][H] fp32: initial hidden state, final hidden state, cell state (in place)
+  float* y; int y_ld, y_col;         // output sequence [B][F][y_ld] or nullptr
+};
+struct LstmMidSeqArgs {
+  LstmMidSeqUnit unit[4];
+  int n_units;
+  const int* seq_lengths;
+  int B, F, H;
+  unsigned* flags;                   // [n_units][H / 8] progress counters (lstm_midseq_flag_uints), zeroed by the launcher
+  int spin_limit;
+  unsigned* timeouts;                // poll_timeout_word()
+};
+size_t lstm_midseq_flag_uints(int n_units, int H);
+bool lstm_midseq_shape_ok(int B, int H, int n_units, const int* ks_in);
+hipError_t launch_lstm_midseq_x3(const LstmMidSeqArgs& a, hipStream_t stream, bool* done);
 hipError_t launch_lstm_split_rows(const float* src, long row_stride, long z_stride, int n_z, int B, int K, int KS,
                                   unsigned short* dst, long dst_z_stride, hipStream_t stream);
 constexpr int LSTM_SEQ_MIN_B = 257;   // below: lstm_mid_kernel / the small-batch kernels

@@ -295,3 +295,103 @@ def test_three_piece_kernels_keep_their_bits_beside_a_storing_kernel_on_another_
         for a, b in zip(got, alone):
             assert torch.equal(a, b)
         side.synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Medium batches, the whole sequence in one cooperative launch (csrc/lstm_midseq_x3.hip)
+@pytest.mark.parametrize('B,F,In,Hd,L', [(36, 64, 72, 512, 2), (17, 9, 144, 512, 2), (32, 5, 144, 256, 2), (64, 33, 72, 64, 1),
+                                         (20, 16, 36, 128, 4), (33, 4, 72, 192, 3),
+                                         (4, 12, 72, 512, 2), (12, 40, 72, 512, 2), (16, 7, 144, 192, 3)])
+def test_medium_batch_whole_sequence_lstm_equals_its_step_launches(B, F, In, Hd, L):
+    """lstm_midseq_x3_kernel (4 .. 64 rows: weights in registers for all steps, hidden states handed over through fresh
+    A planes and progress counters; opt-in, option lstm_midseq = 1) against the launches per wavefront step: from 17 rows on those
+    are lstm_mid_x3_kernel -- same tiles, same products in the same order -- and every output has the same BITS; below, the
+    step launches are the fp32 kernels of a few rows and both are held to a float64 LSTM (reference nn/layers.py:133-157:
+    ragged rows, carried state, zero-padded outputs).  Repeated runs are bit-identical."""
+    from em_pose_amd.nn.layers import RNNLayer
+    torch.manual_seed(B * 7 + F)
+    layer = RNNLayer(In, Hd, L).eval()
+    with torch.no_grad():
+        for p in layer.lstm.parameters():
+            p.mul_(2.0)
+    x = torch.randn(B, F, In)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0], lens[-1] = F, 1
+    h0, c0 = 0.5 * torch.randn(L, B, Hd), 0.5 * torch.randn(L, B, Hd)
+    sd64 = {'lstm.' + k: v.detach().double() for k, v in layer.lstm.state_dict().items()}
+    with torch.no_grad():
+        want = {st is not None: R.lstm_forward(sd64, 'lstm.', x.double(), lens, None if st is None else (h0.double(), c0.double()),
+                                               L, False) for st in (None, 1)}
+    g = layer.to(DEV)
+    outs, err = {}, {}
+    for one_launch in (0, 1):
+        with _Option(b'lstm_midseq', one_launch):
+            first, worst = None, 0.0
+            for rep in range(3 if one_launch else 1):
+                got_all = []
+                for carried in (False, True):
+                    g.init_state = (h0.to(DEV), c0.to(DEV)) if carried else None
+                    y = g(x.to(DEV), lens.to(DEV))
+                    torch.cuda.synchronize()
+                    wy, (wh, wc) = want[carried]
+                    got = (y.cpu(), g.final_state[0].cpu(), g.final_state[1].cpu())
+                    got_all += [t.numpy() for t in got]
+                    worst = max(worst, float((got[0].double() - wy).abs().max()), float((got[1].double() - wh).abs().max()),
+                                float((got[2].double() - wc).abs().max()))
+                if first is None:
+                    first = got_all
+                else:
+                    for a_, b_ in zip(first, got_all):
+                        assert np.array_equal(a_, b_)
+            outs[one_launch], err[one_launch] = first, worst
+    assert _lib.lib().empose_async_status() == 0
+    print('lstm %s vs float64: step launches %.2e, one launch %.2e' % ((B, F, In, Hd, L), err[0], err[1]))
+    assert err[1] < 1e-5 and err[1] <= 1.5 * err[0] + 2e-7
+    if B >= 17:
+        for a_, b_ in zip(outs[0], outs[1]):
+            assert np.array_equal(a_, b_)
+    g.release()
+
+
+@pytest.mark.provokes_poll_timeout
+def test_medium_batch_whole_sequence_lstm_reports_a_poll_that_gave_up():
+    """spin_limit = 1: the polls of lstm_midseq_x3_kernel give up almost at once; empose_async_status() says
+    EMPOSE_ETIMEOUT exactly when the outputs hold NaN, and with the normal limit the layer gives the reference's numbers."""
+    from em_pose_amd.nn.layers import RNNLayer
+    lib = _lib.lib()
+    assert lib.empose_async_status() == 0
+    B, F, In, H, L = 24, 48, 72, 512, 2
+    torch.manual_seed(3)
+    layer = RNNLayer(In, H, L).eval()
+    sd = {'lstm.' + k: v.detach().clone() for k, v in layer.lstm.state_dict().items()}
+    g = layer.to(DEV)
+    x = torch.randn(B, F, In)
+    lens = torch.full((B,), F, dtype=torch.int64)
+    with torch.no_grad():
+        want, _ = R.lstm_forward(sd, 'lstm.', x, lens, None, L, False)
+    timed_out = 0
+    _lib.check(lib.empose_set_option(b'lstm_midseq', 1))
+    g.release()                       # (the workspace is carved for the kernels the options select)
+    for attempt in range(12):
+        if timed_out >= 2:
+            break
+        _lib.check(lib.empose_set_option(b'spin_limit', 1))
+        g.init_state = None
+        got = g(x.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        _lib.check(lib.empose_set_option(b'spin_limit', 0))
+        has_nan = bool(torch.isnan(got).any()) or bool(torch.isnan(g.final_state[0]).any())
+        status = lib.empose_async_status()
+        assert (status == -4) == has_nan, (status, has_nan)
+        if status == -4:
+            timed_out += 1
+            assert b'timed out' in lib.empose_last_error()
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    assert timed_out >= 1, 'spin_limit = 1 never made a poll give up'
+    g.init_state = None
+    got = g(x.to(DEV), lens.to(DEV))
+    torch.cuda.synchronize()
+    assert lib.empose_async_status() == 0
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
+    g.release()
