@@ -302,13 +302,13 @@ class MLP(nn.Module):
         y = self.dropout(bn_prelu_train(linear_train(x, self.input_to_hidden), self.batch_norm, self.activation_fn))
         for block in self.hidden_layers:
             z = y
-            for lin, bn, act in block.dense_specs():
+            mods = list(block.layers)
+            step = 4 if block.use_batch_norm else 3      # (Linear, [BatchNorm1d], PReLU, Dropout) per dense layer
+            for k in range(0, len(mods), step):
+                lin, act, drop = mods[k], mods[k + step - 2], mods[k + step - 1]
                 z = linear_train(z, lin)
-                z = bn_prelu_train(z, bn, act) if bn is not None else act(z)
-                # (the block's Dropout has p = 0 in every released configuration; applied below when it does not)
-            for m in block.layers:
-                if isinstance(m, nn.Dropout) and m.p > 0:
-                    raise NotImplementedError('dropout inside the hidden blocks is not part of the training path')
+                z = bn_prelu_train(z, mods[k + 1], act) if block.use_batch_norm else act(z)
+                z = drop(z)      # p = 0 in every released configuration; a torch op on the GPU when it is not
             y = y + z if block.use_skip else z
         return linear_train(y, self.hidden_to_output)
 
@@ -399,8 +399,6 @@ class RNNLayer(nn.Module):
     def __init__(self, input_size, hidden_size, num_layers, output_size=None, bidirectional=False, dropout=0.0,
                  learn_init_state=False):
         super(RNNLayer, self).__init__()
-        if dropout > 0.0:
-            raise NotImplementedError('input dropout is a training-time feature; the HIP path is inference')
         if bidirectional and learn_init_state:
             raise NotImplementedError('the reference reshapes the learned state to (B, L, H) (layers.py:125-130), which '
                                       'does not fit a bidirectional LSTM')
@@ -410,7 +408,8 @@ class RNNLayer(nn.Module):
         self.learn_init_state = learn_init_state
         self.is_bidirectional = bidirectional
         self.num_directions = 2 if bidirectional else 1
-        self.input_drop = nn.Identity()
+        # dropout on the inputs (reference layers.py:103-106, 140): active in training mode only, i.e. on `forward_torch`
+        self.input_drop = nn.Dropout(p=dropout) if dropout > 0.0 else nn.Identity()
         self.init_state = None
         self.final_state = None
         if self.learn_init_state:
@@ -510,13 +509,29 @@ class RNNLayer(nn.Module):
             y = linear_hip(y.reshape(B * F, -1), self.to_out).reshape(B, F, -1)
         return y
 
+    @staticmethod
+    def _reverse_rows(x, lens):
+        """Every row's first `lens[b]` frames in reverse order, the padding where it was (what a packed sequence hands to
+        the backward direction of a bidirectional LSTM)."""
+        F = x.shape[1]
+        idx = torch.arange(F, device=x.device).unsqueeze(0)
+        n = lens.to(device=x.device, dtype=torch.int64).unsqueeze(1)
+        src = torch.where(idx < n, n - 1 - idx, idx)
+        return torch.gather(x, 1, src.unsqueeze(-1).expand_as(x))
+
     def forward_torch(self, x, seq_lengths, full_length=False):
-        """Training path with an autograd graph (configurations nn/train_engine.py does not cover): the hand-written
-        LSTM forward + back-propagation through time as one autograd Function (reference layers.py:133-157).
-        `full_length=True`: every row spans all F frames (no lengths needed)."""
+        """Training path with an autograd graph (configurations nn/train_engine.py does not cover, and the baselines):
+        the hand-written LSTM forward + back-propagation through time as one autograd Function (reference
+        layers.py:133-157).  `full_length=True`: every row spans all F frames (no lengths needed).
+        A bidirectional stack is composed from the same Function: per layer one pass over the rows as they are and one
+        over the rows reversed within their lengths, outputs concatenated (what nn.LSTM does with a packed sequence)."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
-        if x.is_cuda and not self.is_bidirectional and self.num_layers <= 4 and x.dtype == torch.float32 and \
-                x.shape[2] % 4 == 0:
+        x = self.input_drop(x)
+        if self.learn_init_state and self.training:
+            raise NotImplementedError('a learned initial state is not trained on the HIP path: the LSTM Function takes '
+                                      '(h_0, c_0) as constants')
+        on_hip = x.is_cuda and self.num_layers <= 4 and x.dtype == torch.float32 and x.shape[2] % 4 == 0
+        if on_hip and not self.is_bidirectional:
             # hand-written forward + back-propagation through time; no packing, no host round trip, capturable
             lens = None if full_length else seq_lengths.to(device=x.device, dtype=torch.int32).contiguous()
             h0 = c0 = None
@@ -525,15 +540,43 @@ class RNNLayer(nn.Module):
             weights = [w for unit in self._unit_params() for w in unit]
             y, h_n, c_n = _LstmTrainFn.apply(x, lens, h0, c0, self.num_layers, *weights)
             self.final_state = (h_n, c_n)
-            return y
-        # fallback (bidirectional stacks, CPU tensors): nn.LSTM over packed sequences, as the reference
+            return self._to_out_train(y)
+        if on_hip and self.hidden_size % 2 == 0:
+            B, F = x.shape[0], x.shape[1]
+            lens64 = torch.full((B,), F, dtype=torch.int64, device=x.device) if full_length else \
+                seq_lengths.to(device=x.device, dtype=torch.int64)
+            lens = lens64.to(torch.int32).contiguous()
+            units = list(self._unit_params())
+            hs, cs = [], []
+            for l in range(self.num_layers):
+                outs = []
+                for d in range(2):
+                    u = 2 * l + d
+                    h0 = c0 = None
+                    if self.init_state is not None:
+                        h0, c0 = [t[u:u + 1].detach().to(device=x.device, dtype=torch.float32).contiguous()
+                                  for t in self.init_state]
+                    xin = self._reverse_rows(x, lens64) if d == 1 else x
+                    y, h_n, c_n = _LstmTrainFn.apply(xin.contiguous(), lens, h0, c0, 1, *units[u])
+                    outs.append(self._reverse_rows(y, lens64) if d == 1 else y)
+                    hs.append(h_n)
+                    cs.append(c_n)
+                x = torch.cat(outs, dim=-1)
+            self.final_state = (torch.cat(hs, dim=0), torch.cat(cs, dim=0))
+            return self._to_out_train(x)
+        # fallback (CPU tensors, shapes off the kernels' grid): nn.LSTM over packed sequences, as the reference
         if full_length:
             out, self.final_state = self.lstm(x.transpose(0, 1).contiguous(), self.init_state)
-            return out.transpose(0, 1).contiguous()
+            return self.to_out(out.transpose(0, 1).contiguous())
         packed = pack_padded_sequence(x, seq_lengths.cpu(), batch_first=True, enforce_sorted=False)
         out, self.final_state = self.lstm(packed, self.init_state)
         out, _ = pad_packed_sequence(out, batch_first=True, total_length=x.shape[1])
-        return out
+        return self.to_out(out)
+
+    def _to_out_train(self, y):
+        if isinstance(self.to_out, nn.Linear):
+            return linear_train(y, self.to_out)
+        return y
 
 
 class FeedForwardResidualBlock(nn.Module):
@@ -550,4 +593,7 @@ class FeedForwardResidualBlock(nn.Module):
             lead = x.shape[:-1]
             x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
             return linear_hip(x2, self.dense, resid=x2, act=2).reshape(lead + (self.dense.out_features,))
+        if x.is_cuda and x.dtype == torch.float32:
+            # training: the product and its reverse on the HIP GEMMs (autograd Function), residual and ReLU as torch ops
+            return self.activate(linear_train(x, self.dense) + x)
         return self.activate(self.dense(x) + x)

@@ -234,28 +234,55 @@ class BaseModel(nn.Module):
                                      poses_root=pose_hat[:, :, :3].reshape(n * f, -1))
         return joints.reshape(n, f, -1)
 
+    def _fk_train(self, pose_hat, shape_hat):
+        """`maybe_do_fk` WITH a reverse pass, for the baselines in training mode: the 22 joints and their vector-Jacobian
+        product are the sub-mesh kernels of the LGD path (`_SmplSensorsFn`: empose_smpl_sensors_fwd_bwd / _vjp) through a
+        helper model handle that is built once; its sensors are not used (their cotangents are zero)."""
+        if not self.do_fk:
+            return None
+        n, f = pose_hat.shape[0], pose_hat.shape[1]
+        helper = getattr(self, '_fk_helper', None)
+        if helper is None:
+            from em_pose_amd.helpers.configuration import lgd_config
+            # (kept out of the module tree: its parameters are not the baseline's)
+            net = create_model(lgd_config(12, False, 1, hidden=32), self.smpl)
+            ids = getattr(self, 'fk_vertex_ids', None)    # (a body model smaller than SMPL-H needs its own sensor sites)
+            if ids is not None:
+                net.vertex_ids = [int(v) for v in ids]
+            helper = [net.to(pose_hat.device).eval()]
+            object.__setattr__(self, '_fk_helper', helper)
+        dev = pose_hat.device
+        o_r = torch.eye(3, device=dev).expand(1, 12, 3, 3).contiguous()
+        o_t = torch.zeros(1, 12, 3, device=dev)
+        _, _, joints = _SmplSensorsFn.apply(helper[0], pose_hat.reshape(n * f, -1), shape_hat.reshape(n * f, -1), o_r, o_t,
+                                            n * f)
+        return joints.reshape(n, f, -1)
+
     def _heads(self, features):
         """pose head, optional shape MLP (+ per-window mean), optional FK: shared by the two baselines."""
         n, f = features.shape[0], features.shape[1]
         flat = features.reshape(n * f, -1).contiguous().float()
-        if flat.is_cuda:
+        train = self.training and flat.is_cuda
+        if train:       # autograd Functions over the HIP GEMMs (nn/layers.py): reference models.py:202-216, 303-316
+            pose_hat = linear_train(flat, self.to_pose).reshape(n, f, -1)
+        elif flat.is_cuda:
             pose_hat = linear_hip(flat, self.to_pose).reshape(n, f, -1)
         else:
             pose_hat = self.to_pose(features)
         shape_hat = None
         if self.to_shape is not None:
-            shape_hat = (self.to_shape(flat) if flat.is_cuda else self.to_shape.forward_torch(flat)).reshape(n, f, -1)
+            shape_hat = (self.to_shape(flat) if flat.is_cuda and not train else self.to_shape.forward_torch(flat)) \
+                .reshape(n, f, -1)
             if self.shape_avg:
                 shape_hat = torch.mean(shape_hat, dim=1, keepdim=True).repeat((1, f, 1))
-        joints_hat = self.maybe_do_fk(pose_hat, shape_hat)
+        joints_hat = self._fk_train(pose_hat, shape_hat) if train else self.maybe_do_fk(pose_hat, shape_hat)
         return {'pose_hat': pose_hat[:, :, 3:], 'root_ori_hat': pose_hat[:, :, :3], 'shape_hat': shape_hat,
                 'joints_hat': joints_hat}
 
     def _baseline_backward(self, batch, model_out, writer=None, global_step=None):
-        """Loss values of the two baselines (reference models.py:223-262, 326-366).  The HIP path is inference only, so
-        the outputs carry no autograd graph: in training mode this raises instead of silently skipping the update."""
-        if self.training:
-            raise NotImplementedError('training of the baselines is not available on the HIP path (SURVEY.md 8f-3)')
+        """Loss values of the two baselines and, in training mode, `total_loss.backward()` (reference models.py:223-262,
+        326-366): the outputs of a training-mode forward carry an autograd graph over the HIP kernels (linear layers,
+        LSTM with back-propagation through time, joints with their vector-Jacobian product)."""
         pose_hat, root_hat, shape_hat = model_out['pose_hat'], model_out['root_ori_hat'], model_out['shape_hat']
         dev, n, f = pose_hat.device, batch.batch_size, batch.seq_length
         sl = batch.seq_lengths.to(dev)
@@ -274,6 +301,10 @@ class BaseModel(nn.Module):
                      'fk': fk_loss.item(), 'total_loss': total.item()}
         if writer is not None:
             self.log_loss_vals(loss_vals, writer, global_step)
+        if self.training:
+            if not total.requires_grad:
+                raise RuntimeError('training mode, but the outputs carry no graph: they come from an eval-mode forward')
+            total.backward()
         return total, loss_vals
 
     def log_loss_vals(self, loss_vals, writer, global_step):
@@ -305,10 +336,11 @@ class FeedForwardResNet(BaseModel):
 
     def forward(self, batch, window_size=None, is_new_sequence=True):
         inputs_ = self.prepare_inputs(batch.get_inputs())
-        if inputs_.is_cuda and not self.training:
+        if inputs_.is_cuda:
             n, f = inputs_.shape[0], inputs_.shape[1]
-            x = linear_hip(inputs_.reshape(n * f, -1).contiguous().float(), self.from_input)
-            x = self.blocks(x).reshape(n, f, -1)
+            flat = inputs_.reshape(n * f, -1).contiguous().float()
+            x = linear_train(flat, self.from_input) if self.training else linear_hip(flat, self.from_input)
+            x = self.blocks(x).reshape(n, f, -1)     # (training mode: the blocks build the graph themselves)
         else:
             x = self.blocks(self.from_input(inputs_))
         return self._heads(x)
@@ -341,7 +373,10 @@ class SimpleRNN(BaseModel):
             self.rnn.final_state = None
         self.rnn.init_state = self.rnn.final_state
         inputs_ = self.prepare_inputs(batch.get_inputs())
-        lstm_out = self.rnn(inputs_, batch.seq_lengths)
+        if self.training and inputs_.is_cuda:
+            lstm_out = self.rnn.forward_torch(inputs_.contiguous().float(), batch.seq_lengths)
+        else:
+            lstm_out = self.rnn(inputs_, batch.seq_lengths)
         return self._heads(lstm_out)
 
     def backward(self, batch, model_out, writer=None, global_step=None):

@@ -226,6 +226,41 @@ def reconstruction_loss(gt, hat, seq_lengths=None, marker_mask=None):
     return per_frame.mean()
 
 
+def normal_mse(gt, hat, seq_lengths=None, marker_mask=None):
+    """Squared error summed over joints, padded mean over frames, mean over the batch (reference loss.py:44-62)."""
+    d = hat - gt
+    per_frame = (d * d).sum(-1).sum(-1)
+    if marker_mask is not None:
+        per_frame = per_frame * (marker_mask != 0).all(dim=-1)
+    if seq_lengths is not None:
+        m = mask_from_seq_lengths(seq_lengths, per_frame.shape[1]).to(per_frame.dtype)
+        per_frame = (per_frame * m).sum(-1) / seq_lengths.to(per_frame.dtype)
+    return per_frame.mean()
+
+
+def padded_l1(gt, hat, seq_lengths):
+    """`padded_loss(gt, hat, nn.L1Loss(reduction='none'), seq_lengths)` (reference loss.py:13-20)."""
+    per_frame = (gt - hat).abs().mean(-1)
+    m = mask_from_seq_lengths(seq_lengths, per_frame.shape[1]).to(per_frame.dtype)
+    return ((per_frame * m).sum(-1) / seq_lengths.to(per_frame.dtype)).mean()
+
+
+def baseline_losses(out, poses, shapes, joints_gt, seq_lengths, marker_mask, fk_weight):
+    """The loss of the two baselines (reference models.py:223-262, 326-366).  poses (B,F,66) root first, shapes (B,10),
+    joints_gt (B,F,66).  :return: dict of the reference's loss values + 'total_loss' (tensors)."""
+    B, F = poses.shape[0], poses.shape[1]
+    r = lambda t: t.reshape(B, F, -1, 3)
+    vals = {'pose': normal_mse(r(poses[:, :, 3:]), r(out['pose_hat']), seq_lengths, marker_mask),
+            'root_pose': normal_mse(r(poses[:, :, :3]), r(out['root_ori_hat']), seq_lengths, marker_mask)}
+    zero = torch.zeros((), dtype=poses.dtype)
+    vals['shape'] = padded_l1(shapes.unsqueeze(1).repeat(1, F, 1), out['shape_hat'], seq_lengths) \
+        if out['shape_hat'] is not None else zero
+    vals['fk'] = reconstruction_loss(r(joints_gt), r(out['joints_hat']), seq_lengths, marker_mask) \
+        if out['joints_hat'] is not None else zero
+    vals['total_loss'] = vals['pose'] + vals['root_pose'] + vals['shape'] + fk_weight * vals['fk']
+    return vals
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Networks: the same torch.nn building blocks, addressed through a flat state_dict with the reference's key names
 # (reference layers.py:13-77,80-157).

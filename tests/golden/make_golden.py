@@ -239,6 +239,66 @@ def make_baselines(vids):
                                       'model_name': net.model_name(), 'flags': json.dumps(fl, sort_keys=True)})
 
 
+def make_baseline_train(vids):
+    """Cases J (VERDICT r5 missing #5): one TRAINING step of the baselines -- `net.train()`, `forward(batch)`,
+    `backward(batch, out)` (reference models.py:196-262, 297-366: the losses and `total_loss.backward()`) -- on a ragged
+    batch with missing sensors: loss values, outputs and EVERY parameter gradient (the fixtures' networks are 32 wide).
+    One-ulp input noise moves these gradients by ~1e-7 of their scale (no BatchNorm, no in-forward deposits), so they
+    are compared directly."""
+    from empose.bodymodels.smpl import create_default_smpl_model
+    from empose.nn.models import create_model
+    smpl = create_default_smpl_model(torch.device('cpu'))
+    lgd_net, _ = make_net(lgd_flags(12, True, 1, 32, 32), 5, vids)  # only to synthesise consistent sensor readings
+    cases = (('train_birnn12', baseline_flags('rnn', 12, m_bidirectional=True), 61),
+             ('train_rnn6_l3', baseline_flags('rnn', 6, m_num_layers=3, m_average_shape=False), 62),
+             ('train_resnet12', baseline_flags('resnet', 12, m_num_layers=3, m_skip_connections=True), 63),
+             ('train_resnet6_nofk_noshape', baseline_flags('resnet', 6, m_fk_loss=0.0, m_estimate_shape=False), 64))
+    for tag, fl, seed in cases:
+        torch.manual_seed(seed)
+        net = create_model(ref_config(**fl), smpl)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                if name.startswith('to_pose') or 'hidden_to_output' in name:
+                    p.mul_(3.0)
+        net.train()
+        w = synthetic.make_windows(3, 24, seed, sensors_from_reference(lgd_net, smpl))
+        lengths = torch.tensor([24, 17, 6])
+        masks = np.ones((3, 24, 12), dtype=np.float32)
+        masks[0, 3:6, 4] = 0.0
+        for b, n in enumerate(lengths.tolist()):
+            for k in ('marker_pos', 'marker_oris', 'poses'):
+                w[k][b, n:] = 0.0
+            masks[b, n:] = 0.0
+        batch = real_batch(w, lengths, masks=masks)
+        w = dict(w, marker_masks=masks, seq_lengths=lengths.numpy())
+        B, F = batch.batch_size, batch.seq_length
+        with torch.no_grad():
+            _, jgt = smpl(poses_body=batch.poses_body.reshape(B * F, -1),
+                          betas=batch.shapes.unsqueeze(1).repeat(1, F, 1).reshape(B * F, -1),
+                          poses_root=batch.poses_root.reshape(B * F, -1))
+            batch.joints_gt = jgt[:, :22].reshape(B, F, 66)
+        sd_before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        net.zero_grad()
+        out = net(batch, is_new_sequence=True)
+        total, loss_vals = net.backward(batch, out)      # (training mode: calls total_loss.backward())
+        rec = {'out_' + k: v.detach().numpy() for k, v in out.items() if v is not None}
+        rec['joints_gt'] = batch.joints_gt.numpy()
+        for k, v in loss_vals.items():
+            rec['loss_' + k] = np.asarray(v)
+        n_grads = 0
+        for name, p in net.named_parameters():
+            if name.startswith('smpl.'):
+                continue
+            assert p.grad is not None or not p.requires_grad, name
+            if p.grad is not None:
+                rec['grad/' + name] = p.grad.detach().numpy().copy()
+                n_grads += 1
+        net.load_state_dict(sd_before)
+        print(tag, 'losses', loss_vals, 'gradients', n_grads)
+        save_case(tag, net, w, {'run': rec}, {'n_markers': fl['n_markers'], 'vertex_ids': vids,
+                                              'model_name': net.model_name(), 'flags': json.dumps(fl, sort_keys=True)})
+
+
 def make_preprocess(model, vids):
     """Case G: the reference's ground-truth preprocessing -- NormalizeRoot, SMPLFK and
     SampleMarkersWithOffsets (reference data/transforms.py:229-282,132-226) -- on the small mesh with three synthetic
@@ -705,6 +765,9 @@ def main():
     if '--only-inner-windows' in sys.argv:
         sys.argv.remove('--only-inner-windows')
         return make_inner_windows(vids)
+    if '--only-baseline-train' in sys.argv:
+        sys.argv.remove('--only-baseline-train')
+        return make_baseline_train(vids)
     if '--only-baselines' in sys.argv:
         sys.argv.remove('--only-baselines')
         return make_baselines(vids)

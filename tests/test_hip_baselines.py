@@ -114,8 +114,7 @@ def test_rnn_layer_rejects_what_it_cannot_do():
     layer = RNNLayer(16, 8, 1, bidirectional=True).eval()
     with pytest.raises(_lib.EmposeError):
         layer(torch.zeros(1, 2, 16), torch.tensor([2]))        # CPU tensors: no fallback
-    with pytest.raises(NotImplementedError):
-        RNNLayer(16, 8, 1, dropout=0.1)
+    assert isinstance(RNNLayer(16, 8, 1, dropout=0.1).input_drop, torch.nn.Dropout)   # (round 6: a training-time feature)
     with pytest.raises(NotImplementedError):
         RNNLayer(16, 8, 1, bidirectional=True, learn_init_state=True)
     lib = _lib.lib()
@@ -195,6 +194,77 @@ def test_golden_rnn_baselines_state_carry(name):
         out = net(b, is_new_sequence=new)
         _, loss_vals = net.backward(b, out)
         _check(net, case[tag], out, loss_vals)
+
+
+@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape'])
+def test_golden_baselines_training_step(name):
+    """One training step of the baselines -- train mode, `forward(batch)`, `backward(batch, out)` = the losses and
+    `total_loss.backward()` (reference models.py:196-262, 297-366) -- on a ragged batch with missing sensors, against what
+    the unmodified reference deposited: outputs, loss values and EVERY parameter gradient.  The graph runs over the HIP
+    kernels: linear layers and their reverse (matrix-core GEMM / A^T B), the LSTM with back-propagation through time (a
+    bidirectional stack composed per layer and direction), joints with the sub-mesh vector-Jacobian product."""
+    case = H.load_case(name)
+    net, fl = _build(case)
+    net.fk_vertex_ids = [int(v) for v in case['meta']['vertex_ids']]
+    net.train()
+    w, rec = case['in'], case['run']
+    b = _batch(w, rec, w['seq_lengths'], w['marker_masks'])
+    net.zero_grad()
+    out = net(b)
+    total, loss_vals = net.backward(b, out)
+    torch.cuda.synchronize()
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        if ('out_' + k) in rec:
+            np.testing.assert_allclose(out[k].detach().cpu().numpy(), rec['out_' + k], atol=ATOL, err_msg=k)
+        else:
+            assert out[k] is None
+    for k in ('pose', 'root_pose', 'shape', 'fk', 'total_loss'):
+        np.testing.assert_allclose(loss_vals[k], float(rec['loss_' + k]), rtol=1e-4, atol=1e-5, err_msg=k)
+    params = dict(net.named_parameters())
+    names = [k[len('grad/'):] for k in rec if k.startswith('grad/')]
+    assert len(names) == len([n for n, p in params.items() if not n.startswith('smpl.') and p.requires_grad])
+    worst = 0.0
+    for n in names:
+        want, got = rec['grad/' + n], params[n].grad
+        assert got is not None, n
+        scale = max(float(np.abs(want).max()), 1e-3)
+        err = float(np.abs(got.cpu().numpy() - want).max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-4, (n, err)
+    print('%s: %d gradients, worst error / max-abs of the tensor %.2e' % (name, len(names), worst))
+    # eval mode afterwards: the inference kernels, no graph
+    net.eval()
+    out = net(b)
+    assert not out['pose_hat'].requires_grad
+
+
+def test_training_mode_dropout_is_applied_and_eval_ignores_it():
+    """`m_dropout` (inputs of the RNN) and `m_dropout_hidden` (the shape MLP): every released configuration uses 0.0, the
+    reference's flags exist (configuration.py:164,172; layers.py:30,62,103).  Training mode: two forwards differ (masks are
+    drawn) and the gradients are finite; eval mode: deterministic and equal to the same network without dropout."""
+    flags = dict(m_type='rnn', m_hidden_size=32, m_num_layers=2, m_bidirectional=True, window_size=32, use_marker_pos=True,
+                 use_marker_ori=True, m_estimate_shape=True, m_shape_hidden_size=24, m_average_shape=False, m_fk_loss=0.0,
+                 n_markers=12, m_dropout=0.3, m_dropout_hidden=0.4)
+    torch.manual_seed(9)
+    net = create_model(Configuration.defaults(**flags), SMPLLayer(H.small_model())).to(DEV)
+    plain = create_model(Configuration.defaults(**dict(flags, m_dropout=0.0, m_dropout_hidden=0.0)),
+                         SMPLLayer(H.small_model())).to(DEV)
+    plain.load_state_dict(net.state_dict())
+    case = H.load_case('train_birnn12')
+    w, rec = case['in'], case['run']
+    b = _batch(w, rec, w['seq_lengths'], w['marker_masks'])
+    net.eval(); plain.eval()
+    a1, a2, a3 = net(b), net(b), plain(b)
+    assert torch.equal(a1['pose_hat'], a2['pose_hat']) and torch.equal(a1['pose_hat'], a3['pose_hat'])
+    assert torch.equal(a1['shape_hat'], a3['shape_hat'])
+    net.train()
+    t1, t2 = net(b), net(b)
+    assert not torch.equal(t1['pose_hat'], t2['pose_hat']) and not torch.equal(t1['shape_hat'], t2['shape_hat'])
+    net.zero_grad()
+    total, _ = net.backward(b, t2)
+    for n, p in net.named_parameters():
+        if not n.startswith('smpl.'):
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
 
 
 @pytest.mark.parametrize('m_type', ['rnn', 'resnet'])

@@ -151,6 +151,43 @@ def test_baselines_carry():
         _check_baseline(case['chunk1'], out1, st1)
 
 
+@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape'])
+def test_baselines_training_step(name):
+    """One training step of the reference's baselines (train mode, `forward`, `backward` = the losses and
+    `total_loss.backward()`; reference models.py:196-262, 297-366) on a ragged batch with missing sensors: the oracle's
+    restatement with autograd through its own LSTM loop, body model and losses reproduces the outputs, the loss values
+    and EVERY parameter gradient the reference deposited."""
+    import json
+    case = H.load_case(name)
+    fl = json.loads(str(case['meta']['flags']))
+    w, rec = case['in'], case['run']
+    inp = H.oracle_inputs(w, sl=w['seq_lengths'])
+    sd = {k: v.clone().requires_grad_(True) for k, v in H.sd_to_torch(case['sd'], torch.float32).items()}
+    bm = R.BodyModelTensors(H.small_model(), dtype=torch.float32)
+    common = dict(n_markers=fl['n_markers'], num_layers=fl['m_num_layers'], estimate_shape=fl['m_estimate_shape'],
+                  shape_avg=fl['m_average_shape'], do_fk=fl['m_fk_loss'] > 0, skip=fl.get('m_skip_connections', False))
+    if fl['m_type'] == 'resnet':
+        out = R.resnet_forward(sd, bm, inp, **common)
+    else:
+        out, _ = R.simple_rnn_forward(sd, bm, inp, bidirectional=fl.get('m_bidirectional', False), **common)
+    for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
+        if out[k] is not None:
+            np.testing.assert_allclose(out[k].detach().numpy(), rec['out_' + k], atol=TOL, rtol=0, err_msg=k)
+    vals = R.baseline_losses(out, torch.from_numpy(w['poses']), torch.from_numpy(w['shapes']),
+                             torch.from_numpy(rec['joints_gt']), inp['seq_lengths'], inp['marker_masks'], fl['m_fk_loss'])
+    for k, v in vals.items():
+        np.testing.assert_allclose(float(v.detach()), float(rec['loss_' + k]), rtol=1e-5, atol=1e-6, err_msg=k)
+    vals['total_loss'].backward()
+    names = [k[len('grad/'):] for k in rec if k.startswith('grad/')]
+    assert names
+    for n in names:
+        want = rec['grad/' + n]
+        got = sd[n].grad
+        assert got is not None, n
+        scale = max(float(np.abs(want).max()), 1e-3)
+        np.testing.assert_allclose(got.numpy(), want, atol=2e-5 * scale, rtol=0, err_msg=n)
+
+
 EVAL_ASSETS = os.path.join(H.GOLDEN, 'eval_assets')
 
 
