@@ -395,3 +395,48 @@ def test_medium_batch_whole_sequence_lstm_reports_a_poll_that_gave_up():
     assert lib.empose_async_status() == 0
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=1e-4)
     g.release()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Dropout flags of the LGD model (reference configuration.py:164,172; layers.py:30,62,103-106,140)
+def test_lgd_training_with_dropout_flags_runs_on_the_autograd_path():
+    """`m_dropout` (inputs of the init RNN) and `m_dropout_hidden` (the update MLPs) > 0: no released configuration sets
+    them, the reference accepts them.  The hand-written training engine declines, the autograd path over the same kernels
+    takes the step: masks are drawn (two training-mode forwards differ), every parameter gets a finite gradient, and eval
+    mode is the network without dropout, bit for bit."""
+    from em_pose_amd.data.data import SyntheticBatch
+    from tests import helpers as H
+    case = H.load_case('train_lgdrnn12_n2')
+    meta, w = case['meta'], case['in']
+    vids = [int(v) for v in meta['vertex_ids']]
+    nets = []
+    for p_in, p_hid in ((0.2, 0.3), (0.0, 0.0)):
+        cfg = lgd_config(12, True, 2, hidden=32, rnn_hidden=32, m_dropout=p_in, m_dropout_hidden=p_hid)
+        net = create_model(cfg, SMPLLayer(H.small_model()))
+        missing, unexpected = net.load_state_dict(H.sd_to_torch(case['sd']), strict=False)
+        assert not unexpected and all(k.startswith('smpl.') for k in missing)
+        net.vertex_ids = vids
+        nets.append(net.to(DEV))
+    net, plain = nets
+    batch = SyntheticBatch(w, torch.from_numpy(w['seq_lengths']).to(DEV), device=DEV)
+    batch.joints_gt = torch.from_numpy(w['joints_gt']).to(DEV)
+    net.eval(); plain.eval()
+    a, b = net(batch), plain(batch)
+    for k in ('pose_hat', 'shape_hat', 'root_ori_hat'):
+        assert torch.equal(a[k], b[k]), k
+    net.train()
+    net.zero_grad()
+    o1 = net(batch)
+    assert net._engine is None       # (nn/train_engine.py covers dropout 0 only)
+    p1 = o1['pose_hat'].detach().clone()
+    total, vals = net.backward(batch, o1)
+    o2 = net(batch)
+    assert not torch.equal(p1, o2['pose_hat'].detach())
+    assert np.isfinite(vals['total_loss'])
+    n = 0
+    for name, p in net.named_parameters():
+        if name.startswith('smpl.') or not p.requires_grad:
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+        n += 1
+    assert n >= 14
