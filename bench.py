@@ -414,11 +414,13 @@ def secondary_workloads(args, dev, model):
     # ---- configs[3] stand-in and configs[4], as child processes (their own entry points)
     py = sys.executable
     for key, extra in (('batched', []), ('sequential', ['--sequential'])):
-        r = _json_tail([py, os.path.join(ROOT, 'scripts', 'evaluate_real.py'), '--synthetic', '--repeat', '3', '--json'] + extra, 120)
+        r = _json_tail([py, os.path.join(ROOT, 'scripts', 'evaluate_real.py'), '--synthetic', '--repeat', '8', '--json'] + extra, 180)
         sec['configs3_evaluate_real_synthetic_' + key] = r if 'error' in r else {
             'workload': 'BASELINE configs[3] stand-in: scripts/evaluate_real.py --synthetic%s (36 sequences, 54 030 frames, '
                         'LGD-RNN-6 N=2, 256-frame chunks, carried state), 1 GPU' % (' --sequential' if extra else ''),
-            'frames_per_sec': r.get('frames_per_sec'), 'seconds_per_pass': r.get('seconds'), 'frames': r.get('frames')}
+            'frames_per_sec': r.get('frames_per_sec'), 'seconds_per_pass': r.get('seconds'), 'frames': r.get('frames'),
+            'all_passes_seconds': r.get('seconds_per_pass'),
+            'host_seconds_per_section_last_pass': (r.get('host_seconds_per_section_per_pass') or [None])[-1]}
     fwd_flops = 26.47e6       # dense MFLOP per frame of LGD-RNN-12 N=4; fwd + dX + dW = 3 x
     for key, extra, windows in (('12_windows', ['--steps', '20'], 12), ('256_windows', ['--steps', '8', '--bs_train', '256'], 256)):
         r = _json_tail([py, os.path.join(ROOT, 'scripts', 'train.py'), '--json'] + extra, 180)
