@@ -45,7 +45,11 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
   extern __shared__ __attribute__((aligned(16))) float part[];
   float* hx = part + PART_FLOATS;
   const int H = a.H, B = a.B, F = a.F;
+#ifdef LM3_LAB_TWICE_WGS   // (dev: twice the workgroups, each with every other k-step of its waves -- results are wrong)
+  const int JB = H / BU, jb = blockIdx.x % JB, j0 = jb * BU, lab_half = blockIdx.x / JB;
+#else
   const int jb = blockIdx.x, JB = H / BU, j0 = jb * BU;
+#endif
   const int m0 = blockIdx.y * BM, rt0 = blockIdx.y * 2, RT = (B + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +83,9 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
 
   // ---- the wave's k-steps: g = wave + 4 i
   u32x4_t fa[D][RTS][3], fw[D][3];
-#ifdef LM3_LAB_NOK      // (dev, scripts/dev/lstm_mid_lab.sh: one k-step per wave -- what a launch costs without its K loop)
+#ifdef LM3_LAB_TWICE_WGS
+  const int n_w = ((KS - wave + 3) / 4 + 1 - lab_half) / 2;
+#elif defined(LM3_LAB_NOK)      // (dev, scripts/dev/lstm_mid_lab.sh: one k-step per wave -- what a launch costs without its K loop)
   const int n_w = 1;
 #else
   const int n_w = (KS - wave + 3) / 4;
@@ -87,7 +93,11 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
   const unsigned short* const p_in = U.a3_in; const unsigned short* const p_rec = U.a3_rec;
   const unsigned short* const p_wih = U.w3_ih; const unsigned short* const p_whh = U.w3_hh;
   auto load = [&, p_in, p_rec, p_wih, p_whh](u32x4_t (&A)[RTS][3], u32x4_t (&W)[3], int i) {
+#ifdef LM3_LAB_TWICE_WGS
+    int g = wave + 4 * (i + (lab_half ? ((KS - wave + 3) / 4 + 1) / 2 : 0));   // the other half of the wave's k-steps
+#else
     int g = wave + 4 * i;
+#endif
     g = g < KS ? g : KS - 1;                      // (past the wave's last step: fetched, never multiplied)
     const bool in = g < KS_in;
     const int ks = in ? g : g - KS_in, ksn = in ? KS_in : KS_h;
@@ -183,7 +193,11 @@ __global__ __launch_bounds__(lm3::NT) void lstm_mid_x3_kernel(LstmX3Args a) {
 
 hipError_t launch_lstm_mid_x3(const LstmX3Args& a, hipStream_t stream) {
   if (a.n_units == 0) return hipSuccess;
+#ifdef LM3_LAB_TWICE_WGS
+  dim3 grid(2 * a.H / lm3::BU, (a.B + lm3::BM - 1) / lm3::BM, a.n_units);
+#else
   dim3 grid(a.H / lm3::BU, (a.B + lm3::BM - 1) / lm3::BM, a.n_units);
+#endif
   if (a.B <= 32) {
     auto* fn = lstm_mid_x3_kernel<1, LM3_RING1>;
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(fn), lm3::LDS_BYTES)) return e;

@@ -3,6 +3,8 @@
 # depths (LM3_RING1: launches of at most 32 rows, LM3_RING2: 33..64 rows per workgroup), timed on the stand-alone LSTM
 # (2 x 512, input 60; scripts/dev/bench_lstm_mid.py).
 #   8_6+LM3_LAB_NOK   one k-step per wave: what a launch costs without its K loop (results are wrong)
+#   8_6+LM3_LAB_TWICE_WGS   twice the workgroups, each with every other half of its waves' k-steps (results are wrong):
+#                           what a 16-column tile on all 256 CUs would gain in the K loop
 # usage (container): bash scripts/dev/lstm_mid_lab.sh build ; (GPU box): bash scripts/dev/lstm_mid_lab.sh run
 set -u
 R=$(cd "$(dirname "$0")/../.." && pwd)
