@@ -120,16 +120,42 @@ class RealBatch(ABatch):
                          pad([s.marker_ori_real for s in samples]), pad([s.marker_masks for s in samples]),
                          torch.stack([s.offset_means for s in samples]), torch.stack([s.offset_r for s in samples]))
 
+    PINNED_FIELDS = ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes', 'trans',
+                     'offset_t', 'offset_r')
+
     def pin_memory(self):
         """The hook `torch.utils.data.DataLoader(pin_memory=True)` calls on a custom batch type: every host field into
-        page-locked memory, so that `.to(device, non_blocking=True)` of a field (or of a slice of it) neither stages nor
-        blocks.  A loader's job, once per batch; the evaluation drivers only benefit from it."""
-        for name in ('marker_pos_real', 'marker_ori_real', 'marker_normal_real', 'marker_masks', 'poses', 'shapes', 'trans',
-                     'offset_t', 'offset_r'):
-            f = getattr(self, name)
-            if torch.is_tensor(f) and not f.is_cuda and not f.is_pinned():
-                setattr(self, name, f.contiguous().pin_memory())
+        page-locked memory, so that an upload neither stages nor blocks.  The fields become views of ONE block (each on a
+        256-byte boundary): a consumer that wants the whole batch on the device uploads the block with one copy and takes
+        the same views of it (`device_fields`).  A loader's job, once per batch."""
+        fields = [(n, getattr(self, n)) for n in self.PINNED_FIELDS]
+        if any(not torch.is_tensor(f) or f.is_cuda or f.dtype != torch.float32 for _, f in fields):
+            for n, f in fields:      # (mixed placement / types: field by field)
+                if torch.is_tensor(f) and not f.is_cuda and not f.is_pinned():
+                    setattr(self, n, f.contiguous().pin_memory())
+            return self
+        layout, at = {}, 0
+        for n, f in fields:
+            layout[n] = (at, tuple(f.shape))
+            at += (f.numel() + 63) // 64 * 64
+        block = torch.empty(max(at, 64), dtype=torch.float32, pin_memory=True)
+        for n, f in fields:
+            st, shape = layout[n]
+            view = block[st:st + f.numel()].view(shape)
+            view.copy_(f)
+            setattr(self, n, view)
+        self._pinned_block, self._pinned_layout = block, layout
         return self
+
+    def device_fields(self, device):
+        """{field: tensor on `device`} of the fields above: ONE upload that does not block when the batch is pinned
+        (`pin_memory`) and still in that block, a copy per field otherwise."""
+        block, layout = getattr(self, '_pinned_block', None), getattr(self, '_pinned_layout', None)
+        if block is not None and all(getattr(self, n).data_ptr() == block.data_ptr() + 4 * layout[n][0] and
+                                     tuple(getattr(self, n).shape) == layout[n][1] for n in self.PINNED_FIELDS):
+            d = block.to(device, non_blocking=True)
+            return {n: d[st:st + int(torch.Size(shape).numel())].view(shape) for n, (st, shape) in layout.items()}
+        return {n: getattr(self, n).to(device=device, dtype=C.DTYPE, non_blocking=True) for n in self.PINNED_FIELDS}
 
     def to_gpu(self, device=None):
         device = C.DEVICE if device is None else device

@@ -344,11 +344,14 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
         n_chunks = (sl[0] + window_size - 1) // window_size
         dev = torch.device(device)
         on_gpu = dev.type == 'cuda'
-        # (fields a loader has pinned -- RealBatch.pin_memory -- go up without staging and without blocking the host)
-        up = lambda t: t.to(device=device, dtype=C.DTYPE, non_blocking=True)
+        # (a recording a loader has pinned -- RealBatch.pin_memory -- goes up as ONE block, without staging and without
+        # blocking the host: 36 copies per pass instead of 288)
+        on_dev = [batches[i].device_fields(device) for i in order]
         fields = ('poses', 'trans', 'marker_pos_real', 'marker_ori_real', 'marker_masks')
-        packed = {k: pad_sequence([up(getattr(batches[i], k)[0]) for i in order], batch_first=True) for k in fields}
-        whole = {k: torch.cat([up(getattr(batches[i], k)) for i in order]) for k in ('shapes', 'offset_t', 'offset_r')}
+        packed = {k: pad_sequence([d[k][0] for d in on_dev], batch_first=True) for k in fields}
+        whole = {k: torch.cat([d[k] for d in on_dev]) for k in ('shapes', 'offset_t', 'offset_r')}
+        del on_dev
+        lap('upload_and_pack')
         # the frames that count -- inside the recording and every sensor present -- from the host copies of the masks
         # (numpy: a torch CPU op on a 36 x 256 x 12 block wakes the whole intra-op thread pool)
         valid_all = np.zeros((n, sl[0]), dtype=bool)
@@ -362,6 +365,7 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             if side is None or side.device != dev:
                 side = net._side_stream = torch.cuda.Stream(device=dev)
             net.iter_stream = side
+        lap('valid_frames')
         me_chunks = MetricsEngine(smpl_model)
         placed = on_gpu and me_chunks.angle_glob and hasattr(smpl_model, 'fk_joints')   # (the device path of `compute`)
         # Where every frame's row goes: recording i owns rows base[i] .. base[i + 1] of one block, its valid frames in
@@ -404,7 +408,7 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
         if on_gpu:
             lens_all_dev = lens_all_dev.pin_memory().to(device, non_blocking=True)
         state, first_shape, frames = None, None, 0
-        lap('setup')
+        lap('row_plan')
         for c in range(n_chunks):
             sf = c * window_size
             k = sum(1 for L in sl if L > sf)
