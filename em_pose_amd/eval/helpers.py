@@ -327,6 +327,8 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             _t[0] = now
     from em_pose_amd.nn.models import IterativeErrorFeedback
     assert isinstance(net, IterativeErrorFeedback)
+    if len(batches) == 0:      # (a rank of a multi-GPU run that got no recording)
+        return MetricsEngine(smpl_model), [], 0
     # rows shorter than the chunk are padded: average the shape over their valid frames only, which is what the
     # unpadded one-recording chunk of the sequential driver averages over
     was_valid_only = net.shape_avg_valid_only
