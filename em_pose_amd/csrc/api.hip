@@ -95,6 +95,9 @@ struct Lstm {   // unit u = layer * dirs + direction
   // ... and in the fragment order of lstm_mid_x3.hip (8-unit blocks, the four gates of a unit in one 32-column tile)
   unsigned short* w3m_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned short* w3m_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // ... and in the order of lstm_mid16_x3.hip (4-unit blocks, k-steps of 32)
+  unsigned short* w3q_ih[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned short* w3q_hh[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 }  // namespace
@@ -460,10 +463,14 @@ bool lstm_x3_covers(const Lstm& r, int B) {
     if (!r.w3_ih[l] || !r.w3_hh[l]) return false;
   return true;
 }
-// medium batches (the batched evaluation driver's chunks): lstm_mid_x3.hip
+constexpr int LSTM_MID16_MIN_B = 9;
+// medium batches (the batched evaluation driver's chunks): lstm_mid_x3.hip / lstm_mid16_x3.hip
 bool lstm_x3_mid_covers(const Lstm& r, int B) {
   if (options().lstm_x3 == 0 || options().lstm_mid_x3 == 0 || r.dirs != 1 || r.num_layers > 4) return false;
-  if (B <= LSTM_PERSIST_B || B >= LSTM_SEQ_MIN_B) return false;
+  // from 9 rows with the 4-unit tiles of lstm_mid16_x3.hip (7.0 us per step against 7.8 - 10.7 of lstm_fewrows_kernel at 9 - 16
+  // rows), from 17 with the 8-unit tiles
+  const bool tiles16 = options().lstm_mid16 != 0 && lstm_mid16_shape_ok(B, r.H) && r.w3q_ih[0] && r.w3q_hh[0];
+  if (B < (tiles16 ? LSTM_MID16_MIN_B : LSTM_PERSIST_B + 1) || B >= LSTM_SEQ_MIN_B) return false;
   if (r.H % 32 != 0 || r.input_size % 4 != 0) return false;
   for (int l = 0; l < r.num_layers; ++l)
     if (!r.w3m_ih[l] || !r.w3m_hh[l]) return false;
@@ -714,6 +721,8 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
     }
     // Large batches, inference: the steps on the bf16 matrix path with three bf16 pieces per operand (lstm_x3.hip)
     const bool mid3 = lstm_x3_mid_covers(r, B);
+    // ... up to 64 rows with half the tile, on all 256 CUs (lstm_mid16_x3.hip)
+    const bool mid16 = mid3 && options().lstm_mid16 != 0 && lstm_mid16_shape_ok(B, H) && r.w3q_ih[0] && r.w3q_hh[0];
     if (!done && ws.x3 && !a.unit[0].sv_gates && (lstm_x3_covers(r, B) || mid3)) {
       prof_mark(P_COPY, stream);
       const int KS_in = (r.input_size + 15) / 16, KS_h = H / 16;
@@ -731,7 +740,8 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
           const int t = s - l;
           if (t < 0 || t >= F) continue;
           LstmX3Unit& xu = xa.unit[xa.n_units++];
-          xu.w3_ih = mid3 ? r.w3m_ih[l] : r.w3_ih[l]; xu.w3_hh = mid3 ? r.w3m_hh[l] : r.w3_hh[l]; xu.bias = r.bias[l];
+          xu.w3_ih = mid16 ? r.w3q_ih[l] : mid3 ? r.w3m_ih[l] : r.w3_ih[l];
+          xu.w3_hh = mid16 ? r.w3q_hh[l] : mid3 ? r.w3m_hh[l] : r.w3_hh[l]; xu.bias = r.bias[l];
           xu.a3_in = l == 0 ? ws.x3 + (size_t)t * ws.x3_t_stride : ws.a3[l - 1][(t + 1) & 1];
           xu.ks_in = l == 0 ? KS_in : KS_h;
           xu.a3_rec = ws.a3[l][t & 1]; xu.a3_out = ws.a3[l][(t + 1) & 1];
@@ -740,7 +750,7 @@ int run_lstm(const Lstm& r, int B, int F, const float* x, int ldx, const int* se
         }
         xa.units_per_block = tiles >= 192 ? xa.n_units : 1;
         prof_mark(P_LSTM_STEP, stream);
-        e = mid3 ? launch_lstm_mid_x3(xa, stream)
+        e = mid16 ? launch_lstm_mid16_x3(xa, stream) : mid3 ? launch_lstm_mid_x3(xa, stream)
                  : options().lstm_x3 == 2 ? launch_lstm_rows_x3(xa, stream) : launch_lstm_chain_x3(xa, stream);
         if (e != hipSuccess) return fail(EMPOSE_EHIP, "lstm step (bf16 pieces): %s", hipGetErrorString(e));
       }
@@ -820,6 +830,35 @@ int pack_lstm_x3(std::vector<void*>& allocs, const float* w, int H, int K, unsig
   return EMPOSE_OK;
 }
 
+// ... and in the order of lstm_mid16_x3.hip: [k-step of 32][4-unit block][piece] -> one fragment of the 16x16x32 instruction,
+// lane (n = lane & 15, q = lane >> 4) owns W[gate (n >> 2) * H + block * 4 + (n & 3)][ks * 32 + q * 8 .. + 7]; k past K is zero.
+int pack_lstm_x3_mid16(std::vector<void*>& allocs, const float* w, int H, int K, unsigned short** out) {
+  const int K2 = (K + 31) / 32, JB = H / 4;
+  std::vector<unsigned short> buf((size_t)K2 * JB * 3 * 512, 0);
+  for (int ks = 0; ks < K2; ++ks)
+    for (int jb = 0; jb < JB; ++jb)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 15, q = lane >> 4;
+        const float* row = w + (size_t)((n >> 2) * H + jb * 4 + (n & 3)) * K;
+        for (int e = 0; e < 8; ++e) {
+          const int k = ks * 32 + q * 8 + e;
+          if (k >= K) continue;
+          const unsigned short h = bf16_round(row[k]);
+          const float r1 = row[k] - bf16_value(h);
+          const unsigned short m = bf16_round(r1);
+          const unsigned short l = bf16_round(r1 - bf16_value(m));
+          const size_t at = (((size_t)ks * JB + jb) * 3) * 512 + (size_t)lane * 8 + e;
+          buf[at] = h; buf[at + 512] = m; buf[at + 1024] = l;
+        }
+      }
+  std::vector<float> as_f((buf.size() + 1) / 2);
+  std::memcpy(as_f.data(), buf.data(), buf.size() * 2);
+  float* dev = nullptr;
+  TRY(upload(allocs, as_f.data(), as_f.size(), &dev));
+  *out = reinterpret_cast<unsigned short*>(dev);
+  return EMPOSE_OK;
+}
+
 int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, const float* const* w_ih,
               const float* const* w_hh, const float* const* b_ih, const float* const* b_hh, Lstm* out) {
   if (r.num_layers < 1 || r.num_layers * dirs > 8 || r.hidden_size % 4 != 0 || r.input_size % 4 != 0)
@@ -840,6 +879,8 @@ int pack_lstm(std::vector<void*>& allocs, const empose_lstm_desc& r, int dirs, c
         TRY(pack_lstm_x3(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3_hh[u]));
         TRY(pack_lstm_x3(allocs, w_ih[u], r.hidden_size, k_in, &out->w3m_ih[u], true));
         TRY(pack_lstm_x3(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3m_hh[u], true));
+        TRY(pack_lstm_x3_mid16(allocs, w_ih[u], r.hidden_size, k_in, &out->w3q_ih[u]));
+        TRY(pack_lstm_x3_mid16(allocs, w_hh[u], r.hidden_size, r.hidden_size, &out->w3q_hh[u]));
       }
     }
   return EMPOSE_OK;
@@ -1047,6 +1088,7 @@ int empose_set_option(const char* name, int value) {
       {"mesh_x3", &o.mesh_x3},
       {"lstm_mid_x3", &o.lstm_mid_x3},
       {"lstm_midseq", &o.lstm_midseq},
+      {"lstm_mid16", &o.lstm_mid16},
       {"train_x3", &o.train_x3},
       {"lstm_fewrows", &o.lstm_fewrows},
       {"atb_fast", &o.atb_fast}};
@@ -1100,6 +1142,7 @@ int empose_get_option(const char* name) {
       {"mesh_x3", o.mesh_x3},
       {"lstm_mid_x3", o.lstm_mid_x3},
       {"lstm_midseq", o.lstm_midseq},
+      {"lstm_mid16", o.lstm_mid16},
       {"train_x3", o.train_x3},
       {"lstm_fewrows", o.lstm_fewrows},
       {"atb_fast", o.atb_fast}};

@@ -54,6 +54,8 @@ struct Options {
                           // weight pieces in registers (lstm_midseq_x3.hip) -- built, same bits, measured SLOWER than a launch
                           // per wavefront step (10.5 against 8.2 us per step at 32 rows: a hand-over between XCDs costs more
                           // than a kernel boundary; profiles/r06i_lstm_midseq_lab.txt), so opt-in
+  int lstm_mid16 = 1;     // LSTM steps of 17 .. 64 rows: 64 rows x 4-unit tiles on all 256 CUs (lstm_mid16_x3.hip); 0: the 8-unit
+                          // tiles of lstm_mid_x3.hip (128 workgroups)
   int lstm_mid_x3 = 1;    // LSTM steps of 17 .. 256 rows (inference, uni-directional) on three bf16 pieces, 64 x 8-unit tiles
                           // (lstm_mid_x3.hip); 0: lstm_mid_kernel (fp32 MFMA, operands through LDS)
   int lstm_fewrows = 1;   // LSTM steps of 4 .. 16 rows: all threads of a workgroup split K, lane reduce-scatter (lstm_fewrows_kernel),
@@ -370,6 +372,10 @@ hipError_t launch_lstm_rows_x3(const LstmX3Args& a, hipStream_t stream);
 // the step of MEDIUM batches (17 .. 256 rows): 64 rows x 8 units per workgroup, weights in the 8-unit-block order
 // (api.hip pack_lstm_x3 with mid = true), K split over the waves (lstm_mid_x3.hip; option lstm_mid_x3)
 hipError_t launch_lstm_mid_x3(const LstmX3Args& a, hipStream_t stream);
+// ... at most 64 rows: 4-unit tiles (16 columns, v_mfma_f32_16x16x32_bf16), weights in the order of api.hip
+// pack_lstm_x3_mid16, twice the workgroups (lstm_mid16_x3.hip; option lstm_mid16)
+bool lstm_mid16_shape_ok(int B, int H);
+hipError_t launch_lstm_mid16_x3(const LstmX3Args& a, hipStream_t stream);
 // The whole sequence of a medium batch (B <= 64) in one cooperative launch with the weight pieces in registers
 // (lstm_midseq_x3.hip; option lstm_midseq): same tiles, products and bits as the step launches of lstm_mid_x3.hip.
 struct LstmMidSeqUnit {

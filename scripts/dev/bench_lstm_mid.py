@@ -12,7 +12,7 @@ for kv in sys.argv[1:]:          # NAME=INT kernel-variant switches, e.g. lstm_m
 dev = 'cuda:0'
 layer = RNNLayer(60, 512, 2).eval().to(dev)
 F = 64
-for B in (17, 32, 36, 64, 96, 128, 192, 256, 512):
+for B in (9, 12, 16, 17, 32, 36, 64, 96, 128, 192, 256, 512):
     x = torch.randn(B, F, 60, device=dev)
     lens = torch.full((B,), F, device=dev)
     for _ in range(3): layer(x, lens)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-BATCHES = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 36, 64, 100, 128, 256, 257, 300, 700)   # (17 .. 256: lstm_mid_x3.hip since round 6)
+BATCHES = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 36, 64, 100, 128, 256, 257, 300, 700)   # (9 .. 64: lstm_mid16_x3.hip, .. 256: lstm_mid_x3.hip since round 6)
 BATCHES_R5 = (1, 2, 3, 4, 5, 8, 12, 16, 17, 31, 33, 64, 100, 256, 257, 300, 700)   # (4, 12: the other two sizes of lstm_fewrows_kernel)
 
 
@@ -22,6 +22,7 @@ def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4
     from em_pose_amd import _lib
     from em_pose_amd.nn.layers import RNNLayer
     rng = np.random.default_rng(seed)
+    opt_rng = np.random.default_rng(seed + 7919)     # (its own stream: the cases of a seed stay what they were)
     t_end = time.time() + (seconds if seconds is not None else 1e9)
     n, worst, worst_case, above = 0, 0.0, None, []
     lib = _lib.lib()
@@ -36,6 +37,10 @@ def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4
             # above 256 rows the whole-sequence cooperative kernel (opt-in) in half of the cases, small shapes included
             seq = int(rng.integers(0, 2))
             _lib.check(lib.empose_set_option(b'lstm_seq', seq))
+            # round 6: 9 .. 64 rows on 16-column tiles (default) or 32-column ones; 4 .. 64 rows as one cooperative launch (opt-in)
+            tiles16, one_launch = int(opt_rng.integers(0, 2)), int(opt_rng.integers(0, 2))
+            _lib.check(lib.empose_set_option(b'lstm_mid16', tiles16))
+            _lib.check(lib.empose_set_option(b'lstm_midseq', one_launch))
             torch.manual_seed(n)
             layer = RNNLayer(In, H, L, bidirectional=bi).eval()
             with torch.no_grad():
@@ -55,7 +60,8 @@ def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4
             torch.cuda.synchronize()
             err = max(float((got.cpu() - ref).abs().max()), float((g.final_state[0].cpu() - rh).abs().max()),
                       float((g.final_state[1].cpu() - rc).abs().max()))
-            desc = dict(bi=bi, L=L, H=H, In=In, B=B, F=F, state=state is not None, lstm_seq=seq)
+            desc = dict(bi=bi, L=L, H=H, In=In, B=B, F=F, state=state is not None, lstm_seq=seq, lstm_mid16=tiles16,
+                        lstm_midseq=one_launch)
             if err > 1e-5 or not np.isfinite(err):
                 above.append((n, err, desc))
                 log('lstm case %d above 1e-5: %.3e %s' % (n, err, desc))
@@ -67,6 +73,8 @@ def run(seed=0, seconds=None, n_cases=None, batches=BATCHES, log=print, tol=1e-4
             assert err < tol, 'LSTM MISMATCH seed %d case %d %s: %r' % (seed, n - 1, desc, err)
     finally:
         _lib.check(lib.empose_set_option(b'lstm_seq', 0))
+        _lib.check(lib.empose_set_option(b'lstm_mid16', 1))
+        _lib.check(lib.empose_set_option(b'lstm_midseq', 0))
     return {'n': n, 'worst': worst, 'worst_case': worst_case, 'above_1e5': above}
 
 

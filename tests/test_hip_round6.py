@@ -325,7 +325,8 @@ def test_medium_batch_whole_sequence_lstm_equals_its_step_launches(B, F, In, Hd,
     g = layer.to(DEV)
     outs, err = {}, {}
     for one_launch in (0, 1):
-        with _Option(b'lstm_midseq', one_launch):
+        # (the step launches it shares its bits with: the 8-unit tiles of lstm_mid_x3.hip, not the 4-unit ones that are the default)
+        with _Option(b'lstm_midseq', one_launch), _Option(b'lstm_mid16', 0):
             first, worst = None, 0.0
             for rep in range(3 if one_launch else 1):
                 got_all = []
@@ -440,3 +441,51 @@ def test_lgd_training_with_dropout_flags_runs_on_the_autograd_path():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
         n += 1
     assert n >= 14
+
+
+@pytest.mark.parametrize('B,F,In,Hd,L', [(36, 9, 72, 512, 2), (17, 5, 144, 512, 2), (32, 4, 60, 256, 2), (64, 6, 72, 64, 1),
+                                         (33, 3, 36, 128, 4), (20, 5, 100, 96, 3), (49, 7, 72, 512, 2)])
+def test_lstm_steps_on_sixteen_column_tiles_are_as_accurate_as_the_thirty_two_column_ones(B, F, In, Hd, L):
+    """lstm_mid16_x3_kernel (17 .. 64 rows: 4 hidden units x 4 gates per workgroup on all 256 CUs, v_mfma_f32_16x16x32_bf16,
+    k-steps of 32 -- an input whose k-steps of 16 are odd in number ends on a half step) against a float64 LSTM (reference
+    nn/layers.py:133-157: ragged rows, carried state, zero-padded outputs): no less accurate than lstm_mid_x3_kernel, and
+    repeated runs are bit-identical."""
+    from em_pose_amd.nn.layers import RNNLayer
+    torch.manual_seed(B * 5 + F)
+    layer = RNNLayer(In, Hd, L).eval()
+    with torch.no_grad():
+        for p in layer.lstm.parameters():
+            p.mul_(2.0)
+    x = torch.randn(B, F, In)
+    lens = torch.randint(1, F + 1, (B,))
+    lens[0], lens[-1] = F, 1
+    h0, c0 = 0.5 * torch.randn(L, B, Hd), 0.5 * torch.randn(L, B, Hd)
+    sd64 = {'lstm.' + k: v.detach().double() for k, v in layer.lstm.state_dict().items()}
+    with torch.no_grad():
+        want = {st is not None: R.lstm_forward(sd64, 'lstm.', x.double(), lens, None if st is None else (h0.double(), c0.double()),
+                                               L, False) for st in (None, 1)}
+    g = layer.to(DEV)
+    err = {}
+    for tiles16 in (0, 1):
+        with _Option(b'lstm_mid16', tiles16):
+            first, worst = None, 0.0
+            for rep in range(3 if tiles16 else 1):
+                got_all = []
+                for carried in (False, True):
+                    g.init_state = (h0.to(DEV), c0.to(DEV)) if carried else None
+                    y = g(x.to(DEV), lens.to(DEV))
+                    torch.cuda.synchronize()
+                    wy, (wh, wc) = want[carried]
+                    got = (y.cpu(), g.final_state[0].cpu(), g.final_state[1].cpu())
+                    got_all += [t.numpy() for t in got]
+                    worst = max(worst, float((got[0].double() - wy).abs().max()), float((got[1].double() - wh).abs().max()),
+                                float((got[2].double() - wc).abs().max()))
+                if first is None:
+                    first = got_all
+                else:
+                    for a_, b_ in zip(first, got_all):
+                        assert np.array_equal(a_, b_)
+            err[tiles16] = worst
+    print('lstm %s vs float64: 32-column tiles %.2e, 16-column tiles %.2e' % ((B, F, In, Hd, L), err[0], err[1]))
+    assert err[1] < 1e-5 and err[1] <= 1.5 * err[0] + 2e-7
+    g.release()
