@@ -16,8 +16,8 @@ python bench.py --workload vertices --batch 512 --frames 32 --steps 40 --warmup 
 python bench.py --workload vertices --batch 512 --frames 32 --steps 40 --warmup 8 --no_traffic --option mesh_x3=0 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_fp32_mfma_t16384.json
 python bench.py --workload vertices --arith bf16x3 --batch 512 --frames 32 --steps 10 --warmup 2 --no_traffic 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_vertices_bf16x3_t16384.json
 python scripts/dev/time_mesh.py 16384 0,1,2,3 2>&1 | grep mesh_x3= > gpurun_out/${TAG}_mesh_variants_t16384.txt
-python scripts/evaluate_real.py --synthetic --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
-python scripts/evaluate_real.py --synthetic --sequential --repeat 4 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
+python scripts/evaluate_real.py --synthetic --repeat 10 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_batched.json
+python scripts/evaluate_real.py --synthetic --sequential --repeat 6 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_evaluate_real_synthetic_sequential.json
 python scripts/train.py --steps 30 --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12.json          # default: replayed as a HIP graph
 python scripts/train.py --steps 30 --no_graph --json 2>/dev/null | tail -1 > gpurun_out/${TAG}_train_step_bs12_eager.json
 ( for o in "train_cols=0" "lstm_fewrows=0" "train_cols=0 --option lstm_fewrows=0"; do echo -n "$o: "; python scripts/train.py --steps 30 --json --option $o 2>/dev/null | tail -1; done ) > gpurun_out/${TAG}_train_step_bs12_ablations.txt
