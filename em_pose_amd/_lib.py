@@ -76,7 +76,8 @@ class LstmParams(C.Structure):   # empose_lstm_params: DEVICE pointers
 
 
 class LstmGrads(C.Structure):    # empose_lstm_grads
-    _fields_ = [('w_ih', C.c_void_p * 4), ('w_hh', C.c_void_p * 4), ('b_ih', C.c_void_p * 4), ('b_hh', C.c_void_p * 4)]
+    _fields_ = [('w_ih', C.c_void_p * 4), ('w_hh', C.c_void_p * 4), ('b_ih', C.c_void_p * 4), ('b_hh', C.c_void_p * 4),
+                ('d_h0', C.c_void_p * 4), ('d_c0', C.c_void_p * 4)]
 
 
 class MlpParams(C.Structure):    # empose_mlp_params: DEVICE pointers

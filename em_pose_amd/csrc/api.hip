@@ -2671,6 +2671,17 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
       e = w.wave == 2 ? launch_rec_ksplit(rb, cells, w.rec, stream) : launch_rec_fewrows(rb, cells, stream);
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward (wavefront): %s", hipGetErrorString(e));
     }
+    // ---- the cotangents of the initial state, where asked for: dh_{-1} = dG_0 . W_hh + carry, dc_{-1} = what the cell of
+    // step 0 left in the running cell cotangent
+    for (int l = 0; l < 2; ++l) {
+      if (grads->d_h0[l]) {
+        e = gemm(l == 1 ? w.dgates_up : w.dgates, F * 4 * H, l == 1 ? w.wt_hh_up : w.wt, 4 * H, grads->d_h0[l], H, B, H, 4 * H,
+                 l == 1 ? w.carry_up : w.carry, H);
+        if (e != hipSuccess) return fail(EMPOSE_EHIP, "initial-state cotangent: %s", hipGetErrorString(e));
+      }
+      if (grads->d_c0[l])
+        HIP_TRY(hipMemcpyAsync(grads->d_c0[l], l == 1 ? w.dc_up : w.dc, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
     // ---- the batched products: weight gradients of both layers, the input cotangent of layer 0
     for (int l = 1; l >= 0; --l) {
       const float* sv = save + (size_t)l * 7 * bfh;
@@ -2744,6 +2755,14 @@ int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float
       if (e != hipSuccess) return fail(EMPOSE_EHIP, "recurrent backward gemm: %s", hipGetErrorString(e));
       dh_in = out;
     }
+    // the cotangents of this layer's initial state, where asked for (w.wt still holds W_hh^T, w.carry / w.dc what the cell
+    // of step 0 left)
+    if (grads->d_h0[l]) {
+      e = gemm(w.dgates, F * 4 * H, w.wt, 4 * H, grads->d_h0[l], H, B, H, 4 * H, w.carry, H);
+      if (e != hipSuccess) return fail(EMPOSE_EHIP, "initial-state cotangent: %s", hipGetErrorString(e));
+    }
+    if (grads->d_c0[l])
+      HIP_TRY(hipMemcpyAsync(grads->d_c0[l], w.dc, bh * sizeof(float), hipMemcpyDeviceToDevice, stream));
     AtbArgs ab{};
     ab.A = w.dgates; ab.lda = 4 * H; ab.B = x_l; ab.ldb = ldx_l; ab.C = grads->w_ih[l]; ab.ldc = in_l;
     ab.bias = grads->b_ih[l]; ab.M = B * F; ab.N = 4 * H; ab.K = in_l;

@@ -184,6 +184,7 @@ class _LstmTrainFn(torch.autograd.Function):
                                              _lib.dptr(ws), nbytes, _lib.current_stream()))
         ctx.save_for_backward(x, lens, c0, save, *ws_)
         ctx.n_layers = n_layers
+        ctx.has_state = h0 is not None
         ctx.mark_non_differentiable(h_n, c_n)
         return y, h_n, c_n
 
@@ -202,13 +203,24 @@ class _LstmTrainFn(torch.autograd.Function):
             p.w_ih[l], p.w_hh[l], p.b_ih[l], p.b_hh[l] = [weights[4 * l + k].data_ptr() for k in range(4)]
             g.w_ih[l], g.w_hh[l], g.b_ih[l], g.b_hh[l] = [grads[4 * l + k].data_ptr() for k in range(4)]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        # the cotangents of a given initial state (a learned one, reference layers.py:121-131), where autograd wants them
+        d_h0 = d_c0 = None
+        if ctx.has_state and ctx.needs_input_grad[2]:
+            d_h0 = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        if ctx.has_state and ctx.needs_input_grad[3]:
+            d_c0 = torch.empty(L, B, H, dtype=torch.float32, device=dev)
+        for l in range(L):
+            if d_h0 is not None:
+                g.d_h0[l] = d_h0[l].data_ptr()
+            if d_c0 is not None:
+                g.d_c0[l] = d_c0[l].data_ptr()
         nbytes = lib.empose_lstm_train_workspace_bytes(C.byref(p), B, F)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dy = dy.contiguous()
         _lib.check(lib.empose_lstm_train_bwd(C.byref(p), B, F, _lib.dptr(x), K, _lib.dptr(lens), _lib.dptr(c0),
                                              _lib.dptr(save), _lib.dptr(dy), _lib.dptr(dx), C.byref(g), _lib.dptr(ws),
                                              nbytes, _lib.current_stream()))
-        return (dx, None, None, None, None) + tuple(grads)
+        return (dx, None, d_h0, d_c0, None) + tuple(grads)
 
 
 def bn_prelu_train(x, bn, act):
@@ -527,15 +539,19 @@ class RNNLayer(nn.Module):
         over the rows reversed within their lengths, outputs concatenated (what nn.LSTM does with a packed sequence)."""
         from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
         x = self.input_drop(x)
-        if self.learn_init_state and self.training:
-            raise NotImplementedError('a learned initial state is not trained on the HIP path: the LSTM Function takes '
-                                      '(h_0, c_0) as constants')
         on_hip = x.is_cuda and self.num_layers <= 4 and x.dtype == torch.float32 and x.shape[2] % 4 == 0
         if on_hip and not self.is_bidirectional:
             # hand-written forward + back-propagation through time; no packing, no host round trip, capturable
             lens = None if full_length else seq_lengths.to(device=x.device, dtype=torch.int32).contiguous()
             h0 = c0 = None
-            if self.init_state is not None:
+            if self.learn_init_state:
+                # from the first frame, with a graph (reference layers.py:121-131; it returns (c0, h0) and nn.LSTM reads the
+                # pair as (h_0, c_0): kept).  It replaces a carried state, as in the reference.
+                first = x[:, 0].contiguous()
+                shape = lambda t: t.reshape(-1, self.num_layers, self.hidden_size).transpose(0, 1).contiguous()
+                h0, c0 = shape(linear_train(first, self.to_init_state_c)), shape(linear_train(first, self.to_init_state_h))
+                self.init_state = (h0, c0)
+            elif self.init_state is not None:   # a carried state is a constant (reference models.py:489-492)
                 h0, c0 = [t.detach().to(device=x.device, dtype=torch.float32).contiguous() for t in self.init_state]
             weights = [w for unit in self._unit_params() for w in unit]
             y, h_n, c_n = _LstmTrainFn.apply(x, lens, h0, c0, self.num_layers, *weights)

@@ -522,11 +522,15 @@ typedef struct {
   const float* b_ih[4];   /* [4H] */
   const float* b_hh[4];
 } empose_lstm_params;
-typedef struct {          /* gradient outputs, same shapes; every pointer required */
+typedef struct {          /* gradient outputs, same shapes; every weight / bias pointer required */
   float* w_ih[4];
   float* w_hh[4];
   float* b_ih[4];
   float* b_hh[4];
+  /* optional (NULL: not wanted): the cotangents of the initial state, [B][H] per layer -- what a learned initial state
+   * (reference nn/layers.py:121-131, `learn_init_state`) is trained with */
+  float* d_h0[4];
+  float* d_c0[4];
 } empose_lstm_grads;
 /* floats of the `save` buffer the forward fills for the backward: per layer gates [B][F][4H], cell states [B][F][H],
  * incoming hidden states [B][F][H], output sequence [B][F][H] */
@@ -536,8 +540,9 @@ size_t empose_lstm_train_workspace_bytes(const empose_lstm_params* p, int B, int
 int empose_lstm_train_fwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
                           const float* h0, const float* c0, float* y, float* h_n, float* c_n, float* save,
                           void* workspace, size_t workspace_bytes, empose_stream_t stream);
-/* dy [B][F][H] -> parameter gradients (overwritten) and, if dx != NULL, dx [B][F][input_size].  The final state is not
- * differentiated (it only seeds the next chunk, detached, reference models.py:489-492). */
+/* dy [B][F][H] -> parameter gradients (overwritten), if dx != NULL dx [B][F][input_size], and where grads->d_h0 / d_c0 are
+ * given the cotangents of the initial state.  The final state is not differentiated (it only seeds the next chunk,
+ * detached, reference models.py:489-492). */
 int empose_lstm_train_bwd(const empose_lstm_params* p, int B, int F, const float* x, int ldx, const int* seq_lengths,
                           const float* c0, const float* save, const float* dy, float* dx,
                           const empose_lstm_grads* grads, void* workspace, size_t workspace_bytes,

@@ -252,7 +252,8 @@ def make_baseline_train(vids):
     cases = (('train_birnn12', baseline_flags('rnn', 12, m_bidirectional=True), 61),
              ('train_rnn6_l3', baseline_flags('rnn', 6, m_num_layers=3, m_average_shape=False), 62),
              ('train_resnet12', baseline_flags('resnet', 12, m_num_layers=3, m_skip_connections=True), 63),
-             ('train_resnet6_nofk_noshape', baseline_flags('resnet', 6, m_fk_loss=0.0, m_estimate_shape=False), 64))
+             ('train_resnet6_nofk_noshape', baseline_flags('resnet', 6, m_fk_loss=0.0, m_estimate_shape=False), 64),
+             ('train_rnn6_learninit', baseline_flags('rnn', 6, m_learn_init_state=True, m_average_shape=False), 65))
     for tag, fl, seed in cases:
         torch.manual_seed(seed)
         net = create_model(ref_config(**fl), smpl)

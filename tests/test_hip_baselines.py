@@ -196,13 +196,15 @@ def test_golden_rnn_baselines_state_carry(name):
         _check(net, case[tag], out, loss_vals)
 
 
-@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape'])
+@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape',
+                                  'train_rnn6_learninit'])
 def test_golden_baselines_training_step(name):
     """One training step of the baselines -- train mode, `forward(batch)`, `backward(batch, out)` = the losses and
     `total_loss.backward()` (reference models.py:196-262, 297-366) -- on a ragged batch with missing sensors, against what
     the unmodified reference deposited: outputs, loss values and EVERY parameter gradient.  The graph runs over the HIP
     kernels: linear layers and their reverse (matrix-core GEMM / A^T B), the LSTM with back-propagation through time (a
-    bidirectional stack composed per layer and direction), joints with the sub-mesh vector-Jacobian product."""
+    bidirectional stack composed per layer and direction; a learned initial state through the cotangents of (h_0, c_0)),
+    joints with the sub-mesh vector-Jacobian product."""
     case = H.load_case(name)
     net, fl = _build(case)
     net.fk_vertex_ids = [int(v) for v in case['meta']['vertex_ids']]

@@ -1488,6 +1488,8 @@ def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
     lens = torch.randint(1, F + 1, (B,)) if ragged else torch.full((B,), F)
     lens[0] = F
     state = (0.5 * torch.randn(L, B, H, dtype=torch.float64), 0.5 * torch.randn(L, B, H, dtype=torch.float64)) if carry else None
+    if carry:   # (round 6: the cotangents of a given initial state -- what a learned one is trained with)
+        state = tuple(t.requires_grad_(True) for t in state)
     dy = torch.randn(B, F, H, dtype=torch.float64)
     xr = x.clone().requires_grad_(True)
     packed = pack_padded_sequence(xr, lens, batch_first=True, enforce_sorted=False)
@@ -1499,7 +1501,7 @@ def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
     xg = x.float().to(DEV).requires_grad_(True)
     h0 = c0 = None
     if carry:
-        h0, c0 = state[0].float().to(DEV), state[1].float().to(DEV)
+        h0, c0 = [t.detach().float().to(DEV).requires_grad_(True) for t in state]
     y, h_n, c_n = _LstmTrainFn.apply(xg, lens.to(DEV, torch.int32) if ragged else None, h0, c0, L, *wg)
     (y * dy.float().to(DEV)).sum().backward()
     torch.cuda.synchronize()
@@ -1511,6 +1513,9 @@ def test_lstm_training_forward_backward_vs_torch(B, F, K, H, L, ragged, carry):
     for g_, w in zip(wg, weights):
         scale = max(1.0, float(w.grad.abs().max()))
         np.testing.assert_allclose(g_.grad.cpu().numpy(), w.grad.numpy(), atol=1e-4 * scale)
+    if carry:
+        np.testing.assert_allclose(h0.grad.cpu().numpy(), state[0].grad.numpy(), atol=5e-5)
+        np.testing.assert_allclose(c0.grad.cpu().numpy(), state[1].grad.numpy(), atol=5e-5)
 
 
 def test_lstm_training_forward_whole_sequence_kernel_equals_step_launches():

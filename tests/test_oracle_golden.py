@@ -151,7 +151,8 @@ def test_baselines_carry():
         _check_baseline(case['chunk1'], out1, st1)
 
 
-@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape'])
+@pytest.mark.parametrize('name', ['train_birnn12', 'train_rnn6_l3', 'train_resnet12', 'train_resnet6_nofk_noshape',
+                                  'train_rnn6_learninit'])
 def test_baselines_training_step(name):
     """One training step of the reference's baselines (train mode, `forward`, `backward` = the losses and
     `total_loss.backward()`; reference models.py:196-262, 297-366) on a ragged batch with missing sensors: the oracle's
@@ -169,7 +170,8 @@ def test_baselines_training_step(name):
     if fl['m_type'] == 'resnet':
         out = R.resnet_forward(sd, bm, inp, **common)
     else:
-        out, _ = R.simple_rnn_forward(sd, bm, inp, bidirectional=fl.get('m_bidirectional', False), **common)
+        out, _ = R.simple_rnn_forward(sd, bm, inp, bidirectional=fl.get('m_bidirectional', False),
+                                      learn_init_state=fl.get('m_learn_init_state', False), **common)
     for k in ('pose_hat', 'root_ori_hat', 'shape_hat', 'joints_hat'):
         if out[k] is not None:
             np.testing.assert_allclose(out[k].detach().numpy(), rec['out_' + k], atol=TOL, rtol=0, err_msg=k)
