@@ -470,6 +470,9 @@ def evaluate_sequences_batched(net, batches, smpl_model, device, window_size=256
             _check_async(dev)
         lap('wait_for_device')
         if placed:
+            for i in range(n):          # (a recording without a single frame never ended in a chunk: an empty table row)
+                if results[i] is None:
+                    table_row(i)
             me_all = MetricsEngine(smpl_model)
             me_all.merge({'eucl': rows_np[:, :22], 'eucl_pa': rows_np[:, 22:44], 'angle': rows_np[:, 44:]})
             return me_all, results, frames
