@@ -1150,7 +1150,8 @@ int empose_get_option(const char* name) {
     if (std::strcmp(name, e.n) == 0) return e.v;
   return -1;
 }
-int empose_version(void) { return 2; }   // 2: empose_lgd_io gained suppress_missing / mask_value
+int empose_version(void) { return 3; }   // 2: empose_lgd_io gained suppress_missing / mask_value; 3 (round 6): empose_mlp_params gained
+                                         // weight_x3 / weight_t_x3, empose_lstm_grads gained d_h0 / d_c0 (appended fields)
 const char* empose_arch(void) { return "gfx950"; }
 
 int empose_profile_enable(int on) {
